@@ -1,0 +1,194 @@
+#!/usr/bin/env python
+"""captions/sec of the CapDec caption hot path on MI355X.
+
+  python bench.py --gpus N --steps K --warmup W            (N > 1: launched by torch.distributed.run)
+
+A "step" is one pass of the hot path over one batch of synthetic CLIP embeddings resident in
+HBM: normalise -> mapping network -> GPT-2 KV-cached decode -> token ids (+ RCCL all-gather of
+the ids when N > 1).  Default workload = BASELINE.json's metric configuration (configs[2]):
+5000 x 512-d embeddings per GPU, TransformerMapper (8 layers), prefix_len 10, beam 5,
+entry_length 67, fp32 (the reference's GPT-2 dtype; greedy ids bit-identical to it).
+Weights are the seeded hot-init recipe of capdec_amd/synth.py (no checkpoints offline), which
+never emits the stop token, so every caption runs all 67 steps -- fixed, reproducible work.
+
+Rank 0 prints ONE JSON line (metric/value/... + "roofline" + "cpu_baseline").
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+from capdec_amd import synth  # noqa: E402
+
+PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+STOP_ID, D_EMB = 13, 768
+
+
+def algorithmic_flops_per_caption(P, T, beam, mapper, dims=synth.GPT2_SMALL, D=512, clip_len=10):
+    """SURVEY.md section 8 D.4 (KV-cached minimal algorithm)."""
+    d, V, nl = dims.n_embd, dims.vocab, dims.n_layer
+    f_body = 2.0 * nl * (d * 3 * d + d * d + d * 4 * d + 4 * d * d)
+    f_head = 2.0 * V * d
+    if beam == 1:
+        body_tok, head_rows = P + T - 1, T
+        att = sum(4.0 * d * nl * L for L in range(1, P + T))
+    else:
+        body_tok, head_rows = P + beam * (T - 1), 1 + beam * (T - 1)
+        att = sum(4.0 * d * nl * L for L in range(1, P + 1)) + beam * sum(4.0 * d * nl * (P + i) for i in range(1, T))
+    f = body_tok * f_body + head_rows * f_head + att
+    if mapper == "mlp":
+        f += 2.0 * (D * (d * P // 2) + (d * P // 2) * d * P)
+    else:
+        S = clip_len + P
+        f += 2.0 * D * clip_len * d + 8 * S * 2.0 * (3 * d * d + d * d + 2 * d * 2 * d) + 8 * 4.0 * S * S * d
+    return f
+
+
+def cpu_baseline(mapper, beam, P, T, sample, D=512):
+    """The oracle's reference-shaped path (batch 1, no KV cache, lm_head on every position,
+    fp32 torch CPU ops: the algorithm of reference gpt2_prefix_eval.py:50-198 driven like
+    predictions_runner.py:221-232) timed on this box's host cores on a bounded sample."""
+    from oracle import capdec_oracle as O
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    sd = synth.hot_state_dict(42, mapper, D, P)
+    x = synth.synthetic_clip_embeddings(sample + 1, D, seed=0)
+    with torch.no_grad():
+        pe = O.clip_project(O.normalize_prefix(x), sd, mapper, P)
+        # warm-up caption (lazy init) with a short entry_length, discarded
+        (O.generate_beam_ref(sd, pe[:1], beam, STOP_ID, 2) if beam > 1 else O.generate2_ref(sd, pe[:1], STOP_ID, 2))
+        t0 = time.perf_counter()
+        for r in range(1, sample + 1):
+            e = O.clip_project(O.normalize_prefix(x[r:r + 1]), sd, mapper, P)
+            if beam > 1:
+                O.generate_beam_ref(sd, e, beam, STOP_ID, T)
+            else:
+                O.generate2_ref(sd, e, STOP_ID, T)
+        dt = time.perf_counter() - t0
+    return {"value": sample / dt, "unit": "captions/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{sample} captions of the same workload (batch 1, no KV cache, fp32, T={T}, beam={beam}), "
+                      f"{dt:.1f} s wall, 1 warm-up discarded"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", choices=["beam_transformer", "greedy_mlp"], default="beam_transformer")
+    ap.add_argument("--captions", type=int, default=5000, help="captions per GPU per step (weak scaling)")
+    ap.add_argument("--entry-length", type=int, default=67)
+    ap.add_argument("--prefix-length", type=int, default=10)
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
+    ap.add_argument("--cpu-sample", type=int, default=-1, help="captions for the CPU baseline (0 = skip)")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+
+    from capdec_amd import distributed as cdist
+    from capdec_amd.gpt2_prefix import ClipCaptionModel, MappingType
+    from capdec_amd.predictions_runner import caption_ids
+
+    beam = args.workload == "beam_transformer"
+    mapper = "transformer_encoder" if beam else "mlp"
+    P, T, B = args.prefix_length, args.entry_length, (5 if beam else 1)
+    n_global = args.captions * world if args.scaling == "weak" else args.captions
+    model = ClipCaptionModel(P, clip_length=10, prefix_dim=512, num_layers=8,
+                             mapping_type=MappingType.TransformerEncoder if beam else MappingType.MLP).to(dev).eval()
+    model.load_state_dict(synth.hot_state_dict(42, mapper, 512, P))
+    emb = synth.synthetic_clip_embeddings(n_global, 512, seed=0, normalize=False).to(dev)   # resident in HBM
+    eng = model.engine
+
+    def step():
+        ids, lens, scores = caption_ids(model, emb, STOP_ID, beam=beam, beam_size=5, entry_length=T,
+                                        rank=rank, world=world)
+        return cdist.gather_ids(ids, lens, n_global, scores)
+
+    def barrier():
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        out = step()
+    eng.profile_enable(True)
+    eng.profile_reset()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    barrier()
+    dt = time.perf_counter() - t0
+    prof = eng.profile_get()
+    eng.profile_enable(False)
+    if world > 1:
+        import torch.distributed as dist
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    assert out[0].shape[0] == n_global and int(out[1].min()) >= 1
+
+    if rank == 0:
+        value = n_global * args.steps / dt
+        fam = prof["gemm_f32"]
+        gemm_ms = fam["ms"] / max(fam["launches"], 1)
+        achieved = fam["flops"] / (fam["ms"] * 1e-3) / 1e12 if fam["ms"] > 0 else 0.0
+        n_local = args.captions if args.scaling == "weak" else cdist.shard_size(args.captions, world)
+        alg = algorithmic_flops_per_caption(P, T, B, "transformer" if beam else "mlp") * n_local * args.steps
+        rec = {
+            "metric": "captions/sec (whole node), COCO-val 5k, prefix_len=10 beam=5, 1/2/4/8 GPUs",
+            "value": round(value, 2), "unit": "captions/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True,
+            "scaling": args.scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": ("COCO-val-5k-shaped: %d x 512-d synthetic CLIP embeddings per GPU -> normalise -> "
+                                    "%s -> GPT-2 small KV-cached %s, prefix_len %d, entry_length %d, hot-init seeded "
+                                    "weights (never emit the stop id: all %d steps run)")
+                       % (args.captions if args.scaling == "weak" else n_global,
+                          "TransformerMapper(8 layers)" if beam else "MLP mapper",
+                          "beam-5 decode" if beam else "greedy decode", P, T, T),
+                       "captions_per_step": n_global, "beam": B, "parallelism": f"caption-shard dp{world}",
+                       "tokens_per_s": round(value * T, 1)},
+            "roofline": {"bound": "mfma", "kernel": "gemm_f32_kernel (all GPT-2 / mapper projections; the fused "
+                         "lm_head variant is listed in `kernels`)",
+                         "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                         "avg_launch_ms": round(gemm_ms, 4), "launches": fam["launches"],
+                         "whole_path_frac": round(alg / dt / 1e12 / PEAK_F32_MFMA_TFLOPS, 4)},
+            "kernels": {k: {"ms": round(v["ms"], 2), "launches": v["launches"],
+                            **({"tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2)} if v["flops"] and v["ms"] else {})}
+                        for k, v in prof.items() if v["launches"]},
+        }
+        sample = args.cpu_sample if args.cpu_sample >= 0 else (2 if beam else 6)
+        if world == 1 and sample > 0:
+            rec["cpu_baseline"] = cpu_baseline(mapper, B, P, T, sample)
+        else:
+            rec["cpu_baseline"] = None
+        print(json.dumps(rec), flush=True)
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,61 @@
+"""Build libcapdec_hip.so (gfx950) in-tree with hipcc.  `python -m capdec_amd.build [--force]`."""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB_DIR = os.path.join(HERE, "lib")
+LIB_PATH = os.path.join(LIB_DIR, "libcapdec_hip.so")
+SOURCES = ["capi.hip", "gemm_f32.hip", "elementwise.hip", "attention.hip", "select.hip"]
+HEADERS = [os.path.join(CSRC, "common.h"), os.path.join(os.path.dirname(HERE), "include", "capdec.h")]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
+
+
+def _hipcc() -> str:
+    exe = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(exe):
+        raise RuntimeError("hipcc not found: the HIP extension cannot be built on this machine")
+    return exe
+
+
+def _stale(target: str, deps) -> bool:
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force: bool = False, verbose: bool = True) -> str:
+    """Compile every .hip translation unit to an object, link the shared library.
+    Incremental: only stale objects are rebuilt."""
+    os.makedirs(LIB_DIR, exist_ok=True)
+    obj_dir = os.path.join(LIB_DIR, "obj")
+    os.makedirs(obj_dir, exist_ok=True)
+    hipcc = _hipcc()
+    objs, procs = [], []
+    for src in SOURCES:
+        sp = os.path.join(CSRC, src)
+        op = os.path.join(obj_dir, src.replace(".hip", ".o"))
+        objs.append(op)
+        if force or _stale(op, [sp] + HEADERS):
+            cmd = [hipcc, *FLAGS, "-c", sp, "-o", op]
+            if verbose:
+                print("[capdec build]", " ".join(cmd), flush=True)
+            procs.append((src, subprocess.Popen(cmd)))
+    for src, p in procs:
+        if p.wait() != 0:
+            raise RuntimeError(f"hipcc failed on {src}")
+    if force or procs or _stale(LIB_PATH, objs):
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", LIB_PATH]
+        if verbose:
+            print("[capdec build]", " ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+    return LIB_PATH
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv))

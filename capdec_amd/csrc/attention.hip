@@ -1,0 +1,249 @@
+// Attention kernels (HBM-bound: one query row against a short cached context).
+//
+// GPT-2 decode / prefill: head_dim 64.  One wavefront per (row, head).  The wavefront is four
+// 16-lane groups; a group owns one key position per iteration and its 16 lanes each hold a
+// float4 of the 64-wide head (so a key is one 256-byte coalesced read), dot products are
+// reduced with 4 xor-shuffles, the softmax over <= 256 positions with 64-lane shuffles.
+// The KV cache is [layer][phys_row][head][ctx][64]: consecutive positions of a head are
+// contiguous.  Beam search never copies K/V: row r reads position p from physical row
+// caption*beam + anc[r][p] (ancestor table maintained by the beam-step kernel).
+#include "common.h"
+
+namespace capdec {
+
+constexpr int ATT_CTX_MAX = 256;
+
+__device__ __forceinline__ float dot4(const float4 &a, const float4 &b) {
+    return (a.x * b.x + a.y * b.y) + (a.z * b.z + a.w * b.w);
+}
+__device__ __forceinline__ float group16_sum(float v) {
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// DECODE = true : rows = captions*beam, every row at context length L; own k/v (position L-1)
+//                 taken from qkv and appended to the cache at phys row r.
+// DECODE = false: prefill rows (caption, i), L = i + 1, everything read from the cache at phys
+//                 row caption*beam (written by kv_scatter_prefill beforehand).
+template <bool DECODE>
+__global__ __launch_bounds__(256) void attn_gpt2_kernel(const float *__restrict__ qkv, float *__restrict__ kc,
+                                                        float *__restrict__ vc, int total, int heads, int ctx,
+                                                        int d, int beam, int Lparam, int P,
+                                                        const uint8_t *__restrict__ anc, int anc_stride,
+                                                        float *__restrict__ out) {
+    __shared__ float sc[4][ATT_CTX_MAX];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int grp = lane >> 4, sub = lane & 15;
+    const int gw = blockIdx.x * 4 + wave;
+    const bool active = gw < total;
+    const int row = active ? gw / heads : 0;
+    const int head = active ? gw - row * heads : 0;
+    int L, phys_self;
+    if (DECODE) {
+        L = Lparam;
+        phys_self = row;
+    } else {
+        const int cap = row / P, i = row - cap * P;
+        L = i + 1;
+        phys_self = cap * beam;
+    }
+    const int cap_base = DECODE ? (row / beam) * beam : phys_self;
+    const size_t hstride = (size_t)ctx * 64;
+    const float *qrow = qkv + (size_t)row * 3 * d;
+    float4 q = reinterpret_cast<const float4 *>(qrow + head * 64)[sub];
+    q.x *= 0.125f; q.y *= 0.125f; q.z *= 0.125f; q.w *= 0.125f;     // 1/sqrt(64), exact
+    float4 kcur, vcur;
+    const int Lpast = DECODE ? L - 1 : L;
+    if (DECODE) {
+        kcur = reinterpret_cast<const float4 *>(qrow + d + head * 64)[sub];
+        vcur = reinterpret_cast<const float4 *>(qrow + 2 * d + head * 64)[sub];
+        if (active && grp == 0) {
+            const size_t o = ((size_t)phys_self * heads + head) * hstride + (size_t)(L - 1) * 64;
+            reinterpret_cast<float4 *>(kc + o)[sub] = kcur;
+            reinterpret_cast<float4 *>(vc + o)[sub] = vcur;
+        }
+    }
+    // ---- scores
+    for (int p0 = 0; p0 < Lpast; p0 += 4) {
+        const int p = p0 + grp;
+        if (p < Lpast) {
+            int phys = phys_self;
+            if (DECODE && anc) phys = cap_base + anc[(size_t)row * anc_stride + p];
+            const float4 k = reinterpret_cast<const float4 *>(kc + ((size_t)phys * heads + head) * hstride + (size_t)p * 64)[sub];
+            const float s = group16_sum(dot4(q, k));
+            if (sub == 0) sc[wave][p] = s;
+        }
+    }
+    if (DECODE) {
+        const float s = group16_sum(dot4(q, kcur));
+        if (lane == 0) sc[wave][L - 1] = s;
+    }
+    __syncthreads();
+    // ---- softmax statistics over L positions
+    float mx = -INFINITY;
+    for (int p = lane; p < L; p += 64) mx = fmaxf(mx, sc[wave][p]);
+    mx = wave_max(mx);
+    float sum = 0.f;
+    for (int p = lane; p < L; p += 64) {
+        const float e = expf(sc[wave][p] - mx);
+        sc[wave][p] = e;
+        sum += e;
+    }
+    sum = wave_sum(sum);
+    __syncthreads();
+    // ---- P.V
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int p0 = 0; p0 < Lpast; p0 += 4) {
+        const int p = p0 + grp;
+        if (p < Lpast) {
+            int phys = phys_self;
+            if (DECODE && anc) phys = cap_base + anc[(size_t)row * anc_stride + p];
+            const float4 v = reinterpret_cast<const float4 *>(vc + ((size_t)phys * heads + head) * hstride + (size_t)p * 64)[sub];
+            const float w = sc[wave][p];
+            acc.x += w * v.x; acc.y += w * v.y; acc.z += w * v.z; acc.w += w * v.w;
+        }
+    }
+    if (DECODE && grp == 0) {
+        const float w = sc[wave][L - 1];
+        acc.x += w * vcur.x; acc.y += w * vcur.y; acc.z += w * vcur.z; acc.w += w * vcur.w;
+    }
+#pragma unroll
+    for (int o = 16; o <= 32; o <<= 1) {
+        acc.x += __shfl_xor(acc.x, o, 64);
+        acc.y += __shfl_xor(acc.y, o, 64);
+        acc.z += __shfl_xor(acc.z, o, 64);
+        acc.w += __shfl_xor(acc.w, o, 64);
+    }
+    if (active && grp == 0) {
+        const float inv = 1.0f / sum;
+        reinterpret_cast<float4 *>(out + (size_t)row * d + head * 64)[sub] =
+            make_float4(acc.x * inv, acc.y * inv, acc.z * inv, acc.w * inv);
+    }
+}
+
+// K/V of prefill row (cap, i) -> cache[phys = cap*beam][head][i][:]
+__global__ void kv_scatter_prefill_kernel(const float *__restrict__ qkv, float *__restrict__ kc,
+                                          float *__restrict__ vc, int ncap, int P, int beam, int heads, int ctx,
+                                          int d) {
+    const int nv = d / 4;                       // float4 per row per tensor
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= ncap * P * nv) return;
+    const int c4 = i % nv, row = i / nv;
+    const int cap = row / P, pos = row - cap * P;
+    const int head = (c4 * 4) / 64, within = (c4 * 4) % 64;
+    const size_t o = (((size_t)cap * beam * heads + head) * ctx + pos) * 64 + within;
+    const float *r = qkv + (size_t)row * 3 * d;
+    *reinterpret_cast<float4 *>(kc + o) = reinterpret_cast<const float4 *>(r + d)[c4];
+    *reinterpret_cast<float4 *>(vc + o) = reinterpret_cast<const float4 *>(r + 2 * d)[c4];
+}
+
+int launch_kv_scatter_prefill(hipStream_t st, const float *qkv, const KvCache &c, int layer, int ncap, int P,
+                              int beam) {
+    const int d = c.heads * c.hd;
+    const int tot = ncap * P * (d / 4);
+    if (tot <= 0) return 0;
+    hipLaunchKernelGGL(kv_scatter_prefill_kernel, dim3((tot + 255) / 256), dim3(256), 0, st, qkv,
+                       c.k + layer * c.layer_stride(), c.v + layer * c.layer_stride(), ncap, P, beam, c.heads, c.ctx,
+                       d);
+    CAPDEC_HIP(hipGetLastError());
+    return 0;
+}
+
+int launch_attn_prefill(hipStream_t st, const float *qkv, const KvCache &c, int layer, int ncap, int P, int beam,
+                        float *out) {
+    CAPDEC_CHECK(c.hd == 64, "attention: head_dim must be 64");
+    CAPDEC_CHECK(P <= ATT_CTX_MAX && P <= c.ctx, "attention: prefix longer than the supported context");
+    const int total = ncap * P * c.heads;
+    if (total <= 0) return 0;
+    hipLaunchKernelGGL(attn_gpt2_kernel<false>, dim3((total + 3) / 4), dim3(256), 0, st, qkv,
+                       c.k + layer * c.layer_stride(), c.v + layer * c.layer_stride(), total, c.heads, c.ctx,
+                       c.heads * c.hd, beam, 0, P, (const uint8_t *)nullptr, 0, out);
+    CAPDEC_HIP(hipGetLastError());
+    return 0;
+}
+
+int launch_attn_decode(hipStream_t st, const float *qkv, const KvCache &c, int layer, int rows, int beam, int L,
+                       const uint8_t *anc, int anc_stride, float *out) {
+    CAPDEC_CHECK(c.hd == 64, "attention: head_dim must be 64");
+    CAPDEC_CHECK(L >= 1 && L <= ATT_CTX_MAX && L <= c.ctx, "attention: context length out of range");
+    const int total = rows * c.heads;
+    if (total <= 0) return 0;
+    hipLaunchKernelGGL(attn_gpt2_kernel<true>, dim3((total + 3) / 4), dim3(256), 0, st, qkv,
+                       c.k + layer * c.layer_stride(), c.v + layer * c.layer_stride(), total, c.heads, c.ctx,
+                       c.heads * c.hd, beam, L, 0, anc, anc_stride, out);
+    CAPDEC_HIP(hipGetLastError());
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// TransformerMapper self-attention (reference transformer_mapper.py:22-51): bidirectional, seq =
+// clip_len + P (20 at the headline config), 8 heads x 96.  One block per (caption, head): K and V
+// of the head are staged in LDS ([seq][hd+1], conflict-free for both access directions), each
+// wavefront then serves query rows: lanes over keys for q.k, lanes over channels for p.v.
+__global__ __launch_bounds__(256) void attn_mapper_kernel(const float *__restrict__ q, int ldq,
+                                                          const float *__restrict__ k, const float *__restrict__ v,
+                                                          int ldkv, float *__restrict__ out, int seq, int heads,
+                                                          int hd, float scale) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int ld = hd + 1;
+    float *Ks = sm;                       // [seq][ld]
+    float *Vs = Ks + seq * ld;            // [seq][ld]
+    float *qb = Vs + seq * ld;            // [4][hd]
+    float *pb = qb + 4 * hd;              // [4][seq]
+    const int cap = blockIdx.x / heads, head = blockIdx.x - cap * heads;
+    const int d = heads * hd;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int i = threadIdx.x; i < seq * hd; i += 256) {
+        const int j = i / hd, c = i - j * hd;
+        const size_t o = ((size_t)cap * seq + j) * ldkv + head * hd + c;
+        Ks[j * ld + c] = k[o];
+        Vs[j * ld + c] = v[o];
+    }
+    __syncthreads();
+    for (int i = wave; i < seq; i += 4) {
+        const float *qr = q + ((size_t)cap * seq + i) * ldq + head * hd;
+        for (int c = lane; c < hd; c += 64) qb[wave * hd + c] = qr[c];
+        __builtin_amdgcn_wave_barrier();
+        float mx = -INFINITY;
+        for (int j = lane; j < seq; j += 64) {
+            float s = 0.f;
+            for (int c = 0; c < hd; ++c) s += qb[wave * hd + c] * Ks[j * ld + c];
+            s *= scale;
+            pb[wave * seq + j] = s;
+            mx = fmaxf(mx, s);
+        }
+        mx = wave_max(mx);
+        float sum = 0.f;
+        for (int j = lane; j < seq; j += 64) {
+            const float e = expf(pb[wave * seq + j] - mx);
+            pb[wave * seq + j] = e;
+            sum += e;
+        }
+        sum = wave_sum(sum);
+        __builtin_amdgcn_wave_barrier();
+        const float inv = 1.0f / sum;
+        for (int c = lane; c < hd; c += 64) {
+            float a = 0.f;
+            for (int j = 0; j < seq; ++j) a += pb[wave * seq + j] * Vs[j * ld + c];
+            out[((size_t)cap * seq + i) * d + head * hd + c] = a * inv;
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+int launch_attn_mapper(hipStream_t st, const float *q, int ldq, const float *k, const float *v, int ldkv, float *out,
+                       int n, int seq, int heads, int hd) {
+    if (n <= 0) return 0;
+    const size_t lds = ((size_t)2 * seq * (hd + 1) + 4 * hd + 4 * seq) * sizeof(float);
+    CAPDEC_CHECK(lds <= 160 * 1024, "mapper attention: sequence too long for LDS");
+    if (lds > 64 * 1024)
+        CAPDEC_HIP(hipFuncSetAttribute((const void *)attn_mapper_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)lds));
+    hipLaunchKernelGGL(attn_mapper_kernel, dim3(n * heads), dim3(256), lds, st, q, ldq, k, v, ldkv, out, seq, heads, hd,
+                       (float)pow((double)hd, -0.5));   // python: head_dim ** -0.5
+    CAPDEC_HIP(hipGetLastError());
+    return 0;
+}
+
+}  // namespace capdec

@@ -1,0 +1,762 @@
+// C ABI of libcapdec_hip.so (include/capdec.h) and the host-side orchestration of the
+// KV-cached batched decode.  One context per GPU; everything is enqueued on one HIP stream.
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <memory>
+
+#include "common.h"
+
+namespace capdec {
+
+static thread_local std::string g_err;
+void set_error(const std::string &msg) { g_err = msg; }
+
+// ---------------------------------------------------------------------------- device buffers
+struct DBuf {   // grow-only device buffer
+    void *p = nullptr;
+    size_t cap = 0;
+    int ensure(size_t bytes) {
+        if (bytes <= cap) return 0;
+        if (p) CAPDEC_HIP(hipFree(p));
+        p = nullptr;
+        cap = 0;
+        CAPDEC_HIP(hipMalloc(&p, bytes));
+        cap = bytes;
+        return 0;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+    template <class T> T *as() const { return reinterpret_cast<T *>(p); }
+};
+
+struct Gpt2Layer {
+    float *ln1w, *ln1b, *wqkv, *bqkv, *wproj, *bproj, *ln2w, *ln2b, *wfc, *bfc, *wproj2, *bproj2;
+};
+struct Gpt2 {
+    bool loaded = false;
+    int n_layer = 0, n_head = 0, d = 0, vocab = 0, n_pos = 0;
+    float eps = 1e-5f;
+    float *wte = nullptr, *wpe = nullptr, *lnfw = nullptr, *lnfb = nullptr;
+    std::vector<Gpt2Layer> layers;
+    std::vector<void *> owned;
+};
+struct TMapLayer {
+    float *n1w, *n1b, *wqkv, *wproj, *bproj, *n2w, *n2b, *wfc1, *bfc1, *wfc2, *bfc2;
+};
+struct Mapper {
+    int kind = 0;   // 0 none, 1 mlp, 2 transformer
+    int D = 0, P = 0, d = 768;
+    // mlp
+    int hidden = 0;
+    float *w1 = nullptr, *b1 = nullptr, *w2 = nullptr, *b2 = nullptr;
+    // transformer
+    int clip_len = 0, n_layers = 0, heads = 8, mlp_hidden = 0;
+    float *lin_w = nullptr, *lin_b = nullptr, *prefix_const = nullptr;
+    std::vector<TMapLayer> layers;
+    std::vector<void *> owned;
+};
+
+enum Family { F_GEMM = 0, F_LMHEAD, F_ATTN_DEC, F_ATTN_PRE, F_LN, F_EMBED, F_SELECT, F_MAP_ATTN, F_OTHER, F_COUNT };
+static const char *kFamilyNames[F_COUNT] = {"gemm_f32",  "gemm_f32_lmhead_topk", "attn_decode", "attn_prefill", "layernorm",
+                                            "embed",     "select",               "attn_mapper", "other"};
+
+struct Prof {
+    bool on = false;
+    struct Rec { int fam; hipEvent_t a, b; double flops; };
+    std::vector<Rec> recs;
+    std::vector<hipEvent_t> pool;
+    double ms[F_COUNT] = {0}, flops[F_COUNT] = {0};
+    int64_t launches[F_COUNT] = {0};
+};
+
+}  // namespace capdec
+
+using namespace capdec;
+
+struct capdec_ctx {
+    int device = 0;
+    hipStream_t own_stream = nullptr, stream = nullptr;
+    size_t kv_budget = (size_t)96 << 30;
+    Gpt2 gpt;
+    Mapper map;
+    Prof prof;
+    hipEvent_t t0 = nullptr, t1 = nullptr;
+    // workspaces
+    DBuf h, x, qkv, att, ff, xl, tmax, tsum, cval, cidx, lse, topv, topi, kc, vc;
+    DBuf tokens, scores, seq, stopped, done, anc, next_tok, alive, gids, glens;
+    DBuf m_hid, m_lin, m_seq, m_x, m_qkv, m_att, m_ff;
+    int *alive_host = nullptr;   // pinned
+};
+
+namespace capdec {
+
+// ---------------------------------------------------------------------------- profiling
+static hipEvent_t prof_event(capdec_ctx *c) {
+    if (!c->prof.pool.empty()) {
+        hipEvent_t e = c->prof.pool.back();
+        c->prof.pool.pop_back();
+        return e;
+    }
+    hipEvent_t e = nullptr;
+    (void)hipEventCreate(&e);
+    return e;
+}
+struct ProfScope {
+    capdec_ctx *c;
+    int idx = -1;
+    ProfScope(capdec_ctx *ctx, int fam, double flops = 0.0) : c(ctx) {
+        if (!c->prof.on) return;
+        Prof::Rec r{fam, prof_event(c), prof_event(c), flops};
+        (void)hipEventRecord(r.a, c->stream);
+        c->prof.recs.push_back(r);
+        idx = (int)c->prof.recs.size() - 1;
+    }
+    ~ProfScope() {
+        if (idx >= 0) (void)hipEventRecord(c->prof.recs[idx].b, c->stream);
+    }
+};
+static int prof_collect(capdec_ctx *c) {
+    if (c->prof.recs.empty()) return 0;
+    CAPDEC_HIP(hipStreamSynchronize(c->stream));
+    for (auto &r : c->prof.recs) {
+        float ms = 0.f;
+        CAPDEC_HIP(hipEventElapsedTime(&ms, r.a, r.b));
+        c->prof.ms[r.fam] += ms;
+        c->prof.flops[r.fam] += r.flops;
+        c->prof.launches[r.fam] += 1;
+        c->prof.pool.push_back(r.a);
+        c->prof.pool.push_back(r.b);
+    }
+    c->prof.recs.clear();
+    return 0;
+}
+
+// ---------------------------------------------------------------------------- uploads
+static int upload(std::vector<void *> &owned, const float *h_src, size_t n, float **out) {
+    CAPDEC_CHECK(h_src != nullptr, "weights: null host pointer");
+    void *p = nullptr;
+    CAPDEC_HIP(hipMalloc(&p, n * sizeof(float)));
+    owned.push_back(p);
+    CAPDEC_HIP(hipMemcpy(p, h_src, n * sizeof(float), hipMemcpyHostToDevice));
+    *out = reinterpret_cast<float *>(p);
+    return 0;
+}
+// host [rows, cols] -> device [cols, rows] (Conv1D [in,out] -> k-contiguous [out,in])
+static int upload_transposed(capdec_ctx *c, std::vector<void *> &owned, const float *h_src, int rows, int cols,
+                             float **out) {
+    CAPDEC_CHECK(h_src != nullptr, "weights: null host pointer");
+    void *tmp = nullptr, *p = nullptr;
+    const size_t n = (size_t)rows * cols;
+    CAPDEC_HIP(hipMalloc(&tmp, n * sizeof(float)));
+    if (hipMalloc(&p, n * sizeof(float)) != hipSuccess) {
+        (void)hipFree(tmp);
+        set_error("weights: hipMalloc failed");
+        return 1;
+    }
+    owned.push_back(p);
+    int rc = 0;
+    if (hipMemcpy(tmp, h_src, n * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) rc = 1;
+    if (!rc) rc = launch_transpose(c->stream, (const float *)tmp, (float *)p, rows, cols);
+    if (!rc && hipStreamSynchronize(c->stream) != hipSuccess) rc = 1;
+    (void)hipFree(tmp);
+    if (rc) {
+        set_error("weights: transpose upload failed");
+        return 1;
+    }
+    *out = reinterpret_cast<float *>(p);
+    return 0;
+}
+static void free_all(std::vector<void *> &owned) {
+    for (void *p : owned) (void)hipFree(p);
+    owned.clear();
+}
+
+// ---------------------------------------------------------------------------- GEMM wrappers
+static int gemm(capdec_ctx *c, const float *A, int lda, const float *Bt, int ldb, float *C, int ldc, int M, int N,
+                int K, const float *bias, int act, const float *resid = nullptr, int ldr = 0) {
+    GemmEpilogue e;
+    e.bias = bias;
+    e.act = act;
+    e.resid = resid;
+    e.ldr = ldr;
+    ProfScope ps(c, F_GEMM, 2.0 * M * (double)N * K);
+    return launch_gemm_f32(c->stream, A, lda, Bt, ldb, C, ldc, M, N, K, e);
+}
+
+// ---------------------------------------------------------------------------- GPT-2 body
+struct StepShape {
+    bool prefill;
+    int ncap, P, beam;      // prefill: rows = ncap * P
+    int rows, L;            // decode: rows at context length L
+    const uint8_t *anc;
+    int anc_stride;
+};
+
+static int ensure_body_ws(capdec_ctx *c, int M) {
+    const int d = c->gpt.d;
+    CAPDEC_TRY(c->h.ensure((size_t)M * d * 4));
+    CAPDEC_TRY(c->x.ensure((size_t)M * d * 4));
+    CAPDEC_TRY(c->qkv.ensure((size_t)M * 3 * d * 4));
+    CAPDEC_TRY(c->att.ensure((size_t)M * d * 4));
+    CAPDEC_TRY(c->ff.ensure((size_t)M * 4 * d * 4));
+    return 0;
+}
+
+// h [M, d] (in c->h) -> h after all blocks (ln_f NOT applied)
+static int gpt2_body(capdec_ctx *c, const StepShape &s, const KvCache &kv) {
+    const Gpt2 &g = c->gpt;
+    const int d = g.d, M = s.prefill ? s.ncap * s.P : s.rows;
+    float *h = c->h.as<float>(), *x = c->x.as<float>(), *qkv = c->qkv.as<float>(), *att = c->att.as<float>(),
+          *ff = c->ff.as<float>();
+    for (int l = 0; l < g.n_layer; ++l) {
+        const Gpt2Layer &w = g.layers[l];
+        { ProfScope ps(c, F_LN); CAPDEC_TRY(launch_layernorm(c->stream, h, d, w.ln1w, w.ln1b, g.eps, x, d, M, d)); }
+        CAPDEC_TRY(gemm(c, x, d, w.wqkv, d, qkv, 3 * d, M, 3 * d, d, w.bqkv, CAPDEC_ACT_NONE));
+        if (s.prefill) {
+            ProfScope ps(c, F_ATTN_PRE);
+            CAPDEC_TRY(launch_kv_scatter_prefill(c->stream, qkv, kv, l, s.ncap, s.P, s.beam));
+            CAPDEC_TRY(launch_attn_prefill(c->stream, qkv, kv, l, s.ncap, s.P, s.beam, att));
+        } else {
+            ProfScope ps(c, F_ATTN_DEC);
+            CAPDEC_TRY(launch_attn_decode(c->stream, qkv, kv, l, s.rows, s.beam, s.L, s.anc, s.anc_stride, att));
+        }
+        CAPDEC_TRY(gemm(c, att, d, w.wproj, d, h, d, M, d, d, w.bproj, CAPDEC_ACT_NONE, h, d));
+        { ProfScope ps(c, F_LN); CAPDEC_TRY(launch_layernorm(c->stream, h, d, w.ln2w, w.ln2b, g.eps, x, d, M, d)); }
+        CAPDEC_TRY(gemm(c, x, d, w.wfc, d, ff, 4 * d, M, 4 * d, d, w.bfc, CAPDEC_ACT_GELU_NEW));
+        CAPDEC_TRY(gemm(c, ff, 4 * d, w.wproj2, 4 * d, h, d, M, d, 4 * d, w.bproj2, CAPDEC_ACT_NONE, h, d));
+    }
+    return 0;
+}
+
+// ln_f over `R` rows of h (row stride ldh floats, starting at h0) then the fused lm_head:
+// -> lse [R], topv/topi [R, k]
+static int lm_head_select(capdec_ctx *c, const float *h0, int ldh, int R, int k, float inv_temp) {
+    const Gpt2 &g = c->gpt;
+    const int d = g.d, nt = gemm_tiles_n(g.vocab);
+    CAPDEC_TRY(c->xl.ensure((size_t)R * d * 4));
+    CAPDEC_TRY(c->tmax.ensure((size_t)R * nt * 4));
+    CAPDEC_TRY(c->tsum.ensure((size_t)R * nt * 4));
+    CAPDEC_TRY(c->cval.ensure((size_t)R * nt * k * 4));
+    CAPDEC_TRY(c->cidx.ensure((size_t)R * nt * k * 4));
+    CAPDEC_TRY(c->lse.ensure((size_t)R * 4));
+    CAPDEC_TRY(c->topv.ensure((size_t)R * k * 4));
+    CAPDEC_TRY(c->topi.ensure((size_t)R * k * 4));
+    { ProfScope ps(c, F_LN); CAPDEC_TRY(launch_layernorm(c->stream, h0, ldh, g.lnfw, g.lnfb, g.eps, c->xl.as<float>(), d, R, d)); }
+    {
+        ProfScope ps(c, F_LMHEAD, 2.0 * R * (double)g.vocab * d);
+        CAPDEC_TRY(launch_gemm_f32_topk(c->stream, c->xl.as<float>(), d, g.wte, d, R, g.vocab, d, k, inv_temp,
+                                        c->tmax.as<float>(), c->tsum.as<float>(), c->cval.as<float>(),
+                                        c->cidx.as<int>()));
+    }
+    {
+        ProfScope ps(c, F_SELECT);
+        CAPDEC_TRY(launch_topk_merge(c->stream, c->tmax.as<float>(), c->tsum.as<float>(), c->cval.as<float>(),
+                                     c->cidx.as<int>(), R, nt, k, c->lse.as<float>(), c->topv.as<float>(),
+                                     c->topi.as<int>()));
+    }
+    return 0;
+}
+
+static int ensure_kv(capdec_ctx *c, KvCache &kv, int rows, int ctx) {
+    const Gpt2 &g = c->gpt;
+    kv.rows = rows;
+    kv.heads = g.n_head;
+    kv.ctx = ctx;
+    kv.hd = g.d / g.n_head;
+    const size_t bytes = kv.layer_stride() * g.n_layer * sizeof(float);
+    CAPDEC_TRY(c->kc.ensure(bytes));
+    CAPDEC_TRY(c->vc.ensure(bytes));
+    kv.k = c->kc.as<float>();
+    kv.v = c->vc.as<float>();
+    return 0;
+}
+
+static int poll_alive(capdec_ctx *c, int *alive) {
+    CAPDEC_HIP(hipMemcpyAsync(c->alive_host, c->alive.p, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    CAPDEC_HIP(hipStreamSynchronize(c->stream));
+    *alive = *c->alive_host;
+    return 0;
+}
+
+// captions per chunk so that the fp32 KV cache fits the budget
+static int chunk_captions(capdec_ctx *c, int n, int beam, int ctx) {
+    const Gpt2 &g = c->gpt;
+    const size_t per_cap = (size_t)beam * ctx * g.d * 2 * sizeof(float) * g.n_layer;
+    size_t m = c->kv_budget / std::max<size_t>(per_cap, 1);
+    m = std::max<size_t>(m, 1);
+    return (int)std::min<size_t>(m, (size_t)n);
+}
+
+// ---------------------------------------------------------------------------- decode drivers
+static int decode_chunk(capdec_ctx *c, const float *prefix, int nc, int P, int beam, bool greedy, int stop_id,
+                        int alt_stop_id, int T, float temperature, int *ids, int *lens, float *scores, int *order) {
+    const Gpt2 &g = c->gpt;
+    const int d = g.d;
+    const int ctx = P + T - 1;
+    const int rows = nc * beam;
+    const int k = beam;   // candidates kept per row
+    const float inv_temp = 1.0f / (temperature > 0.f ? temperature : 1.0f);
+    KvCache kv;
+    CAPDEC_TRY(ensure_kv(c, kv, rows, ctx));
+    CAPDEC_TRY(ensure_body_ws(c, std::max(nc * P, rows)));
+    CAPDEC_TRY(c->next_tok.ensure((size_t)rows * 4));
+    CAPDEC_TRY(c->alive.ensure(sizeof(int)));
+    CAPDEC_TRY(c->done.ensure((size_t)rows));
+    BeamState bs;
+    if (!greedy) {
+        CAPDEC_TRY(c->tokens.ensure((size_t)rows * T * 4));
+        CAPDEC_TRY(c->scores.ensure((size_t)rows * 4));
+        CAPDEC_TRY(c->seq.ensure((size_t)rows * 4));
+        CAPDEC_TRY(c->stopped.ensure((size_t)rows));
+        CAPDEC_TRY(c->anc.ensure((size_t)rows * ctx));
+        bs.tokens = c->tokens.as<int>();
+        bs.scores = c->scores.as<float>();
+        bs.seq = c->seq.as<float>();
+        bs.stopped = c->stopped.as<uint8_t>();
+        bs.done = c->done.as<uint8_t>();
+        bs.anc = c->anc.as<uint8_t>();
+        bs.next_tok = c->next_tok.as<int>();
+        bs.alive_count = c->alive.as<int>();
+        CAPDEC_HIP(hipMemsetAsync(bs.tokens, 0, (size_t)rows * T * 4, c->stream));
+        CAPDEC_HIP(hipMemsetAsync(bs.anc, 0, (size_t)rows * ctx, c->stream));
+    } else {
+        CAPDEC_HIP(hipMemsetAsync(ids, 0, (size_t)nc * T * 4, c->stream));
+        CAPDEC_HIP(hipMemsetAsync(lens, 0, (size_t)nc * 4, c->stream));
+    }
+    CAPDEC_HIP(hipMemsetAsync(c->done.p, 0, (size_t)rows, c->stream));
+    CAPDEC_HIP(hipMemsetAsync(c->alive.p, 0, sizeof(int), c->stream));
+
+    // ---- step 0: prefill the prefix (positions 0..P-1), logits of the last prefix row
+    { ProfScope ps(c, F_EMBED); CAPDEC_TRY(launch_embed_prefix(c->stream, prefix, g.wpe, c->h.as<float>(), nc, P, 0, d)); }
+    StepShape sp{};
+    sp.prefill = true;
+    sp.ncap = nc;
+    sp.P = P;
+    sp.beam = beam;
+    CAPDEC_TRY(gpt2_body(c, sp, kv));
+    CAPDEC_TRY(lm_head_select(c, c->h.as<float>() + (size_t)(P - 1) * d, P * d, nc, k, inv_temp));
+    if (greedy) {
+        ProfScope ps(c, F_SELECT);
+        CAPDEC_TRY(launch_greedy_step(c->stream, c->topi.as<int>(), nc, 0, T, stop_id, alt_stop_id, ids, lens,
+                                      c->done.as<uint8_t>(), c->next_tok.as<int>(), c->alive.as<int>()));
+    } else {
+        ProfScope ps(c, F_SELECT);
+        CAPDEC_TRY(launch_beam_init(c->stream, bs, c->lse.as<float>(), c->topv.as<float>(), c->topi.as<int>(), nc,
+                                    beam, k, T, ctx, P, stop_id));
+    }
+    // ---- steps 1..T-1: one token per row per step
+    const int poll_every = 8;
+    for (int i = 1; i < T; ++i) {
+        if ((i - 1) % poll_every == 0) {
+            int alive = 0;
+            CAPDEC_TRY(poll_alive(c, &alive));
+            if (alive == 0) break;
+        }
+        const int pos = P + i - 1;   // position of the token fed this step
+        CAPDEC_HIP(hipMemsetAsync(c->alive.p, 0, sizeof(int), c->stream));
+        {
+            ProfScope ps(c, F_EMBED);
+            CAPDEC_TRY(launch_embed_tokens(c->stream, c->next_tok.as<int>(), g.wte, g.wpe + (size_t)pos * d,
+                                           c->h.as<float>(), rows, d));
+        }
+        StepShape sd{};
+        sd.prefill = false;
+        sd.rows = rows;
+        sd.beam = beam;
+        sd.L = pos + 1;
+        sd.anc = greedy ? nullptr : bs.anc;
+        sd.anc_stride = ctx;
+        CAPDEC_TRY(gpt2_body(c, sd, kv));
+        CAPDEC_TRY(lm_head_select(c, c->h.as<float>(), d, rows, k, inv_temp));
+        ProfScope ps(c, F_SELECT);
+        if (greedy) {
+            CAPDEC_TRY(launch_greedy_step(c->stream, c->topi.as<int>(), rows, i, T, stop_id, alt_stop_id, ids, lens,
+                                          c->done.as<uint8_t>(), c->next_tok.as<int>(), c->alive.as<int>()));
+        } else {
+            CAPDEC_TRY(launch_beam_step(c->stream, bs, c->lse.as<float>(), c->topv.as<float>(), c->topi.as<int>(), nc,
+                                        beam, k, T, ctx, i, pos, g.vocab, stop_id));
+        }
+    }
+    if (!greedy) {
+        ProfScope ps(c, F_SELECT);
+        CAPDEC_TRY(launch_beam_finalize(c->stream, bs, nc, beam, T, ids, lens, scores, order));
+    }
+    return 0;
+}
+
+static int decode_common(capdec_ctx *c, const float *prefix, int n, int P, int beam, bool greedy, int stop_id,
+                         int alt_stop_id, int T, float temperature, int *ids, int *lens, float *scores,
+                         int *order) {
+    CAPDEC_CHECK(c && c->gpt.loaded, "decode: GPT-2 weights not loaded");
+    CAPDEC_CHECK(n >= 0 && P >= 1 && T >= 1, "decode: bad sizes");
+    CAPDEC_CHECK(P + T - 1 <= c->gpt.n_pos, "decode: prefix + entry_length exceeds n_positions");
+    CAPDEC_CHECK(P + T - 1 <= 256 && T <= 128, "decode: context > 256 or entry_length > 128 not supported");
+    CAPDEC_CHECK(beam >= 1 && beam <= 8, "decode: beam size must be in 1..8");
+    CAPDEC_CHECK(c->gpt.d / c->gpt.n_head == 64, "decode: head_dim must be 64");
+    CAPDEC_HIP(hipSetDevice(c->device));
+    if (n == 0) return 0;
+    const int ctx = P + T - 1;
+    const int chunk = chunk_captions(c, n, beam, ctx);
+    for (int c0 = 0; c0 < n; c0 += chunk) {
+        const int nc = std::min(chunk, n - c0);
+        CAPDEC_TRY(decode_chunk(c, prefix + (size_t)c0 * P * c->gpt.d, nc, P, beam, greedy, stop_id, alt_stop_id, T,
+                                temperature, ids + (size_t)c0 * beam * T, lens + (size_t)c0 * beam,
+                                scores ? scores + (size_t)c0 * beam : nullptr,
+                                order ? order + (size_t)c0 * beam : nullptr));
+    }
+    CAPDEC_HIP(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+// ---------------------------------------------------------------------------- mapper forward
+static int mapper_chunk(capdec_ctx *c, const float *x, int n, float *out) {
+    Mapper &m = c->map;
+    const int d = m.d;
+    if (m.kind == 1) {
+        CAPDEC_TRY(c->m_hid.ensure((size_t)n * m.hidden * 4));
+        CAPDEC_TRY(gemm(c, x, m.D, m.w1, m.D, c->m_hid.as<float>(), m.hidden, n, m.hidden, m.D, m.b1, CAPDEC_ACT_TANH));
+        CAPDEC_TRY(gemm(c, c->m_hid.as<float>(), m.hidden, m.w2, m.hidden, out, m.P * d, n, m.P * d, m.hidden, m.b2,
+                        CAPDEC_ACT_NONE));
+        return 0;
+    }
+    const int S = m.clip_len + m.P, M = n * S, hd = d / m.heads;
+    CAPDEC_TRY(c->m_lin.ensure((size_t)n * m.clip_len * d * 4));
+    CAPDEC_TRY(c->m_seq.ensure((size_t)M * d * 4));
+    CAPDEC_TRY(c->m_x.ensure((size_t)M * d * 4));
+    CAPDEC_TRY(c->m_qkv.ensure((size_t)M * 3 * d * 4));
+    CAPDEC_TRY(c->m_att.ensure((size_t)M * d * 4));
+    CAPDEC_TRY(c->m_ff.ensure((size_t)M * m.mlp_hidden * 4));
+    float *seq = c->m_seq.as<float>(), *xn = c->m_x.as<float>(), *qkv = c->m_qkv.as<float>(),
+          *att = c->m_att.as<float>(), *ff = c->m_ff.as<float>();
+    CAPDEC_TRY(gemm(c, x, m.D, m.lin_w, m.D, c->m_lin.as<float>(), m.clip_len * d, n, m.clip_len * d, m.D, m.lin_b,
+                    CAPDEC_ACT_NONE));
+    { ProfScope ps(c, F_OTHER); CAPDEC_TRY(launch_tmapper_concat(c->stream, c->m_lin.as<float>(), m.prefix_const, seq, n, m.clip_len, m.P, d)); }
+    for (int l = 0; l < m.n_layers; ++l) {
+        const TMapLayer &w = m.layers[l];
+        { ProfScope ps(c, F_LN); CAPDEC_TRY(launch_layernorm(c->stream, seq, d, w.n1w, w.n1b, 1e-5f, xn, d, M, d)); }
+        CAPDEC_TRY(gemm(c, xn, d, w.wqkv, d, qkv, 3 * d, M, 3 * d, d, nullptr, CAPDEC_ACT_NONE));
+        { ProfScope ps(c, F_MAP_ATTN); CAPDEC_TRY(launch_attn_mapper(c->stream, qkv, 3 * d, qkv + d, qkv + 2 * d, 3 * d, att, n, S, m.heads, hd)); }
+        CAPDEC_TRY(gemm(c, att, d, w.wproj, d, seq, d, M, d, d, w.bproj, CAPDEC_ACT_NONE, seq, d));
+        { ProfScope ps(c, F_LN); CAPDEC_TRY(launch_layernorm(c->stream, seq, d, w.n2w, w.n2b, 1e-5f, xn, d, M, d)); }
+        CAPDEC_TRY(gemm(c, xn, d, w.wfc1, d, ff, m.mlp_hidden, M, m.mlp_hidden, d, w.bfc1, CAPDEC_ACT_RELU));
+        CAPDEC_TRY(gemm(c, ff, m.mlp_hidden, w.wfc2, m.mlp_hidden, seq, d, M, d, m.mlp_hidden, w.bfc2, CAPDEC_ACT_NONE,
+                        seq, d));
+    }
+    { ProfScope ps(c, F_OTHER); CAPDEC_TRY(launch_tmapper_take(c->stream, seq, out, n, m.clip_len, m.P, d)); }
+    return 0;
+}
+
+}  // namespace capdec
+
+// =============================================================================== C ABI
+extern "C" {
+
+int capdec_abi_version(void) { return CAPDEC_ABI_VERSION; }
+const char *capdec_last_error(void) { return g_err.c_str(); }
+
+int capdec_create(int device_id, capdec_ctx **out) {
+    CAPDEC_CHECK(out != nullptr, "create: null out pointer");
+    int ndev = 0;
+    CAPDEC_HIP(hipGetDeviceCount(&ndev));
+    CAPDEC_CHECK(device_id >= 0 && device_id < ndev, "create: no such HIP device");
+    CAPDEC_HIP(hipSetDevice(device_id));
+    hipDeviceProp_t prop;
+    CAPDEC_HIP(hipGetDeviceProperties(&prop, device_id));
+    if (std::string(prop.gcnArchName).find("gfx950") == std::string::npos) {
+        set_error(std::string("create: libcapdec_hip is built for gfx950 (MI355X) only, found ") + prop.gcnArchName);
+        return 1;
+    }
+    std::unique_ptr<capdec_ctx> c(new capdec_ctx());
+    c->device = device_id;
+    CAPDEC_HIP(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
+    c->stream = c->own_stream;
+    CAPDEC_HIP(hipEventCreate(&c->t0));
+    CAPDEC_HIP(hipEventCreate(&c->t1));
+    CAPDEC_HIP(hipHostMalloc((void **)&c->alive_host, sizeof(int), hipHostMallocDefault));
+    *out = c.release();
+    return 0;
+}
+
+void capdec_destroy(capdec_ctx *c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    free_all(c->gpt.owned);
+    free_all(c->map.owned);
+    DBuf *bufs[] = {&c->h, &c->x, &c->qkv, &c->att, &c->ff, &c->xl, &c->tmax, &c->tsum, &c->cval, &c->cidx,
+                    &c->lse, &c->topv, &c->topi, &c->kc, &c->vc, &c->tokens, &c->scores, &c->seq, &c->stopped,
+                    &c->done, &c->anc, &c->next_tok, &c->alive, &c->gids, &c->glens, &c->m_hid, &c->m_lin, &c->m_seq,
+                    &c->m_x, &c->m_qkv, &c->m_att, &c->m_ff};
+    for (DBuf *b : bufs) b->release();
+    for (auto &r : c->prof.recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+    for (auto e : c->prof.pool) (void)hipEventDestroy(e);
+    if (c->t0) (void)hipEventDestroy(c->t0);
+    if (c->t1) (void)hipEventDestroy(c->t1);
+    if (c->alive_host) (void)hipHostFree(c->alive_host);
+    if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+    delete c;
+}
+
+int capdec_set_stream(capdec_ctx *c, void *hip_stream) {
+    CAPDEC_CHECK(c, "null context");
+    c->stream = hip_stream ? reinterpret_cast<hipStream_t>(hip_stream) : c->own_stream;
+    return 0;
+}
+int capdec_synchronize(capdec_ctx *c) {
+    CAPDEC_CHECK(c, "null context");
+    CAPDEC_HIP(hipStreamSynchronize(c->stream));
+    return 0;
+}
+int capdec_set_kv_budget(capdec_ctx *c, size_t bytes) {
+    CAPDEC_CHECK(c, "null context");
+    c->kv_budget = bytes ? bytes : ((size_t)96 << 30);
+    return 0;
+}
+int capdec_malloc(capdec_ctx *c, size_t bytes, void **d_ptr) {
+    CAPDEC_CHECK(c && d_ptr, "null argument");
+    CAPDEC_HIP(hipSetDevice(c->device));
+    CAPDEC_HIP(hipMalloc(d_ptr, bytes ? bytes : 1));
+    return 0;
+}
+int capdec_free(capdec_ctx *c, void *d_ptr) {
+    CAPDEC_CHECK(c, "null context");
+    if (d_ptr) CAPDEC_HIP(hipFree(d_ptr));
+    return 0;
+}
+int capdec_memcpy_h2d(capdec_ctx *c, void *d_dst, const void *h_src, size_t bytes) {
+    CAPDEC_CHECK(c, "null context");
+    if (!bytes) return 0;
+    CAPDEC_HIP(hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, c->stream));
+    CAPDEC_HIP(hipStreamSynchronize(c->stream));
+    return 0;
+}
+int capdec_memcpy_d2h(capdec_ctx *c, void *h_dst, const void *d_src, size_t bytes) {
+    CAPDEC_CHECK(c, "null context");
+    if (!bytes) return 0;
+    CAPDEC_HIP(hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, c->stream));
+    CAPDEC_HIP(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int capdec_load_gpt2(capdec_ctx *c, const capdec_gpt2_weights *w) {
+    CAPDEC_CHECK(c && w, "null argument");
+    CAPDEC_CHECK(w->n_layer >= 1 && w->n_head >= 1 && w->vocab >= 8 && w->n_pos >= 1, "load_gpt2: bad geometry");
+    CAPDEC_CHECK(w->n_embd % w->n_head == 0 && w->n_embd / w->n_head == 64, "load_gpt2: head_dim must be 64");
+    CAPDEC_CHECK(w->n_embd % 32 == 0 && w->n_embd <= 1024, "load_gpt2: n_embd must be a multiple of 32, <= 1024");
+    CAPDEC_HIP(hipSetDevice(c->device));
+    Gpt2 &g = c->gpt;
+    free_all(g.owned);
+    g = Gpt2();
+    g.n_layer = w->n_layer; g.n_head = w->n_head; g.d = w->n_embd; g.vocab = w->vocab; g.n_pos = w->n_pos;
+    g.eps = w->ln_eps > 0 ? w->ln_eps : 1e-5f;
+    const int d = g.d;
+    CAPDEC_TRY(upload(g.owned, w->wte, (size_t)g.vocab * d, &g.wte));
+    CAPDEC_TRY(upload(g.owned, w->wpe, (size_t)g.n_pos * d, &g.wpe));
+    CAPDEC_TRY(upload(g.owned, w->ln_f_w, d, &g.lnfw));
+    CAPDEC_TRY(upload(g.owned, w->ln_f_b, d, &g.lnfb));
+    g.layers.resize(g.n_layer);
+    for (int l = 0; l < g.n_layer; ++l) {
+        const capdec_gpt2_layer &s = w->layers[l];
+        Gpt2Layer &t = g.layers[l];
+        CAPDEC_TRY(upload(g.owned, s.ln_1_w, d, &t.ln1w));
+        CAPDEC_TRY(upload(g.owned, s.ln_1_b, d, &t.ln1b));
+        CAPDEC_TRY(upload_transposed(c, g.owned, s.c_attn_w, d, 3 * d, &t.wqkv));
+        CAPDEC_TRY(upload(g.owned, s.c_attn_b, 3 * d, &t.bqkv));
+        CAPDEC_TRY(upload_transposed(c, g.owned, s.c_proj_w, d, d, &t.wproj));
+        CAPDEC_TRY(upload(g.owned, s.c_proj_b, d, &t.bproj));
+        CAPDEC_TRY(upload(g.owned, s.ln_2_w, d, &t.ln2w));
+        CAPDEC_TRY(upload(g.owned, s.ln_2_b, d, &t.ln2b));
+        CAPDEC_TRY(upload_transposed(c, g.owned, s.c_fc_w, d, 4 * d, &t.wfc));
+        CAPDEC_TRY(upload(g.owned, s.c_fc_b, 4 * d, &t.bfc));
+        CAPDEC_TRY(upload_transposed(c, g.owned, s.mlp_c_proj_w, 4 * d, d, &t.wproj2));
+        CAPDEC_TRY(upload(g.owned, s.mlp_c_proj_b, d, &t.bproj2));
+    }
+    g.loaded = true;
+    return 0;
+}
+
+int capdec_load_mapper_mlp(capdec_ctx *c, int D, int P, int hidden, const float *w1, const float *b1, const float *w2,
+                           const float *b2) {
+    CAPDEC_CHECK(c, "null context");
+    CAPDEC_CHECK(D % 32 == 0 && hidden % 32 == 0 && P >= 1, "load_mapper_mlp: dims must be multiples of 32");
+    CAPDEC_HIP(hipSetDevice(c->device));
+    Mapper &m = c->map;
+    free_all(m.owned);
+    m = Mapper();
+    m.D = D; m.P = P; m.hidden = hidden;
+    m.d = c->gpt.loaded ? c->gpt.d : 768;
+    CAPDEC_TRY(upload(m.owned, w1, (size_t)hidden * D, &m.w1));
+    CAPDEC_TRY(upload(m.owned, b1, hidden, &m.b1));
+    CAPDEC_TRY(upload(m.owned, w2, (size_t)m.P * m.d * hidden, &m.w2));
+    CAPDEC_TRY(upload(m.owned, b2, (size_t)m.P * m.d, &m.b2));
+    m.kind = 1;
+    return 0;
+}
+
+int capdec_load_mapper_transformer(capdec_ctx *c, const capdec_tmapper_weights *w) {
+    CAPDEC_CHECK(c && w, "null argument");
+    CAPDEC_CHECK(w->prefix_dim % 32 == 0 && w->d % 32 == 0 && w->mlp_hidden % 32 == 0, "load_mapper_transformer: dims must be multiples of 32");
+    CAPDEC_CHECK(w->num_heads >= 1 && w->d % w->num_heads == 0, "load_mapper_transformer: bad head count");
+    CAPDEC_CHECK(w->clip_length >= 1 && w->prefix_length >= 1 && w->num_layers >= 1, "load_mapper_transformer: bad geometry");
+    CAPDEC_HIP(hipSetDevice(c->device));
+    Mapper &m = c->map;
+    free_all(m.owned);
+    m = Mapper();
+    m.D = w->prefix_dim; m.P = w->prefix_length; m.clip_len = w->clip_length; m.n_layers = w->num_layers;
+    m.heads = w->num_heads; m.d = w->d; m.mlp_hidden = w->mlp_hidden;
+    const int d = m.d;
+    CAPDEC_TRY(upload(m.owned, w->linear_w, (size_t)m.clip_len * d * m.D, &m.lin_w));
+    CAPDEC_TRY(upload(m.owned, w->linear_b, (size_t)m.clip_len * d, &m.lin_b));
+    CAPDEC_TRY(upload(m.owned, w->prefix_const, (size_t)m.P * d, &m.prefix_const));
+    m.layers.resize(m.n_layers);
+    for (int l = 0; l < m.n_layers; ++l) {
+        const capdec_tmapper_layer &s = w->layers[l];
+        TMapLayer &t = m.layers[l];
+        CAPDEC_TRY(upload(m.owned, s.norm1_w, d, &t.n1w));
+        CAPDEC_TRY(upload(m.owned, s.norm1_b, d, &t.n1b));
+        // fused projection [3d, d] = [to_queries ; to_keys_values] -> rows [q | k | v]
+        CAPDEC_CHECK(s.to_queries_w && s.to_keys_values_w, "load_mapper_transformer: null weight");
+        void *p = nullptr;
+        CAPDEC_HIP(hipMalloc(&p, (size_t)3 * d * d * 4));
+        m.owned.push_back(p);
+        t.wqkv = (float *)p;
+        CAPDEC_HIP(hipMemcpy(t.wqkv, s.to_queries_w, (size_t)d * d * 4, hipMemcpyHostToDevice));
+        CAPDEC_HIP(hipMemcpy(t.wqkv + (size_t)d * d, s.to_keys_values_w, (size_t)2 * d * d * 4, hipMemcpyHostToDevice));
+        CAPDEC_TRY(upload(m.owned, s.project_w, (size_t)d * d, &t.wproj));
+        CAPDEC_TRY(upload(m.owned, s.project_b, d, &t.bproj));
+        CAPDEC_TRY(upload(m.owned, s.norm2_w, d, &t.n2w));
+        CAPDEC_TRY(upload(m.owned, s.norm2_b, d, &t.n2b));
+        CAPDEC_TRY(upload(m.owned, s.fc1_w, (size_t)m.mlp_hidden * d, &t.wfc1));
+        CAPDEC_TRY(upload(m.owned, s.fc1_b, m.mlp_hidden, &t.bfc1));
+        CAPDEC_TRY(upload(m.owned, s.fc2_w, (size_t)d * m.mlp_hidden, &t.wfc2));
+        CAPDEC_TRY(upload(m.owned, s.fc2_b, d, &t.bfc2));
+    }
+    m.kind = 2;
+    return 0;
+}
+
+int capdec_normalize_prefix(capdec_ctx *c, const float *x, int n, int dim, int normalize, const float *offset,
+                            float *out) {
+    CAPDEC_CHECK(c && x && out && n >= 0 && dim >= 1, "normalize_prefix: bad argument");
+    CAPDEC_HIP(hipSetDevice(c->device));
+    ProfScope ps(c, F_OTHER);
+    return launch_normalize_prefix(c->stream, x, n, dim, normalize, offset, out);
+}
+
+int capdec_noise_inject(capdec_ctx *c, const float *x, int n, int dim, float variance, const float *offset,
+                        int uniform, int dont_norm, uint64_t seed, const float *noise, const float *u, float *out) {
+    CAPDEC_CHECK(c && x && out && n >= 0 && dim >= 1, "noise_inject: bad argument");
+    CAPDEC_CHECK(variance >= 0.f, "noise_inject: negative variance");
+    CAPDEC_HIP(hipSetDevice(c->device));
+    ProfScope ps(c, F_OTHER);
+    return launch_noise_inject(c->stream, x, n, dim, variance, offset, uniform, dont_norm, seed, noise, u, out);
+}
+
+int capdec_mapper_forward(capdec_ctx *c, const float *x, int n, float *out) {
+    CAPDEC_CHECK(c && c->map.kind != 0, "mapper_forward: no mapper loaded");
+    CAPDEC_CHECK(x && out && n >= 0, "mapper_forward: bad argument");
+    CAPDEC_HIP(hipSetDevice(c->device));
+    const Mapper &m = c->map;
+    const int chunk = 8192;
+    for (int c0 = 0; c0 < n; c0 += chunk) {
+        const int nc = std::min(chunk, n - c0);
+        CAPDEC_TRY(mapper_chunk(c, x + (size_t)c0 * m.D, nc, out + (size_t)c0 * m.P * m.d));
+    }
+    return 0;
+}
+
+int capdec_gpt2_logits(capdec_ctx *c, const float *embeds, int n, int L, int all_positions, float *logits) {
+    CAPDEC_CHECK(c && c->gpt.loaded, "gpt2_logits: GPT-2 weights not loaded");
+    CAPDEC_CHECK(embeds && logits && n >= 1 && L >= 1 && L <= 256 && L <= c->gpt.n_pos, "gpt2_logits: bad argument");
+    CAPDEC_HIP(hipSetDevice(c->device));
+    const Gpt2 &g = c->gpt;
+    const int d = g.d;
+    KvCache kv;
+    CAPDEC_TRY(ensure_kv(c, kv, n, L));
+    CAPDEC_TRY(ensure_body_ws(c, n * L));
+    { ProfScope ps(c, F_EMBED); CAPDEC_TRY(launch_embed_prefix(c->stream, embeds, g.wpe, c->h.as<float>(), n, L, 0, d)); }
+    StepShape sp{};
+    sp.prefill = true;
+    sp.ncap = n;
+    sp.P = L;
+    sp.beam = 1;
+    CAPDEC_TRY(gpt2_body(c, sp, kv));
+    const int R = all_positions ? n * L : n;
+    CAPDEC_TRY(c->xl.ensure((size_t)R * d * 4));
+    const float *h0 = all_positions ? c->h.as<float>() : c->h.as<float>() + (size_t)(L - 1) * d;
+    const int ldh = all_positions ? d : L * d;
+    { ProfScope ps(c, F_LN); CAPDEC_TRY(launch_layernorm(c->stream, h0, ldh, g.lnfw, g.lnfb, g.eps, c->xl.as<float>(), d, R, d)); }
+    CAPDEC_TRY(gemm(c, c->xl.as<float>(), d, g.wte, d, logits, g.vocab, R, g.vocab, d, nullptr, CAPDEC_ACT_NONE));
+    return 0;
+}
+
+int capdec_wte_lookup(capdec_ctx *c, const int32_t *ids, int n, float *out) {
+    CAPDEC_CHECK(c && c->gpt.loaded, "wte_lookup: GPT-2 weights not loaded");
+    CAPDEC_HIP(hipSetDevice(c->device));
+    ProfScope ps(c, F_EMBED);
+    return launch_gather_rows(c->stream, c->gpt.wte, ids, out, n, c->gpt.d);
+}
+
+int capdec_decode_greedy(capdec_ctx *c, const float *prefix, int n, int P, int stop_id, int alt_stop_id,
+                         int entry_length, int32_t *ids, int32_t *lens) {
+    CAPDEC_CHECK(c && (n == 0 || (prefix && ids && lens)), "decode_greedy: null argument");
+    return decode_common(c, prefix, n, P, 1, true, stop_id, alt_stop_id, entry_length, 1.0f, ids, lens, nullptr,
+                         nullptr);
+}
+
+int capdec_decode_beam(capdec_ctx *c, const float *prefix, int n, int P, int beam, int stop_id, int entry_length,
+                       float temperature, int32_t *ids, int32_t *lens, float *scores, int32_t *order) {
+    CAPDEC_CHECK(c && (n == 0 || (prefix && ids && lens && scores)), "decode_beam: null argument");
+    CAPDEC_CHECK(c->gpt.loaded && c->gpt.vocab >= beam, "decode_beam: vocabulary smaller than the beam");
+    return decode_common(c, prefix, n, P, beam, false, stop_id, -1, entry_length, temperature, ids, lens, scores,
+                         order);
+}
+
+int capdec_gemm_f32(capdec_ctx *c, const float *a, int lda, const float *bt, int ldb, float *cc, int ldc, int M, int N,
+                    int K, const float *bias, const float *resid, int ldr, int act) {
+    CAPDEC_CHECK(c && a && bt && cc, "gemm: null argument");
+    CAPDEC_HIP(hipSetDevice(c->device));
+    return gemm(c, a, lda, bt, ldb, cc, ldc, M, N, K, bias, act, resid, ldr);
+}
+
+int capdec_timer_start(capdec_ctx *c) {
+    CAPDEC_CHECK(c, "null context");
+    CAPDEC_HIP(hipEventRecord(c->t0, c->stream));
+    return 0;
+}
+int capdec_timer_stop_ms(capdec_ctx *c, float *ms) {
+    CAPDEC_CHECK(c && ms, "null argument");
+    CAPDEC_HIP(hipEventRecord(c->t1, c->stream));
+    CAPDEC_HIP(hipEventSynchronize(c->t1));
+    CAPDEC_HIP(hipEventElapsedTime(ms, c->t0, c->t1));
+    return 0;
+}
+int capdec_profile_enable(capdec_ctx *c, int on) {
+    CAPDEC_CHECK(c, "null context");
+    c->prof.on = on != 0;
+    return 0;
+}
+int capdec_profile_reset(capdec_ctx *c) {
+    CAPDEC_CHECK(c, "null context");
+    CAPDEC_TRY(prof_collect(c));
+    for (int f = 0; f < F_COUNT; ++f) { c->prof.ms[f] = 0; c->prof.flops[f] = 0; c->prof.launches[f] = 0; }
+    return 0;
+}
+int capdec_profile_get(capdec_ctx *c, int *count, const char **names, float *ms, int64_t *launches, double *flops) {
+    CAPDEC_CHECK(c && count, "null argument");
+    CAPDEC_TRY(prof_collect(c));
+    *count = F_COUNT;
+    for (int f = 0; f < F_COUNT; ++f) {
+        if (names) names[f] = kFamilyNames[f];
+        if (ms) ms[f] = (float)c->prof.ms[f];
+        if (launches) launches[f] = c->prof.launches[f];
+        if (flops) flops[f] = c->prof.flops[f];
+    }
+    return 0;
+}
+
+}  // extern "C"

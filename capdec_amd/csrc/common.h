@@ -1,0 +1,131 @@
+// Shared declarations for libcapdec_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+
+#include "../../include/capdec.h"
+
+namespace capdec {
+
+void set_error(const std::string &msg);
+
+#define CAPDEC_HIP(expr)                                                                         \
+    do {                                                                                         \
+        hipError_t _e = (expr);                                                                  \
+        if (_e != hipSuccess) {                                                                  \
+            ::capdec::set_error(std::string(#expr) + ": " + hipGetErrorString(_e) + " (" +       \
+                                __FILE__ + ":" + std::to_string(__LINE__) + ")");               \
+            return 1;                                                                            \
+        }                                                                                        \
+    } while (0)
+
+#define CAPDEC_CHECK(cond, msg)                                                                  \
+    do {                                                                                         \
+        if (!(cond)) {                                                                           \
+            ::capdec::set_error(std::string(msg) + " [" #cond "]");                              \
+            return 1;                                                                            \
+        }                                                                                        \
+    } while (0)
+
+#define CAPDEC_TRY(expr)                                                                         \
+    do {                                                                                         \
+        int _r = (expr);                                                                         \
+        if (_r) return _r;                                                                       \
+    } while (0)
+
+constexpr int WAVE = 64;
+
+// ---- wave-level helpers (64-wide wavefronts) ------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// ---- launch geometry of the f32 MFMA GEMM ----------------------------------------------
+constexpr int GEMM_BM = 128, GEMM_BN = 128, GEMM_BK = 32;
+constexpr int TOPK_MAX = 8;
+
+// gemm_f32.hip
+struct GemmEpilogue {
+    const float *bias = nullptr;   // [N]
+    const float *resid = nullptr;  // [M, ldr] added after the activation
+    int ldr = 0;
+    int act = CAPDEC_ACT_NONE;
+};
+int launch_gemm_f32(hipStream_t st, const float *A, int lda, const float *Bt, int ldb, float *C, int ldc,
+                    int M, int N, int K, const GemmEpilogue &epi);
+// lm_head: logits tile never leaves the CU; per (row, 128-column tile) emits max, sum exp(x - max)
+// and the top-k (value, column) pairs.
+int launch_gemm_f32_topk(hipStream_t st, const float *A, int lda, const float *Bt, int ldb, int M, int N, int K,
+                         int k, float inv_temp, float *tile_max, float *tile_sum, float *cand_val, int *cand_idx);
+inline int gemm_tiles_n(int N) { return (N + GEMM_BN - 1) / GEMM_BN; }
+
+// elementwise.hip
+int launch_layernorm(hipStream_t st, const float *x, int ldx, const float *w, const float *b, float eps, float *y,
+                     int ldy, int rows, int d);
+int launch_embed_tokens(hipStream_t st, const int *tok, const float *wte, const float *wpe_row, float *h, int rows,
+                        int d);
+int launch_embed_prefix(hipStream_t st, const float *prefix, const float *wpe, float *h, int n, int P, int pos0,
+                        int d);
+int launch_gather_rows(hipStream_t st, const float *table, const int *ids, float *out, int rows, int d);
+int launch_normalize_prefix(hipStream_t st, const float *x, int n, int dim, int normalize, const float *offset,
+                            float *out);
+int launch_noise_inject(hipStream_t st, const float *x, int n, int dim, float variance, const float *offset,
+                        int uniform, int dont_norm, uint64_t seed, const float *noise, const float *u, float *out);
+int launch_tmapper_concat(hipStream_t st, const float *lin, const float *prefix_const, float *seq, int n,
+                          int clip_len, int P, int d);
+int launch_tmapper_take(hipStream_t st, const float *seq, float *out, int n, int clip_len, int P, int d);
+int launch_transpose(hipStream_t st, const float *in, float *out, int rows, int cols);  // out[c][r] = in[r][c]
+
+// attention.hip
+struct KvCache {
+    float *k = nullptr;  // [layer][phys_row][head][ctx][hd]
+    float *v = nullptr;
+    int rows = 0, heads = 0, ctx = 0, hd = 0;
+    size_t layer_stride() const { return (size_t)rows * heads * ctx * hd; }
+};
+// write K/V of `rows` prefill rows (row = caption * P + i) into phys row caption*beam, position i
+int launch_kv_scatter_prefill(hipStream_t st, const float *qkv, const KvCache &c, int layer, int ncap, int P,
+                              int beam);
+// prefill: query row (caption, i) attends cache positions 0..i of phys row caption*beam
+int launch_attn_prefill(hipStream_t st, const float *qkv, const KvCache &c, int layer, int ncap, int P, int beam,
+                        float *out);
+// decode: row r (caption = r / beam) at position L-1: its own k/v come from qkv (and are written to the cache
+// at phys row r), positions p < L-1 from phys row caption*beam + anc[r][p] (anc == nullptr -> r itself)
+int launch_attn_decode(hipStream_t st, const float *qkv, const KvCache &c, int layer, int rows, int beam, int L,
+                       const uint8_t *anc, int anc_stride, float *out);
+// TransformerMapper self-attention (no mask): q / k / v rows of n*seq tokens (row strides ldq, ldkv), head-major
+int launch_attn_mapper(hipStream_t st, const float *q, int ldq, const float *k, const float *v, int ldkv, float *out,
+                       int n, int seq, int heads, int hd);
+
+// select.hip
+int launch_topk_merge(hipStream_t st, const float *tile_max, const float *tile_sum, const float *cand_val,
+                      const int *cand_idx, int rows, int ntiles, int k, float *lse, float *top_val, int *top_idx);
+struct BeamState {
+    int *tokens = nullptr;      // [ncap, beam, T]
+    float *scores = nullptr;    // [ncap, beam]  running SUM of log-probs (reference `scores`)
+    float *seq = nullptr;       // [ncap, beam]  reference `seq_lengths` (fp32)
+    uint8_t *stopped = nullptr; // [ncap, beam]
+    uint8_t *done = nullptr;    // [ncap]  caption's loop has broken (all beams stopped)
+    uint8_t *anc = nullptr;     // [ncap, beam, ctx]
+    int *next_tok = nullptr;    // [ncap * beam]
+    int *alive_count = nullptr; // [1] captions still running (device counter, polled by the host)
+};
+int launch_beam_init(hipStream_t st, const BeamState &s, const float *lse, const float *top_val, const int *top_idx,
+                     int ncap, int beam, int k, int T, int ctx, int P, int stop_id);
+int launch_beam_step(hipStream_t st, const BeamState &s, const float *lse, const float *top_val, const int *top_idx,
+                     int ncap, int beam, int k, int T, int ctx, int step, int pos_new, int vocab, int stop_id);
+int launch_beam_finalize(hipStream_t st, const BeamState &s, int ncap, int beam, int T, int *ids, int *lens,
+                         float *scores, int *order);
+int launch_greedy_step(hipStream_t st, const int *top_idx, int rows, int step, int T, int stop_id, int alt_stop_id,
+                       int *ids, int *lens, uint8_t *done, int *next_tok, int *alive_count);
+
+}  // namespace capdec

@@ -1,0 +1,296 @@
+// Memory-bound row kernels: LayerNorm, embedding gathers, prefix normalise / noise injection,
+// TransformerMapper sequence assembly, weight transposes.  One wavefront per row wherever a
+// row reduction is needed (64-lane shuffle reductions, float4 accesses).
+#include "common.h"
+
+namespace capdec {
+
+// ---------------------------------------------------------------------------- LayerNorm
+// y = (x - mean) * rsqrt(var + eps) * w + b, biased variance, two-pass in registers.
+// One wavefront per row; d <= 64 * 4 * LN_MAXV.
+constexpr int LN_MAXV = 4;   // float4s per lane -> d <= 1024
+__global__ __launch_bounds__(256) void layernorm_kernel(const float *__restrict__ x, int ldx,
+                                                        const float *__restrict__ w, const float *__restrict__ b,
+                                                        float eps, float *__restrict__ y, int ldy, int rows, int d) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float *xr = x + (size_t)row * ldx;
+    const int nv = d >> 2;   // float4 count
+    float4 v[LN_MAXV];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+        const int idx = lane + 64 * i;
+        if (idx < nv) {
+            v[i] = reinterpret_cast<const float4 *>(xr)[idx];
+            s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+        } else {
+            v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
+    const float mean = wave_sum(s) / (float)d;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+        const int idx = lane + 64 * i;
+        if (idx < nv) {
+            const float a = v[i].x - mean, bb = v[i].y - mean, c = v[i].z - mean, e = v[i].w - mean;
+            q += (a * a + bb * bb) + (c * c + e * e);
+        }
+    }
+    const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)d + eps);
+    float *yr = y + (size_t)row * ldy;
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+        const int idx = lane + 64 * i;
+        if (idx < nv) {
+            const float4 ww = reinterpret_cast<const float4 *>(w)[idx];
+            const float4 bb = reinterpret_cast<const float4 *>(b)[idx];
+            float4 o;
+            o.x = (v[i].x - mean) * rstd * ww.x + bb.x;
+            o.y = (v[i].y - mean) * rstd * ww.y + bb.y;
+            o.z = (v[i].z - mean) * rstd * ww.z + bb.z;
+            o.w = (v[i].w - mean) * rstd * ww.w + bb.w;
+            reinterpret_cast<float4 *>(yr)[idx] = o;
+        }
+    }
+}
+
+int launch_layernorm(hipStream_t st, const float *x, int ldx, const float *w, const float *b, float eps, float *y,
+                     int ldy, int rows, int d) {
+    CAPDEC_CHECK(d % 4 == 0 && d <= 256 * LN_MAXV && ldx % 4 == 0 && ldy % 4 == 0, "layernorm: unsupported width");
+    if (rows <= 0) return 0;
+    hipLaunchKernelGGL(layernorm_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, x, ldx, w, b, eps, y, ldy, rows, d);
+    CAPDEC_HIP(hipGetLastError());
+    return 0;
+}
+
+// ---------------------------------------------------------------------------- embeddings
+// h[row] = wte[tok[row]] + wpe_row   (all rows of a decode step share one position)
+__global__ void embed_tokens_kernel(const int *__restrict__ tok, const float *__restrict__ wte,
+                                    const float *__restrict__ wpe_row, float *__restrict__ h, int rows, int nv) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows * nv) return;
+    const int row = i / nv, c = i - row * nv;
+    const float4 a = reinterpret_cast<const float4 *>(wte + (size_t)tok[row] * nv * 4)[c];
+    const float4 p = reinterpret_cast<const float4 *>(wpe_row)[c];
+    reinterpret_cast<float4 *>(h)[i] = make_float4(a.x + p.x, a.y + p.y, a.z + p.z, a.w + p.w);
+}
+int launch_embed_tokens(hipStream_t st, const int *tok, const float *wte, const float *wpe_row, float *h, int rows,
+                        int d) {
+    if (rows <= 0) return 0;
+    const int n = rows * (d / 4);
+    hipLaunchKernelGGL(embed_tokens_kernel, dim3((n + 255) / 256), dim3(256), 0, st, tok, wte, wpe_row, h, rows,
+                       d / 4);
+    CAPDEC_HIP(hipGetLastError());
+    return 0;
+}
+
+// h[(c, i)] = prefix[(c, i)] + wpe[pos0 + i]
+__global__ void embed_prefix_kernel(const float *__restrict__ prefix, const float *__restrict__ wpe,
+                                    float *__restrict__ h, int n, int P, int pos0, int nv) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n * P * nv) return;
+    const int c = i % nv, p = (i / nv) % P;
+    const float4 a = reinterpret_cast<const float4 *>(prefix)[i];
+    const float4 w = reinterpret_cast<const float4 *>(wpe + (size_t)(pos0 + p) * nv * 4)[c];
+    reinterpret_cast<float4 *>(h)[i] = make_float4(a.x + w.x, a.y + w.y, a.z + w.z, a.w + w.w);
+}
+int launch_embed_prefix(hipStream_t st, const float *prefix, const float *wpe, float *h, int n, int P, int pos0,
+                        int d) {
+    const int tot = n * P * (d / 4);
+    if (tot <= 0) return 0;
+    hipLaunchKernelGGL(embed_prefix_kernel, dim3((tot + 255) / 256), dim3(256), 0, st, prefix, wpe, h, n, P, pos0,
+                       d / 4);
+    CAPDEC_HIP(hipGetLastError());
+    return 0;
+}
+
+__global__ void gather_rows_kernel(const float *__restrict__ table, const int *__restrict__ ids,
+                                   float *__restrict__ out, int rows, int nv) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows * nv) return;
+    const int row = i / nv, c = i - row * nv;
+    reinterpret_cast<float4 *>(out)[i] = reinterpret_cast<const float4 *>(table + (size_t)ids[row] * nv * 4)[c];
+}
+int launch_gather_rows(hipStream_t st, const float *table, const int *ids, float *out, int rows, int d) {
+    if (rows <= 0) return 0;
+    const int n = rows * (d / 4);
+    hipLaunchKernelGGL(gather_rows_kernel, dim3((n + 255) / 256), dim3(256), 0, st, table, ids, out, rows, d / 4);
+    CAPDEC_HIP(hipGetLastError());
+    return 0;
+}
+
+// ---------------------------------------------------------------------------- prefix stage
+// One wavefront per row; dim arbitrary (scalar strided loop; rows are 512 / 640 floats).
+__global__ __launch_bounds__(256) void normalize_prefix_kernel(const float *__restrict__ x, int n, int dim,
+                                                               int normalize, const float *__restrict__ offset,
+                                                               float *__restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= n) return;
+    const float *xr = x + (size_t)row * dim;
+    float s = 0.f;
+    for (int i = lane; i < dim; i += 64) s += xr[i] * xr[i];
+    const float nrm = sqrtf(wave_sum(s));
+    for (int i = lane; i < dim; i += 64) {
+        float v = xr[i];
+        if (normalize) v = v / nrm;               // reference: prefix / prefix.norm(2, -1), no eps
+        if (offset) v += offset[i];
+        out[(size_t)row * dim + i] = v;
+    }
+}
+int launch_normalize_prefix(hipStream_t st, const float *x, int n, int dim, int normalize, const float *offset,
+                            float *out) {
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(normalize_prefix_kernel, dim3((n + 3) / 4), dim3(256), 0, st, x, n, dim, normalize, offset,
+                       out);
+    CAPDEC_HIP(hipGetLastError());
+    return 0;
+}
+
+// Philox4x32-10 counter RNG (Salmon et al.): key = seed, counter = (element index, stream).
+__device__ __forceinline__ void philox4x32(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
+                                           uint32_t k1, uint32_t (&o)[4]) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1;
+        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    o[0] = c0; o[1] = c1; o[2] = c2; o[3] = c3;
+}
+__device__ __forceinline__ float u01(uint32_t x) { return ((float)(x >> 8) + 0.5f) * (1.0f / 16777216.0f); }
+__device__ __forceinline__ float philox_normal(uint64_t seed, uint64_t idx, uint32_t stream) {
+    uint32_t o[4];
+    philox4x32((uint32_t)idx, (uint32_t)(idx >> 32), stream, 0u, (uint32_t)seed, (uint32_t)(seed >> 32), o);
+    const float r = sqrtf(-2.0f * logf(u01(o[0])));
+    return r * cosf(6.283185307179586f * u01(o[1]));   // Box-Muller
+}
+__device__ __forceinline__ float philox_uniform(uint64_t seed, uint64_t idx, uint32_t stream) {
+    uint32_t o[4];
+    philox4x32((uint32_t)idx, (uint32_t)(idx >> 32), stream, 0u, (uint32_t)seed, (uint32_t)(seed >> 32), o);
+    return ((float)(o[0] >> 8)) * (1.0f / 16777216.0f);   // [0, 1) like torch.rand
+}
+
+// reference train.py:27-39 (variance != 0): normalise -> + noise -> + offset -> normalise.
+// F.normalize: x / max(||x||, 1e-12).  One wavefront per row, row kept in LDS-free registers
+// by re-reading x (rows are <= 2.5 KB, L1-resident).
+__global__ __launch_bounds__(256) void noise_inject_kernel(const float *__restrict__ x, int n, int dim, float std,
+                                                           const float *__restrict__ offset, int uniform,
+                                                           int dont_norm, uint64_t seed,
+                                                           const float *__restrict__ noise,
+                                                           const float *__restrict__ u, float *__restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= n) return;
+    const float *xr = x + (size_t)row * dim;
+    float inv1 = 1.f;
+    if (!dont_norm) {
+        float s = 0.f;
+        for (int i = lane; i < dim; i += 64) s += xr[i] * xr[i];
+        inv1 = 1.0f / fmaxf(sqrtf(wave_sum(s)), 1e-12f);
+    }
+    // noise scale: Gaussian -> std; uniform ball -> u^(1/dim) * std / max(||g||, 1e-12)
+    float nscale = std;
+    if (uniform) {
+        float s = 0.f;
+        for (int i = lane; i < dim; i += 64) {
+            const float g = noise ? noise[(size_t)row * dim + i] : philox_normal(seed, (uint64_t)row * dim + i, 0u);
+            s += g * g;
+        }
+        const float gn = fmaxf(sqrtf(wave_sum(s)), 1e-12f);
+        const float uu = u ? u[row] : philox_uniform(seed, (uint64_t)row, 1u);
+        nscale = powf(uu, 1.0f / (float)dim) * std / gn;
+    }
+    float s2 = 0.f;
+    for (int i = lane; i < dim; i += 64) {
+        const float g = noise ? noise[(size_t)row * dim + i] : philox_normal(seed, (uint64_t)row * dim + i, 0u);
+        float v = (dont_norm ? xr[i] : xr[i] * inv1);
+        v = v + g * nscale;
+        if (offset) v += offset[i];
+        out[(size_t)row * dim + i] = v;
+        s2 += v * v;
+    }
+    const float inv2 = 1.0f / fmaxf(sqrtf(wave_sum(s2)), 1e-12f);
+    for (int i = lane; i < dim; i += 64) out[(size_t)row * dim + i] *= inv2;
+}
+int launch_noise_inject(hipStream_t st, const float *x, int n, int dim, float variance, const float *offset,
+                        int uniform, int dont_norm, uint64_t seed, const float *noise, const float *u, float *out) {
+    if (n <= 0) return 0;
+    if (variance == 0.0f) {   // reference returns x unchanged (train.py:28-29)
+        if (out != x) CAPDEC_HIP(hipMemcpyAsync(out, x, (size_t)n * dim * sizeof(float), hipMemcpyDeviceToDevice, st));
+        return 0;
+    }
+    CAPDEC_CHECK(out != x, "noise_inject: in-place not supported");
+    hipLaunchKernelGGL(noise_inject_kernel, dim3((n + 3) / 4), dim3(256), 0, st, x, n, dim, sqrtf(variance), offset,
+                       uniform, dont_norm, seed, noise, u, out);
+    CAPDEC_HIP(hipGetLastError());
+    return 0;
+}
+
+// ---------------------------------------------------------------------------- TransformerMapper glue
+// seq[c, 0:clip_len] = lin[c].view(clip_len, d); seq[c, clip_len:] = prefix_const
+__global__ void tmapper_concat_kernel(const float *__restrict__ lin, const float *__restrict__ pc,
+                                      float *__restrict__ seq, int n, int clip_len, int P, int nv) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int S = clip_len + P;
+    if (i >= n * S * nv) return;
+    const int c = i % nv, s = (i / nv) % S, cap = i / (nv * S);
+    float4 v;
+    if (s < clip_len) v = reinterpret_cast<const float4 *>(lin)[((size_t)cap * clip_len + s) * nv + c];
+    else v = reinterpret_cast<const float4 *>(pc)[(size_t)(s - clip_len) * nv + c];
+    reinterpret_cast<float4 *>(seq)[i] = v;
+}
+int launch_tmapper_concat(hipStream_t st, const float *lin, const float *prefix_const, float *seq, int n,
+                          int clip_len, int P, int d) {
+    const int tot = n * (clip_len + P) * (d / 4);
+    if (tot <= 0) return 0;
+    hipLaunchKernelGGL(tmapper_concat_kernel, dim3((tot + 255) / 256), dim3(256), 0, st, lin, prefix_const, seq, n,
+                       clip_len, P, d / 4);
+    CAPDEC_HIP(hipGetLastError());
+    return 0;
+}
+__global__ void tmapper_take_kernel(const float *__restrict__ seq, float *__restrict__ out, int n, int clip_len,
+                                    int P, int nv) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n * P * nv) return;
+    const int c = i % nv, p = (i / nv) % P, cap = i / (nv * P);
+    reinterpret_cast<float4 *>(out)[i] =
+        reinterpret_cast<const float4 *>(seq)[((size_t)cap * (clip_len + P) + clip_len + p) * nv + c];
+}
+int launch_tmapper_take(hipStream_t st, const float *seq, float *out, int n, int clip_len, int P, int d) {
+    const int tot = n * P * (d / 4);
+    if (tot <= 0) return 0;
+    hipLaunchKernelGGL(tmapper_take_kernel, dim3((tot + 255) / 256), dim3(256), 0, st, seq, out, n, clip_len, P,
+                       d / 4);
+    CAPDEC_HIP(hipGetLastError());
+    return 0;
+}
+
+// out[c][r] = in[r][c], 32x32 LDS tiles (+1 pad), used once per Conv1D weight at load time.
+__global__ void transpose_kernel(const float *__restrict__ in, float *__restrict__ out, int rows, int cols) {
+    __shared__ float tile[32][33];
+    const int bx = blockIdx.x * 32, by = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 256 threads: 32 x 8
+    for (int j = ty; j < 32; j += 8) {
+        const int r = by + j, c = bx + tx;
+        if (r < rows && c < cols) tile[j][tx] = in[(size_t)r * cols + c];
+    }
+    __syncthreads();
+    for (int j = ty; j < 32; j += 8) {
+        const int c = bx + j, r = by + tx;
+        if (r < rows && c < cols) out[(size_t)c * rows + r] = tile[tx][j];
+    }
+}
+int launch_transpose(hipStream_t st, const float *in, float *out, int rows, int cols) {
+    hipLaunchKernelGGL(transpose_kernel, dim3((cols + 31) / 32, (rows + 31) / 32), dim3(256), 0, st, in, out, rows,
+                       cols);
+    CAPDEC_HIP(hipGetLastError());
+    return 0;
+}
+
+}  // namespace capdec

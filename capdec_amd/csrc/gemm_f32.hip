@@ -1,0 +1,312 @@
+// fp32 MFMA GEMM for gfx950:  C[M,N] = epi( A[M,K] . Bt[N,K]^T )
+//
+// Every dense projection of the caption path runs here (GPT-2 Conv1D = addmm with W [in,out],
+// transposed once at load time to [out,in]; nn.Linear weights are already [out,in]; the tied
+// lm_head is wte [vocab, d]).  v_mfma_f32_32x32x2_f32 is an exact fp32 fma chain (no TF32 on
+// CDNA4), which is what keeps greedy token ids identical to the fp32 reference.
+//
+// Tiling: 128x128 block tile, BK = 32, 256 threads = 4 wavefronts (2x2), each wavefront owns a
+// 64x64 sub-tile = 2x2 MFMA 32x32 accumulators (64 accumulator registers).  Both operands are
+// k-contiguous, staged through LDS as [128][36] fp32 (row stride 36 dwords: 16-byte aligned
+// and conflict-free for ds_read_b128 by 16-lane groups).  The two half-waves of an MFMA
+// 32x32x2 supply k and k+1; we let half h own k in [16h, 16h+16) of the BK tile (a k
+// permutation applied to A and B alike), so each lane fetches its 16 k-values of a row with
+// four ds_read_b128.  Register-staged double buffering: global loads of tile t+1 are issued
+// before the 64 MFMAs of tile t and written to the other LDS buffer after them, one barrier
+// per tile.
+#include "common.h"
+
+namespace capdec {
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+
+constexpr int LDS_LD = 36;                            // padded row stride (floats)
+constexpr int TILE_F = GEMM_BM * LDS_LD;              // floats per operand tile buffer
+constexpr int CT_LD = 129;                            // epilogue tile row stride (top-k variant)
+
+__device__ __forceinline__ float act_apply(float v, int act) {
+    switch (act) {
+        case CAPDEC_ACT_TANH: return tanhf(v);
+        case CAPDEC_ACT_RELU: return fmaxf(v, 0.f);
+        case CAPDEC_ACT_GELU_NEW: {
+            // transformers NewGELUActivation: 0.5 x (1 + tanh(sqrt(2/pi) (x + 0.044715 x^3)))
+            const float c = 0.7978845608028654f;
+            return 0.5f * v * (1.f + tanhf(c * (v + 0.044715f * v * v * v)));
+        }
+        default: return v;
+    }
+}
+
+// XCD-aware, L2-friendly tile order: consecutive ids of one XCD walk 8 M-tiles per N-tile.
+__device__ __forceinline__ void tile_coords(int tiles_m, int tiles_n, int &tm, int &tn) {
+    const int nwg = tiles_m * tiles_n;
+    int id = blockIdx.x;
+    {   // bijective XCD remap: blocks b, b+8, b+16.. (same XCD) get contiguous ids
+        const int q = nwg >> 3, r = nwg & 7, xcd = id & 7, idx = id >> 3;
+        id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    constexpr int GM = 8;
+    const int per_group = GM * tiles_n;
+    const int group = id / per_group;
+    const int first_m = group * GM;
+    const int gsz = min(tiles_m - first_m, GM);
+    const int in_g = id - group * per_group;
+    tm = first_m + in_g % gsz;
+    tn = in_g / gsz;
+}
+
+struct MainLoop {
+    f32x16 acc[2][2];
+};
+
+// Shared main loop: accumulates the 128x128 tile at (m0, n0) into per-wave accumulators.
+__device__ __forceinline__ void gemm_mainloop(const float *__restrict__ A, int lda, const float *__restrict__ Bt,
+                                              int ldb, int M, int N, int K, int m0, int n0, float *smem,
+                                              f32x16 (&acc)[2][2]) {
+    const int t = threadIdx.x;
+    const int lane = t & 63, wave = t >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int half = lane >> 5, l32 = lane & 31;
+
+    float *As = smem;                 // [2][128][36]
+    float *Bs = smem + 2 * TILE_F;    // [2][128][36]
+
+    // global staging: 4 float4 per thread per operand; idx = t + 256 i -> row idx>>3, k-quad idx&7
+    float4 ra[4], rb[4];
+    const int srow = t >> 3, skq = (t & 7) * 4;
+    const float *ap[4];
+    const float *bp[4];
+    bool av[4], bv[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = srow + 32 * i;
+        av[i] = (m0 + row) < M;
+        bv[i] = (n0 + row) < N;
+        ap[i] = A + (size_t)(av[i] ? m0 + row : 0) * lda + skq;
+        bp[i] = Bt + (size_t)(bv[i] ? n0 + row : 0) * ldb + skq;
+    }
+    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    auto gload = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            ra[i] = av[i] ? *reinterpret_cast<const float4 *>(ap[i] + k0) : z4;
+            rb[i] = bv[i] ? *reinterpret_cast<const float4 *>(bp[i] + k0) : z4;
+        }
+    };
+    auto lstore = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int off = buf * TILE_F + (srow + 32 * i) * LDS_LD + skq;
+            *reinterpret_cast<float4 *>(As + off) = ra[i];
+            *reinterpret_cast<float4 *>(Bs + off) = rb[i];
+        }
+    };
+
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int nk = K / GEMM_BK;
+    gload(0);
+    lstore(0);
+    __syncthreads();
+
+    const int a_off = (wm * 64 + l32) * LDS_LD + 16 * half;
+    const int b_off = (wn * 64 + l32) * LDS_LD + 16 * half;
+
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nk) gload((kt + 1) * GEMM_BK);
+        float4 fa[2][4], fb[2][4];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                fa[i][q] = *reinterpret_cast<const float4 *>(As + buf * TILE_F + a_off + i * 32 * LDS_LD + 4 * q);
+                fb[i][q] = *reinterpret_cast<const float4 *>(Bs + buf * TILE_F + b_off + i * 32 * LDS_LD + 4 * q);
+            }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                float a0, a1, b0, b1;
+                if (c == 0) { a0 = fa[0][q].x; a1 = fa[1][q].x; b0 = fb[0][q].x; b1 = fb[1][q].x; }
+                else if (c == 1) { a0 = fa[0][q].y; a1 = fa[1][q].y; b0 = fb[0][q].y; b1 = fb[1][q].y; }
+                else if (c == 2) { a0 = fa[0][q].z; a1 = fa[1][q].z; b0 = fb[0][q].z; b1 = fb[1][q].z; }
+                else { a0 = fa[0][q].w; a1 = fa[1][q].w; b0 = fb[0][q].w; b1 = fb[1][q].w; }
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+            }
+        }
+        if (kt + 1 < nk) lstore(buf ^ 1);
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const float *__restrict__ A, int lda,
+                                                          const float *__restrict__ Bt, int ldb, float *C, int ldc,
+                                                          int M, int N, int K, const float *__restrict__ bias,
+                                                          const float *resid, int ldr, int act, int tiles_m,
+                                                          int tiles_n) {
+    __shared__ __attribute__((aligned(16))) float smem[4 * TILE_F];
+    int tm, tn;
+    tile_coords(tiles_m, tiles_n, tm, tn);
+    const int m0 = tm * GEMM_BM, n0 = tn * GEMM_BN;
+    f32x16 acc[2][2];
+    gemm_mainloop(A, lda, Bt, ldb, M, N, K, m0, n0, smem, acc);
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wm = wave >> 1, wn = wave & 1, half = lane >> 5, l32 = lane & 31;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int col = n0 + wn * 64 + j * 32 + l32;
+        if (col >= N) continue;
+        const float bv = bias ? bias[col] : 0.f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                if (row < M) {
+                    float v = act_apply(acc[i][j][r] + bv, act);
+                    if (resid) v += resid[(size_t)row * ldr + col];
+                    C[(size_t)row * ldc + col] = v;
+                }
+            }
+        }
+    }
+}
+
+// lm_head variant: per (row, 128-col tile) max, sum exp(x - max) and top-k (value, column).
+// The logits tile goes accumulators -> LDS (reusing the staging buffers) -> 16-lane groups,
+// one row per group, 8 columns per lane; nothing but ~ (2 + 2k) words per (row, tile) reaches HBM.
+template <int KSEL>
+__global__ __launch_bounds__(256, 2) void gemm_f32_topk_kernel(const float *__restrict__ A, int lda,
+                                                               const float *__restrict__ Bt, int ldb, int M, int N,
+                                                               int K, float inv_temp, float *tile_max,
+                                                               float *tile_sum, float *cand_val, int *cand_idx,
+                                                               int tiles_m, int tiles_n) {
+    __shared__ __attribute__((aligned(16))) float smem[4 * TILE_F];
+    static_assert(GEMM_BM * CT_LD <= 4 * TILE_F, "epilogue tile must fit the staging buffers");
+    int tm, tn;
+    tile_coords(tiles_m, tiles_n, tm, tn);
+    const int m0 = tm * GEMM_BM, n0 = tn * GEMM_BN;
+    f32x16 acc[2][2];
+    gemm_mainloop(A, lda, Bt, ldb, M, N, K, m0, n0, smem, acc);   // ends with a barrier
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wm = wave >> 1, wn = wave & 1, half = lane >> 5, l32 = lane & 31;
+    float *Ct = smem;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                Ct[row * CT_LD + wn * 64 + j * 32 + l32] = acc[i][j][r] * inv_temp;
+            }
+    __syncthreads();
+
+    const int grp = lane >> 4, sub = lane & 15;
+    for (int it = 0; it < 8; ++it) {
+        const int rl = wave * 32 + it * 4 + grp;
+        const int row = m0 + rl;
+        float v[8];
+        int ci[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int cl = sub + 16 * j;
+            ci[j] = n0 + cl;
+            v[j] = (ci[j] < N) ? Ct[rl * CT_LD + cl] : -INFINITY;
+        }
+        float mx = v[0];
+#pragma unroll
+        for (int j = 1; j < 8; ++j) mx = fmaxf(mx, v[j]);
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+        float se = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) se += __expf(v[j] - mx);
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) se += __shfl_xor(se, o, 64);
+        const size_t tbase = (size_t)row * tiles_n + tn;
+        if (row < M && sub == 0) {
+            tile_max[tbase] = mx;
+            tile_sum[tbase] = se;
+        }
+#pragma unroll
+        for (int kk = 0; kk < KSEL; ++kk) {
+            // lane-local best (lowest column wins ties: columns ascend with j)
+            float bv = v[0];
+            int bj = 0;
+#pragma unroll
+            for (int j = 1; j < 8; ++j)
+                if (v[j] > bv) { bv = v[j]; bj = j; }
+            int bc = sub + 16 * bj;   // local column
+            float gv = bv;
+            int gc = bc;
+#pragma unroll
+            for (int o = 8; o > 0; o >>= 1) {
+                const float ov = __shfl_xor(gv, o, 64);
+                const int oc = __shfl_xor(gc, o, 64);
+                if (ov > gv || (ov == gv && oc < gc)) { gv = ov; gc = oc; }
+            }
+            if (gc == bc) {           // this lane owned the winner: retire it
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    if (j == bj) v[j] = -INFINITY;
+            }
+            if (row < M && sub == kk) {
+                cand_val[tbase * KSEL + kk] = gv;
+                cand_idx[tbase * KSEL + kk] = n0 + gc;
+            }
+        }
+    }
+}
+
+int launch_gemm_f32(hipStream_t st, const float *A, int lda, const float *Bt, int ldb, float *C, int ldc, int M,
+                    int N, int K, const GemmEpilogue &epi) {
+    CAPDEC_CHECK(M > 0 && N > 0 && K > 0, "gemm: empty problem");
+    CAPDEC_CHECK(K % GEMM_BK == 0, "gemm: K must be a multiple of 32");
+    CAPDEC_CHECK(lda % 4 == 0 && ldb % 4 == 0, "gemm: lda/ldb must be multiples of 4 (16-byte rows)");
+    CAPDEC_CHECK((((uintptr_t)A | (uintptr_t)Bt) & 15) == 0, "gemm: operands must be 16-byte aligned");
+    const int tiles_m = (M + GEMM_BM - 1) / GEMM_BM, tiles_n = (N + GEMM_BN - 1) / GEMM_BN;
+    hipLaunchKernelGGL(gemm_f32_kernel, dim3(tiles_m * tiles_n), dim3(256), 0, st, A, lda, Bt, ldb, C, ldc, M, N, K,
+                       epi.bias, epi.resid, epi.ldr, epi.act, tiles_m, tiles_n);
+    CAPDEC_HIP(hipGetLastError());
+    return 0;
+}
+
+int launch_gemm_f32_topk(hipStream_t st, const float *A, int lda, const float *Bt, int ldb, int M, int N, int K,
+                         int k, float inv_temp, float *tile_max, float *tile_sum, float *cand_val, int *cand_idx) {
+    CAPDEC_CHECK(M > 0 && N > 0 && K > 0, "gemm_topk: empty problem");
+    CAPDEC_CHECK(K % GEMM_BK == 0, "gemm_topk: K must be a multiple of 32");
+    CAPDEC_CHECK(lda % 4 == 0 && ldb % 4 == 0, "gemm_topk: lda/ldb must be multiples of 4");
+    const int tiles_m = (M + GEMM_BM - 1) / GEMM_BM, tiles_n = (N + GEMM_BN - 1) / GEMM_BN;
+    dim3 grid(tiles_m * tiles_n), block(256);
+#define LAUNCH_TOPK(KS)                                                                                         \
+    hipLaunchKernelGGL(gemm_f32_topk_kernel<KS>, grid, block, 0, st, A, lda, Bt, ldb, M, N, K, inv_temp, tile_max, \
+                       tile_sum, cand_val, cand_idx, tiles_m, tiles_n)
+    switch (k) {
+        case 1: LAUNCH_TOPK(1); break;
+        case 2: LAUNCH_TOPK(2); break;
+        case 3: LAUNCH_TOPK(3); break;
+        case 4: LAUNCH_TOPK(4); break;
+        case 5: LAUNCH_TOPK(5); break;
+        case 6: LAUNCH_TOPK(6); break;
+        case 7: LAUNCH_TOPK(7); break;
+        case 8: LAUNCH_TOPK(8); break;
+        default: CAPDEC_CHECK(false, "gemm_topk: k must be in 1..8");
+    }
+#undef LAUNCH_TOPK
+    CAPDEC_HIP(hipGetLastError());
+    return 0;
+}
+
+}  // namespace capdec

@@ -1,0 +1,49 @@
+"""Caption-batch data parallelism (the only parallel dimension of the path, SURVEY.md section 8
+row E): rank r decodes the contiguous block [r*ceil(N/R), (r+1)*ceil(N/R)) of the embedding
+matrix with replicated weights; the single exchange is an all-gather of int32 token ids /
+lengths (+ fp32 beam scores) over RCCL (torch.distributed backend "nccl"; "gloo" in CPU tests).
+Rank order preserves caption order, so the gathered matrix equals the 1-GPU result."""
+from __future__ import annotations
+
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def shard_bounds(n: int, rank: int, world: int) -> Tuple[int, int]:
+    per = (n + world - 1) // world
+    lo = min(rank * per, n)
+    return lo, min(lo + per, n)
+
+
+def shard_size(n: int, world: int) -> int:
+    return (n + world - 1) // world
+
+
+def gather_rows(local: torch.Tensor, n_total: int, group=None) -> torch.Tensor:
+    """all-gather row blocks produced under :func:`shard_bounds`: every rank pads its block to
+    ceil(N/R) rows, one all_gather_into_tensor moves them, the padding is cut off again."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return local[:n_total]
+    world = dist.get_world_size(group)
+    per = shard_size(n_total, world)
+    pad = torch.zeros((per,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    pad[:local.shape[0]] = local
+    out = torch.empty((world * per,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    if hasattr(dist, "all_gather_into_tensor") and local.is_cuda:
+        dist.all_gather_into_tensor(out, pad.contiguous(), group=group)
+    else:
+        parts = [torch.empty_like(pad) for _ in range(world)]
+        dist.all_gather(parts, pad.contiguous(), group=group)
+        out = torch.cat(parts, dim=0)
+    return out[:n_total]
+
+
+def gather_ids(ids: torch.Tensor, lens: torch.Tensor, n_total: int, scores: Optional[torch.Tensor] = None,
+               group=None):
+    """token ids [n_local, (beam,) T] int32 + lens [n_local(, beam)] (+ scores) -> global."""
+    g_ids = gather_rows(ids, n_total, group)
+    g_lens = gather_rows(lens, n_total, group)
+    g_scores = gather_rows(scores, n_total, group) if scores is not None else None
+    return g_ids, g_lens, g_scores

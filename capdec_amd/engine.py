@@ -1,0 +1,267 @@
+"""Host-side driver of one MI355X: owns a ``capdec_ctx`` and hands device pointers of torch
+CUDA(HIP) tensors to the C ABI.  torch is plumbing only (device memory, streams); all
+arithmetic happens in libcapdec_hip.so."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, Optional, Tuple
+
+import numpy as np
+import torch
+
+from . import _capi
+from ._capi import CapdecError, check
+
+
+def _f32(t: torch.Tensor) -> np.ndarray:
+    """contiguous fp32 host array view of a (CPU) tensor; fp16 pickles are upcast like the
+    reference's `.float()` (train.py:70)."""
+    return np.ascontiguousarray(t.detach().to("cpu", torch.float32).numpy())
+
+
+def _fp(a: np.ndarray):
+    return a.ctypes.data_as(_capi.c_float_p)
+
+
+class Engine:
+    """One context per GPU / rank."""
+
+    def __init__(self, device: int = 0, kv_budget_bytes: int = 0):
+        if not torch.cuda.is_available():
+            raise CapdecError("capdec_amd needs a HIP device (MI355X); none is visible and there is no CPU fallback")
+        self.lib = _capi.load_library()
+        self.device_index = int(device)
+        self.device = torch.device("cuda", self.device_index)
+        h = C.c_void_p()
+        check(self.lib.capdec_create(self.device_index, C.byref(h)), "capdec_create")
+        self._h = h
+        if kv_budget_bytes:
+            check(self.lib.capdec_set_kv_budget(self._h, kv_budget_bytes), "set_kv_budget")
+        self.gpt_dims: Optional[Dict[str, int]] = None
+        self.mapper: Optional[Dict[str, int]] = None
+
+    # ------------------------------------------------------------------ lifetime
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            self.lib.capdec_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _sync_stream(self):
+        """run on torch's current stream so torch copies and our kernels stay ordered"""
+        s = torch.cuda.current_stream(self.device).cuda_stream
+        check(self.lib.capdec_set_stream(self._h, C.c_void_p(s)), "set_stream")
+
+    def synchronize(self):
+        check(self.lib.capdec_synchronize(self._h), "synchronize")
+
+    def _dev(self, t: torch.Tensor, dtype=torch.float32) -> torch.Tensor:
+        return t.to(device=self.device, dtype=dtype).contiguous()
+
+    # ------------------------------------------------------------------ weights
+    def load_gpt2(self, sd: Dict[str, torch.Tensor], prefix: str = "gpt.", n_head: int = 12, ln_eps: float = 1e-5):
+        """Accepts the reference checkpoint layout (train.py:359-371): tied
+        ``gpt.lm_head.weight`` is checked against wte; transformers-4.24 buffers
+        ``h.{i}.attn.bias`` / ``.attn.masked_bias`` are ignored."""
+        t = prefix + "transformer."
+        wte = _f32(sd[t + "wte.weight"])
+        lm = sd.get(prefix + "lm_head.weight")
+        if lm is not None and lm.data_ptr() != sd[t + "wte.weight"].data_ptr():
+            if not torch.equal(lm.float().cpu(), sd[t + "wte.weight"].float().cpu()):
+                raise CapdecError("checkpoint lm_head.weight differs from wte.weight (untied heads are not supported)")
+        wpe = _f32(sd[t + "wpe.weight"])
+        n_layer = 0
+        while f"{t}h.{n_layer}.ln_1.weight" in sd:
+            n_layer += 1
+        if n_layer == 0:
+            raise CapdecError(f"no GPT-2 blocks under {t!r}")
+        keep = [wte, wpe]
+        layers = (_capi.Gpt2Layer * n_layer)()
+        names = [("ln_1_w", "ln_1.weight"), ("ln_1_b", "ln_1.bias"), ("c_attn_w", "attn.c_attn.weight"),
+                 ("c_attn_b", "attn.c_attn.bias"), ("c_proj_w", "attn.c_proj.weight"), ("c_proj_b", "attn.c_proj.bias"),
+                 ("ln_2_w", "ln_2.weight"), ("ln_2_b", "ln_2.bias"), ("c_fc_w", "mlp.c_fc.weight"),
+                 ("c_fc_b", "mlp.c_fc.bias"), ("mlp_c_proj_w", "mlp.c_proj.weight"), ("mlp_c_proj_b", "mlp.c_proj.bias")]
+        for i in range(n_layer):
+            for field, key in names:
+                a = _f32(sd[f"{t}h.{i}.{key}"])
+                keep.append(a)
+                setattr(layers[i], field, _fp(a))
+        d = wte.shape[1]
+        if tuple(_f32(sd[f"{t}h.0.attn.c_attn.weight"]).shape) != (d, 3 * d):
+            raise CapdecError("c_attn.weight must be Conv1D layout [d, 3d]")
+        lnw, lnb = _f32(sd[t + "ln_f.weight"]), _f32(sd[t + "ln_f.bias"])
+        keep += [lnw, lnb]
+        w = _capi.Gpt2Weights(n_layer, n_head, d, wte.shape[0], wpe.shape[0], ln_eps, _fp(wte), _fp(wpe), layers,
+                              _fp(lnw), _fp(lnb))
+        check(self.lib.capdec_load_gpt2(self._h, C.byref(w)), "capdec_load_gpt2")
+        self.gpt_dims = dict(n_layer=n_layer, n_head=n_head, d=d, vocab=wte.shape[0], n_pos=wpe.shape[0])
+
+    def load_mapper_mlp(self, sd: Dict[str, torch.Tensor], prefix: str = "clip_project."):
+        w1, b1 = _f32(sd[prefix + "model.0.weight"]), _f32(sd[prefix + "model.0.bias"])
+        w2, b2 = _f32(sd[prefix + "model.2.weight"]), _f32(sd[prefix + "model.2.bias"])
+        d = self.gpt_dims["d"] if self.gpt_dims else 768
+        hidden, D = w1.shape
+        P = w2.shape[0] // d
+        check(self.lib.capdec_load_mapper_mlp(self._h, D, P, hidden, _fp(w1), _fp(b1), _fp(w2), _fp(b2)),
+              "capdec_load_mapper_mlp")
+        self.mapper = dict(kind="mlp", D=D, P=P, d=d)
+
+    def load_mapper_transformer(self, sd: Dict[str, torch.Tensor], prefix: str = "clip_project.", num_heads: int = 8):
+        lw, lb = _f32(sd[prefix + "linear.weight"]), _f32(sd[prefix + "linear.bias"])
+        pc = _f32(sd[prefix + "prefix_const"])
+        P, d = pc.shape
+        clip_len = lw.shape[0] // d
+        n_layers = 0
+        while f"{prefix}transformer.layers.{n_layers}.norm1.weight" in sd:
+            n_layers += 1
+        keep = [lw, lb, pc]
+        layers = (_capi.TMapperLayer * n_layers)()
+        names = [("norm1_w", "norm1.weight"), ("norm1_b", "norm1.bias"), ("to_queries_w", "attn.to_queries.weight"),
+                 ("to_keys_values_w", "attn.to_keys_values.weight"), ("project_w", "attn.project.weight"),
+                 ("project_b", "attn.project.bias"), ("norm2_w", "norm2.weight"), ("norm2_b", "norm2.bias"),
+                 ("fc1_w", "mlp.fc1.weight"), ("fc1_b", "mlp.fc1.bias"), ("fc2_w", "mlp.fc2.weight"),
+                 ("fc2_b", "mlp.fc2.bias")]
+        for i in range(n_layers):
+            for field, key in names:
+                a = _f32(sd[f"{prefix}transformer.layers.{i}.{key}"])
+                keep.append(a)
+                setattr(layers[i], field, _fp(a))
+        hid = _f32(sd[f"{prefix}transformer.layers.0.mlp.fc1.weight"]).shape[0]
+        w = _capi.TMapperWeights(lw.shape[1], P, clip_len, n_layers, num_heads, d, hid, _fp(lw), _fp(lb), _fp(pc), layers)
+        check(self.lib.capdec_load_mapper_transformer(self._h, C.byref(w)), "capdec_load_mapper_transformer")
+        self.mapper = dict(kind="transformer", D=lw.shape[1], P=P, d=d, clip_length=clip_len, num_layers=n_layers)
+
+    # ------------------------------------------------------------------ prefix stage
+    def normalize_prefix(self, x: torch.Tensor, normalize: bool = True, offset: Optional[torch.Tensor] = None) -> torch.Tensor:
+        x = self._dev(x)
+        n, dim = x.shape
+        out = torch.empty_like(x)
+        off = self._dev(offset).reshape(-1) if offset is not None else None
+        self._sync_stream()
+        check(self.lib.capdec_normalize_prefix(self._h, x.data_ptr(), n, dim, int(normalize),
+                                               off.data_ptr() if off is not None else None, out.data_ptr()),
+              "capdec_normalize_prefix")
+        return out
+
+    def noise_inject(self, x: torch.Tensor, variance: float, offset: Optional[torch.Tensor] = None,
+                     uniform: bool = False, dont_norm: bool = False, seed: int = 0,
+                     noise: Optional[torch.Tensor] = None, u: Optional[torch.Tensor] = None) -> torch.Tensor:
+        x = self._dev(x)
+        n, dim = x.shape
+        out = torch.empty_like(x)
+        off = self._dev(offset).reshape(-1) if offset is not None else None
+        nz = self._dev(noise) if noise is not None else None
+        uu = self._dev(u) if u is not None else None
+        self._sync_stream()
+        check(self.lib.capdec_noise_inject(self._h, x.data_ptr(), n, dim, float(variance),
+                                           off.data_ptr() if off is not None else None, int(uniform), int(dont_norm),
+                                           int(seed) & 0xFFFFFFFFFFFFFFFF, nz.data_ptr() if nz is not None else None,
+                                           uu.data_ptr() if uu is not None else None, out.data_ptr()),
+              "capdec_noise_inject")
+        return out
+
+    def mapper_forward(self, x: torch.Tensor) -> torch.Tensor:
+        if self.mapper is None:
+            raise CapdecError("no mapper loaded")
+        x = self._dev(x)
+        n = x.shape[0]
+        if x.shape[1] != self.mapper["D"]:
+            raise CapdecError(f"mapper expects prefix_dim {self.mapper['D']}, got {x.shape[1]}")
+        out = torch.empty(n, self.mapper["P"], self.mapper["d"], device=self.device, dtype=torch.float32)
+        if n:
+            self._sync_stream()
+            check(self.lib.capdec_mapper_forward(self._h, x.data_ptr(), n, out.data_ptr()), "capdec_mapper_forward")
+        return out
+
+    # ------------------------------------------------------------------ GPT-2
+    def gpt2_logits(self, embeds: torch.Tensor, all_positions: bool = True) -> torch.Tensor:
+        e = self._dev(embeds)
+        n, L, d = e.shape
+        V = self.gpt_dims["vocab"]
+        out = torch.empty((n, L, V) if all_positions else (n, V), device=self.device, dtype=torch.float32)
+        self._sync_stream()
+        check(self.lib.capdec_gpt2_logits(self._h, e.data_ptr(), n, L, int(all_positions), out.data_ptr()),
+              "capdec_gpt2_logits")
+        return out
+
+    def wte(self, ids: torch.Tensor) -> torch.Tensor:
+        shape = tuple(ids.shape)
+        i = self._dev(ids.reshape(-1), torch.int32)
+        out = torch.empty(i.numel(), self.gpt_dims["d"], device=self.device, dtype=torch.float32)
+        self._sync_stream()
+        check(self.lib.capdec_wte_lookup(self._h, i.data_ptr(), i.numel(), out.data_ptr()), "capdec_wte_lookup")
+        return out.view(*shape, -1)
+
+    # ------------------------------------------------------------------ decode
+    def decode_greedy(self, prefix_embed: torch.Tensor, stop_id: int, entry_length: int = 67,
+                      alt_stop_id: int = 764) -> Tuple[torch.Tensor, torch.Tensor]:
+        p = self._dev(prefix_embed)
+        n, P, _ = p.shape
+        ids = torch.empty(n, entry_length, device=self.device, dtype=torch.int32)
+        lens = torch.empty(n, device=self.device, dtype=torch.int32)
+        self._sync_stream()
+        check(self.lib.capdec_decode_greedy(self._h, p.data_ptr(), n, P, int(stop_id), int(alt_stop_id),
+                                            int(entry_length), ids.data_ptr(), lens.data_ptr()), "capdec_decode_greedy")
+        return ids, lens
+
+    def decode_beam(self, prefix_embed: torch.Tensor, stop_id: int, beam_size: int = 5, entry_length: int = 67,
+                    temperature: float = 1.0):
+        """-> ids [n, beam, T], lens [n, beam], mean-log-prob scores [n, beam] (sorted by score
+        descending, like the list generate_beam returns) and order [n, beam] (reference's
+        internal beam index of each returned row)."""
+        p = self._dev(prefix_embed)
+        n, P, _ = p.shape
+        ids = torch.empty(n, beam_size, entry_length, device=self.device, dtype=torch.int32)
+        lens = torch.empty(n, beam_size, device=self.device, dtype=torch.int32)
+        scores = torch.empty(n, beam_size, device=self.device, dtype=torch.float32)
+        order = torch.empty(n, beam_size, device=self.device, dtype=torch.int32)
+        self._sync_stream()
+        check(self.lib.capdec_decode_beam(self._h, p.data_ptr(), n, P, int(beam_size), int(stop_id), int(entry_length),
+                                          float(temperature), ids.data_ptr(), lens.data_ptr(), scores.data_ptr(),
+                                          order.data_ptr()), "capdec_decode_beam")
+        return ids, lens, scores, order
+
+    # ------------------------------------------------------------------ hooks
+    def gemm(self, a: torch.Tensor, bt: torch.Tensor, bias=None, resid=None, act: int = 0) -> torch.Tensor:
+        a, bt = self._dev(a), self._dev(bt)
+        M, K = a.shape
+        N = bt.shape[0]
+        out = torch.empty(M, N, device=self.device, dtype=torch.float32)
+        b = self._dev(bias) if bias is not None else None
+        r = self._dev(resid) if resid is not None else None
+        self._sync_stream()
+        check(self.lib.capdec_gemm_f32(self._h, a.data_ptr(), K, bt.data_ptr(), K, out.data_ptr(), N, M, N, K,
+                                       b.data_ptr() if b is not None else None,
+                                       r.data_ptr() if r is not None else None, N, act), "capdec_gemm_f32")
+        return out
+
+    def profile_enable(self, on: bool = True):
+        check(self.lib.capdec_profile_enable(self._h, int(on)), "profile_enable")
+
+    def profile_reset(self):
+        check(self.lib.capdec_profile_reset(self._h), "profile_reset")
+
+    def profile_get(self) -> Dict[str, Dict[str, float]]:
+        cnt = C.c_int(0)
+        names = (C.c_char_p * 16)()
+        ms = (C.c_float * 16)()
+        launches = (C.c_int64 * 16)()
+        flops = (C.c_double * 16)()
+        check(self.lib.capdec_profile_get(self._h, C.byref(cnt), names, ms, launches, flops), "profile_get")
+        return {names[i].decode(): dict(ms=float(ms[i]), launches=int(launches[i]), flops=float(flops[i]))
+                for i in range(cnt.value)}
+
+
+_engines: Dict[int, Engine] = {}
+
+
+def get_engine(device: int = 0) -> Engine:
+    """process-wide engine per device index"""
+    if device not in _engines:
+        _engines[device] = Engine(device)
+    return _engines[device]

@@ -1,0 +1,223 @@
+"""Drop-in surface of reference ``gpt2_prefix.py`` for the caption hot path: ``MappingType``
+(:15-18), ``MLP`` (:114-126), ``ClipCaptionModel`` (:139-171), ``ClipCaptionPrefix`` (:178-186).
+
+Same names, constructor arguments and attribute surface (``.clip_project``, ``.gpt``,
+``.gpt.transformer.wte``, ``.prefix_length``, ``.load_state_dict``, ``.eval``, ``.to``,
+``.parameters``), but the arithmetic runs in libcapdec_hip.so on an MI355X.  The training
+forward/backward (reference :145-155) is out of scope: ``forward`` raises.
+"""
+from __future__ import annotations
+
+from collections import OrderedDict
+from enum import Enum
+from types import SimpleNamespace
+from typing import Dict, Iterator, Optional, Tuple
+
+import torch
+
+from . import synth
+from ._capi import CapdecError
+from .engine import Engine
+
+
+class MappingType(Enum):
+    """reference gpt2_prefix.py:15-18; ``Transformer`` is train.py:42-44's name for the encoder."""
+    MLP = 'mlp'
+    TransformerEncoder = 'transformer_encoder'
+    TransformerDecoder = 'transformer_decoder'
+    Transformer = 'transformer_encoder'   # alias (same value -> same member)
+
+
+def _device_index(device) -> int:
+    if isinstance(device, int):
+        return device
+    d = torch.device(device)
+    if d.type != "cuda":
+        raise CapdecError(f"capdec_amd runs on HIP devices only (got {d}); there is no CPU fallback")
+    return d.index or 0
+
+
+class _HipModule:
+    """Minimal nn.Module-like shell: a named fp32 state dict on the host plus a lazily created
+    Engine (the HIP context that holds the device copy)."""
+
+    def __init__(self):
+        self._sd: "OrderedDict[str, torch.Tensor]" = OrderedDict()
+        self._engine: Optional[Engine] = None
+        self._device_index = 0
+        self._dirty = True
+        self.training = False
+
+    # --- nn.Module-ish API the reference's callers use
+    def eval(self):
+        self.training = False
+        return self
+
+    def train(self, mode: bool = True):
+        self.training = mode
+        return self
+
+    def to(self, device):
+        idx = _device_index(device)
+        if idx != self._device_index and self._engine is not None:
+            self._engine.close()
+            self._engine = None
+            self._dirty = True
+        self._device_index = idx
+        return self
+
+    def cuda(self, device: int = 0):
+        return self.to(torch.device("cuda", device))
+
+    def state_dict(self) -> "OrderedDict[str, torch.Tensor]":
+        return OrderedDict(self._sd)
+
+    def parameters(self, recurse: bool = True) -> Iterator[torch.Tensor]:
+        """Device-resident handles; the reference only uses them to find the device
+        (gpt2_prefix_eval.py:64,135)."""
+        dev = torch.device("cuda", self._device_index)
+        if not self._sd:
+            yield torch.empty(0, device=dev)
+        for v in self._sd.values():
+            yield torch.empty(0, device=dev, dtype=torch.float32)
+
+    @property
+    def engine(self) -> Engine:
+        if self._engine is None:
+            self._engine = Engine(self._device_index)
+            self._dirty = True
+        if self._dirty:
+            self._upload(self._engine)
+            self._dirty = False
+        return self._engine
+
+    def _upload(self, eng: Engine):
+        raise NotImplementedError
+
+    def __call__(self, *a, **k):
+        return self.forward(*a, **k)
+
+
+class MLP(_HipModule):
+    """reference gpt2_prefix.py:114-126: Linear -> Tanh -> Linear for ``sizes`` of length 3
+    (the only shape ClipCaptionModel builds, :167-168)."""
+
+    def __init__(self, sizes: Tuple[int, ...], bias=True, act=None, _owner: Optional[_HipModule] = None):
+        super().__init__()
+        if len(sizes) != 3 or not bias:
+            raise CapdecError("MLP mapper: only the 3-size, biased form used by ClipCaptionModel is supported")
+        self.sizes = tuple(int(s) for s in sizes)
+        self._owner = _owner
+
+    def load_state_dict(self, sd: Dict[str, torch.Tensor], strict: bool = True):
+        need = ["model.0.weight", "model.0.bias", "model.2.weight", "model.2.bias"]
+        missing = [k for k in need if k not in sd]
+        if missing and strict:
+            raise RuntimeError(f"Missing key(s) in state_dict: {missing}")
+        for k in need:
+            self._sd[k] = sd[k].detach().float().cpu()
+        self._dirty = True
+        return SimpleNamespace(missing_keys=missing, unexpected_keys=[k for k in sd if k not in need])
+
+    def _upload(self, eng: Engine):
+        eng.load_mapper_mlp({"clip_project." + k: v for k, v in self._sd.items()})
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        eng = self._owner.engine if self._owner is not None else self.engine
+        return eng.mapper_forward(x).reshape(x.shape[0], -1)   # [B, P*768] like nn.Sequential
+
+
+class ClipCaptionModel(_HipModule):
+    """reference gpt2_prefix.py:139-171 (ctor kwargs of :157-158; ``prefix_size`` is accepted as
+    the train.py:262 spelling of ``prefix_dim``)."""
+
+    def __init__(self, prefix_length: int, clip_length: Optional[int] = None, prefix_dim: int = 640,
+                 num_layers: int = 8, mapping_type: MappingType = MappingType.TransformerEncoder,
+                 prefix_size: Optional[int] = None, gpt2_dims: synth.GPT2Dims = synth.GPT2_SMALL):
+        super().__init__()
+        from . import transformer_mapper
+        if prefix_size is not None:
+            prefix_dim = prefix_size
+        clip_length = prefix_length if clip_length is None else clip_length
+        self.prefix_length = prefix_length
+        self.clip_length = clip_length
+        self.prefix_dim = prefix_dim
+        self.num_layers = num_layers
+        self.mapping_type = mapping_type
+        self.gpt_dims = gpt2_dims
+        self.gpt_embedding_size = gpt2_dims.n_embd
+        self.gpt = _Gpt2Facade(self)
+        if mapping_type == MappingType.TransformerEncoder:
+            self.clip_project = transformer_mapper.TransformerMapper(prefix_dim, self.gpt_embedding_size, prefix_length,
+                                                                     clip_length, num_layers, _owner=self)
+        elif mapping_type == MappingType.MLP:
+            self.clip_project = MLP((prefix_dim, (self.gpt_embedding_size * prefix_length) // 2,
+                                     self.gpt_embedding_size * prefix_length), _owner=self)
+        else:
+            raise CapdecError("MappingType.TransformerDecoder (TransformerEncoderDecoder) is outside the hot path")
+
+    def get_dummy_token(self, batch_size: int, device) -> torch.Tensor:
+        return torch.zeros(batch_size, self.prefix_length, dtype=torch.int64, device=device)
+
+    def load_state_dict(self, sd: Dict[str, torch.Tensor], strict: bool = True):
+        """Reference checkpoints (train.py:359-371).  Ignores the transformers-4.24 buffers
+        ``gpt.transformer.h.{i}.attn.bias`` / ``.attn.masked_bias``; accepts fp16 tensors."""
+        mapper_keys = [k for k in sd if k.startswith("clip_project.")]
+        gpt_keys = [k for k in sd if k.startswith("gpt.") and not (k.endswith(".attn.bias") or k.endswith(".attn.masked_bias"))]
+        if strict and (not mapper_keys or "gpt.transformer.wte.weight" not in sd):
+            raise RuntimeError("Missing key(s) in state_dict: clip_project.* / gpt.transformer.wte.weight")
+        self._sd = OrderedDict((k, sd[k].detach().float().cpu()) for k in mapper_keys + gpt_keys)
+        self.clip_project.load_state_dict({k[len("clip_project."):]: self._sd[k] for k in mapper_keys}, strict=strict)
+        self._dirty = True
+        unexpected = [k for k in sd if k not in self._sd and not (k.endswith(".attn.bias") or k.endswith(".attn.masked_bias"))]
+        if strict and unexpected:
+            raise RuntimeError(f"Unexpected key(s) in state_dict: {unexpected}")
+        return SimpleNamespace(missing_keys=[], unexpected_keys=unexpected)
+
+    def _upload(self, eng: Engine):
+        if "gpt.transformer.wte.weight" not in self._sd:
+            raise CapdecError("ClipCaptionModel has no weights: call load_state_dict(checkpoint) first")
+        eng.load_gpt2(self._sd, "gpt.", n_head=self.gpt_dims.n_head, ln_eps=self.gpt_dims.ln_eps)
+        self.clip_project._upload(eng)
+
+    def forward(self, tokens, prefix, mask=None, labels=None):
+        raise CapdecError("ClipCaptionModel.forward is the TRAINING forward (reference gpt2_prefix.py:145-155); "
+                          "training is outside the accelerated caption path")
+
+
+class ClipCaptionPrefix(ClipCaptionModel):
+    """reference gpt2_prefix.py:178-186: exposes only the mapper's parameters."""
+
+    def parameters(self, recurse: bool = True):
+        dev = torch.device("cuda", self._device_index)
+        for k in self._sd:
+            if k.startswith("clip_project."):
+                yield torch.empty(0, device=dev)
+
+    def train(self, mode: bool = True):
+        super().train(mode)
+        return self
+
+
+class _Gpt2Facade:
+    """What the decode code touches on ``model.gpt`` (reference gpt2_prefix_eval.py:74-76,105,
+    151,163,181; predictions_runner.py:186)."""
+
+    def __init__(self, owner: ClipCaptionModel):
+        self._owner = owner
+        self.transformer = SimpleNamespace(wte=self._wte)
+
+    def _wte(self, ids: torch.Tensor) -> torch.Tensor:
+        return self._owner.engine.wte(ids)
+
+    def get_input_embeddings(self):
+        w = self._owner._sd["gpt.transformer.wte.weight"]
+        return SimpleNamespace(weight=w.to(torch.device("cuda", self._owner._device_index)))
+
+    def eval(self):
+        return self
+
+    def __call__(self, inputs_embeds: torch.Tensor = None, **kw):
+        if inputs_embeds is None or kw.get("labels") is not None:
+            raise CapdecError("model.gpt(...) supports inference on inputs_embeds only")
+        return SimpleNamespace(logits=self._owner.engine.gpt2_logits(inputs_embeds, all_positions=True))

@@ -1,0 +1,60 @@
+"""Batched counterpart of the per-image loop of reference ``predictions_runner.make_preds``
+(:194-234,300-301): embeddings -> normalise (+ modality offset) -> ``clip_project`` ->
+``generate_beam`` / ``generate2`` -> ``{"caption": text.lower(), "image_id": ...}``.
+``generate_beam`` / ``generate2`` are re-exported here because the reference imports them
+into this module (:13) and BASELINE.json's north_star names them under it."""
+from __future__ import annotations
+
+import json
+from typing import Dict, List, Optional, Sequence
+
+import torch
+
+from . import distributed as cdist
+from .gpt2_prefix import ClipCaptionModel, MappingType  # noqa: F401
+from .gpt2_prefix_eval import (decode_beam_ids, decode_greedy_ids, generate2, generate2_batch,  # noqa: F401
+                               generate_beam, generate_beam_batch)
+
+
+def prefix_from_embeddings(model: ClipCaptionModel, embeddings: torch.Tensor, dont_normalize_prefix: bool = False,
+                           modality_offset: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """reference :221-228 for a batch: ``prefix / prefix.norm(2,-1)``; ``+ offset``;
+    ``clip_project(prefix).reshape(N, P, -1)``."""
+    eng = model.engine
+    x = eng.normalize_prefix(embeddings, normalize=not dont_normalize_prefix, offset=modality_offset)
+    return model.clip_project(x).reshape(x.shape[0], model.prefix_length, -1)
+
+
+def caption_ids(model: ClipCaptionModel, embeddings: torch.Tensor, stop_token_index: int, beam: bool = True,
+                beam_size: int = 5, entry_length: int = 67, dont_normalize_prefix: bool = False,
+                modality_offset: Optional[torch.Tensor] = None, rank: int = 0, world: int = 1):
+    """The whole device-side path for this rank's shard of ``embeddings`` [N, D].
+    Returns (ids [n_local, T] int32 of the best caption, lens [n_local]) and, for beam, the
+    mean-log-prob score of the best beam."""
+    lo, hi = cdist.shard_bounds(embeddings.shape[0], rank, world)
+    pe = prefix_from_embeddings(model, embeddings[lo:hi], dont_normalize_prefix, modality_offset)
+    if beam:
+        ids, lens, scores, _ = decode_beam_ids(model, pe, stop_token_index, beam_size, entry_length)
+        return ids[:, 0].contiguous(), lens[:, 0].contiguous(), scores[:, 0].contiguous()
+    ids, lens = decode_greedy_ids(model, pe, stop_token_index, entry_length)
+    return ids, lens, None
+
+
+def make_preds(data: Sequence[Dict], embeddings: torch.Tensor, model: ClipCaptionModel, tokenizer,
+               out_path: Optional[str] = None, beam: bool = True, entry_length: int = 67,
+               dont_normalize_prefix: bool = False, modality_offset: Optional[torch.Tensor] = None,
+               rank: int = 0, world: int = 1) -> List[Dict]:
+    """``data[i]`` = {"image_id": ...}; ``embeddings[i]`` its CLIP embedding.  Writes the
+    reference's predictions JSON (``[{"caption": lower-cased text, "image_id": id}]``, :260-261,
+    :301) -- the whole list, not only every 99th flush."""
+    stop = tokenizer.encode('.')[0]
+    ids, lens, _ = caption_ids(model, embeddings, stop, beam, 5, entry_length, dont_normalize_prefix,
+                               modality_offset, rank, world)
+    ids, lens, _ = cdist.gather_ids(ids, lens, embeddings.shape[0])
+    ids, lens = ids.cpu().numpy(), lens.cpu().numpy()
+    new_data = [{"caption": tokenizer.decode(list(ids[i, :int(lens[i])])).lower(), "image_id": d["image_id"]}
+                for i, d in enumerate(data)]
+    if out_path and rank == 0:
+        with open(out_path, 'w') as outfile:
+            json.dump(new_data, outfile)
+    return new_data

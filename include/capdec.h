@@ -1,0 +1,172 @@
+/*
+ * capdec.h -- C ABI of libcapdec_hip.so: the MI355X (gfx950) caption hot path of CapDec.
+ *
+ *   CLIP embedding -> (normalise / noise) -> mapping network -> GPT-2 KV-cached decode
+ *   (greedy | beam) -> token ids
+ *
+ * The reference (DavidHuji/CapDec) is pure Python: its "plugin API" for this path is a set
+ * of Python names, not an FFI.  Each entry point below cites the reference interface it
+ * replaces (file:line under the reference tree); capdec_amd/ (ctypes) binds exactly these
+ * symbols and re-exposes the reference names (MappingType, MLP, TransformerMapper,
+ * ClipCaptionModel, generate2, generate_beam, noise_injection).  INTEGRATION.md shows the
+ * stub a reference maintainer would add.
+ *
+ * Conventions
+ *   - every function returns 0 on success, non-zero on failure; capdec_last_error() returns
+ *     a thread-local message for the last failure on the calling thread.
+ *   - one capdec_ctx per GPU / rank, driven by one host thread at a time.
+ *   - "h_" pointers are host memory (read during the call), "d_" pointers are device memory
+ *     on the context's GPU; bulk data (embeddings in, token ids out) stays on the device.
+ *   - all work is enqueued on the context's HIP stream (own stream, or one adopted with
+ *     capdec_set_stream); decode calls synchronise that stream before returning.
+ *   - tensors are dense row-major fp32 / int32 unless stated.
+ */
+#ifndef CAPDEC_H
+#define CAPDEC_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CAPDEC_ABI_VERSION 1
+
+typedef struct capdec_ctx capdec_ctx;
+
+/* activation codes for capdec_gemm_f32 (test hook) */
+enum { CAPDEC_ACT_NONE = 0, CAPDEC_ACT_TANH = 1, CAPDEC_ACT_RELU = 2, CAPDEC_ACT_GELU_NEW = 3 };
+
+/* ---- context ------------------------------------------------------------------------ */
+int capdec_abi_version(void);
+const char *capdec_last_error(void);
+/* replaces `device = CUDA(0); model = model.to(device)` (reference predictions_runner.py:154-155) */
+int capdec_create(int device_id, capdec_ctx **out);
+void capdec_destroy(capdec_ctx *ctx);
+/* adopt an external hipStream_t (e.g. torch's current stream); NULL = the context's own stream */
+int capdec_set_stream(capdec_ctx *ctx, void *hip_stream);
+int capdec_synchronize(capdec_ctx *ctx);
+/* cap on bytes the decode KV cache may take (captions are processed in chunks that fit);
+ * 0 = default (96 GiB of the 288 GB HBM3E) */
+int capdec_set_kv_budget(capdec_ctx *ctx, size_t bytes);
+
+/* raw device memory for hosts that do not bring their own allocator (torch is optional) */
+int capdec_malloc(capdec_ctx *ctx, size_t bytes, void **d_ptr);
+int capdec_free(capdec_ctx *ctx, void *d_ptr);
+int capdec_memcpy_h2d(capdec_ctx *ctx, void *d_dst, const void *h_src, size_t bytes);
+int capdec_memcpy_d2h(capdec_ctx *ctx, void *h_dst, const void *d_src, size_t bytes);
+
+/* ---- weights -------------------------------------------------------------------------
+ * replaces `model.load_state_dict(torch.load(ckpt))` (reference predictions_runner.py:461);
+ * layouts are the checkpoint's own: GPT-2 Conv1D matrices [in, out], nn.Linear [out, in]. */
+typedef struct capdec_gpt2_layer {
+    const float *ln_1_w, *ln_1_b;            /* [d] */
+    const float *c_attn_w, *c_attn_b;        /* [d, 3d], [3d] */
+    const float *c_proj_w, *c_proj_b;        /* [d, d], [d] */
+    const float *ln_2_w, *ln_2_b;            /* [d] */
+    const float *c_fc_w, *c_fc_b;            /* [d, 4d], [4d] */
+    const float *mlp_c_proj_w, *mlp_c_proj_b;/* [4d, d], [d] */
+} capdec_gpt2_layer;
+
+typedef struct capdec_gpt2_weights {
+    int n_layer, n_head, n_embd, vocab, n_pos;
+    float ln_eps;
+    const float *wte;                        /* [vocab, d]  (lm_head is tied to it) */
+    const float *wpe;                        /* [n_pos, d] */
+    const capdec_gpt2_layer *layers;         /* [n_layer] */
+    const float *ln_f_w, *ln_f_b;            /* [d] */
+} capdec_gpt2_weights;
+
+/* transformers.GPT2LMHeadModel as owned by ClipCaptionModel.gpt (reference gpt2_prefix.py:162) */
+int capdec_load_gpt2(capdec_ctx *ctx, const capdec_gpt2_weights *h_w);
+
+/* MLP mapper: reference gpt2_prefix.py:114-126, sizes (D, d*P/2, d*P) at :167-168 */
+int capdec_load_mapper_mlp(capdec_ctx *ctx, int prefix_dim, int prefix_length, int hidden,
+                           const float *h_w1, const float *h_b1,   /* [hidden, D], [hidden] */
+                           const float *h_w2, const float *h_b2);  /* [d*P, hidden], [d*P] */
+
+typedef struct capdec_tmapper_layer {
+    const float *norm1_w, *norm1_b;          /* [d] */
+    const float *to_queries_w;               /* [d, d]   (no bias) */
+    const float *to_keys_values_w;           /* [2d, d]  (no bias) */
+    const float *project_w, *project_b;      /* [d, d], [d] */
+    const float *norm2_w, *norm2_b;          /* [d] */
+    const float *fc1_w, *fc1_b;              /* [hid, d], [hid] */
+    const float *fc2_w, *fc2_b;              /* [d, hid], [d] */
+} capdec_tmapper_layer;
+
+typedef struct capdec_tmapper_weights {
+    int prefix_dim, prefix_length, clip_length, num_layers, num_heads, d, mlp_hidden;
+    const float *linear_w, *linear_b;        /* [clip_length*d, D], [clip_length*d] */
+    const float *prefix_const;               /* [P, d] */
+    const capdec_tmapper_layer *layers;      /* [num_layers] */
+} capdec_tmapper_weights;
+
+/* TransformerMapper: reference transformer_mapper.py:113-127 (8 heads, pre-LN, ReLU MLP) */
+int capdec_load_mapper_transformer(capdec_ctx *ctx, const capdec_tmapper_weights *h_w);
+
+/* ---- prefix stage -------------------------------------------------------------------- */
+/* `prefix / prefix.norm(2,-1)` then `+ offset` (reference predictions_runner.py:221-224);
+ * d_offset [D] may be NULL; normalize=0 mirrors --dont_normalize_prefix.  In place if out==x. */
+int capdec_normalize_prefix(capdec_ctx *ctx, const float *d_x, int n, int dim, int normalize,
+                            const float *d_offset, float *d_out);
+
+/* noise_injection (reference train.py:27-39): variance==0 -> copy of x (NOT normalised).
+ * d_noise [n,dim]: unit-variance draw standing for torch.randn (NULL -> on-device Philox
+ * stream seeded by `seed`).  uniform!=0 -> get_uniform_ball_noise (train.py:18-24) using
+ * d_noise as the Gaussian direction and d_u [n] as the torch.rand draw (NULL -> Philox). */
+int capdec_noise_inject(capdec_ctx *ctx, const float *d_x, int n, int dim, float variance,
+                        const float *d_offset, int uniform, int dont_norm, uint64_t seed,
+                        const float *d_noise, const float *d_u, float *d_out);
+
+/* `model.clip_project(prefix)` (reference predictions_runner.py:228; gpt2_prefix.py:145-147):
+ * d_x [n, D] -> d_out [n, P, d] with whichever mapper is loaded. */
+int capdec_mapper_forward(capdec_ctx *ctx, const float *d_x, int n, float *d_out);
+
+/* ---- GPT-2 --------------------------------------------------------------------------- */
+/* `model.gpt(inputs_embeds=x).logits` (reference gpt2_prefix_eval.py:76-77,163-164).
+ * d_embeds [n, L, d].  all_positions!=0 -> d_logits [n, L, vocab] (what the reference
+ * materialises); 0 -> d_logits [n, vocab], last position only (what it uses). */
+int capdec_gpt2_logits(capdec_ctx *ctx, const float *d_embeds, int n, int L, int all_positions,
+                       float *d_logits);
+/* `model.gpt.transformer.wte(ids)` (reference gpt2_prefix_eval.py:105,181): d_out [n, d] */
+int capdec_wte_lookup(capdec_ctx *ctx, const int32_t *d_ids, int n, float *d_out);
+
+/* ---- decode -------------------------------------------------------------------------- */
+/* generate2, batched (reference gpt2_prefix_eval.py:118-198; top-p filter + argmax == argmax).
+ * d_prefix [n, P, d] -> d_ids [n, entry_length] (zero padded), d_lens [n] = number of tokens
+ * INCLUDING the stop token.  A row stops at stop_id or alt_stop_id (764 in the reference,
+ * :187; pass -1 to disable). */
+int capdec_decode_greedy(capdec_ctx *ctx, const float *d_prefix, int n, int P, int stop_id,
+                         int alt_stop_id, int entry_length, int32_t *d_ids, int32_t *d_lens);
+
+/* generate_beam, batched (reference gpt2_prefix_eval.py:50-115).  d_prefix [n, P, d] ->
+ * d_ids [n, beam, entry_length], d_lens [n, beam] (= int(seq_lengths)), d_scores [n, beam]
+ * (= scores / seq_lengths, :110).  Beams are sorted by score descending (:113-114), so
+ * d_ids[i][0] is what `generate_beam(...)[0]` decodes (predictions_runner.py:230).
+ * d_order [n, beam] (may be NULL) receives the reference's internal beam index of each row. */
+int capdec_decode_beam(capdec_ctx *ctx, const float *d_prefix, int n, int P, int beam, int stop_id,
+                       int entry_length, float temperature, int32_t *d_ids, int32_t *d_lens,
+                       float *d_scores, int32_t *d_order);
+
+/* ---- measurement / test hooks -------------------------------------------------------- */
+/* C[M,N] = act(A[M,K] . Bt[N,K]^T + bias[N]) + resid[M,N]; bias / resid may be NULL.
+ * The MFMA GEMM every projection above runs on (nn.Linear weights are already [N,K]). */
+int capdec_gemm_f32(capdec_ctx *ctx, const float *d_a, int lda, const float *d_bt, int ldb,
+                    float *d_c, int ldc, int M, int N, int K, const float *d_bias,
+                    const float *d_resid, int ldr, int act);
+/* hipEvent timers on the context's stream -- the reference's Timer (predictions_runner.py:125-150) */
+int capdec_timer_start(capdec_ctx *ctx);
+int capdec_timer_stop_ms(capdec_ctx *ctx, float *ms);   /* records, synchronises, returns elapsed */
+/* per-kernel-family accumulated device time of the last decode call (hipEvents around every
+ * launch when profiling is enabled): caller arrays of capacity 16, *count entries are filled */
+int capdec_profile_enable(capdec_ctx *ctx, int on);
+int capdec_profile_get(capdec_ctx *ctx, int *count, const char **names, float *ms, int64_t *launches,
+                       double *flops);   /* flops: algorithmic FLOPs issued by the family (0 for non-GEMM) */
+int capdec_profile_reset(capdec_ctx *ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CAPDEC_H */

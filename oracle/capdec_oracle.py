@@ -1,0 +1,357 @@
+"""CPU oracle for the CapDec caption hot path -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+
+Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may
+import this file; ``capdec_amd`` never does (the product path is HIP-only and raises when
+the extension is missing).
+
+It is a plain-torch (CPU, fp32) restatement of the reference algorithm, function by
+function, each citing the reference ``file:line`` it follows.  Two families:
+
+* reference-shaped (batch 1, NO KV cache, lm_head on every position) -- ``generate2_ref`` /
+  ``generate_beam_ref``: the algorithm of reference gpt2_prefix_eval.py:50-198 exactly as
+  the reference executes it; this is what ``cpu_baseline`` times.
+* KV-cached, batched -- ``greedy_cached`` / ``beam_cached``: the algorithm the HIP
+  kernels implement; same results, O(T) instead of O(T^2); used for larger parity cases.
+
+Pinning: the reference has no tests or golden vectors of its own, and
+the GPT-2 arithmetic lives in the un-vendored dependency ``transformers`` (pinned 4.24.0 in
+reference requirments.txt:12; 5.15.0 installed here).  The oracle is therefore pinned
+against outputs of the reference itself, imported in the build container by
+``tools/gen_golden.py`` -> ``tests/golden/*.npz`` (checked by
+``tests/test_oracle_vs_golden.py``).  CLIP towers are not restated here (package absent).
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+import torch.nn.functional as F
+
+Tensor = torch.Tensor
+SD = Dict[str, Tensor]
+
+
+# ----------------------------------------------------------------------------------------
+# prefix stage
+# ----------------------------------------------------------------------------------------
+def normalize_prefix(prefix: Tensor, offset: Optional[Tensor] = None, dont_normalize: bool = False) -> Tensor:
+    """reference predictions_runner.py:221-224: ``prefix / prefix.norm(2, -1)`` (no eps)
+    then ``+ offset_to_add_in_inference``.  Written for B == 1 in the reference; batched here
+    with keepdim."""
+    if not dont_normalize:
+        prefix = prefix / prefix.norm(2, -1, keepdim=True)
+    if offset is not None:
+        prefix = prefix + offset
+    return prefix
+
+
+def uniform_ball_noise(shape, radius: float, gauss: Tensor, u: Tensor) -> Tensor:
+    """reference train.py:18-24 with the two random draws supplied by the caller
+    (``gauss`` ~ randn(shape), ``u`` ~ rand(shape[0]))."""
+    sphere = F.normalize(gauss, dim=1)
+    u = u ** (1.0 / shape[1])
+    return (sphere.T * u * radius).T
+
+
+def noise_injection(x: Tensor, variance: float = 0.001, modality_offset: Optional[Tensor] = None,
+                    uniform_noise: bool = False, dont_norm: bool = False, *,
+                    noise: Optional[Tensor] = None, u: Optional[Tensor] = None) -> Tensor:
+    """reference train.py:27-39.  ``variance == 0`` returns x UNCHANGED (not normalised).
+    ``noise`` stands for the ``torch.randn(x.shape)`` draw (unit variance, scaled by std here),
+    ``u`` for the ``torch.rand`` draw of the uniform-ball variant."""
+    if variance == 0.0:
+        return x
+    std = math.sqrt(variance)
+    if not dont_norm:
+        x = F.normalize(x, dim=1)
+    if noise is None:
+        noise = torch.randn(x.shape)
+    if uniform_noise:
+        if u is None:
+            u = torch.rand(x.shape[0])
+        x = x + uniform_ball_noise(x.shape, std, noise, u)
+    else:
+        x = x + noise * std
+    if modality_offset is not None:
+        x = x + modality_offset
+    return F.normalize(x, dim=1)
+
+
+# ----------------------------------------------------------------------------------------
+# mapping networks
+# ----------------------------------------------------------------------------------------
+def mlp_mapper(x: Tensor, sd: SD, pfx: str = "clip_project.") -> Tensor:
+    """reference gpt2_prefix.py:114-126 built at :167-168: Linear -> Tanh -> Linear.
+    x [B, D] -> [B, P*768]."""
+    h = torch.tanh(F.linear(x, sd[pfx + "model.0.weight"], sd[pfx + "model.0.bias"]))
+    return F.linear(h, sd[pfx + "model.2.weight"], sd[pfx + "model.2.bias"])
+
+
+def _mapper_attention(x: Tensor, sd: SD, l: str, num_heads: int = 8) -> Tensor:
+    """reference transformer_mapper.py:22-51 (self-attention, no mask, q/kv bias=False)."""
+    b, n, c = x.shape
+    hd = c // num_heads
+    q = F.linear(x, sd[l + "attn.to_queries.weight"]).reshape(b, n, num_heads, hd)
+    kv = F.linear(x, sd[l + "attn.to_keys_values.weight"]).reshape(b, n, 2, num_heads, hd)
+    k, v = kv[:, :, 0], kv[:, :, 1]
+    att = torch.einsum("bnhd,bmhd->bnmh", q, k) * (hd ** -0.5)
+    att = att.softmax(dim=2)
+    out = torch.einsum("bnmh,bmhd->bnhd", att, v).reshape(b, n, c)
+    return F.linear(out, sd[l + "attn.project.weight"], sd[l + "attn.project.bias"])
+
+
+def transformer_mapper(x: Tensor, sd: SD, clip_length: int, num_layers: int = 8,
+                       pfx: str = "clip_project.") -> Tensor:
+    """reference transformer_mapper.py:113-127 -> Transformer :76-110 -> TransformerLayer :54-73.
+    x [B, D] -> [B, P, 768] (rows clip_length: of the sequence)."""
+    d = sd[pfx + "prefix_const"].shape[1]
+    h = F.linear(x, sd[pfx + "linear.weight"], sd[pfx + "linear.bias"]).view(x.shape[0], clip_length, d)
+    const = sd[pfx + "prefix_const"].unsqueeze(0).expand(x.shape[0], -1, -1)
+    h = torch.cat((h, const), dim=1)
+    for i in range(num_layers):
+        l = f"{pfx}transformer.layers.{i}."
+        a = F.layer_norm(h, (d,), sd[l + "norm1.weight"], sd[l + "norm1.bias"], 1e-5)
+        h = h + _mapper_attention(a, sd, l)
+        m = F.layer_norm(h, (d,), sd[l + "norm2.weight"], sd[l + "norm2.bias"], 1e-5)
+        m = F.linear(torch.relu(F.linear(m, sd[l + "mlp.fc1.weight"], sd[l + "mlp.fc1.bias"])),
+                     sd[l + "mlp.fc2.weight"], sd[l + "mlp.fc2.bias"])
+        h = h + m
+    return h[:, clip_length:]
+
+
+def clip_project(x: Tensor, sd: SD, mapping_type: str, prefix_length: int, clip_length: int = 10,
+                 num_layers: int = 8) -> Tensor:
+    """``model.clip_project(prefix).reshape(B, P, -1)`` (reference predictions_runner.py:228)."""
+    if mapping_type == "mlp":
+        return mlp_mapper(x, sd).reshape(x.shape[0], prefix_length, -1)
+    return transformer_mapper(x, sd, clip_length, num_layers).reshape(x.shape[0], prefix_length, -1)
+
+
+# ----------------------------------------------------------------------------------------
+# GPT-2 (third-party transformers.GPT2LMHeadModel; formulae per SURVEY.md section 3.4)
+# ----------------------------------------------------------------------------------------
+def gelu_new(x: Tensor) -> Tensor:
+    """transformers activations.py:65-66 (NewGELUActivation)."""
+    return 0.5 * x * (1.0 + torch.tanh(math.sqrt(2.0 / math.pi) * (x + 0.044715 * torch.pow(x, 3.0))))
+
+
+def _n_layer(sd: SD, g: str) -> int:
+    n = 0
+    while f"{g}transformer.h.{n}.ln_1.weight" in sd:
+        n += 1
+    return n
+
+
+def gpt2_hidden(embeds: Tensor, sd: SD, n_head: int = 12, g: str = "gpt.", pos0: int = 0,
+                cache: Optional[list] = None) -> Tensor:
+    """GPT2Model.forward on ``inputs_embeds`` [N, L, d]: h = x + wpe[pos]; 12 x
+    {h += c_proj(causal MHA(c_attn(ln_1 h))); h += mlp.c_proj(gelu_new(c_fc(ln_2 h)))}; ln_f.
+    Conv1D = addmm(bias, x, W) with W [in, out] (transformers pytorch_utils.py:117-121).
+    With ``cache`` (list of per-layer [K, V] tensors [N, heads, L_past, hd]) the new rows sit
+    at positions pos0.. and attend to the cached past plus themselves (causal)."""
+    N, L, d = embeds.shape
+    hd = d // n_head
+    t = g + "transformer."
+    h = embeds + sd[t + "wpe.weight"][pos0:pos0 + L]
+    for i in range(_n_layer(sd, g)):
+        b = f"{t}h.{i}."
+        a = F.layer_norm(h, (d,), sd[b + "ln_1.weight"], sd[b + "ln_1.bias"], 1e-5)
+        qkv = torch.addmm(sd[b + "attn.c_attn.bias"], a.reshape(-1, d), sd[b + "attn.c_attn.weight"]).view(N, L, 3 * d)
+        q, k, v = qkv.split(d, dim=2)
+        q = q.view(N, L, n_head, hd).transpose(1, 2)
+        k = k.view(N, L, n_head, hd).transpose(1, 2)
+        v = v.view(N, L, n_head, hd).transpose(1, 2)
+        if cache is not None:
+            if cache[i] is not None:
+                k = torch.cat((cache[i][0], k), dim=2)
+                v = torch.cat((cache[i][1], v), dim=2)
+            cache[i] = [k, v]
+        Lk = k.shape[2]
+        w = torch.matmul(q, k.transpose(-1, -2)) / math.sqrt(hd)
+        causal = torch.ones(Lk, Lk, dtype=torch.bool).tril()[Lk - L:, :]
+        w = torch.where(causal, w, torch.full((), torch.finfo(w.dtype).min))
+        w = w.softmax(dim=-1)
+        o = torch.matmul(w, v).transpose(1, 2).reshape(N, L, d)
+        o = torch.addmm(sd[b + "attn.c_proj.bias"], o.reshape(-1, d), sd[b + "attn.c_proj.weight"]).view(N, L, d)
+        h = h + o
+        m = F.layer_norm(h, (d,), sd[b + "ln_2.weight"], sd[b + "ln_2.bias"], 1e-5)
+        m = torch.addmm(sd[b + "mlp.c_fc.bias"], m.reshape(-1, d), sd[b + "mlp.c_fc.weight"])
+        m = gelu_new(m)
+        m = torch.addmm(sd[b + "mlp.c_proj.bias"], m, sd[b + "mlp.c_proj.weight"]).view(N, L, d)
+        h = h + m
+    return F.layer_norm(h, (d,), sd[t + "ln_f.weight"], sd[t + "ln_f.bias"], 1e-5)
+
+
+def gpt2_logits(embeds: Tensor, sd: SD, n_head: int = 12, g: str = "gpt.") -> Tensor:
+    """``model.gpt(inputs_embeds=x).logits`` -- ALL positions [N, L, V], tied lm_head
+    (what the reference computes every step, gpt2_prefix_eval.py:76-77,163-164)."""
+    h = gpt2_hidden(embeds, sd, n_head, g)
+    return torch.matmul(h, sd[g + "transformer.wte.weight"].t())
+
+
+def wte(ids: Tensor, sd: SD, g: str = "gpt.") -> Tensor:
+    return sd[g + "transformer.wte.weight"][ids]
+
+
+# ----------------------------------------------------------------------------------------
+# reference-shaped decode (batch 1, no KV cache): what the reference executes
+# ----------------------------------------------------------------------------------------
+def generate2_ref(sd: SD, embed: Tensor, stop_id: int = 13, entry_length: int = 67, top_p: float = 0.8,
+                  temperature: float = 1.0, alt_stop_id: int = 764, n_head: int = 12,
+                  margins: Optional[list] = None) -> List[int]:
+    """reference gpt2_prefix_eval.py:118-198 with ``embed`` [1, P, d] given.  Keeps the sort /
+    cumsum / top-p masking the reference performs (the arg-max is unaffected: rank 0 is
+    never removed, :172).  Returns the id list INCLUDING the stop token."""
+    generated = embed
+    tokens: List[int] = []
+    for _ in range(entry_length):
+        logits = gpt2_logits(generated, sd, n_head)[:, -1, :] / (temperature if temperature > 0 else 1.0)
+        sorted_logits, sorted_indices = torch.sort(logits, descending=True)
+        if margins is not None:
+            margins.append(float(sorted_logits[0, 0] - sorted_logits[0, 1]))
+        cumulative = torch.cumsum(F.softmax(sorted_logits, dim=-1), dim=-1)
+        remove = cumulative > top_p
+        remove[..., 1:] = remove[..., :-1].clone()
+        remove[..., 0] = 0
+        logits[:, sorted_indices[remove]] = -float("inf")
+        nxt = torch.argmax(logits, -1).unsqueeze(0)
+        generated = torch.cat((generated, wte(nxt, sd)), dim=1)
+        tokens.append(int(nxt.item()))
+        if tokens[-1] == stop_id or tokens[-1] == alt_stop_id:
+            break
+    return tokens
+
+
+def generate_beam_ref(sd: SD, embed: Tensor, beam_size: int = 5, stop_id: int = 13, entry_length: int = 67,
+                      temperature: float = 1.0, n_head: int = 12) -> Tuple[Tensor, Tensor, Tensor, Tensor]:
+    """reference gpt2_prefix_eval.py:50-115 with ``embed`` [1, P, d] given.  Returns the
+    function's final internal state: ``tokens`` int64 [beam, T], ``seq_lengths`` fp32 [beam],
+    mean-log-prob ``scores`` fp32 [beam] (after ``scores / seq_lengths``, :110) and
+    ``order = scores.argsort(descending=True)`` (:113); the reference returns
+    ``decode(tokens[b, :int(seq_lengths[b])])`` for b in order."""
+    tokens = None
+    scores = None
+    seq_lengths = torch.ones(beam_size)
+    is_stopped = torch.zeros(beam_size, dtype=torch.bool)
+    generated = embed
+    for _ in range(entry_length):
+        logits = gpt2_logits(generated, sd, n_head)[:, -1, :] / (temperature if temperature > 0 else 1.0)
+        logits = logits.softmax(-1).log()
+        if scores is None:
+            scores, next_tokens = logits.topk(beam_size, -1)
+            generated = generated.expand(beam_size, *generated.shape[1:])
+            next_tokens, scores = next_tokens.permute(1, 0), scores.squeeze(0)
+            tokens = next_tokens
+        else:
+            logits[is_stopped] = -float("inf")
+            logits[is_stopped, 0] = 0
+            scores_sum = scores[:, None] + logits
+            seq_lengths[~is_stopped] += 1
+            scores_sum_average = scores_sum / seq_lengths[:, None]
+            scores_sum_average, next_tokens = scores_sum_average.view(-1).topk(beam_size, -1)
+            source = next_tokens // scores_sum.shape[1]
+            seq_lengths = seq_lengths[source]
+            next_tokens = (next_tokens % scores_sum.shape[1]).unsqueeze(1)
+            tokens = torch.cat((tokens[source], next_tokens), dim=1)
+            generated = generated[source]
+            scores = scores_sum_average * seq_lengths
+            is_stopped = is_stopped[source]
+        emb = wte(next_tokens.squeeze(), sd).view(generated.shape[0], 1, -1)
+        generated = torch.cat((generated, emb), dim=1)
+        is_stopped = is_stopped + next_tokens.eq(stop_id).squeeze()
+        if is_stopped.all():
+            break
+    scores = scores / seq_lengths
+    order = scores.argsort(descending=True)
+    return tokens, seq_lengths, scores, order
+
+
+# ----------------------------------------------------------------------------------------
+# KV-cached batched decode: the algorithm the HIP kernels implement
+# ----------------------------------------------------------------------------------------
+def greedy_cached(sd: SD, prefix: Tensor, stop_id: int = 13, entry_length: int = 67, alt_stop_id: int = 764,
+                  n_head: int = 12) -> Tuple[Tensor, Tensor]:
+    """Batched greedy with a KV cache.  prefix [N, P, d] -> ids int32 [N, entry_length]
+    (zero padded) and lens int32 [N] (count INCLUDING the stop token), equal row by row
+    to ``generate2_ref``."""
+    N, P, d = prefix.shape
+    g = "gpt."
+    cache: list = [None] * _n_layer(sd, g)
+    W = sd[g + "transformer.wte.weight"]
+    ids = torch.zeros(N, entry_length, dtype=torch.int32)
+    lens = torch.zeros(N, dtype=torch.int32)
+    done = torch.zeros(N, dtype=torch.bool)
+    h = gpt2_hidden(prefix, sd, n_head, g, 0, cache)[:, -1]
+    for i in range(entry_length):
+        nxt = torch.argmax(h @ W.t(), -1)
+        ids[~done, i] = nxt[~done].to(torch.int32)
+        lens[~done] += 1
+        done = done | (nxt == stop_id) | (nxt == alt_stop_id)
+        if bool(done.all()) or i == entry_length - 1:
+            break
+        h = gpt2_hidden(W[nxt].unsqueeze(1), sd, n_head, g, P + i, cache)[:, -1]
+    return ids, lens
+
+
+def beam_cached(sd: SD, prefix: Tensor, beam_size: int = 5, stop_id: int = 13, entry_length: int = 67,
+                temperature: float = 1.0, n_head: int = 12) -> Tuple[Tensor, Tensor, Tensor]:
+    """Batched beam search with a KV cache, per caption identical in arithmetic to
+    ``generate_beam_ref`` (same fp32 op order for sum / mean / sum score juggling).
+    prefix [N, P, d] -> tokens int32 [N, beam, entry_length] (zero padded), seq_lengths int32
+    [N, beam], scores fp32 [N, beam]; rows in the reference's INTERNAL beam order -- sort by
+    ``scores`` descending (stable) to get the returned order."""
+    N, P, d = prefix.shape
+    g = "gpt."
+    B = beam_size
+    nl = _n_layer(sd, g)
+    cache: list = [None] * nl
+    W = sd[g + "transformer.wte.weight"]
+    V = W.shape[0]
+    temp = temperature if temperature > 0 else 1.0
+    h = gpt2_hidden(prefix, sd, n_head, g, 0, cache)[:, -1]
+    logp = ((h @ W.t()) / temp).softmax(-1).log()
+    scores, nxt = logp.topk(B, -1)                      # [N, B]
+    tokens = torch.zeros(N, B, entry_length, dtype=torch.int64)
+    tokens[:, :, 0] = nxt
+    seq = torch.ones(N, B)
+    stopped = nxt.eq(stop_id)
+    for i in range(nl):                                 # expand the prefix cache to beams
+        cache[i] = [c.repeat_interleave(B, dim=0) for c in cache[i]]
+    alive = ~stopped.all(dim=1)                         # captions whose loop has not broken
+    for i in range(1, entry_length):
+        if not bool(alive.any()):
+            break
+        x = W[nxt.reshape(-1)].unsqueeze(1)
+        h = gpt2_hidden(x, sd, n_head, g, P + i - 1, cache)[:, -1]
+        logp = ((h @ W.t()) / temp).softmax(-1).log().view(N, B, V)
+        logp[stopped] = -float("inf")
+        logp[stopped, 0] = 0
+        ssum = scores[:, :, None] + logp
+        seq_new = seq + (~stopped).float()
+        avg = ssum / seq_new[:, :, None]
+        avg_top, flat = avg.view(N, -1).topk(B, -1)
+        src = flat // V
+        tok = flat % V
+        seq_sel = torch.gather(seq_new, 1, src)
+        tok_hist = torch.gather(tokens, 1, src[:, :, None].expand(-1, -1, entry_length)).clone()
+        tok_hist[:, :, i] = tok
+        stopped_sel = torch.gather(stopped, 1, src) | tok.eq(stop_id)
+        # captions that already broke out of the reference loop keep their state
+        a = alive
+        tokens[a] = tok_hist[a]
+        seq[a] = seq_sel[a]
+        scores[a] = (avg_top * seq_sel)[a]
+        stopped[a] = stopped_sel[a]
+        nxt = torch.where(a[:, None], tok, nxt)
+        rows = (torch.arange(N)[:, None] * B + torch.where(a[:, None], src, torch.arange(B)[None, :])).reshape(-1)
+        for l in range(nl):
+            cache[l] = [c[rows] for c in cache[l]]
+        alive = alive & ~stopped.all(dim=1)
+    final = scores / seq
+    return tokens.to(torch.int32), seq.to(torch.int32), final
+
+
+def beam_output_order(scores: Tensor) -> Tensor:
+    """``scores.argsort(descending=True)`` of reference gpt2_prefix_eval.py:113, per caption."""
+    return scores.argsort(dim=-1, descending=True)

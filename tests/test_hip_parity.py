@@ -1,0 +1,333 @@
+"""Parity of the HIP path (through the C ABI / ctypes) against the CPU oracle and the golden
+fixtures captured from the reference.  Needs an MI355X: ``pytest -m gpu``.
+
+Tolerances (fp32 path): token ids / lengths / beam order bit-exact; beam mean-log-prob
+scores 1e-4 (north_star); logits 2e-4 abs; mapper outputs 2e-4 abs."""
+import numpy as np
+import pytest
+import torch
+
+from capdec_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+T = torch.from_numpy
+
+
+@pytest.fixture(scope="module")
+def eng():
+    from capdec_amd.engine import Engine
+    e = Engine(0)
+    yield e
+    e.close()
+
+
+def _model(dims, mapping, D, seed=42, P=10, clip_length=10, num_layers=8):
+    from capdec_amd.gpt2_prefix import ClipCaptionModel, MappingType
+    mt = {"mlp": MappingType.MLP, "transformer_encoder": MappingType.TransformerEncoder}[mapping]
+    m = ClipCaptionModel(P, clip_length=clip_length, prefix_dim=D, num_layers=num_layers, mapping_type=mt,
+                         gpt2_dims=dims).to("cuda:0").eval()
+    sd = synth.hot_state_dict(seed, mapping, D, P, clip_length, num_layers, dims)
+    m.load_state_dict(sd)
+    return m, sd
+
+
+class FakeTok:
+    def __init__(self, stop):
+        self.stop = stop
+
+    def encode(self, s):
+        return [self.stop]
+
+    def decode(self, ids):
+        return " ".join(str(int(i)) for i in ids)
+
+
+# ----------------------------------------------------------------------------------- GEMM
+@pytest.mark.parametrize("M,N,K", [(1, 8, 32), (5, 130, 64), (128, 128, 768), (257, 1531, 768), (300, 2304, 768),
+                                   (77, 768, 3072), (1000, 50257, 768)])
+def test_gemm_f32_vs_fp64(eng, M, N, K):
+    g = torch.Generator().manual_seed(M * 7 + N)
+    a = torch.randn(M, K, generator=g)
+    bt = torch.randn(N, K, generator=g) * 0.1
+    # asymmetric operands: a transposed / row-col swapped result cannot pass
+    ref = (a.double() @ bt.double().t())
+    out = eng.gemm(a, bt).cpu()
+    scale = (a.abs().double() @ bt.abs().double().t())
+    assert float(((out.double() - ref).abs() / scale).max()) < 5e-7      # fp32 round-off class
+
+
+@pytest.mark.parametrize("act", [0, 1, 2, 3])
+def test_gemm_epilogues(eng, act):
+    from oracle import capdec_oracle as O
+    g = torch.Generator().manual_seed(act)
+    M, N, K = 193, 333, 96
+    a, bt = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g) * 0.3
+    bias, resid = torch.randn(N, generator=g), torch.randn(M, N, generator=g)
+    y = a @ bt.t() + bias
+    y = [y, torch.tanh(y), torch.relu(y), O.gelu_new(y)][act] + resid
+    out = eng.gemm(a, bt, bias=bias, resid=resid, act=act).cpu()
+    np.testing.assert_allclose(out.numpy(), y.numpy(), atol=2e-5, rtol=1e-5)
+
+
+# ----------------------------------------------------------------------------------- mappers
+@pytest.mark.parametrize("D", [512, 640])
+def test_mlp_mapper(eng, golden, D):
+    g = golden("mappers")
+    eng.load_mapper_mlp(synth.hot_mlp_mapper_state_dict(43, D, 10))
+    y = eng.mapper_forward(T(g[f"x_{D}"])).cpu().reshape(4, -1)
+    np.testing.assert_allclose(y.numpy(), g[f"mlp_{D}"], atol=2e-5)
+
+
+@pytest.mark.parametrize("D", [512, 640])
+def test_transformer_mapper(eng, golden, D):
+    g = golden("mappers")
+    eng.load_mapper_transformer(synth.hot_transformer_mapper_state_dict(43, D, 10, 10, 8))
+    y = eng.mapper_forward(T(g[f"x_{D}"])).cpu()
+    np.testing.assert_allclose(y.numpy(), g[f"tm_{D}"], atol=2e-4)
+
+
+def test_transformer_mapper_ragged_geometry(eng, golden):
+    g = golden("mappers")
+    eng.load_mapper_transformer(synth.hot_transformer_mapper_state_dict(44, 512, 5, 7, 3))
+    y = eng.mapper_forward(T(g["x_p5"])).cpu()
+    assert y.shape == (3, 5, 768)
+    np.testing.assert_allclose(y.numpy(), g["tm_p5"], atol=2e-4)
+
+
+def test_mapper_long_sequence_vs_oracle(eng):
+    """prefix_length 40 + clip_length 40 (the notebook's geometry): 80-token sequences"""
+    from oracle import capdec_oracle as O
+    sd = synth.hot_transformer_mapper_state_dict(9, 512, 40, 40, 2)
+    x = synth.synthetic_clip_embeddings(3, 512, seed=3)
+    eng.load_mapper_transformer(sd)
+    y = eng.mapper_forward(x).cpu()
+    np.testing.assert_allclose(y.numpy(), O.transformer_mapper(x, sd, 40, 2).numpy(), atol=3e-4)
+
+
+def test_mapper_empty_batch(eng):
+    eng.load_mapper_mlp(synth.hot_mlp_mapper_state_dict(43, 512, 10))
+    assert eng.mapper_forward(torch.zeros(0, 512)).shape == (0, 10, 768)
+
+
+# ----------------------------------------------------------------------------------- noise
+def test_noise_injection(golden):
+    from capdec_amd import train as ct
+    g = golden("noise")
+    x, noise, u = T(g["x"]).cuda(), T(g["noise"]), T(g["u"])
+    off = T(g["offset_to_add_in_training"])
+    assert ct.noise_injection(x, 0.0) is x
+    np.testing.assert_allclose(ct.noise_injection(x, 0.016, noise=noise).cpu().numpy(), g["v016"], atol=1e-6)
+    np.testing.assert_allclose(ct.noise_injection(x, 0.016, off, noise=noise).cpu().numpy(), g["v016_off"], atol=1e-6)
+    np.testing.assert_allclose(ct.noise_injection(x, 0.016, dont_norm=True, noise=noise).cpu().numpy(),
+                               g["v016_dontnorm"], atol=1e-6)
+    np.testing.assert_allclose(ct.noise_injection(x, 0.016, uniform_noise=True, noise=noise, u=u).cpu().numpy(),
+                               g["v016_uniform"], atol=1e-6)
+    np.testing.assert_allclose(ct.get_uniform_ball_noise((6, 640), 0.3, noise=noise, u=u).cpu().numpy(), g["ball"],
+                               atol=1e-6)
+
+
+def test_noise_statistics_philox():
+    """on-device Philox draw: RNG streams differ between back-ends, so pin the distribution:
+    for unit rows and sigma^2 = 0.016 at D = 512 the pre-normalisation noise norm is
+    sqrt(512 * 0.016) = 2.86 and outputs are unit-norm, seed-repeatable."""
+    from capdec_amd import train as ct
+    x = synth.synthetic_clip_embeddings(4096, 512, seed=0).cuda()
+    a = ct.noise_injection(x, 0.016, seed=123)
+    b = ct.noise_injection(x, 0.016, seed=123)
+    c = ct.noise_injection(x, 0.016, seed=124)
+    assert torch.equal(a, b) and not torch.equal(a, c)
+    np.testing.assert_allclose(a.norm(dim=1).cpu().numpy(), 1.0, atol=1e-5)
+    # zeros + N(0,1), normalised -> uniform direction: component mean 0, variance 1/512
+    from capdec_amd.engine import get_engine
+    v = get_engine(0).noise_inject(torch.zeros(20000, 512).cuda(), 1.0, None, False, True, seed=77).cpu().numpy()
+    assert abs(v.mean()) < 1e-3 and abs(v.var() * 512 - 1.0) < 0.02
+    cos = (a * x).sum(1).cpu().numpy()                               # E[cos] ~ 1 / sqrt(1 + 512 * 0.016)
+    assert abs(cos.mean() - 1 / np.sqrt(1 + 512 * 0.016)) < 0.01
+
+
+def test_normalize_prefix(eng, golden):
+    g = golden("noise")
+    x = T(g["x"])
+    off = T(g["offset_to_add_in_inference"])
+    y = eng.normalize_prefix(x, True, off).cpu()
+    ref = x / x.norm(2, -1, keepdim=True) + off
+    np.testing.assert_allclose(y.numpy(), ref.numpy(), atol=1e-6)
+    np.testing.assert_array_equal(eng.normalize_prefix(x, False, None).cpu().numpy(), x.numpy())
+
+
+# ----------------------------------------------------------------------------------- GPT-2 logits
+def _check_logits(eng, g, dims):
+    sd = synth.hot_gpt2_state_dict(42, dims)
+    assert synth.state_dict_checksum(sd) == int(g["gpt_crc"]), "RNG drift: weights differ from fixture"
+    eng.load_gpt2(sd)
+    for L in (1, 10, 23, 77):
+        x = T(g[f"x_L{L}"])
+        full = eng.gpt2_logits(x, all_positions=True).cpu()
+        last = eng.gpt2_logits(x, all_positions=False).cpu()
+        np.testing.assert_array_equal(full[:, -1].numpy(), last.numpy())
+        np.testing.assert_allclose(last[:, ::5].numpy(), g[f"last_sub_L{L}"], atol=2e-4)
+        np.testing.assert_array_equal(last.topk(8, -1).indices.numpy(), g[f"top_i_L{L}"])
+        np.testing.assert_allclose(torch.logsumexp(last, -1).numpy(), g[f"lse_L{L}"], atol=1e-4)
+        step = max(1, dims.vocab // 64)
+        np.testing.assert_allclose(full[:, :, ::step].numpy(), g[f"allpos_sub_L{L}"], atol=2e-4)
+
+
+def test_gpt2_logits_tiny(eng, golden):
+    _check_logits(eng, golden("gpt2_logits_tiny"), synth.GPT2_TINY)
+
+
+def test_gpt2_logits_small(eng, golden):
+    _check_logits(eng, golden("gpt2_logits_small"), synth.GPT2_SMALL)
+
+
+def test_wte_lookup(eng):
+    sd = synth.hot_gpt2_state_dict(42, synth.GPT2_TINY)
+    eng.load_gpt2(sd)
+    ids = torch.tensor([[0, 5, 1530], [7, 7, 3]])
+    np.testing.assert_array_equal(eng.wte(ids).cpu().numpy(), sd["gpt.transformer.wte.weight"][ids].numpy())
+
+
+# ----------------------------------------------------------------------------------- decode vs golden
+def _check_decode(g, dims):
+    from capdec_amd import gpt2_prefix_eval as E
+    # greedy: config-1 shape (8 x 640-d, MLP mapper)
+    model, sd = _model(dims, "mlp", 640)
+    assert synth.state_dict_checksum(sd) == int(g["greedy_sd_crc"]), "RNG drift"
+    pe = model.clip_project(T(g["greedy_x"])).reshape(8, 10, -1)
+    np.testing.assert_allclose(pe.cpu().numpy(), g["greedy_prefix_embed"], atol=2e-5)
+    pe = T(g["greedy_prefix_embed"])           # decode from the reference's own fp32 prefix
+    stop = int(g["greedy_stop_id"])
+    for el in (12, 67):
+        ids, lens = E.decode_greedy_ids(model, pe, stop, el)
+        np.testing.assert_array_equal(lens.cpu().numpy(), g[f"greedy_lens_T{el}"])
+        np.testing.assert_array_equal(ids.cpu().numpy(), g[f"greedy_ids_T{el}"])
+    ids, lens = E.decode_greedy_ids(model, pe, dims.vocab + 5, 67, alt_stop_id=-1)
+    np.testing.assert_array_equal(ids.cpu().numpy(), g["greedy_ids_nostop"])
+    # reference signature, one caption at a time
+    for r in range(8):
+        n = int(g["greedy_lens_T12"][r])
+        want = " ".join(str(int(v)) for v in g["greedy_ids_T12"][r][:n])
+        if n == 1:
+            with pytest.raises(TypeError):      # reference :191 raises when the first token stops
+                E.generate2(model, FakeTok(stop), embed=pe[r:r + 1], entry_length=12)
+        else:
+            assert E.generate2(model, FakeTok(stop), embed=pe[r:r + 1], entry_length=12) == want
+    # beam: config-3 shape (512-d, TransformerMapper, beam 5)
+    model, sd = _model(dims, "transformer_encoder", 512)
+    assert synth.state_dict_checksum(sd) == int(g["beam_sd_crc"]), "RNG drift"
+    nb = g["beam_x"].shape[0]
+    pe = model.clip_project(T(g["beam_x"])).reshape(nb, 10, -1)
+    np.testing.assert_allclose(pe.cpu().numpy(), g["beam_prefix_embed"], atol=2e-4)
+    pe = T(g["beam_prefix_embed"])
+    for el in (12, 67):
+        for name, st in (("nostop", dims.vocab + 5), ("stop", int(g["beam_stop_id"]))):
+            ids, lens, scores, order = E.decode_beam_ids(model, pe, st, 5, el)
+            ids, lens, scores, order = (t.cpu().numpy() for t in (ids, lens, scores, order))
+            gt, gl = g[f"beam_{name}_tokens_T{el}"], g[f"beam_{name}_seqlen_T{el}"]
+            gs, go = g[f"beam_{name}_scores_T{el}"], g[f"beam_{name}_order_T{el}"]
+            np.testing.assert_array_equal(order, go)                     # same beams, same ranking
+            for r in range(nb):
+                np.testing.assert_array_equal(ids[r], gt[r][go[r]])
+                np.testing.assert_array_equal(lens[r], gl[r][go[r]].astype(np.int32))
+                np.testing.assert_allclose(scores[r], gs[r][go[r]], atol=1e-4)
+    st = int(g["beam_stop_id"])
+    for r in range(nb):
+        got = E.generate_beam(model, FakeTok(st), embed=pe[r:r + 1], entry_length=12)
+        gt, gl, go = g["beam_stop_tokens_T12"][r], g["beam_stop_seqlen_T12"][r], g["beam_stop_order_T12"][r]
+        want = [" ".join(str(int(v)) for v in gt[b][:int(gl[b])]) for b in go]
+        assert got == want
+
+
+def test_decode_tiny_vs_reference_golden(golden):
+    _check_decode(golden("decode_tiny"), synth.GPT2_TINY)
+
+
+def test_decode_small_vs_reference_golden(golden):
+    """full GPT-2 small geometry (12 layers, V = 50257): greedy ids bit-identical to the reference"""
+    _check_decode(golden("decode_small"), synth.GPT2_SMALL)
+
+
+# ----------------------------------------------------------------------------------- decode vs oracle, bigger batches
+def test_batched_decode_vs_oracle_and_chunking():
+    from capdec_amd import gpt2_prefix_eval as E
+    from oracle import capdec_oracle as O
+    dims = synth.GPT2_TINY
+    model, sd = _model(dims, "mlp", 512, seed=7)
+    x = synth.synthetic_clip_embeddings(37, 512, seed=11)          # ragged vs the 128-row GEMM tile
+    pe = model.clip_project(x).reshape(37, 10, -1).cpu()
+    ids_o, lens_o = O.greedy_cached(sd, pe, stop_id=443, entry_length=20)
+    ids, lens = E.decode_greedy_ids(model, pe, 443, 20)
+    np.testing.assert_array_equal(ids.cpu().numpy(), ids_o.numpy())
+    np.testing.assert_array_equal(lens.cpu().numpy(), lens_o.numpy())
+    tok_o, seq_o, sc_o = O.beam_cached(sd, pe, 5, 614, 20)
+    order_o = O.beam_output_order(sc_o)
+    def run():
+        i, l, s, o = E.decode_beam_ids(model, pe, 614, 5, 20)
+        return i.cpu().numpy(), l.cpu().numpy(), s.cpu().numpy(), o.cpu().numpy()
+    i1, l1, s1, o1 = run()
+    np.testing.assert_array_equal(o1, order_o.numpy())
+    for r in range(37):
+        np.testing.assert_array_equal(i1[r], tok_o[r][order_o[r]].numpy())
+        np.testing.assert_array_equal(l1[r], seq_o[r][order_o[r]].numpy())
+        np.testing.assert_allclose(s1[r], sc_o[r][order_o[r]].numpy(), atol=1e-4)
+    # tiny KV budget -> many chunks; results must not change
+    from capdec_amd import _capi
+    _capi.check(model.engine.lib.capdec_set_kv_budget(model.engine._h, 3 * 5 * 29 * 768 * 2 * 4 * 2), "budget")
+    i2, l2, s2, o2 = run()
+    np.testing.assert_array_equal(i1, i2)
+    np.testing.assert_array_equal(l1, l2)
+    np.testing.assert_array_equal(s1, s2)
+    # other beam widths
+    for bw in (1, 3, 8):
+        tok_o, seq_o, sc_o = O.beam_cached(sd, pe[:6], bw, 614, 9)
+        od = O.beam_output_order(sc_o)
+        i, l, s, o = E.decode_beam_ids(model, pe[:6], 614, bw, 9)
+        for r in range(6):
+            np.testing.assert_array_equal(i.cpu().numpy()[r], tok_o[r][od[r]].numpy())
+
+
+def test_decode_edge_cases():
+    from capdec_amd import gpt2_prefix_eval as E
+    from capdec_amd._capi import CapdecError
+    model, sd = _model(synth.GPT2_TINY, "mlp", 512, seed=7)
+    empty = torch.zeros(0, 10, 768)
+    ids, lens = E.decode_greedy_ids(model, empty, 13, 5)
+    assert ids.shape == (0, 5) and lens.shape == (0,)
+    pe = torch.randn(2, 1, 768, generator=torch.Generator().manual_seed(0))       # prefix_length 1
+    ids, lens = E.decode_greedy_ids(model, pe, 10 ** 6, 1)                       # entry_length 1
+    assert ids.shape == (2, 1) and (lens.cpu() == 1).all()
+    with pytest.raises(CapdecError):                                             # beyond n_positions (128)
+        E.decode_greedy_ids(model, torch.zeros(1, 100, 768), 13, 67)
+    with pytest.raises(CapdecError):
+        E.decode_beam_ids(model, pe, 13, 9, 5)                                   # beam > 8
+
+
+def test_full_size_properties():
+    """BASELINE geometry (GPT-2 small, P = 10, T = 67, beam 5) where the oracle is too slow:
+    size-independent properties -- determinism, batch-composition invariance, beam-1 == greedy,
+    scores sorted, lengths consistent with stop ids."""
+    from capdec_amd import gpt2_prefix_eval as E
+    model, sd = _model(synth.GPT2_SMALL, "transformer_encoder", 512)
+    x = synth.synthetic_clip_embeddings(96, 512, seed=0)
+    pe = model.clip_project(x).reshape(96, 10, -1)
+    ids, lens = E.decode_greedy_ids(model, pe, 13, 67)
+    ids2, lens2 = E.decode_greedy_ids(model, pe, 13, 67)
+    assert torch.equal(ids, ids2) and torch.equal(lens, lens2)
+    sub = torch.tensor([5, 90, 17, 3])
+    ids_s, lens_s = E.decode_greedy_ids(model, pe[sub.cuda()], 13, 67)
+    assert torch.equal(ids_s, ids[sub.cuda()]) and torch.equal(lens_s, lens[sub.cuda()])
+    b_ids, b_lens, b_sc, _ = E.decode_beam_ids(model, pe[:16], 13, 1, 67)
+    # beam-1 stops only on stop_id (generate_beam has no alt id 764): compare the common prefix
+    n = torch.minimum(b_lens[:, 0], lens[:16]).cpu()
+    for r in range(16):
+        assert torch.equal(b_ids[r, 0, :n[r]].cpu(), ids[r, :n[r]].cpu())
+    i5, l5, s5, _ = E.decode_beam_ids(model, pe[:32], 13, 5, 67)
+    s5 = s5.cpu()
+    assert bool((s5[:, :-1] >= s5[:, 1:]).all()) and bool(torch.isfinite(s5).all())
+    assert int(l5.min()) >= 1 and int(l5.max()) <= 67
+    # a stop id taken from the output must cut exactly there (greedy)
+    first = int(ids[0, 3])
+    ids_c, lens_c = E.decode_greedy_ids(model, pe[:1], first, 67)
+    k = int((ids[0] == first).nonzero()[0])
+    assert int(lens_c[0]) == k + 1 and torch.equal(ids_c[0, :k + 1], ids[0, :k + 1])

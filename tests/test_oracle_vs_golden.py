@@ -1,0 +1,150 @@
+"""Pin the CPU oracle (oracle/capdec_oracle.py) against outputs of the reference itself
+(tests/golden/*.npz, produced by tools/gen_golden.py from the reference import)."""
+import numpy as np
+import pytest
+import torch
+
+from capdec_amd import synth
+from oracle import capdec_oracle as O
+
+T = torch.from_numpy
+
+
+def _sd_gpt(dims):
+    return synth.hot_gpt2_state_dict(42, dims)
+
+
+# ------------------------------------------------------------------ mappers
+@pytest.mark.parametrize("D", [512, 640])
+def test_mlp_mapper(golden, D):
+    g = golden("mappers")
+    sd = synth.hot_mlp_mapper_state_dict(43, D, 10)
+    assert synth.state_dict_checksum(sd) == int(g[f"mlp_{D}_crc"]), "RNG drift: weights differ from fixture"
+    y = O.mlp_mapper(T(g[f"x_{D}"]), sd)
+    np.testing.assert_allclose(y.numpy(), g[f"mlp_{D}"], rtol=0, atol=1e-5)
+
+
+@pytest.mark.parametrize("D", [512, 640])
+def test_transformer_mapper(golden, D):
+    g = golden("mappers")
+    sd = synth.hot_transformer_mapper_state_dict(43, D, 10, 10, 8)
+    assert synth.state_dict_checksum(sd) == int(g[f"tm_{D}_crc"])
+    y = O.transformer_mapper(T(g[f"x_{D}"]), sd, 10, 8)
+    np.testing.assert_allclose(y.numpy(), g[f"tm_{D}"], rtol=0, atol=2e-4)
+
+
+def test_transformer_mapper_ragged_geometry(golden):
+    g = golden("mappers")
+    sd = synth.hot_transformer_mapper_state_dict(44, 512, 5, 7, 3)
+    y = O.transformer_mapper(T(g["x_p5"]), sd, 7, 3)
+    assert y.shape == (3, 5, 768)
+    np.testing.assert_allclose(y.numpy(), g["tm_p5"], rtol=0, atol=2e-4)
+
+
+# ------------------------------------------------------------------ noise
+def test_noise_injection(golden):
+    g = golden("noise")
+    x, noise, u = T(g["x"]), T(g["noise"]), T(g["u"])
+    off = T(g["offset_to_add_in_training"])
+    assert O.noise_injection(x, 0.0) is x                      # variance 0: unchanged, not normalised
+    np.testing.assert_array_equal(O.noise_injection(x, 0.0).numpy(), g["v0"])
+    np.testing.assert_allclose(O.noise_injection(x, 0.016, noise=noise).numpy(), g["v016"], atol=1e-6)
+    np.testing.assert_allclose(O.noise_injection(x, 0.016, off, noise=noise).numpy(), g["v016_off"], atol=1e-6)
+    np.testing.assert_allclose(O.noise_injection(x, 0.016, dont_norm=True, noise=noise).numpy(),
+                               g["v016_dontnorm"], atol=1e-6)
+    np.testing.assert_allclose(O.noise_injection(x, 0.016, uniform_noise=True, noise=noise, u=u).numpy(),
+                               g["v016_uniform"], atol=1e-6)
+    ball = O.uniform_ball_noise((6, 640), 0.3, noise, u)
+    np.testing.assert_allclose(ball.numpy(), g["ball"], atol=1e-7)
+    assert float(ball.norm(dim=1).max()) <= 0.3 + 1e-6
+
+
+def test_normalize_prefix(golden):
+    g = golden("noise")
+    x = T(g["x"])
+    y = O.normalize_prefix(x[:1], T(g["offset_to_add_in_inference"]))
+    ref = x[:1] / x[:1].norm(2, -1) + T(g["offset_to_add_in_inference"])   # predictions_runner.py:222-224, B = 1
+    np.testing.assert_array_equal(y.numpy(), ref.numpy())
+
+
+# ------------------------------------------------------------------ GPT-2 logits
+def _check_logits(g, dims):
+    sd = _sd_gpt(dims)
+    assert synth.state_dict_checksum(sd) == int(g["gpt_crc"]), "RNG drift"
+    for L in (1, 10, 23, 77):
+        x = T(g[f"x_L{L}"])
+        logits = O.gpt2_logits(x, sd)
+        last = logits[:, -1]
+        np.testing.assert_allclose(last[:, ::5].numpy(), g[f"last_sub_L{L}"], atol=2e-4)
+        np.testing.assert_array_equal(last.topk(8, -1).indices.numpy(), g[f"top_i_L{L}"])
+        np.testing.assert_allclose(torch.logsumexp(last, -1).numpy(), g[f"lse_L{L}"], atol=1e-4)
+        step = max(1, dims.vocab // 64)
+        np.testing.assert_allclose(logits[:, :, ::step].numpy(), g[f"allpos_sub_L{L}"], atol=2e-4)
+        # cached single-step == uncached last position
+        if L > 1:
+            cache = [None] * dims.n_layer
+            O.gpt2_hidden(x[:, :-1], sd, cache=cache)
+            h = O.gpt2_hidden(x[:, -1:], sd, pos0=L - 1, cache=cache)[:, -1]
+            lc = h @ sd["gpt.transformer.wte.weight"].t()
+            np.testing.assert_allclose(lc.numpy(), last.numpy(), atol=2e-4)
+
+
+def test_gpt2_logits_tiny(golden):
+    _check_logits(golden("gpt2_logits_tiny"), synth.GPT2_TINY)
+
+
+@pytest.mark.slow
+def test_gpt2_logits_small(golden):
+    _check_logits(golden("gpt2_logits_small"), synth.GPT2_SMALL)
+
+
+# ------------------------------------------------------------------ decode
+def _check_decode(g, dims, n_ref_greedy, n_ref_beam):
+    # greedy -- config 1 shape
+    sd = synth.hot_state_dict(42, "mlp", 640, 10, dims=dims)
+    assert synth.state_dict_checksum(sd) == int(g["greedy_sd_crc"]), "RNG drift"
+    x = T(g["greedy_x"])
+    pe = O.clip_project(x, sd, "mlp", 10)
+    np.testing.assert_allclose(pe.numpy(), g["greedy_prefix_embed"], atol=1e-5)
+    pe = T(g["greedy_prefix_embed"])
+    stop = int(g["greedy_stop_id"])
+    for el in (12, 67):
+        ids, lens = O.greedy_cached(sd, pe, stop_id=stop, entry_length=el)
+        np.testing.assert_array_equal(lens.numpy(), g[f"greedy_lens_T{el}"])
+        np.testing.assert_array_equal(ids.numpy(), g[f"greedy_ids_T{el}"])
+    ids, lens = O.greedy_cached(sd, pe, stop_id=dims.vocab + 5, entry_length=67, alt_stop_id=-1)
+    np.testing.assert_array_equal(ids.numpy(), g["greedy_ids_nostop"])
+    for r in range(n_ref_greedy):                       # reference-shaped (no cache) variant
+        t = O.generate2_ref(sd, pe[r:r + 1], stop_id=stop, entry_length=12)
+        assert t == list(g["greedy_ids_T12"][r][:int(g["greedy_lens_T12"][r])])
+    # beam -- config 3 shape
+    sd = synth.hot_state_dict(42, "transformer_encoder", 512, 10, dims=dims)
+    assert synth.state_dict_checksum(sd) == int(g["beam_sd_crc"]), "RNG drift"
+    pe = O.clip_project(T(g["beam_x"]), sd, "transformer_encoder", 10)
+    np.testing.assert_allclose(pe.numpy(), g["beam_prefix_embed"], atol=2e-4)
+    pe = T(g["beam_prefix_embed"])
+    for el in (12, 67):
+        for name, st in (("nostop", dims.vocab + 5), ("stop", int(g["beam_stop_id"]))):
+            tok, seq, sc = O.beam_cached(sd, pe, 5, st, el)
+            np.testing.assert_array_equal(tok.numpy(), g[f"beam_{name}_tokens_T{el}"])
+            np.testing.assert_array_equal(seq.numpy(), g[f"beam_{name}_seqlen_T{el}"].astype(np.int32))
+            np.testing.assert_allclose(sc.numpy(), g[f"beam_{name}_scores_T{el}"], atol=1e-4)
+            np.testing.assert_array_equal(O.beam_output_order(sc).numpy(), g[f"beam_{name}_order_T{el}"])
+    st = int(g["beam_stop_id"])
+    for r in range(n_ref_beam):
+        tok, seq, sc, order = O.generate_beam_ref(sd, pe[r:r + 1], 5, st, 12)
+        T12 = g["beam_stop_tokens_T12"][r]
+        np.testing.assert_array_equal(tok.numpy(), T12[:, :tok.shape[1]])
+        assert not T12[:, tok.shape[1]:].any()
+        np.testing.assert_array_equal(seq.numpy(), g["beam_stop_seqlen_T12"][r])
+        np.testing.assert_allclose(sc.numpy(), g["beam_stop_scores_T12"][r], atol=1e-4)
+        np.testing.assert_array_equal(order.numpy(), g["beam_stop_order_T12"][r])
+
+
+def test_decode_tiny(golden):
+    _check_decode(golden("decode_tiny"), synth.GPT2_TINY, 8, 6)
+
+
+@pytest.mark.slow
+def test_decode_small(golden):
+    _check_decode(golden("decode_small"), synth.GPT2_SMALL, 1, 1)

@@ -1,0 +1,277 @@
+#!/usr/bin/env python
+"""Generate tests/golden/*.npz by running the REFERENCE implementation (imported from
+/root/reference, build container only) on seeded inputs and seeded "hot" weights.
+
+Only inputs, seeds and outputs are written -- never reference source.  The reference has
+no tests of its own; these files are the pins the oracle
+(oracle/capdec_oracle.py) and the HIP path are checked against.
+
+Shim sequence = SURVEY.md Appendix A (transformers>=5 has no AdamW; clip / pycocotools are
+not installed; train.py hard-codes cuda:0; no 'gpt2' checkpoint offline).
+
+usage: python tools/gen_golden.py [--only NAME ...]
+"""
+from __future__ import annotations
+
+import argparse
+import os
+import pickle
+import sys
+import types
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+REF = "/root/reference"
+OUT = os.path.join(ROOT, "tests", "golden")
+
+from capdec_amd import synth  # noqa: E402
+
+
+# ---------------------------------------------------------------------------- reference import
+def import_reference():
+    sys.path.insert(0, REF)
+    import transformers
+    from transformers import GPT2LMHeadModel, GPT2Tokenizer, get_linear_schedule_with_warmup
+    stub = types.ModuleType("transformers")
+    stub.GPT2LMHeadModel, stub.GPT2Tokenizer = GPT2LMHeadModel, GPT2Tokenizer
+    stub.AdamW, stub.get_linear_schedule_with_warmup = torch.optim.AdamW, get_linear_schedule_with_warmup
+    real = sys.modules["transformers"]
+    sys.modules["transformers"] = stub
+    sys.modules["clip"] = types.ModuleType("clip")
+    pc, pcc = types.ModuleType("pycocotools"), types.ModuleType("pycocotools.coco")
+    pcc.COCO = object
+    sys.modules["pycocotools"], sys.modules["pycocotools.coco"] = pc, pcc
+    import gpt2_prefix, gpt2_prefix_eval, transformer_mapper, train as ref_train  # noqa: E401
+    sys.modules["transformers"] = real
+    ref_train.device = torch.device("cpu")
+    return gpt2_prefix, gpt2_prefix_eval, transformer_mapper, ref_train
+
+
+class FakeTok:
+    """generate_* only need encode('.')[0] and decode(ids)."""
+
+    def __init__(self, stop=13):
+        self.stop = stop
+
+    def encode(self, s):
+        return [self.stop]
+
+    def decode(self, ids):
+        return " ".join(str(int(i)) for i in ids)
+
+
+def build_ref_model(gpt2_prefix, dims, mapping_type, prefix_dim, P, clip_length=10, num_layers=8, seed=42):
+    from transformers import GPT2Config, GPT2LMHeadModel
+    cfg = GPT2Config(n_layer=dims.n_layer, n_head=dims.n_head, n_embd=dims.n_embd, vocab_size=dims.vocab,
+                     n_positions=dims.n_pos)
+    GPT2LMHeadModel.from_pretrained = staticmethod(lambda name, *a, **k: GPT2LMHeadModel(cfg))
+    mt = {"mlp": gpt2_prefix.MappingType.MLP, "transformer_encoder": gpt2_prefix.MappingType.TransformerEncoder}[mapping_type]
+    model = gpt2_prefix.ClipCaptionModel(P, clip_length=clip_length, prefix_dim=prefix_dim, num_layers=num_layers,
+                                         mapping_type=mt).eval()
+    sd = synth.hot_state_dict(seed, mapping_type, prefix_dim, P, clip_length, num_layers, dims)
+    missing, unexpected = model.load_state_dict(sd, strict=False)
+    assert not unexpected, unexpected
+    assert all(".attn.bias" in m or ".attn.masked_bias" in m for m in missing), missing
+    return model, sd
+
+
+def capture_beam(gpt2_prefix_eval, model, tok, embed, entry_length):
+    """Run reference generate_beam and capture its final locals via sys.setprofile."""
+    got = {}
+
+    def prof(frame, event, arg):
+        if event == "return" and frame.f_code.co_name == "generate_beam":
+            loc = frame.f_locals
+            got["tokens"] = loc["tokens"].cpu().numpy().astype(np.int64)
+            got["seq_lengths"] = loc["seq_lengths"].cpu().numpy().astype(np.float32)
+            got["scores"] = loc["scores"].cpu().numpy().astype(np.float32)
+            got["order"] = loc["order"].cpu().numpy().astype(np.int64)
+
+    sys.setprofile(prof)
+    try:
+        texts = gpt2_prefix_eval.generate_beam(model, tok, embed=embed, entry_length=entry_length)
+    finally:
+        sys.setprofile(None)
+    got["texts"] = texts
+    return got
+
+
+def pad_tokens(tok, T, beam=5):
+    out = np.zeros((beam, T), np.int64)
+    out[:, :tok.shape[1]] = tok
+    return out
+
+
+# ---------------------------------------------------------------------------- fixture writers
+def gen_mappers(refs):
+    gpt2_prefix, _, transformer_mapper, _ = refs
+    out = {}
+    for D in (512, 640):
+        x = synth.synthetic_clip_embeddings(4, D, seed=10 + D)
+        out[f"x_{D}"] = x.numpy()
+        sd = synth.hot_mlp_mapper_state_dict(43, D, 10)
+        m = gpt2_prefix.MLP((D, 3840, 7680)).eval()
+        m.load_state_dict({k[len("clip_project."):]: v for k, v in sd.items()})
+        with torch.no_grad():
+            out[f"mlp_{D}"] = m(x).numpy()
+        out[f"mlp_{D}_crc"] = np.uint32(synth.state_dict_checksum(sd))
+        sd = synth.hot_transformer_mapper_state_dict(43, D, 10, 10, 8)
+        m = transformer_mapper.TransformerMapper(D, 768, 10, 10, 8).eval()
+        m.load_state_dict({k[len("clip_project."):]: v for k, v in sd.items()})
+        with torch.no_grad():
+            out[f"tm_{D}"] = m(x).numpy()
+        out[f"tm_{D}_crc"] = np.uint32(synth.state_dict_checksum(sd))
+    # a second geometry: prefix_length 5, clip_length 7, 3 layers (ragged vs the default)
+    x = synth.synthetic_clip_embeddings(3, 512, seed=77)
+    sd = synth.hot_transformer_mapper_state_dict(44, 512, 5, 7, 3)
+    m = transformer_mapper.TransformerMapper(512, 768, 5, 7, 3).eval()
+    m.load_state_dict({k[len("clip_project."):]: v for k, v in sd.items()})
+    with torch.no_grad():
+        out["x_p5"], out["tm_p5"] = x.numpy(), m(x).numpy()
+    np.savez_compressed(os.path.join(OUT, "mappers.npz"), **out)
+    print("mappers.npz", {k: getattr(v, "shape", v) for k, v in out.items()})
+
+
+def gen_noise(refs):
+    _, _, _, ref_train = refs
+    out = {}
+    centers = pickle.load(open(os.path.join(REF, "others", "CLIP_embeddings_centers_info.pkl"), "rb"))
+    off = centers["offset_to_add_in_training"].float()
+    out["offset_to_add_in_training"] = off.numpy()
+    out["offset_to_add_in_inference"] = centers["offset_to_add_in_inference"].float().numpy()
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(6, 640, generator=g) * 3.0
+    noise = torch.randn(6, 640, generator=g)
+    u = torch.rand(6, generator=g)
+    out["x"], out["noise"], out["u"] = x.numpy(), noise.numpy(), u.numpy()
+    real_randn, real_rand = torch.randn, torch.rand
+    try:
+        torch.randn = lambda *a, **k: noise.clone()
+        torch.rand = lambda *a, **k: u.clone()
+        out["v0"] = ref_train.noise_injection(x.clone(), 0.0).numpy()
+        out["v016"] = ref_train.noise_injection(x.clone(), 0.016).numpy()
+        out["v016_off"] = ref_train.noise_injection(x.clone(), 0.016, modality_offset=off).numpy()
+        out["v016_dontnorm"] = ref_train.noise_injection(x.clone(), 0.016, dont_norm=True).numpy()
+        out["v016_uniform"] = ref_train.noise_injection(x.clone(), 0.016, uniform_noise=True).numpy()
+        out["ball"] = ref_train.get_uniform_ball_noise((6, 640), radius=0.3).numpy()
+    finally:
+        torch.randn, torch.rand = real_randn, real_rand
+    np.savez_compressed(os.path.join(OUT, "noise.npz"), **out)
+    print("noise.npz", {k: v.shape for k, v in out.items()})
+
+
+def gen_gpt2_logits(refs, dims, tag):
+    gpt2_prefix = refs[0]
+    model, sd = build_ref_model(gpt2_prefix, dims, "mlp", 512, 10)
+    out = {"gpt_crc": np.uint32(synth.state_dict_checksum({k: v for k, v in sd.items() if k.startswith("gpt.")}))}
+    g = torch.Generator().manual_seed(7)
+    for L in (1, 10, 23, 77):
+        x = torch.randn(2, L, 768, generator=g) * 0.5
+        with torch.no_grad():
+            logits = model.gpt(inputs_embeds=x).logits  # [2, L, V]
+        last = logits[:, -1, :]
+        out[f"x_L{L}"] = x.numpy()
+        out[f"last_sub_L{L}"] = last[:, ::5].numpy()
+        tv, ti = last.topk(8, -1)
+        out[f"top_v_L{L}"], out[f"top_i_L{L}"] = tv.numpy(), ti.numpy()
+        out[f"lse_L{L}"] = torch.logsumexp(last, -1).numpy()
+        # logits of every position for a few columns (checks non-last rows / causal mask)
+        out[f"allpos_sub_L{L}"] = logits[:, :, :: max(1, dims.vocab // 64)].numpy()
+    np.savez_compressed(os.path.join(OUT, f"gpt2_logits_{tag}.npz"), **out)
+    print(f"gpt2_logits_{tag}.npz written")
+
+
+def gen_decode(refs, dims, tag, n_greedy, n_beam, lengths):
+    gpt2_prefix, gpt2_prefix_eval = refs[0], refs[1]
+    out = {}
+    # ---- greedy: config 1 shape -- 8 x 640-d embeddings, MLP mapper, P = 10
+    model, sd = build_ref_model(gpt2_prefix, dims, "mlp", 640, 10)
+    out["greedy_sd_crc"] = np.uint32(synth.state_dict_checksum(sd))
+    x = synth.synthetic_clip_embeddings(n_greedy, 640, seed=1)
+    out["greedy_x"] = x.numpy()
+    T = max(lengths)
+    ids_free = np.zeros((n_greedy, T), np.int64)
+    with torch.no_grad():
+        pe = model.clip_project(x).reshape(n_greedy, 10, -1)
+        out["greedy_prefix_embed"] = pe.numpy()
+        # pass 1: stop id that never fires (-> full-length sequences)
+        for r in range(n_greedy):
+            txt = gpt2_prefix_eval.generate2(model, FakeTok(stop=dims.vocab + 5), embed=pe[r:r + 1], entry_length=T)
+            ids_free[r] = [int(t) for t in txt.split()]
+    out["greedy_ids_nostop"] = ids_free
+    # pass 2: choose a stop id that occurs mid-sequence in several rows
+    vals, counts = np.unique(ids_free[:, 2:], return_counts=True)
+    stop = int(vals[np.argmax(counts)])
+    out["greedy_stop_id"] = np.int64(stop)
+    for el in lengths:
+        ids = np.zeros((n_greedy, el), np.int64)
+        lens = np.zeros(n_greedy, np.int64)
+        with torch.no_grad():
+            for r in range(n_greedy):
+                txt = gpt2_prefix_eval.generate2(model, FakeTok(stop=stop), embed=pe[r:r + 1], entry_length=el)
+                t = [int(v) for v in txt.split()]
+                ids[r, :len(t)], lens[r] = t, len(t)
+        out[f"greedy_ids_T{el}"], out[f"greedy_lens_T{el}"] = ids, lens
+    # ---- beam: config 3 shape -- 512-d embeddings, TransformerMapper(8 layers), P = 10, beam 5
+    model, sd = build_ref_model(gpt2_prefix, dims, "transformer_encoder", 512, 10)
+    out["beam_sd_crc"] = np.uint32(synth.state_dict_checksum(sd))
+    x = synth.synthetic_clip_embeddings(n_beam, 512, seed=2)
+    out["beam_x"] = x.numpy()
+    with torch.no_grad():
+        pe = model.clip_project(x).reshape(n_beam, 10, -1)
+        out["beam_prefix_embed"] = pe.numpy()
+        first = [capture_beam(gpt2_prefix_eval, model, FakeTok(stop=dims.vocab + 5), pe[r:r + 1], min(lengths))
+                 for r in range(n_beam)]
+    allt = np.concatenate([f["tokens"][:, 1:].reshape(-1) for f in first])
+    vals, counts = np.unique(allt, return_counts=True)
+    stop = int(vals[np.argmax(counts)])
+    out["beam_stop_id"] = np.int64(stop)
+    for el in lengths:
+        for name, st in (("nostop", dims.vocab + 5), ("stop", stop)):
+            toks = np.zeros((n_beam, 5, el), np.int64)
+            seql = np.zeros((n_beam, 5), np.float32)
+            scs = np.zeros((n_beam, 5), np.float32)
+            order = np.zeros((n_beam, 5), np.int64)
+            with torch.no_grad():
+                for r in range(n_beam):
+                    got = capture_beam(gpt2_prefix_eval, model, FakeTok(stop=st), pe[r:r + 1], el)
+                    toks[r] = pad_tokens(got["tokens"], el)
+                    seql[r], scs[r], order[r] = got["seq_lengths"], got["scores"], got["order"]
+                    # the texts the function returns must equal decode(tokens[b,:len]) in `order`
+                    exp = [" ".join(str(int(v)) for v in got["tokens"][b, :int(got["seq_lengths"][b])]) for b in got["order"]]
+                    assert exp == got["texts"], (exp, got["texts"])
+            out[f"beam_{name}_tokens_T{el}"] = toks
+            out[f"beam_{name}_seqlen_T{el}"] = seql
+            out[f"beam_{name}_scores_T{el}"] = scs
+            out[f"beam_{name}_order_T{el}"] = order
+    np.savez_compressed(os.path.join(OUT, f"decode_{tag}.npz"), **out)
+    print(f"decode_{tag}.npz written; greedy stop {out['greedy_stop_id']}, beam stop {out['beam_stop_id']}")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--only", nargs="*", default=None)
+    args = ap.parse_args()
+    os.makedirs(OUT, exist_ok=True)
+    torch.set_num_threads(os.cpu_count() or 8)
+    refs = import_reference()
+    jobs = {
+        "mappers": lambda: gen_mappers(refs),
+        "noise": lambda: gen_noise(refs),
+        "logits_tiny": lambda: gen_gpt2_logits(refs, synth.GPT2_TINY, "tiny"),
+        "logits_small": lambda: gen_gpt2_logits(refs, synth.GPT2_SMALL, "small"),
+        "decode_tiny": lambda: gen_decode(refs, synth.GPT2_TINY, "tiny", 8, 6, (12, 67)),
+        "decode_small": lambda: gen_decode(refs, synth.GPT2_SMALL, "small", 8, 4, (12, 67)),
+    }
+    for name, fn in jobs.items():
+        if args.only and name not in args.only:
+            continue
+        print("==", name)
+        fn()
+
+
+if __name__ == "__main__":
+    main()
