@@ -7,6 +7,11 @@ import ctypes as C
 import os
 from typing import Optional
 
+# torch first: it brings its own libamdhip64.so.7; loading ours afterwards makes the dynamic
+# linker reuse that one runtime instead of mapping /opt/rocm's copy next to it (two HIP
+# runtimes in one process lose the device).
+import torch  # noqa: F401
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libcapdec_hip.so")
 
@@ -47,6 +52,7 @@ SIGNATURES = {
     "capdec_create": (C.c_int, [C.c_int, C.POINTER(_VP)]),
     "capdec_destroy": (None, [_VP]),
     "capdec_set_stream": (C.c_int, [_VP, _VP]),
+    "capdec_use_own_stream": (C.c_int, [_VP]),
     "capdec_synchronize": (C.c_int, [_VP]),
     "capdec_set_kv_budget": (C.c_int, [_VP, C.c_size_t]),
     "capdec_malloc": (C.c_int, [_VP, C.c_size_t, C.POINTER(_VP)]),

@@ -503,7 +503,12 @@ void capdec_destroy(capdec_ctx *c) {
 
 int capdec_set_stream(capdec_ctx *c, void *hip_stream) {
     CAPDEC_CHECK(c, "null context");
-    c->stream = hip_stream ? reinterpret_cast<hipStream_t>(hip_stream) : c->own_stream;
+    c->stream = reinterpret_cast<hipStream_t>(hip_stream);   // NULL = HIP's default stream
+    return 0;
+}
+int capdec_use_own_stream(capdec_ctx *c) {
+    CAPDEC_CHECK(c, "null context");
+    c->stream = c->own_stream;
     return 0;
 }
 int capdec_synchronize(capdec_ctx *c) {

@@ -44,8 +44,11 @@ const char *capdec_last_error(void);
 /* replaces `device = CUDA(0); model = model.to(device)` (reference predictions_runner.py:154-155) */
 int capdec_create(int device_id, capdec_ctx **out);
 void capdec_destroy(capdec_ctx *ctx);
-/* adopt an external hipStream_t (e.g. torch's current stream); NULL = the context's own stream */
+/* enqueue on an external hipStream_t (e.g. torch's current stream).  NULL is a valid handle:
+ * HIP's default (null) stream.  capdec_use_own_stream() goes back to the context's private
+ * non-blocking stream (the default after capdec_create). */
 int capdec_set_stream(capdec_ctx *ctx, void *hip_stream);
+int capdec_use_own_stream(capdec_ctx *ctx);
 int capdec_synchronize(capdec_ctx *ctx);
 /* cap on bytes the decode KV cache may take (captions are processed in chunks that fit);
  * 0 = default (96 GiB of the 288 GB HBM3E) */
