@@ -80,7 +80,7 @@ using namespace capdec;
 struct capdec_ctx {
     int device = 0;
     hipStream_t own_stream = nullptr, stream = nullptr;
-    size_t kv_budget = (size_t)96 << 30;
+    size_t kv_budget = (size_t)192 << 30;
     Gpt2 gpt;
     Mapper map;
     Prof prof;
@@ -518,7 +518,7 @@ int capdec_synchronize(capdec_ctx *c) {
 }
 int capdec_set_kv_budget(capdec_ctx *c, size_t bytes) {
     CAPDEC_CHECK(c, "null context");
-    c->kv_budget = bytes ? bytes : ((size_t)96 << 30);
+    c->kv_budget = bytes ? bytes : ((size_t)192 << 30);
     return 0;
 }
 int capdec_malloc(capdec_ctx *c, size_t bytes, void **d_ptr) {

@@ -55,10 +55,6 @@ __device__ __forceinline__ void tile_coords(int tiles_m, int tiles_n, int &tm, i
     tn = in_g / gsz;
 }
 
-struct MainLoop {
-    f32x16 acc[2][2];
-};
-
 // Shared main loop: accumulates the 128x128 tile at (m0, n0) into per-wave accumulators.
 __device__ __forceinline__ void gemm_mainloop(const float *__restrict__ A, int lda, const float *__restrict__ Bt,
                                               int ldb, int M, int N, int K, int m0, int n0, float *smem,
@@ -71,36 +67,38 @@ __device__ __forceinline__ void gemm_mainloop(const float *__restrict__ A, int l
     float *As = smem;                 // [2][128][36]
     float *Bs = smem + 2 * TILE_F;    // [2][128][36]
 
-    // global staging: 4 float4 per thread per operand; idx = t + 256 i -> row idx>>3, k-quad idx&7
-    float4 ra[4], rb[4];
+    // global staging: 4 float4 per thread per operand; idx = t + 256 i -> row idx>>3, k-quad idx&7.
+    // Rows past M (N) are clamped to the last valid row: they only feed C rows (columns) that are
+    // never stored, so no predication is needed and every load is a plain global_load_dwordx4.
     const int srow = t >> 3, skq = (t & 7) * 4;
-    const float *ap[4];
-    const float *bp[4];
-    bool av[4], bv[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int row = srow + 32 * i;
-        av[i] = (m0 + row) < M;
-        bv[i] = (n0 + row) < N;
-        ap[i] = A + (size_t)(av[i] ? m0 + row : 0) * lda + skq;
-        bp[i] = Bt + (size_t)(bv[i] ? n0 + row : 0) * ldb + skq;
-    }
-    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    auto gload = [&](int k0) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            ra[i] = av[i] ? *reinterpret_cast<const float4 *>(ap[i] + k0) : z4;
-            rb[i] = bv[i] ? *reinterpret_cast<const float4 *>(bp[i] + k0) : z4;
-        }
-    };
-    auto lstore = [&](int buf) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int off = buf * TILE_F + (srow + 32 * i) * LDS_LD + skq;
-            *reinterpret_cast<float4 *>(As + off) = ra[i];
-            *reinterpret_cast<float4 *>(Bs + off) = rb[i];
-        }
-    };
+    const float *ap0 = A + (size_t)min(m0 + srow, M - 1) * lda + skq;
+    const float *ap1 = A + (size_t)min(m0 + srow + 32, M - 1) * lda + skq;
+    const float *ap2 = A + (size_t)min(m0 + srow + 64, M - 1) * lda + skq;
+    const float *ap3 = A + (size_t)min(m0 + srow + 96, M - 1) * lda + skq;
+    const float *bp0 = Bt + (size_t)min(n0 + srow, N - 1) * ldb + skq;
+    const float *bp1 = Bt + (size_t)min(n0 + srow + 32, N - 1) * ldb + skq;
+    const float *bp2 = Bt + (size_t)min(n0 + srow + 64, N - 1) * ldb + skq;
+    const float *bp3 = Bt + (size_t)min(n0 + srow + 96, N - 1) * ldb + skq;
+    float4 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3;
+#define GLOAD(k0)                                                  \
+    ra0 = *reinterpret_cast<const float4 *>(ap0 + (k0));           \
+    rb0 = *reinterpret_cast<const float4 *>(bp0 + (k0));           \
+    ra1 = *reinterpret_cast<const float4 *>(ap1 + (k0));           \
+    rb1 = *reinterpret_cast<const float4 *>(bp1 + (k0));           \
+    ra2 = *reinterpret_cast<const float4 *>(ap2 + (k0));           \
+    rb2 = *reinterpret_cast<const float4 *>(bp2 + (k0));           \
+    ra3 = *reinterpret_cast<const float4 *>(ap3 + (k0));           \
+    rb3 = *reinterpret_cast<const float4 *>(bp3 + (k0));
+    const int st_off = srow * LDS_LD + skq;
+#define LSTORE(buf)                                                                              \
+    *reinterpret_cast<float4 *>(As + (buf) * TILE_F + st_off) = ra0;                             \
+    *reinterpret_cast<float4 *>(Bs + (buf) * TILE_F + st_off) = rb0;                             \
+    *reinterpret_cast<float4 *>(As + (buf) * TILE_F + st_off + 32 * LDS_LD) = ra1;               \
+    *reinterpret_cast<float4 *>(Bs + (buf) * TILE_F + st_off + 32 * LDS_LD) = rb1;               \
+    *reinterpret_cast<float4 *>(As + (buf) * TILE_F + st_off + 64 * LDS_LD) = ra2;               \
+    *reinterpret_cast<float4 *>(Bs + (buf) * TILE_F + st_off + 64 * LDS_LD) = rb2;               \
+    *reinterpret_cast<float4 *>(As + (buf) * TILE_F + st_off + 96 * LDS_LD) = ra3;               \
+    *reinterpret_cast<float4 *>(Bs + (buf) * TILE_F + st_off + 96 * LDS_LD) = rb3;
 
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -110,8 +108,8 @@ __device__ __forceinline__ void gemm_mainloop(const float *__restrict__ A, int l
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     const int nk = K / GEMM_BK;
-    gload(0);
-    lstore(0);
+    GLOAD(0)
+    LSTORE(0)
     __syncthreads();
 
     const int a_off = (wm * 64 + l32) * LDS_LD + 16 * half;
@@ -119,33 +117,29 @@ __device__ __forceinline__ void gemm_mainloop(const float *__restrict__ A, int l
 
     for (int kt = 0; kt < nk; ++kt) {
         const int buf = kt & 1;
-        if (kt + 1 < nk) gload((kt + 1) * GEMM_BK);
-        float4 fa[2][4], fb[2][4];
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                fa[i][q] = *reinterpret_cast<const float4 *>(As + buf * TILE_F + a_off + i * 32 * LDS_LD + 4 * q);
-                fb[i][q] = *reinterpret_cast<const float4 *>(Bs + buf * TILE_F + b_off + i * 32 * LDS_LD + 4 * q);
-            }
+        const bool more = kt + 1 < nk;
+        if (more) { GLOAD((kt + 1) * GEMM_BK) }
+        const float *Ab = As + buf * TILE_F + a_off;
+        const float *Bb = Bs + buf * TILE_F + b_off;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                float a0, a1, b0, b1;
-                if (c == 0) { a0 = fa[0][q].x; a1 = fa[1][q].x; b0 = fb[0][q].x; b1 = fb[1][q].x; }
-                else if (c == 1) { a0 = fa[0][q].y; a1 = fa[1][q].y; b0 = fb[0][q].y; b1 = fb[1][q].y; }
-                else if (c == 2) { a0 = fa[0][q].z; a1 = fa[1][q].z; b0 = fb[0][q].z; b1 = fb[1][q].z; }
-                else { a0 = fa[0][q].w; a1 = fa[1][q].w; b0 = fb[0][q].w; b1 = fb[1][q].w; }
-                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
-            }
+            const float4 fa0 = *reinterpret_cast<const float4 *>(Ab + 4 * q);
+            const float4 fa1 = *reinterpret_cast<const float4 *>(Ab + 32 * LDS_LD + 4 * q);
+            const float4 fb0 = *reinterpret_cast<const float4 *>(Bb + 4 * q);
+            const float4 fb1 = *reinterpret_cast<const float4 *>(Bb + 32 * LDS_LD + 4 * q);
+#define MFMA4(c)                                                                          \
+    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa0.c, fb0.c, acc[0][0], 0, 0, 0);    \
+    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa0.c, fb1.c, acc[0][1], 0, 0, 0);    \
+    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa1.c, fb0.c, acc[1][0], 0, 0, 0);    \
+    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa1.c, fb1.c, acc[1][1], 0, 0, 0);
+            MFMA4(x) MFMA4(y) MFMA4(z) MFMA4(w)
+#undef MFMA4
         }
-        if (kt + 1 < nk) lstore(buf ^ 1);
+        if (more) { LSTORE(buf ^ 1) }
         __syncthreads();
     }
+#undef GLOAD
+#undef LSTORE
 }
 
 __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const float *__restrict__ A, int lda,

@@ -51,7 +51,7 @@ int capdec_set_stream(capdec_ctx *ctx, void *hip_stream);
 int capdec_use_own_stream(capdec_ctx *ctx);
 int capdec_synchronize(capdec_ctx *ctx);
 /* cap on bytes the decode KV cache may take (captions are processed in chunks that fit);
- * 0 = default (96 GiB of the 288 GB HBM3E) */
+ * 0 = default (192 GiB of the 288 GB HBM3E) */
 int capdec_set_kv_budget(capdec_ctx *ctx, size_t bytes);
 
 /* raw device memory for hosts that do not bring their own allocator (torch is optional) */

@@ -199,7 +199,7 @@ def wte(ids: Tensor, sd: SD, g: str = "gpt.") -> Tensor:
 # ----------------------------------------------------------------------------------------
 def generate2_ref(sd: SD, embed: Tensor, stop_id: int = 13, entry_length: int = 67, top_p: float = 0.8,
                   temperature: float = 1.0, alt_stop_id: int = 764, n_head: int = 12,
-                  margins: Optional[list] = None) -> List[int]:
+                  margins: Optional[list] = None, on_step=None) -> List[int]:
     """reference gpt2_prefix_eval.py:118-198 with ``embed`` [1, P, d] given.  Keeps the sort /
     cumsum / top-p masking the reference performs (the arg-max is unaffected: rank 0 is
     never removed, :172).  Returns the id list INCLUDING the stop token."""
@@ -220,12 +220,15 @@ def generate2_ref(sd: SD, embed: Tensor, stop_id: int = 13, entry_length: int = 
         tokens.append(int(nxt.item()))
         if tokens[-1] == stop_id or tokens[-1] == alt_stop_id:
             break
+        if on_step is not None and on_step(len(tokens) - 1, 1, generated.shape[1] - 1):
+            break
     return tokens
 
 
 def generate_beam_ref(sd: SD, embed: Tensor, beam_size: int = 5, stop_id: int = 13, entry_length: int = 67,
-                      temperature: float = 1.0, n_head: int = 12) -> Tuple[Tensor, Tensor, Tensor, Tensor]:
-    """reference gpt2_prefix_eval.py:50-115 with ``embed`` [1, P, d] given.  Returns the
+                      temperature: float = 1.0, n_head: int = 12, on_step=None) -> Tuple[Tensor, Tensor, Tensor, Tensor]:
+    """reference gpt2_prefix_eval.py:50-115 with ``embed`` [1, P, d] given (``on_step`` as in
+    generate2_ref).  Returns the
     function's final internal state: ``tokens`` int64 [beam, T], ``seq_lengths`` fp32 [beam],
     mean-log-prob ``scores`` fp32 [beam] (after ``scores / seq_lengths``, :110) and
     ``order = scores.argsort(descending=True)`` (:113); the reference returns
@@ -235,7 +238,8 @@ def generate_beam_ref(sd: SD, embed: Tensor, beam_size: int = 5, stop_id: int = 
     seq_lengths = torch.ones(beam_size)
     is_stopped = torch.zeros(beam_size, dtype=torch.bool)
     generated = embed
-    for _ in range(entry_length):
+    for it in range(entry_length):
+        rows_in, L_in = generated.shape[0], generated.shape[1]
         logits = gpt2_logits(generated, sd, n_head)[:, -1, :] / (temperature if temperature > 0 else 1.0)
         logits = logits.softmax(-1).log()
         if scores is None:
@@ -261,6 +265,8 @@ def generate_beam_ref(sd: SD, embed: Tensor, beam_size: int = 5, stop_id: int = 
         generated = torch.cat((generated, emb), dim=1)
         is_stopped = is_stopped + next_tokens.eq(stop_id).squeeze()
         if is_stopped.all():
+            break
+        if on_step is not None and on_step(it, rows_in, L_in):
             break
     scores = scores / seq_lengths
     order = scores.argsort(descending=True)
