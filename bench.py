@@ -47,7 +47,7 @@ def algorithmic_flops_per_caption(P, T, beam, mapper, dims=synth.GPT2_SMALL, D=5
     f = body_tok * f_body + head_rows * f_head + att
     if mapper == "mlp":
         f += 2.0 * (D * (d * P // 2) + (d * P // 2) * d * P)
-    else:
+    elif mapper == "transformer":
         S = clip_len + P
         f += 2.0 * D * clip_len * d + 8 * S * 2.0 * (3 * d * d + d * d + 2 * d * 2 * d) + 8 * 4.0 * S * S * d
     return f

@@ -1,0 +1,176 @@
+"""CPU-side tests: the C-ABI library loads and exports every symbol include/capdec.h declares,
+the host façade mirrors the reference surface, shard/gather index math (gloo, world_size 2),
+and the product path fails loudly without a GPU (no CPU fallback)."""
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_c_abi_exports_every_header_symbol():
+    from capdec_amd import _capi, build
+    if not os.path.exists(_capi.LIB_PATH):
+        build.build()
+    header = open(os.path.join(ROOT, "include", "capdec.h")).read()
+    declared = set(re.findall(r"\b(capdec_[a-z0-9_]+)\s*\(", header))
+    declared -= {"capdec_ctx"}
+    assert len(declared) >= 25
+    assert declared == set(_capi.SIGNATURES), declared ^ set(_capi.SIGNATURES)
+    lib = _capi.load_library()                      # binds every symbol or raises
+    for name in declared:
+        assert hasattr(lib, name)
+    assert lib.capdec_abi_version() == 1
+    # the library is built for gfx950 and links the HIP runtime only (no torch types in the ABI)
+    out = subprocess.run(["nm", "-D", "--defined-only", _capi.LIB_PATH], capture_output=True, text=True).stdout
+    exported = {l.split()[-1] for l in out.splitlines() if " T " in l and "capdec_" in l.split()[-1][:7]}
+    assert declared <= exported
+
+
+def test_no_cpu_fallback_without_gpu():
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from capdec_amd._capi import CapdecError
+    from capdec_amd.engine import Engine
+    from capdec_amd.gpt2_prefix import ClipCaptionModel, MappingType
+    from capdec_amd import synth
+    with pytest.raises(CapdecError):
+        Engine(0)
+    m = ClipCaptionModel(10, prefix_dim=512, mapping_type=MappingType.MLP, gpt2_dims=synth.GPT2_TINY)
+    m.load_state_dict(synth.hot_state_dict(1, "mlp", 512, 10, dims=synth.GPT2_TINY))
+    with pytest.raises(CapdecError):
+        m.clip_project(torch.zeros(1, 512))        # needs the HIP device: must raise, never compute on CPU
+
+
+def test_product_code_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "capdec_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                txt = open(os.path.join(dirpath, f)).read()
+                assert "oracle" not in txt.replace("no oracle", ""), f"{f} mentions the oracle"
+
+
+def test_facade_surface_matches_reference_names():
+    from capdec_amd import gpt2_prefix, gpt2_prefix_eval, predictions_runner, train, transformer_mapper, synth
+    MT = gpt2_prefix.MappingType
+    assert MT('mlp') is MT.MLP and MT('transformer_encoder') is MT.TransformerEncoder
+    assert MT.Transformer is MT.TransformerEncoder and train.MappingType is MT
+    for name in ("generate_beam", "generate2"):
+        assert getattr(predictions_runner, name) is getattr(gpt2_prefix_eval, name)
+    import inspect
+    sig = inspect.signature(gpt2_prefix_eval.generate_beam)
+    assert list(sig.parameters) == ["model", "tokenizer", "beam_size", "prompt", "embed", "entry_length", "temperature", "stop_token"]
+    assert sig.parameters["beam_size"].default == 5 and sig.parameters["entry_length"].default == 67
+    sig = inspect.signature(gpt2_prefix_eval.generate2)
+    assert list(sig.parameters) == ["model", "tokenizer", "tokens", "prompt", "embed", "entry_count", "entry_length",
+                                    "top_p", "temperature", "stop_token"]
+    sig = inspect.signature(train.noise_injection)
+    assert list(sig.parameters)[:5] == ["x", "variance", "modality_offset", "uniform_noise", "dont_norm"]
+    assert sig.parameters["variance"].default == 0.001
+    sig = inspect.signature(gpt2_prefix.ClipCaptionModel.__init__)
+    assert list(sig.parameters)[1:6] == ["prefix_length", "clip_length", "prefix_dim", "num_layers", "mapping_type"]
+    assert sig.parameters["prefix_dim"].default == 640
+    m = gpt2_prefix.ClipCaptionModel(10, prefix_dim=512, mapping_type=MT.MLP, gpt2_dims=synth.GPT2_TINY)
+    assert isinstance(m.clip_project, gpt2_prefix.MLP) and m.prefix_length == 10 and m.gpt_embedding_size == 768
+    m2 = gpt2_prefix.ClipCaptionModel(10, prefix_size=512, gpt2_dims=synth.GPT2_TINY)       # train.py spelling
+    assert isinstance(m2.clip_project, transformer_mapper.TransformerMapper) and m2.prefix_dim == 512
+    assert train.noise_injection(torch.ones(2, 4), 0.0).equal(torch.ones(2, 4))              # variance 0: identity
+
+
+def test_state_dict_loading_rules():
+    from capdec_amd import synth
+    from capdec_amd.gpt2_prefix import ClipCaptionModel, MappingType
+    dims = synth.GPT2_TINY
+    sd = synth.hot_state_dict(3, "transformer_encoder", 512, 10, dims=dims)
+    m = ClipCaptionModel(10, prefix_dim=512, gpt2_dims=dims)
+    # transformers-4.24 checkpoints carry attn.bias / attn.masked_bias buffers: ignored, not rejected
+    old = dict(sd)
+    old["gpt.transformer.h.0.attn.bias"] = torch.ones(1, 1, 8, 8, dtype=torch.uint8)
+    old["gpt.transformer.h.0.attn.masked_bias"] = torch.tensor(-1e4)
+    res = m.load_state_dict(old)
+    assert not res.unexpected_keys and "gpt.transformer.h.0.attn.bias" not in m.state_dict()
+    # fp16 checkpoints are upcast like the reference's .float()
+    m.load_state_dict({k: v.half() for k, v in sd.items()})
+    assert all(v.dtype == torch.float32 for v in m.state_dict().values())
+    with pytest.raises(RuntimeError):
+        m.load_state_dict({k: v for k, v in sd.items() if not k.startswith("clip_project.")})
+    with pytest.raises(RuntimeError):
+        m.load_state_dict({**sd, "bogus.weight": torch.zeros(1)})
+    mm = ClipCaptionModel(10, prefix_dim=512, mapping_type=MappingType.MLP, gpt2_dims=dims)
+    with pytest.raises(RuntimeError):                                # transformer checkpoint into an MLP model
+        mm.load_state_dict(sd)
+
+
+def test_synth_recipe_is_deterministic():
+    from capdec_amd import synth
+    a = synth.hot_state_dict(42, "mlp", 640, 10, dims=synth.GPT2_TINY)
+    b = synth.hot_state_dict(42, "mlp", 640, 10, dims=synth.GPT2_TINY)
+    assert synth.state_dict_checksum(a) == synth.state_dict_checksum(b)
+    assert a["gpt.lm_head.weight"] is a["gpt.transformer.wte.weight"]
+    assert a["gpt.transformer.h.0.attn.c_attn.weight"].shape == (768, 2304)          # Conv1D [in, out]
+    assert a["clip_project.model.0.weight"].shape == (3840, 640)                      # nn.Linear [out, in]
+    x = synth.synthetic_clip_embeddings(5, 512, 0)
+    np.testing.assert_allclose(x.norm(dim=1).numpy(), 1.0, atol=1e-6)
+
+
+def test_algorithmic_work_matches_survey():
+    sys.path.insert(0, ROOT)
+    import bench
+    g = bench.algorithmic_flops_per_caption(10, 67, 1, "none")
+    b = bench.algorithmic_flops_per_caption(10, 67, 5, "none")
+    assert abs(g / 1e9 - 18.19) < 0.05 and abs(b / 1e9 - 83.8) < 0.2
+    assert abs(bench.algorithmic_flops_per_caption(10, 12, 1, "none") / 1e9 - 4.50) < 0.02
+
+
+def test_shard_bounds_cover_exactly():
+    from capdec_amd.distributed import shard_bounds, shard_size
+    for n in (0, 1, 7, 8, 5000, 5001):
+        for w in (1, 2, 3, 4, 8):
+            spans = [shard_bounds(n, r, w) for r in range(w)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            assert all(hi - lo <= shard_size(n, w) for lo, hi in spans)
+
+
+_WORKER = r"""
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+from capdec_amd import distributed as cd
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{sys.argv[2]}", rank=rank, world_size=world)
+N, T = 11, 6                                     # ragged: 11 rows over 2 ranks -> 6 + 5
+full = torch.arange(N * 2 * T, dtype=torch.int32).view(N, 2, T)
+lens = (torch.arange(N * 2, dtype=torch.int32) % T + 1).view(N, 2)
+scores = torch.arange(N * 2, dtype=torch.float32).view(N, 2) * -0.5
+lo, hi = cd.shard_bounds(N, rank, world)
+g_ids, g_lens, g_sc = cd.gather_ids(full[lo:hi].clone(), lens[lo:hi].clone(), N, scores[lo:hi].clone())
+assert torch.equal(g_ids, full) and torch.equal(g_lens, lens) and torch.equal(g_sc, scores), rank
+# greedy-shaped ids [n, T] and an empty shard (N < world handled by padding)
+g2, l2, _ = cd.gather_ids(full[lo:hi, 0].clone(), lens[lo:hi, 0].clone(), N)
+assert torch.equal(g2, full[:, 0]) and torch.equal(l2, lens[:, 0])
+lo1, hi1 = cd.shard_bounds(1, rank, world)
+g3 = cd.gather_rows(full[lo1:hi1, 0].clone(), 1)
+assert torch.equal(g3, full[:1, 0])
+dist.destroy_process_group()
+print("OK", rank)
+"""
+
+
+def test_gather_ids_gloo_world_size_2(tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(_WORKER)
+    port = 29500 + (os.getpid() % 2000)
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, str(script), ROOT, str(port)], env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=180)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    assert all("OK" in o for o in outs)
