@@ -44,6 +44,27 @@ class TMapperWeights(C.Structure):
                 ("layers", C.POINTER(TMapperLayer))]
 
 
+class ClipBlock(C.Structure):
+    _fields_ = [(n, c_float_p) for n in (
+        "ln_1_w", "ln_1_b", "in_proj_w", "in_proj_b", "out_proj_w", "out_proj_b", "ln_2_w", "ln_2_b",
+        "c_fc_w", "c_fc_b", "c_proj_w", "c_proj_b")]
+
+
+class ClipTextWeights(C.Structure):
+    _fields_ = [("context_length", C.c_int), ("vocab", C.c_int), ("width", C.c_int), ("heads", C.c_int),
+                ("layers", C.c_int), ("embed_dim", C.c_int), ("token_embedding", c_float_p),
+                ("positional_embedding", c_float_p), ("blocks", C.POINTER(ClipBlock)), ("ln_final_w", c_float_p),
+                ("ln_final_b", c_float_p), ("text_projection", c_float_p)]
+
+
+class ClipVisionWeights(C.Structure):
+    _fields_ = [("image_size", C.c_int), ("patch", C.c_int), ("width", C.c_int), ("heads", C.c_int),
+                ("layers", C.c_int), ("embed_dim", C.c_int), ("conv1_w", c_float_p), ("class_embedding", c_float_p),
+                ("positional_embedding", c_float_p), ("ln_pre_w", c_float_p), ("ln_pre_b", c_float_p),
+                ("blocks", C.POINTER(ClipBlock)), ("ln_post_w", c_float_p), ("ln_post_b", c_float_p),
+                ("proj", c_float_p)]
+
+
 #: every symbol include/capdec.h declares: name -> (restype, argtypes)
 _VP = C.c_void_p
 SIGNATURES = {
@@ -62,6 +83,10 @@ SIGNATURES = {
     "capdec_load_gpt2": (C.c_int, [_VP, C.POINTER(Gpt2Weights)]),
     "capdec_load_mapper_mlp": (C.c_int, [_VP, C.c_int, C.c_int, C.c_int, c_float_p, c_float_p, c_float_p, c_float_p]),
     "capdec_load_mapper_transformer": (C.c_int, [_VP, C.POINTER(TMapperWeights)]),
+    "capdec_load_clip_text": (C.c_int, [_VP, C.POINTER(ClipTextWeights)]),
+    "capdec_load_clip_vision": (C.c_int, [_VP, C.POINTER(ClipVisionWeights)]),
+    "capdec_clip_encode_text": (C.c_int, [_VP, _VP, C.c_int, _VP]),
+    "capdec_clip_encode_image": (C.c_int, [_VP, _VP, C.c_int, _VP]),
     "capdec_normalize_prefix": (C.c_int, [_VP, _VP, C.c_int, C.c_int, C.c_int, _VP, _VP]),
     "capdec_noise_inject": (C.c_int, [_VP, _VP, C.c_int, C.c_int, C.c_float, _VP, C.c_int, C.c_int, C.c_uint64,
                                       _VP, _VP, _VP]),

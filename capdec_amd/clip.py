@@ -1,0 +1,66 @@
+"""Drop-in surface of the `clip` package calls the reference makes (embeddings_generator.py:49,
+72-89; predictions_runner.py:158-161,212-220): ``load`` -> (model, preprocess) with
+``model.encode_text(tokens)`` / ``model.encode_image(images)`` running as HIP kernels.
+
+Differences that follow from the offline environment (no checkpoint / BPE vocabulary files):
+``load`` takes an OpenAI-CLIP state dict (or a ``.pt`` path holding one) instead of a model name
+to download; ``tokenize`` needs a vocabulary file and otherwise raises.  Only ViT towers
+(ViT-B/32: head_dim 64) are supported; the reference's default RN50x4 image tower is out of
+scope (its pre-extracted 640-d embeddings are supported downstream).  Compute is fp32 (the
+reference's GPU path is fp16, cast `.float()` by its callers)."""
+from __future__ import annotations
+
+from typing import Dict, Optional, Union
+
+import torch
+
+from ._capi import CapdecError
+from .engine import Engine
+
+
+class ClipModel:
+    def __init__(self, state_dict: Dict[str, torch.Tensor], device=0):
+        idx = device if isinstance(device, int) else (torch.device(device).index or 0)
+        self._engine = Engine(idx)
+        sd = {k: v for k, v in state_dict.items()}
+        self.has_vision = "visual.conv1.weight" in sd
+        self._engine.load_clip(sd, text=True, vision=self.has_vision)
+        self.context_length = self._engine.clip_text["context_length"]
+        self.device = self._engine.device
+
+    def eval(self):
+        return self
+
+    def encode_text(self, text: torch.Tensor) -> torch.Tensor:
+        """int tokens [N, 77] -> [N, 512] (not normalised, reference embeddings_generator.py:86-87)"""
+        return self._engine.clip_encode_text(text)
+
+    def encode_image(self, image: torch.Tensor) -> torch.Tensor:
+        if not self.has_vision:
+            raise CapdecError("this CLIP state dict has no ViT visual tower")
+        return self._engine.clip_encode_image(image)
+
+
+def load(name_or_state_dict: Union[str, Dict[str, torch.Tensor]], device=0, jit: bool = False):
+    """``clip.load("ViT-B/32", device=device, jit=False)`` -> (model, preprocess).  Pass the state dict
+    (or the path of a ``torch.save``d one / an OpenAI ``.pt`` archive readable by torch.load)."""
+    if isinstance(name_or_state_dict, str):
+        obj = torch.load(name_or_state_dict, map_location="cpu")
+        sd = obj.state_dict() if hasattr(obj, "state_dict") else obj
+    else:
+        sd = name_or_state_dict
+    return ClipModel(sd, device), preprocess_tensor
+
+
+def preprocess_tensor(image: torch.Tensor) -> torch.Tensor:
+    """Normalisation step of the reference's transform (mean / std of predictions_runner.py:121) for a
+    float image tensor [3, 224, 224] in [0, 1]; resize / crop / decoding stay with the caller (PIL and
+    torchvision are not part of this package)."""
+    mean = torch.tensor((0.48145466, 0.4578275, 0.40821073), device=image.device).view(3, 1, 1)
+    std = torch.tensor((0.26862954, 0.26130258, 0.27577711), device=image.device).view(3, 1, 1)
+    return (image - mean) / std
+
+
+def tokenize(texts, context_length: int = 77, truncate: bool = False):
+    raise CapdecError("clip.tokenize needs the CLIP BPE vocabulary (bpe_simple_vocab_16e6.txt.gz), which is not "
+                      "available offline; pass pre-tokenised int [N, 77] rows to encode_text")

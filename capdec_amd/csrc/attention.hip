@@ -29,7 +29,7 @@ __device__ __forceinline__ float group16_sum(float v) {
 template <bool DECODE>
 __global__ __launch_bounds__(256) void attn_gpt2_kernel(const float *__restrict__ qkv, float *__restrict__ kc,
                                                         float *__restrict__ vc, int total, int heads, int ctx,
-                                                        int d, int beam, int Lparam, int P,
+                                                        int d, int beam, int Lparam, int P, int causal,
                                                         const uint8_t *__restrict__ anc, int anc_stride,
                                                         float *__restrict__ out) {
     __shared__ float sc[4][ATT_CTX_MAX];
@@ -45,7 +45,7 @@ __global__ __launch_bounds__(256) void attn_gpt2_kernel(const float *__restrict_
         phys_self = row;
     } else {
         const int cap = row / P, i = row - cap * P;
-        L = i + 1;
+        L = causal ? i + 1 : P;                  // CLIP's vision tower attends to the whole sequence
         phys_self = cap * beam;
     }
     const int cap_base = DECODE ? (row / beam) * beam : phys_self;
@@ -151,14 +151,14 @@ int launch_kv_scatter_prefill(hipStream_t st, const float *qkv, const KvCache &c
 }
 
 int launch_attn_prefill(hipStream_t st, const float *qkv, const KvCache &c, int layer, int ncap, int P, int beam,
-                        float *out) {
+                        float *out, bool causal) {
     CAPDEC_CHECK(c.hd == 64, "attention: head_dim must be 64");
     CAPDEC_CHECK(P <= ATT_CTX_MAX && P <= c.ctx, "attention: prefix longer than the supported context");
     const int total = ncap * P * c.heads;
     if (total <= 0) return 0;
     hipLaunchKernelGGL(attn_gpt2_kernel<false>, dim3((total + 3) / 4), dim3(256), 0, st, qkv,
                        c.k + layer * c.layer_stride(), c.v + layer * c.layer_stride(), total, c.heads, c.ctx,
-                       c.heads * c.hd, beam, 0, P, (const uint8_t *)nullptr, 0, out);
+                       c.heads * c.hd, beam, 0, P, causal ? 1 : 0, (const uint8_t *)nullptr, 0, out);
     CAPDEC_HIP(hipGetLastError());
     return 0;
 }
@@ -171,7 +171,7 @@ int launch_attn_decode(hipStream_t st, const float *qkv, const KvCache &c, int l
     if (total <= 0) return 0;
     hipLaunchKernelGGL(attn_gpt2_kernel<true>, dim3((total + 3) / 4), dim3(256), 0, st, qkv,
                        c.k + layer * c.layer_stride(), c.v + layer * c.layer_stride(), total, c.heads, c.ctx,
-                       c.heads * c.hd, beam, L, 0, anc, anc_stride, out);
+                       c.heads * c.hd, beam, L, 0, 1, anc, anc_stride, out);
     CAPDEC_HIP(hipGetLastError());
     return 0;
 }

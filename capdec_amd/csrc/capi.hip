@@ -60,6 +60,20 @@ struct Mapper {
     std::vector<void *> owned;
 };
 
+// CLIP tower = the same pre-LN block stack as GPT-2 (fused qkv, 4w MLP) with QuickGELU
+struct Tower {
+    bool loaded = false;
+    int n_layer = 0, n_head = 0, d = 0, embed = 0;
+    std::vector<Gpt2Layer> layers;
+    std::vector<void *> owned;
+    // text
+    int ctx = 0, vocab = 0;
+    float *tok_emb = nullptr, *pos_emb = nullptr, *lnf_w = nullptr, *lnf_b = nullptr, *proj_t = nullptr;  // proj_t [embed, d]
+    // vision
+    int image = 0, patch = 0, ntok = 0;
+    float *conv_w = nullptr, *cls = nullptr, *ln_pre_w = nullptr, *ln_pre_b = nullptr;
+};
+
 enum Family { F_GEMM = 0, F_LMHEAD, F_ATTN_DEC, F_ATTN_PRE, F_LN, F_EMBED, F_SELECT, F_MAP_ATTN, F_OTHER, F_COUNT };
 static const char *kFamilyNames[F_COUNT] = {"gemm_f32",  "gemm_f32_lmhead_topk", "attn_decode", "attn_prefill", "layernorm",
                                             "embed",     "select",               "attn_mapper", "other"};
@@ -83,12 +97,14 @@ struct capdec_ctx {
     size_t kv_budget = (size_t)192 << 30;
     Gpt2 gpt;
     Mapper map;
+    Tower clip_text, clip_vision;
     Prof prof;
     hipEvent_t t0 = nullptr, t1 = nullptr;
     // workspaces
     DBuf h, x, qkv, att, ff, xl, tmax, tsum, cval, cidx, lse, topv, topi, kc, vc;
     DBuf tokens, scores, seq, stopped, done, anc, next_tok, alive, gids, glens;
     DBuf m_hid, m_lin, m_seq, m_x, m_qkv, m_att, m_ff;
+    DBuf t_idx, t_patch, t_pout;
     int *alive_host = nullptr;   // pinned
 };
 
@@ -196,8 +212,7 @@ struct StepShape {
     int anc_stride;
 };
 
-static int ensure_body_ws(capdec_ctx *c, int M) {
-    const int d = c->gpt.d;
+static int ensure_body_ws(capdec_ctx *c, int M, int d) {
     CAPDEC_TRY(c->h.ensure((size_t)M * d * 4));
     CAPDEC_TRY(c->x.ensure((size_t)M * d * 4));
     CAPDEC_TRY(c->qkv.ensure((size_t)M * 3 * d * 4));
@@ -206,30 +221,45 @@ static int ensure_body_ws(capdec_ctx *c, int M) {
     return 0;
 }
 
-// h [M, d] (in c->h) -> h after all blocks (ln_f NOT applied)
-static int gpt2_body(capdec_ctx *c, const StepShape &s, const KvCache &kv) {
-    const Gpt2 &g = c->gpt;
+// h [M, d] (in c->h) -> h after all blocks (final LN NOT applied).  The same pre-LN block serves
+// GPT-2 (gelu_new, causal, KV cache kept) and the CLIP towers (QuickGELU; one scratch "layer" of
+// K/V reused by every block; the vision tower is not causal).
+struct StackCfg {
+    const std::vector<Gpt2Layer> *layers;
+    int n_layer, d;
+    float eps;
+    int act;
+    bool causal, keep_kv;
+};
+static int stack_body(capdec_ctx *c, const StackCfg &g, const StepShape &s, const KvCache &kv) {
     const int d = g.d, M = s.prefill ? s.ncap * s.P : s.rows;
     float *h = c->h.as<float>(), *x = c->x.as<float>(), *qkv = c->qkv.as<float>(), *att = c->att.as<float>(),
           *ff = c->ff.as<float>();
     for (int l = 0; l < g.n_layer; ++l) {
-        const Gpt2Layer &w = g.layers[l];
+        const Gpt2Layer &w = (*g.layers)[l];
+        const int kl = g.keep_kv ? l : 0;
         { ProfScope ps(c, F_LN); CAPDEC_TRY(launch_layernorm(c->stream, h, d, w.ln1w, w.ln1b, g.eps, x, d, M, d)); }
         CAPDEC_TRY(gemm(c, x, d, w.wqkv, d, qkv, 3 * d, M, 3 * d, d, w.bqkv, CAPDEC_ACT_NONE));
         if (s.prefill) {
             ProfScope ps(c, F_ATTN_PRE);
-            CAPDEC_TRY(launch_kv_scatter_prefill(c->stream, qkv, kv, l, s.ncap, s.P, s.beam));
-            CAPDEC_TRY(launch_attn_prefill(c->stream, qkv, kv, l, s.ncap, s.P, s.beam, att));
+            CAPDEC_TRY(launch_kv_scatter_prefill(c->stream, qkv, kv, kl, s.ncap, s.P, s.beam));
+            CAPDEC_TRY(launch_attn_prefill(c->stream, qkv, kv, kl, s.ncap, s.P, s.beam, att, g.causal));
         } else {
             ProfScope ps(c, F_ATTN_DEC);
-            CAPDEC_TRY(launch_attn_decode(c->stream, qkv, kv, l, s.rows, s.beam, s.L, s.anc, s.anc_stride, att));
+            CAPDEC_TRY(launch_attn_decode(c->stream, qkv, kv, kl, s.rows, s.beam, s.L, s.anc, s.anc_stride, att));
         }
         CAPDEC_TRY(gemm(c, att, d, w.wproj, d, h, d, M, d, d, w.bproj, CAPDEC_ACT_NONE, h, d));
         { ProfScope ps(c, F_LN); CAPDEC_TRY(launch_layernorm(c->stream, h, d, w.ln2w, w.ln2b, g.eps, x, d, M, d)); }
-        CAPDEC_TRY(gemm(c, x, d, w.wfc, d, ff, 4 * d, M, 4 * d, d, w.bfc, CAPDEC_ACT_GELU_NEW));
+        CAPDEC_TRY(gemm(c, x, d, w.wfc, d, ff, 4 * d, M, 4 * d, d, w.bfc, g.act));
         CAPDEC_TRY(gemm(c, ff, 4 * d, w.wproj2, 4 * d, h, d, M, d, 4 * d, w.bproj2, CAPDEC_ACT_NONE, h, d));
     }
     return 0;
+}
+
+static int gpt2_body(capdec_ctx *c, const StepShape &s, const KvCache &kv) {
+    const Gpt2 &g = c->gpt;
+    StackCfg cfg{&g.layers, g.n_layer, g.d, g.eps, CAPDEC_ACT_GELU_NEW, true, true};
+    return stack_body(c, cfg, s, kv);
 }
 
 // ln_f over `R` rows of h (row stride ldh floats, starting at h0) then the fused lm_head:
@@ -261,13 +291,13 @@ static int lm_head_select(capdec_ctx *c, const float *h0, int ldh, int R, int k,
     return 0;
 }
 
-static int ensure_kv(capdec_ctx *c, KvCache &kv, int rows, int ctx) {
+static int ensure_kv(capdec_ctx *c, KvCache &kv, int rows, int ctx, int heads = 0, int hd = 0, int layers = 0) {
     const Gpt2 &g = c->gpt;
     kv.rows = rows;
-    kv.heads = g.n_head;
+    kv.heads = heads ? heads : g.n_head;
     kv.ctx = ctx;
-    kv.hd = g.d / g.n_head;
-    const size_t bytes = kv.layer_stride() * g.n_layer * sizeof(float);
+    kv.hd = hd ? hd : g.d / g.n_head;
+    const size_t bytes = kv.layer_stride() * (layers ? layers : g.n_layer) * sizeof(float);
     CAPDEC_TRY(c->kc.ensure(bytes));
     CAPDEC_TRY(c->vc.ensure(bytes));
     kv.k = c->kc.as<float>();
@@ -302,7 +332,7 @@ static int decode_chunk(capdec_ctx *c, const float *prefix, int nc, int P, int b
     const float inv_temp = 1.0f / (temperature > 0.f ? temperature : 1.0f);
     KvCache kv;
     CAPDEC_TRY(ensure_kv(c, kv, rows, ctx));
-    CAPDEC_TRY(ensure_body_ws(c, std::max(nc * P, rows)));
+    CAPDEC_TRY(ensure_body_ws(c, std::max(nc * P, rows), d));
     CAPDEC_TRY(c->next_tok.ensure((size_t)rows * 4));
     CAPDEC_TRY(c->alive.ensure(sizeof(int)));
     CAPDEC_TRY(c->done.ensure((size_t)rows));
@@ -450,6 +480,84 @@ static int mapper_chunk(capdec_ctx *c, const float *x, int n, float *out) {
     return 0;
 }
 
+// ---------------------------------------------------------------------------- CLIP towers
+static int upload_blocks(capdec_ctx *c, Tower &t, const capdec_clip_block *blocks) {
+    const int d = t.d;
+    t.layers.resize(t.n_layer);
+    for (int l = 0; l < t.n_layer; ++l) {
+        const capdec_clip_block &s = blocks[l];
+        Gpt2Layer &w = t.layers[l];
+        CAPDEC_TRY(upload(t.owned, s.ln_1_w, d, &w.ln1w));
+        CAPDEC_TRY(upload(t.owned, s.ln_1_b, d, &w.ln1b));
+        CAPDEC_TRY(upload(t.owned, s.in_proj_w, (size_t)3 * d * d, &w.wqkv));     // already [out, in]
+        CAPDEC_TRY(upload(t.owned, s.in_proj_b, 3 * d, &w.bqkv));
+        CAPDEC_TRY(upload(t.owned, s.out_proj_w, (size_t)d * d, &w.wproj));
+        CAPDEC_TRY(upload(t.owned, s.out_proj_b, d, &w.bproj));
+        CAPDEC_TRY(upload(t.owned, s.ln_2_w, d, &w.ln2w));
+        CAPDEC_TRY(upload(t.owned, s.ln_2_b, d, &w.ln2b));
+        CAPDEC_TRY(upload(t.owned, s.c_fc_w, (size_t)4 * d * d, &w.wfc));
+        CAPDEC_TRY(upload(t.owned, s.c_fc_b, 4 * d, &w.bfc));
+        CAPDEC_TRY(upload(t.owned, s.c_proj_w, (size_t)4 * d * d, &w.wproj2));
+        CAPDEC_TRY(upload(t.owned, s.c_proj_b, d, &w.bproj2));
+    }
+    return 0;
+}
+
+// one chunk of captions through the text tower: tokens [n, ctx] -> out [n, embed]
+static int clip_text_chunk(capdec_ctx *c, const int *tokens, int n, float *out) {
+    Tower &t = c->clip_text;
+    const int d = t.d, L = t.ctx;
+    KvCache kv;
+    CAPDEC_TRY(ensure_kv(c, kv, n, L, t.n_head, d / t.n_head, 1));
+    CAPDEC_TRY(ensure_body_ws(c, n * L, d));
+    CAPDEC_TRY(c->t_idx.ensure((size_t)n * 4));
+    CAPDEC_TRY(c->xl.ensure((size_t)2 * n * d * 4));
+    { ProfScope ps(c, F_EMBED); CAPDEC_TRY(launch_clip_text_embed(c->stream, tokens, t.tok_emb, t.pos_emb, c->h.as<float>(), n, L, d)); }
+    StepShape sp{};
+    sp.prefill = true;
+    sp.ncap = n;
+    sp.P = L;
+    sp.beam = 1;
+    StackCfg cfg{&t.layers, t.n_layer, d, 1e-5f, CAPDEC_ACT_QUICK_GELU, true, false};
+    CAPDEC_TRY(stack_body(c, cfg, sp, kv));
+    float *rows = c->xl.as<float>(), *rows_ln = c->xl.as<float>() + (size_t)n * d;
+    {
+        ProfScope ps(c, F_EMBED);
+        CAPDEC_TRY(launch_eot_index(c->stream, tokens, c->t_idx.as<int>(), n, L));
+        CAPDEC_TRY(launch_gather_rows(c->stream, c->h.as<float>(), c->t_idx.as<int>(), rows, n, d));
+    }
+    { ProfScope ps(c, F_LN); CAPDEC_TRY(launch_layernorm(c->stream, rows, d, t.lnf_w, t.lnf_b, 1e-5f, rows_ln, d, n, d)); }
+    return gemm(c, rows_ln, d, t.proj_t, d, out, t.embed, n, t.embed, d, nullptr, CAPDEC_ACT_NONE);
+}
+
+// one chunk of images through the vision tower: pixels [n, 3, S, S] -> out [n, embed]
+static int clip_vision_chunk(capdec_ctx *c, const float *pixels, int n, float *out) {
+    Tower &t = c->clip_vision;
+    const int d = t.d, L = t.ntok, np = t.ntok - 1, kdim = 3 * t.patch * t.patch;
+    KvCache kv;
+    CAPDEC_TRY(ensure_kv(c, kv, n, L, t.n_head, d / t.n_head, 1));
+    CAPDEC_TRY(ensure_body_ws(c, n * L, d));
+    CAPDEC_TRY(c->t_patch.ensure((size_t)n * np * kdim * 4));
+    CAPDEC_TRY(c->t_pout.ensure((size_t)n * np * d * 4));
+    CAPDEC_TRY(c->xl.ensure((size_t)n * d * 4));
+    { ProfScope ps(c, F_EMBED); CAPDEC_TRY(launch_im2col_patches(c->stream, pixels, c->t_patch.as<float>(), n, t.image, t.patch)); }
+    CAPDEC_TRY(gemm(c, c->t_patch.as<float>(), kdim, t.conv_w, kdim, c->t_pout.as<float>(), d, n * np, d, kdim, nullptr,
+                    CAPDEC_ACT_NONE));
+    // ln_pre runs in place on the assembled sequence (x holds the pre-LN copy)
+    { ProfScope ps(c, F_EMBED); CAPDEC_TRY(launch_vision_assemble(c->stream, c->t_pout.as<float>(), t.cls, t.pos_emb, c->x.as<float>(), n, L, d)); }
+    { ProfScope ps(c, F_LN); CAPDEC_TRY(launch_layernorm(c->stream, c->x.as<float>(), d, t.ln_pre_w, t.ln_pre_b, 1e-5f, c->h.as<float>(), d, n * L, d)); }
+    StepShape sp{};
+    sp.prefill = true;
+    sp.ncap = n;
+    sp.P = L;
+    sp.beam = 1;
+    StackCfg cfg{&t.layers, t.n_layer, d, 1e-5f, CAPDEC_ACT_QUICK_GELU, false, false};
+    CAPDEC_TRY(stack_body(c, cfg, sp, kv));
+    // ln_post on the class token (row 0 of every sequence: row stride L*d)
+    { ProfScope ps(c, F_LN); CAPDEC_TRY(launch_layernorm(c->stream, c->h.as<float>(), L * d, t.lnf_w, t.lnf_b, 1e-5f, c->xl.as<float>(), d, n, d)); }
+    return gemm(c, c->xl.as<float>(), d, t.proj_t, d, out, t.embed, n, t.embed, d, nullptr, CAPDEC_ACT_NONE);
+}
+
 }  // namespace capdec
 
 // =============================================================================== C ABI
@@ -487,10 +595,12 @@ void capdec_destroy(capdec_ctx *c) {
     (void)hipStreamSynchronize(c->stream);
     free_all(c->gpt.owned);
     free_all(c->map.owned);
+    free_all(c->clip_text.owned);
+    free_all(c->clip_vision.owned);
     DBuf *bufs[] = {&c->h, &c->x, &c->qkv, &c->att, &c->ff, &c->xl, &c->tmax, &c->tsum, &c->cval, &c->cidx,
                     &c->lse, &c->topv, &c->topi, &c->kc, &c->vc, &c->tokens, &c->scores, &c->seq, &c->stopped,
                     &c->done, &c->anc, &c->next_tok, &c->alive, &c->gids, &c->glens, &c->m_hid, &c->m_lin, &c->m_seq,
-                    &c->m_x, &c->m_qkv, &c->m_att, &c->m_ff};
+                    &c->m_x, &c->m_qkv, &c->m_att, &c->m_ff, &c->t_idx, &c->t_patch, &c->t_pout};
     for (DBuf *b : bufs) b->release();
     for (auto &r : c->prof.recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
     for (auto e : c->prof.pool) (void)hipEventDestroy(e);
@@ -644,6 +754,82 @@ int capdec_load_mapper_transformer(capdec_ctx *c, const capdec_tmapper_weights *
     return 0;
 }
 
+int capdec_load_clip_text(capdec_ctx *c, const capdec_clip_text_weights *w) {
+    CAPDEC_CHECK(c && w, "null argument");
+    CAPDEC_CHECK(w->width % 32 == 0 && w->heads >= 1 && w->width / w->heads == 64 && w->width % w->heads == 0,
+                 "load_clip_text: head_dim must be 64");
+    CAPDEC_CHECK(w->context_length >= 1 && w->context_length <= 256 && w->layers >= 1 && w->embed_dim >= 1 && w->vocab >= 2,
+                 "load_clip_text: bad geometry");
+    CAPDEC_HIP(hipSetDevice(c->device));
+    Tower &t = c->clip_text;
+    free_all(t.owned);
+    t = Tower();
+    t.n_layer = w->layers; t.n_head = w->heads; t.d = w->width; t.embed = w->embed_dim; t.ctx = w->context_length;
+    t.vocab = w->vocab;
+    CAPDEC_TRY(upload(t.owned, w->token_embedding, (size_t)t.vocab * t.d, &t.tok_emb));
+    CAPDEC_TRY(upload(t.owned, w->positional_embedding, (size_t)t.ctx * t.d, &t.pos_emb));
+    CAPDEC_TRY(upload(t.owned, w->ln_final_w, t.d, &t.lnf_w));
+    CAPDEC_TRY(upload(t.owned, w->ln_final_b, t.d, &t.lnf_b));
+    CAPDEC_TRY(upload_transposed(c, t.owned, w->text_projection, t.d, t.embed, &t.proj_t));
+    CAPDEC_TRY(upload_blocks(c, t, w->blocks));
+    t.loaded = true;
+    return 0;
+}
+
+int capdec_load_clip_vision(capdec_ctx *c, const capdec_clip_vision_weights *w) {
+    CAPDEC_CHECK(c && w, "null argument");
+    CAPDEC_CHECK(w->width % 32 == 0 && w->heads >= 1 && w->width % w->heads == 0 && w->width / w->heads == 64,
+                 "load_clip_vision: head_dim must be 64");
+    CAPDEC_CHECK(w->patch >= 4 && w->patch % 4 == 0 && w->image_size % w->patch == 0 && (3 * w->patch * w->patch) % 32 == 0,
+                 "load_clip_vision: bad patch geometry");
+    CAPDEC_HIP(hipSetDevice(c->device));
+    Tower &t = c->clip_vision;
+    free_all(t.owned);
+    t = Tower();
+    t.n_layer = w->layers; t.n_head = w->heads; t.d = w->width; t.embed = w->embed_dim; t.image = w->image_size;
+    t.patch = w->patch;
+    const int g = t.image / t.patch;
+    t.ntok = g * g + 1;
+    CAPDEC_CHECK(t.ntok <= 256, "load_clip_vision: more than 256 tokens per image");
+    CAPDEC_TRY(upload(t.owned, w->conv1_w, (size_t)t.d * 3 * t.patch * t.patch, &t.conv_w));
+    CAPDEC_TRY(upload(t.owned, w->class_embedding, t.d, &t.cls));
+    CAPDEC_TRY(upload(t.owned, w->positional_embedding, (size_t)t.ntok * t.d, &t.pos_emb));
+    CAPDEC_TRY(upload(t.owned, w->ln_pre_w, t.d, &t.ln_pre_w));
+    CAPDEC_TRY(upload(t.owned, w->ln_pre_b, t.d, &t.ln_pre_b));
+    CAPDEC_TRY(upload(t.owned, w->ln_post_w, t.d, &t.lnf_w));
+    CAPDEC_TRY(upload(t.owned, w->ln_post_b, t.d, &t.lnf_b));
+    CAPDEC_TRY(upload_transposed(c, t.owned, w->proj, t.d, t.embed, &t.proj_t));
+    CAPDEC_TRY(upload_blocks(c, t, w->blocks));
+    t.loaded = true;
+    return 0;
+}
+
+int capdec_clip_encode_text(capdec_ctx *c, const int32_t *tokens, int n, float *out) {
+    CAPDEC_CHECK(c && c->clip_text.loaded, "clip_encode_text: text tower not loaded");
+    CAPDEC_CHECK(n >= 0 && (n == 0 || (tokens && out)), "clip_encode_text: bad argument");
+    CAPDEC_HIP(hipSetDevice(c->device));
+    const Tower &t = c->clip_text;
+    const int chunk = 4096;
+    for (int c0 = 0; c0 < n; c0 += chunk) {
+        const int nc = std::min(chunk, n - c0);
+        CAPDEC_TRY(clip_text_chunk(c, tokens + (size_t)c0 * t.ctx, nc, out + (size_t)c0 * t.embed));
+    }
+    return 0;
+}
+
+int capdec_clip_encode_image(capdec_ctx *c, const float *pixels, int n, float *out) {
+    CAPDEC_CHECK(c && c->clip_vision.loaded, "clip_encode_image: vision tower not loaded");
+    CAPDEC_CHECK(n >= 0 && (n == 0 || (pixels && out)), "clip_encode_image: bad argument");
+    CAPDEC_HIP(hipSetDevice(c->device));
+    const Tower &t = c->clip_vision;
+    const int chunk = 2048;
+    for (int c0 = 0; c0 < n; c0 += chunk) {
+        const int nc = std::min(chunk, n - c0);
+        CAPDEC_TRY(clip_vision_chunk(c, pixels + (size_t)c0 * 3 * t.image * t.image, nc, out + (size_t)c0 * t.embed));
+    }
+    return 0;
+}
+
 int capdec_normalize_prefix(capdec_ctx *c, const float *x, int n, int dim, int normalize, const float *offset,
                             float *out) {
     CAPDEC_CHECK(c && x && out && n >= 0 && dim >= 1, "normalize_prefix: bad argument");
@@ -682,7 +868,7 @@ int capdec_gpt2_logits(capdec_ctx *c, const float *embeds, int n, int L, int all
     const int d = g.d;
     KvCache kv;
     CAPDEC_TRY(ensure_kv(c, kv, n, L));
-    CAPDEC_TRY(ensure_body_ws(c, n * L));
+    CAPDEC_TRY(ensure_body_ws(c, n * L, d));
     { ProfScope ps(c, F_EMBED); CAPDEC_TRY(launch_embed_prefix(c->stream, embeds, g.wpe, c->h.as<float>(), n, L, 0, d)); }
     StepShape sp{};
     sp.prefill = true;

@@ -84,6 +84,13 @@ int launch_tmapper_concat(hipStream_t st, const float *lin, const float *prefix_
                           int clip_len, int P, int d);
 int launch_tmapper_take(hipStream_t st, const float *seq, float *out, int n, int clip_len, int P, int d);
 int launch_transpose(hipStream_t st, const float *in, float *out, int rows, int cols);  // out[c][r] = in[r][c]
+// CLIP glue
+int launch_clip_text_embed(hipStream_t st, const int *tokens, const float *tok_emb, const float *pos_emb, float *h,
+                           int n, int L, int d);
+int launch_eot_index(hipStream_t st, const int *tokens, int *flat_idx, int n, int L);   // n*L + argmax_t tokens[n,t]
+int launch_im2col_patches(hipStream_t st, const float *pixels, float *patches, int n, int S, int patch);
+int launch_vision_assemble(hipStream_t st, const float *patch_out, const float *cls, const float *pos, float *seq,
+                           int n, int ntok, int d);
 
 // attention.hip
 struct KvCache {
@@ -97,7 +104,7 @@ int launch_kv_scatter_prefill(hipStream_t st, const float *qkv, const KvCache &c
                               int beam);
 // prefill: query row (caption, i) attends cache positions 0..i of phys row caption*beam
 int launch_attn_prefill(hipStream_t st, const float *qkv, const KvCache &c, int layer, int ncap, int P, int beam,
-                        float *out);
+                        float *out, bool causal = true);
 // decode: row r (caption = r / beam) at position L-1: its own k/v come from qkv (and are written to the cache
 // at phys row r), positions p < L-1 from phys row caption*beam + anc[r][p] (anc == nullptr -> r itself)
 int launch_attn_decode(hipStream_t st, const float *qkv, const KvCache &c, int layer, int rows, int beam, int L,

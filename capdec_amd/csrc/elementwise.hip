@@ -293,4 +293,95 @@ int launch_transpose(hipStream_t st, const float *in, float *out, int rows, int 
     return 0;
 }
 
+// ---------------------------------------------------------------------------- CLIP glue
+// h[(n, t)] = token_embedding[tokens[n, t]] + positional_embedding[t]
+__global__ void clip_text_embed_kernel(const int *__restrict__ tokens, const float *__restrict__ tok_emb,
+                                       const float *__restrict__ pos_emb, float *__restrict__ h, int n, int L,
+                                       int nv) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n * L * nv) return;
+    const int c = i % nv, row = i / nv, t = row % L;
+    const float4 a = reinterpret_cast<const float4 *>(tok_emb + (size_t)tokens[row] * nv * 4)[c];
+    const float4 p = reinterpret_cast<const float4 *>(pos_emb + (size_t)t * nv * 4)[c];
+    reinterpret_cast<float4 *>(h)[i] = make_float4(a.x + p.x, a.y + p.y, a.z + p.z, a.w + p.w);
+}
+int launch_clip_text_embed(hipStream_t st, const int *tokens, const float *tok_emb, const float *pos_emb, float *h,
+                           int n, int L, int d) {
+    const int tot = n * L * (d / 4);
+    if (tot <= 0) return 0;
+    hipLaunchKernelGGL(clip_text_embed_kernel, dim3((tot + 255) / 256), dim3(256), 0, st, tokens, tok_emb, pos_emb, h, n,
+                       L, d / 4);
+    CAPDEC_HIP(hipGetLastError());
+    return 0;
+}
+
+// flat_idx[n] = n*L + argmax_t tokens[n, t]  (first maximum, like torch.argmax: the EOT position)
+__global__ void eot_index_kernel(const int *__restrict__ tokens, int *__restrict__ flat_idx, int n, int L) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n) return;
+    int best = tokens[(size_t)r * L], bi = 0;
+    for (int t = 1; t < L; ++t) {
+        const int v = tokens[(size_t)r * L + t];
+        if (v > best) { best = v; bi = t; }
+    }
+    flat_idx[r] = r * L + bi;
+}
+int launch_eot_index(hipStream_t st, const int *tokens, int *flat_idx, int n, int L) {
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(eot_index_kernel, dim3((n + 255) / 256), dim3(256), 0, st, tokens, flat_idx, n, L);
+    CAPDEC_HIP(hipGetLastError());
+    return 0;
+}
+
+// conv(kernel = stride = patch, no bias) as a GEMM: patches[(n, py, px)][(c, ky, kx)] = pixels[n, c, py*p+ky, px*p+kx]
+__global__ void im2col_patches_kernel(const float *__restrict__ pixels, float *__restrict__ patches, int n, int S,
+                                      int patch) {
+    const int g = S / patch, kq = patch / 4;           // float4 along kx
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t tot = (size_t)n * g * g * 3 * patch * kq;
+    if (i >= tot) return;
+    const int x4 = i % kq;
+    size_t r = i / kq;
+    const int ky = r % patch; r /= patch;
+    const int c = r % 3; r /= 3;
+    const int px = r % g; r /= g;
+    const int py = r % g;
+    const int img = r / g;
+    const float4 v = *reinterpret_cast<const float4 *>(
+        pixels + (((size_t)img * 3 + c) * S + (py * patch + ky)) * S + px * patch + x4 * 4);
+    reinterpret_cast<float4 *>(patches)[i] = v;
+}
+int launch_im2col_patches(hipStream_t st, const float *pixels, float *patches, int n, int S, int patch) {
+    CAPDEC_CHECK(S % patch == 0 && patch % 4 == 0, "im2col: bad patch geometry");
+    const int g = S / patch;
+    const size_t tot = (size_t)n * g * g * 3 * patch * (patch / 4);
+    if (tot == 0) return 0;
+    hipLaunchKernelGGL(im2col_patches_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, pixels, patches, n,
+                       S, patch);
+    CAPDEC_HIP(hipGetLastError());
+    return 0;
+}
+
+// seq[n, 0] = class_embedding + pos[0]; seq[n, 1 + p] = patch_out[n*(ntok-1) + p] + pos[1 + p]
+__global__ void vision_assemble_kernel(const float *__restrict__ patch_out, const float *__restrict__ cls,
+                                       const float *__restrict__ pos, float *__restrict__ seq, int n, int ntok,
+                                       int nv) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n * ntok * nv) return;
+    const int c = i % nv, t = (i / nv) % ntok, img = i / (nv * ntok);
+    const float4 p = reinterpret_cast<const float4 *>(pos)[(size_t)t * nv + c];
+    const float4 a = t == 0 ? reinterpret_cast<const float4 *>(cls)[c]
+                            : reinterpret_cast<const float4 *>(patch_out)[((size_t)img * (ntok - 1) + t - 1) * nv + c];
+    reinterpret_cast<float4 *>(seq)[i] = make_float4(a.x + p.x, a.y + p.y, a.z + p.z, a.w + p.w);
+}
+int launch_vision_assemble(hipStream_t st, const float *patch_out, const float *cls, const float *pos, float *seq,
+                           int n, int ntok, int d) {
+    const int tot = n * ntok * (d / 4);
+    if (tot <= 0) return 0;
+    hipLaunchKernelGGL(vision_assemble_kernel, dim3((tot + 255) / 256), dim3(256), 0, st, patch_out, cls, pos, seq, n,
+                       ntok, d / 4);
+    CAPDEC_HIP(hipGetLastError());
+    return 0;
+}
+
 }  // namespace capdec

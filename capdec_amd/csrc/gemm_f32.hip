@@ -14,14 +14,14 @@
 // four ds_read_b128.  Register-staged double buffering: global loads of tile t+1 are issued
 // before the 64 MFMAs of tile t and written to the other LDS buffer after them, one barrier
 // per tile.
+#include <cstdlib>
+
 #include "common.h"
 
 namespace capdec {
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 
-constexpr int LDS_LD = 36;                            // padded row stride (floats)
-constexpr int TILE_F = GEMM_BM * LDS_LD;              // floats per operand tile buffer
 constexpr int CT_LD = 129;                            // epilogue tile row stride (top-k variant)
 
 __device__ __forceinline__ float act_apply(float v, int act) {
@@ -33,6 +33,7 @@ __device__ __forceinline__ float act_apply(float v, int act) {
             const float c = 0.7978845608028654f;
             return 0.5f * v * (1.f + tanhf(c * (v + 0.044715f * v * v * v)));
         }
+        case CAPDEC_ACT_QUICK_GELU: return v / (1.f + __expf(-1.702f * v));   // x * sigmoid(1.702 x)
         default: return v;
     }
 }
@@ -56,49 +57,72 @@ __device__ __forceinline__ void tile_coords(int tiles_m, int tiles_n, int &tm, i
 }
 
 // Shared main loop: accumulates the 128x128 tile at (m0, n0) into per-wave accumulators.
+// BK = k-depth of one LDS stage (32: 72 KB LDS, 2 blocks/CU; 16: 40 KB, 3 blocks/CU).
+template <int BK>
+struct Tile {
+    static constexpr int LD = BK + 4;                  // padded row stride (floats), 16-byte aligned
+    static constexpr int TILE = GEMM_BM * LD;          // floats per operand stage
+    static constexpr int KQ = BK / 4;                  // float4 per row
+    static constexpr int ROWS_PER_PASS = 256 / KQ;
+    static constexpr int NP = GEMM_BM / ROWS_PER_PASS; // staging passes per operand
+    static constexpr int NQ = BK / 8;                  // ds_read_b128 per row per half-wave
+    static constexpr int SMEM_FLOATS = 4 * TILE;
+};
+
+template <int BK, int ABL = 0>
 __device__ __forceinline__ void gemm_mainloop(const float *__restrict__ A, int lda, const float *__restrict__ Bt,
                                               int ldb, int M, int N, int K, int m0, int n0, float *smem,
                                               f32x16 (&acc)[2][2]) {
+    using TL = Tile<BK>;
+    constexpr int LD = TL::LD, TILE = TL::TILE, NP = TL::NP, NQ = TL::NQ;
     const int t = threadIdx.x;
     const int lane = t & 63, wave = t >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int half = lane >> 5, l32 = lane & 31;
 
-    float *As = smem;                 // [2][128][36]
-    float *Bs = smem + 2 * TILE_F;    // [2][128][36]
+    float *As = smem;               // [2][128][LD]
+    float *Bs = smem + 2 * TILE;    // [2][128][LD]
 
-    // global staging: 4 float4 per thread per operand; idx = t + 256 i -> row idx>>3, k-quad idx&7.
-    // Rows past M (N) are clamped to the last valid row: they only feed C rows (columns) that are
-    // never stored, so no predication is needed and every load is a plain global_load_dwordx4.
-    const int srow = t >> 3, skq = (t & 7) * 4;
+    // global staging: NP float4 per thread per operand.  Rows past M (N) are clamped to the last
+    // valid row: they only feed C rows (columns) that are never stored, so no predication is
+    // needed and every load is a plain global_load_dwordx4.
+    const int srow = t / TL::KQ, skq = (t % TL::KQ) * 4;
+    // (named scalars, not arrays: arrays assigned under `if (more)` end up in scratch memory)
+    constexpr int RP = TL::ROWS_PER_PASS;
     const float *ap0 = A + (size_t)min(m0 + srow, M - 1) * lda + skq;
-    const float *ap1 = A + (size_t)min(m0 + srow + 32, M - 1) * lda + skq;
-    const float *ap2 = A + (size_t)min(m0 + srow + 64, M - 1) * lda + skq;
-    const float *ap3 = A + (size_t)min(m0 + srow + 96, M - 1) * lda + skq;
+    const float *ap1 = A + (size_t)min(m0 + srow + RP, M - 1) * lda + skq;
+    const float *ap2 = A + (size_t)min(m0 + srow + 2 * RP, M - 1) * lda + skq;
+    const float *ap3 = A + (size_t)min(m0 + srow + 3 * RP, M - 1) * lda + skq;
     const float *bp0 = Bt + (size_t)min(n0 + srow, N - 1) * ldb + skq;
-    const float *bp1 = Bt + (size_t)min(n0 + srow + 32, N - 1) * ldb + skq;
-    const float *bp2 = Bt + (size_t)min(n0 + srow + 64, N - 1) * ldb + skq;
-    const float *bp3 = Bt + (size_t)min(n0 + srow + 96, N - 1) * ldb + skq;
+    const float *bp1 = Bt + (size_t)min(n0 + srow + RP, N - 1) * ldb + skq;
+    const float *bp2 = Bt + (size_t)min(n0 + srow + 2 * RP, N - 1) * ldb + skq;
+    const float *bp3 = Bt + (size_t)min(n0 + srow + 3 * RP, N - 1) * ldb + skq;
     float4 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3;
-#define GLOAD(k0)                                                  \
-    ra0 = *reinterpret_cast<const float4 *>(ap0 + (k0));           \
-    rb0 = *reinterpret_cast<const float4 *>(bp0 + (k0));           \
-    ra1 = *reinterpret_cast<const float4 *>(ap1 + (k0));           \
-    rb1 = *reinterpret_cast<const float4 *>(bp1 + (k0));           \
-    ra2 = *reinterpret_cast<const float4 *>(ap2 + (k0));           \
-    rb2 = *reinterpret_cast<const float4 *>(bp2 + (k0));           \
-    ra3 = *reinterpret_cast<const float4 *>(ap3 + (k0));           \
-    rb3 = *reinterpret_cast<const float4 *>(bp3 + (k0));
-    const int st_off = srow * LDS_LD + skq;
-#define LSTORE(buf)                                                                              \
-    *reinterpret_cast<float4 *>(As + (buf) * TILE_F + st_off) = ra0;                             \
-    *reinterpret_cast<float4 *>(Bs + (buf) * TILE_F + st_off) = rb0;                             \
-    *reinterpret_cast<float4 *>(As + (buf) * TILE_F + st_off + 32 * LDS_LD) = ra1;               \
-    *reinterpret_cast<float4 *>(Bs + (buf) * TILE_F + st_off + 32 * LDS_LD) = rb1;               \
-    *reinterpret_cast<float4 *>(As + (buf) * TILE_F + st_off + 64 * LDS_LD) = ra2;               \
-    *reinterpret_cast<float4 *>(Bs + (buf) * TILE_F + st_off + 64 * LDS_LD) = rb2;               \
-    *reinterpret_cast<float4 *>(As + (buf) * TILE_F + st_off + 96 * LDS_LD) = ra3;               \
-    *reinterpret_cast<float4 *>(Bs + (buf) * TILE_F + st_off + 96 * LDS_LD) = rb3;
+    ra2 = ra3 = rb2 = rb3 = make_float4(0.f, 0.f, 0.f, 0.f);
+#define GLOAD(k0)                                                          \
+    ra0 = *reinterpret_cast<const float4 *>(ap0 + (k0));                   \
+    rb0 = *reinterpret_cast<const float4 *>(bp0 + (k0));                   \
+    ra1 = *reinterpret_cast<const float4 *>(ap1 + (k0));                   \
+    rb1 = *reinterpret_cast<const float4 *>(bp1 + (k0));                   \
+    if constexpr (NP > 2) {                                                \
+        ra2 = *reinterpret_cast<const float4 *>(ap2 + (k0));               \
+        rb2 = *reinterpret_cast<const float4 *>(bp2 + (k0));               \
+        ra3 = *reinterpret_cast<const float4 *>(ap3 + (k0));               \
+        rb3 = *reinterpret_cast<const float4 *>(bp3 + (k0));               \
+    }
+    const int st_off = srow * LD + skq;
+#define LSTORE(buf)                                                                           \
+    *reinterpret_cast<float4 *>(As + (buf) * TILE + st_off) = ra0;                            \
+    *reinterpret_cast<float4 *>(Bs + (buf) * TILE + st_off) = rb0;                            \
+    *reinterpret_cast<float4 *>(As + (buf) * TILE + st_off + RP * LD) = ra1;                  \
+    *reinterpret_cast<float4 *>(Bs + (buf) * TILE + st_off + RP * LD) = rb1;                  \
+    if constexpr (NP > 2) {                                                                   \
+        *reinterpret_cast<float4 *>(As + (buf) * TILE + st_off + 2 * RP * LD) = ra2;          \
+        *reinterpret_cast<float4 *>(Bs + (buf) * TILE + st_off + 2 * RP * LD) = rb2;          \
+        *reinterpret_cast<float4 *>(As + (buf) * TILE + st_off + 3 * RP * LD) = ra3;          \
+        *reinterpret_cast<float4 *>(Bs + (buf) * TILE + st_off + 3 * RP * LD) = rb3;          \
+    }
+    static_assert(NP == 2 || NP == 4, "staging passes");
 
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -107,26 +131,26 @@ __device__ __forceinline__ void gemm_mainloop(const float *__restrict__ A, int l
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    const int nk = K / GEMM_BK;
+    const int nk = K / BK;
     GLOAD(0)
     LSTORE(0)
     __syncthreads();
 
-    const int a_off = (wm * 64 + l32) * LDS_LD + 16 * half;
-    const int b_off = (wn * 64 + l32) * LDS_LD + 16 * half;
+    const int a_off = (wm * 64 + l32) * LD + (BK / 2) * half;
+    const int b_off = (wn * 64 + l32) * LD + (BK / 2) * half;
 
     for (int kt = 0; kt < nk; ++kt) {
         const int buf = kt & 1;
         const bool more = kt + 1 < nk;
-        if (more) { GLOAD((kt + 1) * GEMM_BK) }
-        const float *Ab = As + buf * TILE_F + a_off;
-        const float *Bb = Bs + buf * TILE_F + b_off;
+        if (more && (ABL < 1)) { GLOAD((kt + 1) * BK) }
+        const float *Ab = As + buf * TILE + a_off;
+        const float *Bb = Bs + buf * TILE + b_off;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
+        for (int q = 0; q < NQ; ++q) {
             const float4 fa0 = *reinterpret_cast<const float4 *>(Ab + 4 * q);
-            const float4 fa1 = *reinterpret_cast<const float4 *>(Ab + 32 * LDS_LD + 4 * q);
+            const float4 fa1 = *reinterpret_cast<const float4 *>(Ab + 32 * LD + 4 * q);
             const float4 fb0 = *reinterpret_cast<const float4 *>(Bb + 4 * q);
-            const float4 fb1 = *reinterpret_cast<const float4 *>(Bb + 32 * LDS_LD + 4 * q);
+            const float4 fb1 = *reinterpret_cast<const float4 *>(Bb + 32 * LD + 4 * q);
 #define MFMA4(c)                                                                          \
     acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa0.c, fb0.c, acc[0][0], 0, 0, 0);    \
     acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa0.c, fb1.c, acc[0][1], 0, 0, 0);    \
@@ -135,24 +159,27 @@ __device__ __forceinline__ void gemm_mainloop(const float *__restrict__ A, int l
             MFMA4(x) MFMA4(y) MFMA4(z) MFMA4(w)
 #undef MFMA4
         }
-        if (more) { LSTORE(buf ^ 1) }
-        __syncthreads();
+        if (ABL < 2) {
+            if (more) { LSTORE(buf ^ 1) }
+            __syncthreads();
+        }
     }
 #undef GLOAD
 #undef LSTORE
 }
 
-__global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const float *__restrict__ A, int lda,
+template <int BK, int OCC, int ABL = 0>
+__global__ __launch_bounds__(256, OCC) void gemm_f32_kernel(const float *__restrict__ A, int lda,
                                                           const float *__restrict__ Bt, int ldb, float *C, int ldc,
                                                           int M, int N, int K, const float *__restrict__ bias,
                                                           const float *resid, int ldr, int act, int tiles_m,
                                                           int tiles_n) {
-    __shared__ __attribute__((aligned(16))) float smem[4 * TILE_F];
+    __shared__ __attribute__((aligned(16))) float smem[Tile<BK>::SMEM_FLOATS];
     int tm, tn;
     tile_coords(tiles_m, tiles_n, tm, tn);
     const int m0 = tm * GEMM_BM, n0 = tn * GEMM_BN;
     f32x16 acc[2][2];
-    gemm_mainloop(A, lda, Bt, ldb, M, N, K, m0, n0, smem, acc);
+    gemm_mainloop<BK, ABL>(A, lda, Bt, ldb, M, N, K, m0, n0, smem, acc);
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wm = wave >> 1, wn = wave & 1, half = lane >> 5, l32 = lane & 31;
@@ -179,88 +206,90 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const float *__restric
 // lm_head variant: per (row, 128-col tile) max, sum exp(x - max) and top-k (value, column).
 // The logits tile goes accumulators -> LDS (reusing the staging buffers) -> 16-lane groups,
 // one row per group, 8 columns per lane; nothing but ~ (2 + 2k) words per (row, tile) reaches HBM.
-template <int KSEL>
-__global__ __launch_bounds__(256, 2) void gemm_f32_topk_kernel(const float *__restrict__ A, int lda,
-                                                               const float *__restrict__ Bt, int ldb, int M, int N,
-                                                               int K, float inv_temp, float *tile_max,
-                                                               float *tile_sum, float *cand_val, int *cand_idx,
-                                                               int tiles_m, int tiles_n) {
-    __shared__ __attribute__((aligned(16))) float smem[4 * TILE_F];
-    static_assert(GEMM_BM * CT_LD <= 4 * TILE_F, "epilogue tile must fit the staging buffers");
+template <int KSEL, int BK, int OCC>
+__global__ __launch_bounds__(256, OCC) void gemm_f32_topk_kernel(const float *__restrict__ A, int lda,
+                                                                 const float *__restrict__ Bt, int ldb, int M, int N,
+                                                                 int K, float inv_temp, float *tile_max,
+                                                                 float *tile_sum, float *cand_val, int *cand_idx,
+                                                                 int tiles_m, int tiles_n) {
+    __shared__ __attribute__((aligned(16))) float smem[Tile<BK>::SMEM_FLOATS];
+    static_assert(64 * CT_LD <= Tile<BK>::SMEM_FLOATS, "half an epilogue tile must fit the staging buffers");
     int tm, tn;
     tile_coords(tiles_m, tiles_n, tm, tn);
     const int m0 = tm * GEMM_BM, n0 = tn * GEMM_BN;
     f32x16 acc[2][2];
-    gemm_mainloop(A, lda, Bt, ldb, M, N, K, m0, n0, smem, acc);   // ends with a barrier
+    gemm_mainloop<BK>(A, lda, Bt, ldb, M, N, K, m0, n0, smem, acc);   // ends with a barrier
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wm = wave >> 1, wn = wave & 1, half = lane >> 5, l32 = lane & 31;
-    float *Ct = smem;
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                Ct[row * CT_LD + wn * 64 + j * 32 + l32] = acc[i][j][r] * inv_temp;
-            }
-    __syncthreads();
-
     const int grp = lane >> 4, sub = lane & 15;
-    for (int it = 0; it < 8; ++it) {
-        const int rl = wave * 32 + it * 4 + grp;
-        const int row = m0 + rl;
-        float v[8];
-        int ci[8];
+    float *Ct = smem;                                   // [64][CT_LD]: one 64-row half of the tile at a time
+    for (int hh = 0; hh < 2; ++hh) {
+        if (wm == hh) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int cl = sub + 16 * j;
-            ci[j] = n0 + cl;
-            v[j] = (ci[j] < N) ? Ct[rl * CT_LD + cl] : -INFINITY;
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int row = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                        Ct[row * CT_LD + wn * 64 + j * 32 + l32] = acc[i][j][r] * inv_temp;
+                    }
         }
-        float mx = v[0];
+        __syncthreads();
+        for (int it = 0; it < 4; ++it) {
+            const int rl = wave * 16 + it * 4 + grp;       // row within the half
+            const int row = m0 + hh * 64 + rl;
+            float v[8];
 #pragma unroll
-        for (int j = 1; j < 8; ++j) mx = fmaxf(mx, v[j]);
+            for (int j = 0; j < 8; ++j) {
+                const int cl = sub + 16 * j;
+                v[j] = (n0 + cl < N) ? Ct[rl * CT_LD + cl] : -INFINITY;
+            }
+            float mx = v[0];
 #pragma unroll
-        for (int o = 8; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
-        float se = 0.f;
+            for (int j = 1; j < 8; ++j) mx = fmaxf(mx, v[j]);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) se += __expf(v[j] - mx);
+            for (int o = 8; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+            float se = 0.f;
 #pragma unroll
-        for (int o = 8; o > 0; o >>= 1) se += __shfl_xor(se, o, 64);
-        const size_t tbase = (size_t)row * tiles_n + tn;
-        if (row < M && sub == 0) {
-            tile_max[tbase] = mx;
-            tile_sum[tbase] = se;
+            for (int j = 0; j < 8; ++j) se += __expf(v[j] - mx);
+#pragma unroll
+            for (int o = 8; o > 0; o >>= 1) se += __shfl_xor(se, o, 64);
+            const size_t tbase = (size_t)row * tiles_n + tn;
+            if (row < M && sub == 0) {
+                tile_max[tbase] = mx;
+                tile_sum[tbase] = se;
+            }
+#pragma unroll
+            for (int kk = 0; kk < KSEL; ++kk) {
+                // lane-local best (lowest column wins ties: columns ascend with j)
+                float bv = v[0];
+                int bj = 0;
+#pragma unroll
+                for (int j = 1; j < 8; ++j)
+                    if (v[j] > bv) { bv = v[j]; bj = j; }
+                const int bc = sub + 16 * bj;   // local column
+                float gv = bv;
+                int gc = bc;
+#pragma unroll
+                for (int o = 8; o > 0; o >>= 1) {
+                    const float ov = __shfl_xor(gv, o, 64);
+                    const int oc = __shfl_xor(gc, o, 64);
+                    if (ov > gv || (ov == gv && oc < gc)) { gv = ov; gc = oc; }
+                }
+                if (gc == bc) {           // this lane owned the winner: retire it
+#pragma unroll
+                    for (int j = 0; j < 8; ++j)
+                        if (j == bj) v[j] = -INFINITY;
+                }
+                if (row < M && sub == kk) {
+                    cand_val[tbase * KSEL + kk] = gv;
+                    cand_idx[tbase * KSEL + kk] = n0 + gc;
+                }
+            }
         }
-#pragma unroll
-        for (int kk = 0; kk < KSEL; ++kk) {
-            // lane-local best (lowest column wins ties: columns ascend with j)
-            float bv = v[0];
-            int bj = 0;
-#pragma unroll
-            for (int j = 1; j < 8; ++j)
-                if (v[j] > bv) { bv = v[j]; bj = j; }
-            int bc = sub + 16 * bj;   // local column
-            float gv = bv;
-            int gc = bc;
-#pragma unroll
-            for (int o = 8; o > 0; o >>= 1) {
-                const float ov = __shfl_xor(gv, o, 64);
-                const int oc = __shfl_xor(gc, o, 64);
-                if (ov > gv || (ov == gv && oc < gc)) { gv = ov; gc = oc; }
-            }
-            if (gc == bc) {           // this lane owned the winner: retire it
-#pragma unroll
-                for (int j = 0; j < 8; ++j)
-                    if (j == bj) v[j] = -INFINITY;
-            }
-            if (row < M && sub == kk) {
-                cand_val[tbase * KSEL + kk] = gv;
-                cand_idx[tbase * KSEL + kk] = n0 + gc;
-            }
-        }
+        __syncthreads();
     }
 }
 
@@ -271,8 +300,23 @@ int launch_gemm_f32(hipStream_t st, const float *A, int lda, const float *Bt, in
     CAPDEC_CHECK(lda % 4 == 0 && ldb % 4 == 0, "gemm: lda/ldb must be multiples of 4 (16-byte rows)");
     CAPDEC_CHECK((((uintptr_t)A | (uintptr_t)Bt) & 15) == 0, "gemm: operands must be 16-byte aligned");
     const int tiles_m = (M + GEMM_BM - 1) / GEMM_BM, tiles_n = (N + GEMM_BN - 1) / GEMM_BN;
-    hipLaunchKernelGGL(gemm_f32_kernel, dim3(tiles_m * tiles_n), dim3(256), 0, st, A, lda, Bt, ldb, C, ldc, M, N, K,
-                       epi.bias, epi.resid, epi.ldr, epi.act, tiles_m, tiles_n);
+    // BK 16 (40 KB LDS, 3-4 blocks per CU) measured faster on the wide / deep projections, BK 32 on the
+    // N = K = 768 ones; CAPDEC_GEMM_BK overrides (tuning knob)
+    static const int bk_env = [] { const char *e = getenv("CAPDEC_GEMM_BK"); return e ? atoi(e) : 0; }();
+    const int bk = bk_env ? bk_env : ((N >= 3072 || K >= 2048) ? 16 : 32);
+    static const int abl = [] { const char *e = getenv("CAPDEC_GEMM_ABL"); return e ? atoi(e) : 0; }();
+    if (abl == 1)
+        hipLaunchKernelGGL((gemm_f32_kernel<32, 2, 1>), dim3(tiles_m * tiles_n), dim3(256), 0, st, A, lda, Bt, ldb, C, ldc,
+                           M, N, K, epi.bias, epi.resid, epi.ldr, epi.act, tiles_m, tiles_n);
+    else if (abl == 2)
+        hipLaunchKernelGGL((gemm_f32_kernel<32, 2, 2>), dim3(tiles_m * tiles_n), dim3(256), 0, st, A, lda, Bt, ldb, C, ldc,
+                           M, N, K, epi.bias, epi.resid, epi.ldr, epi.act, tiles_m, tiles_n);
+    else if (bk == 16)
+        hipLaunchKernelGGL((gemm_f32_kernel<16, 3>), dim3(tiles_m * tiles_n), dim3(256), 0, st, A, lda, Bt, ldb, C, ldc, M,
+                           N, K, epi.bias, epi.resid, epi.ldr, epi.act, tiles_m, tiles_n);
+    else
+        hipLaunchKernelGGL((gemm_f32_kernel<32, 2>), dim3(tiles_m * tiles_n), dim3(256), 0, st, A, lda, Bt, ldb, C, ldc, M,
+                           N, K, epi.bias, epi.resid, epi.ldr, epi.act, tiles_m, tiles_n);
     CAPDEC_HIP(hipGetLastError());
     return 0;
 }
@@ -284,9 +328,14 @@ int launch_gemm_f32_topk(hipStream_t st, const float *A, int lda, const float *B
     CAPDEC_CHECK(lda % 4 == 0 && ldb % 4 == 0, "gemm_topk: lda/ldb must be multiples of 4");
     const int tiles_m = (M + GEMM_BM - 1) / GEMM_BM, tiles_n = (N + GEMM_BN - 1) / GEMM_BN;
     dim3 grid(tiles_m * tiles_n), block(256);
-#define LAUNCH_TOPK(KS)                                                                                         \
-    hipLaunchKernelGGL(gemm_f32_topk_kernel<KS>, grid, block, 0, st, A, lda, Bt, ldb, M, N, K, inv_temp, tile_max, \
-                       tile_sum, cand_val, cand_idx, tiles_m, tiles_n)
+    static const int bk = [] { const char *e = getenv("CAPDEC_LMHEAD_BK"); return e ? atoi(e) : 16; }();
+#define LAUNCH_TOPK(KS)                                                                                          \
+    if (bk == 16)                                                                                                \
+        hipLaunchKernelGGL((gemm_f32_topk_kernel<KS, 16, 3>), grid, block, 0, st, A, lda, Bt, ldb, M, N, K, inv_temp, \
+                           tile_max, tile_sum, cand_val, cand_idx, tiles_m, tiles_n);                            \
+    else                                                                                                         \
+        hipLaunchKernelGGL((gemm_f32_topk_kernel<KS, 32, 2>), grid, block, 0, st, A, lda, Bt, ldb, M, N, K, inv_temp, \
+                           tile_max, tile_sum, cand_val, cand_idx, tiles_m, tiles_n)
     switch (k) {
         case 1: LAUNCH_TOPK(1); break;
         case 2: LAUNCH_TOPK(2); break;

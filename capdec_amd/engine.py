@@ -178,6 +178,83 @@ class Engine:
             check(self.lib.capdec_mapper_forward(self._h, x.data_ptr(), n, out.data_ptr()), "capdec_mapper_forward")
         return out
 
+    # ------------------------------------------------------------------ CLIP towers
+    def _clip_blocks(self, sd, prefix: str, layers: int, keep: list):
+        blocks = (_capi.ClipBlock * layers)()
+        names = [("ln_1_w", "ln_1.weight"), ("ln_1_b", "ln_1.bias"), ("in_proj_w", "attn.in_proj_weight"),
+                 ("in_proj_b", "attn.in_proj_bias"), ("out_proj_w", "attn.out_proj.weight"),
+                 ("out_proj_b", "attn.out_proj.bias"), ("ln_2_w", "ln_2.weight"), ("ln_2_b", "ln_2.bias"),
+                 ("c_fc_w", "mlp.c_fc.weight"), ("c_fc_b", "mlp.c_fc.bias"), ("c_proj_w", "mlp.c_proj.weight"),
+                 ("c_proj_b", "mlp.c_proj.bias")]
+        for i in range(layers):
+            for field, key in names:
+                a = _f32(sd[f"{prefix}transformer.resblocks.{i}.{key}"])
+                keep.append(a)
+                setattr(blocks[i], field, _fp(a))
+        return blocks
+
+    @staticmethod
+    def _count_blocks(sd, prefix: str) -> int:
+        n = 0
+        while f"{prefix}transformer.resblocks.{n}.ln_1.weight" in sd:
+            n += 1
+        return n
+
+    def load_clip(self, sd: Dict[str, torch.Tensor], text: bool = True, vision: bool = True):
+        """OpenAI CLIP ViT state dict (what `clip.load(...)[0].state_dict()` holds; fp16 weights are
+        upcast).  ModifiedResNet visual towers (RN50x4) are not supported."""
+        keep: list = []
+        if text:
+            te, pe = _f32(sd["token_embedding.weight"]), _f32(sd["positional_embedding"])
+            proj = _f32(sd["text_projection"])
+            lw, lb = _f32(sd["ln_final.weight"]), _f32(sd["ln_final.bias"])
+            keep += [te, pe, proj, lw, lb]
+            layers = self._count_blocks(sd, "")
+            width = te.shape[1]
+            w = _capi.ClipTextWeights(pe.shape[0], te.shape[0], width, width // 64, layers, proj.shape[1], _fp(te),
+                                      _fp(pe), self._clip_blocks(sd, "", layers, keep), _fp(lw), _fp(lb), _fp(proj))
+            check(self.lib.capdec_load_clip_text(self._h, C.byref(w)), "capdec_load_clip_text")
+            self.clip_text = dict(context_length=pe.shape[0], embed_dim=proj.shape[1], vocab=te.shape[0])
+        if vision:
+            if "visual.conv1.weight" not in sd or "visual.class_embedding" not in sd:
+                raise CapdecError("only ViT visual towers are supported (no visual.conv1/class_embedding in the state dict)")
+            cw = _f32(sd["visual.conv1.weight"])
+            ce, pe = _f32(sd["visual.class_embedding"]), _f32(sd["visual.positional_embedding"])
+            l1w, l1b = _f32(sd["visual.ln_pre.weight"]), _f32(sd["visual.ln_pre.bias"])
+            l2w, l2b = _f32(sd["visual.ln_post.weight"]), _f32(sd["visual.ln_post.bias"])
+            proj = _f32(sd["visual.proj"])
+            keep += [cw, ce, pe, l1w, l1b, l2w, l2b, proj]
+            width, patch = cw.shape[0], cw.shape[-1]
+            image = int(round((pe.shape[0] - 1) ** 0.5)) * patch
+            layers = self._count_blocks(sd, "visual.")
+            w = _capi.ClipVisionWeights(image, patch, width, width // 64, layers, proj.shape[1], _fp(cw), _fp(ce), _fp(pe),
+                                        _fp(l1w), _fp(l1b), self._clip_blocks(sd, "visual.", layers, keep), _fp(l2w),
+                                        _fp(l2b), _fp(proj))
+            check(self.lib.capdec_load_clip_vision(self._h, C.byref(w)), "capdec_load_clip_vision")
+            self.clip_vision = dict(image_size=image, embed_dim=proj.shape[1])
+
+    def clip_encode_text(self, tokens: torch.Tensor) -> torch.Tensor:
+        t = self._dev(tokens, torch.int32)
+        n = t.shape[0]
+        if t.shape[1] != self.clip_text["context_length"]:
+            raise CapdecError(f"token rows must have context_length {self.clip_text['context_length']}")
+        out = torch.empty(n, self.clip_text["embed_dim"], device=self.device, dtype=torch.float32)
+        if n:
+            self._sync_stream()
+            check(self.lib.capdec_clip_encode_text(self._h, t.data_ptr(), n, out.data_ptr()), "capdec_clip_encode_text")
+        return out
+
+    def clip_encode_image(self, pixels: torch.Tensor) -> torch.Tensor:
+        x = self._dev(pixels)
+        n, S = x.shape[0], self.clip_vision["image_size"]
+        if tuple(x.shape[1:]) != (3, S, S):
+            raise CapdecError(f"images must be [n, 3, {S}, {S}] (already preprocessed)")
+        out = torch.empty(n, self.clip_vision["embed_dim"], device=self.device, dtype=torch.float32)
+        if n:
+            self._sync_stream()
+            check(self.lib.capdec_clip_encode_image(self._h, x.data_ptr(), n, out.data_ptr()), "capdec_clip_encode_image")
+        return out
+
     # ------------------------------------------------------------------ GPT-2
     def gpt2_logits(self, embeds: torch.Tensor, all_positions: bool = True) -> torch.Tensor:
         e = self._dev(embeds)

@@ -151,3 +151,93 @@ def state_dict_checksum(sd) -> int:
     for k in sorted(sd):
         c = zlib.crc32(np.ascontiguousarray(sd[k].detach().cpu().numpy()).tobytes(), c)
     return c & 0xFFFFFFFF
+
+
+# ----------------------------------------------------------------------------------------------
+# CLIP ViT-B/32 (reference dependency `clip`, openai/CLIP; call sites embeddings_generator.py:49,86,89,
+# predictions_runner.py:158-161,212-220).  Key names are those of an OpenAI CLIP state dict.
+@dataclass(frozen=True)
+class ClipDims:
+    embed_dim: int = 512
+    # text tower
+    context_length: int = 77
+    vocab_size: int = 49408
+    text_width: int = 512
+    text_heads: int = 8
+    text_layers: int = 12
+    # vision tower (ViT-B/32)
+    image_size: int = 224
+    patch: int = 32
+    vision_width: int = 768
+    vision_heads: int = 12
+    vision_layers: int = 12
+
+
+CLIP_VIT_B32 = ClipDims()
+#: reduced depth for fast CPU tests (same widths, so the same kernels run)
+CLIP_TINY = ClipDims(text_layers=2, vision_layers=2, vocab_size=49408)
+
+
+def _hot_resblocks(g, sd, prefix: str, width: int, layers: int):
+    for i in range(layers):
+        b = f"{prefix}transformer.resblocks.{i}."
+        sd[b + "ln_1.weight"] = _randn(g, width, std=0.1, mean=1.0)
+        sd[b + "ln_1.bias"] = _randn(g, width, std=0.1)
+        sd[b + "attn.in_proj_weight"] = _randn(g, 3 * width, width, std=0.06)
+        sd[b + "attn.in_proj_bias"] = _randn(g, 3 * width, std=0.02)
+        sd[b + "attn.out_proj.weight"] = _randn(g, width, width, std=0.06)
+        sd[b + "attn.out_proj.bias"] = _randn(g, width, std=0.02)
+        sd[b + "ln_2.weight"] = _randn(g, width, std=0.1, mean=1.0)
+        sd[b + "ln_2.bias"] = _randn(g, width, std=0.1)
+        sd[b + "mlp.c_fc.weight"] = _randn(g, 4 * width, width, std=0.06)
+        sd[b + "mlp.c_fc.bias"] = _randn(g, 4 * width, std=0.02)
+        sd[b + "mlp.c_proj.weight"] = _randn(g, width, 4 * width, std=0.06)
+        sd[b + "mlp.c_proj.bias"] = _randn(g, width, std=0.02)
+
+
+def hot_clip_state_dict(seed: int = 43, dims: ClipDims = CLIP_VIT_B32) -> "OrderedDict[str, torch.Tensor]":
+    """Seeded 'hot' CLIP ViT-B/32 weights under OpenAI state-dict names (text + visual towers)."""
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    sd: "OrderedDict[str, torch.Tensor]" = OrderedDict()
+    w = dims.text_width
+    sd["token_embedding.weight"] = _randn(g, dims.vocab_size, w, std=0.15)
+    sd["positional_embedding"] = _randn(g, dims.context_length, w, std=0.05)
+    _hot_resblocks(g, sd, "", w, dims.text_layers)
+    sd["ln_final.weight"] = _randn(g, w, std=0.1, mean=1.0)
+    sd["ln_final.bias"] = _randn(g, w, std=0.1)
+    sd["text_projection"] = _randn(g, w, dims.embed_dim, std=w ** -0.5)
+    v = dims.vision_width
+    n_tok = (dims.image_size // dims.patch) ** 2 + 1
+    sd["visual.conv1.weight"] = _randn(g, v, 3, dims.patch, dims.patch, std=0.02)
+    sd["visual.class_embedding"] = _randn(g, v, std=0.15)
+    sd["visual.positional_embedding"] = _randn(g, n_tok, v, std=0.05)
+    sd["visual.ln_pre.weight"] = _randn(g, v, std=0.1, mean=1.0)
+    sd["visual.ln_pre.bias"] = _randn(g, v, std=0.1)
+    _hot_resblocks(g, sd, "visual.", v, dims.vision_layers)
+    sd["visual.ln_post.weight"] = _randn(g, v, std=0.1, mean=1.0)
+    sd["visual.ln_post.bias"] = _randn(g, v, std=0.1)
+    sd["visual.proj"] = _randn(g, v, dims.embed_dim, std=v ** -0.5)
+    sd["logit_scale"] = torch.tensor(2.6592)
+    return sd
+
+
+def synthetic_clip_tokens(n: int, seed: int = 2, context_length: int = 77, vocab: int = 49408,
+                          min_len: int = 8, max_len: int = 20) -> torch.Tensor:
+    """int64 [n, 77] rows shaped like clip.tokenize output (reference embeddings_generator.py:80-85):
+    SOT 49406, 8-20 random ids in [1, 49405], EOT 49407, zero padding."""
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    out = torch.zeros(n, context_length, dtype=torch.int64)
+    lens = torch.randint(min_len, max_len + 1, (n,), generator=g)
+    body = torch.randint(1, vocab - 2, (n, max_len), generator=g)
+    out[:, 0] = vocab - 2
+    for r in range(n):
+        L = int(lens[r])
+        out[r, 1:1 + L] = body[r, :L]
+        out[r, 1 + L] = vocab - 1
+    return out
+
+
+def synthetic_images(n: int, seed: int = 4, size: int = 224) -> torch.Tensor:
+    """fp32 [n, 3, size, size] ~ N(0,1): stands for already-preprocessed (normalised) pixels."""
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    return torch.randn(n, 3, size, size, generator=g, dtype=torch.float32)

@@ -36,7 +36,8 @@ extern "C" {
 typedef struct capdec_ctx capdec_ctx;
 
 /* activation codes for capdec_gemm_f32 (test hook) */
-enum { CAPDEC_ACT_NONE = 0, CAPDEC_ACT_TANH = 1, CAPDEC_ACT_RELU = 2, CAPDEC_ACT_GELU_NEW = 3 };
+enum { CAPDEC_ACT_NONE = 0, CAPDEC_ACT_TANH = 1, CAPDEC_ACT_RELU = 2, CAPDEC_ACT_GELU_NEW = 3,
+       CAPDEC_ACT_QUICK_GELU = 4 };
 
 /* ---- context ------------------------------------------------------------------------ */
 int capdec_abi_version(void);
@@ -126,6 +127,49 @@ int capdec_noise_inject(capdec_ctx *ctx, const float *d_x, int n, int dim, float
 /* `model.clip_project(prefix)` (reference predictions_runner.py:228; gpt2_prefix.py:145-147):
  * d_x [n, D] -> d_out [n, P, d] with whichever mapper is loaded. */
 int capdec_mapper_forward(capdec_ctx *ctx, const float *d_x, int n, float *d_out);
+
+/* ---- CLIP ViT-B/32 towers --------------------------------------------------------------
+ * replaces `clip.load("ViT-B/32", device, jit=False)` + `encode_text` / `encode_image`
+ * (reference embeddings_generator.py:49,86,89; predictions_runner.py:161,218,220).  Pointers are
+ * the tensors of an OpenAI CLIP state dict, in its own layouts (nn.Linear / in_proj [out,in];
+ * text_projection / visual.proj [width, embed_dim]).  head_dim must be 64 (ViT-B/32: 512/8, 768/12). */
+typedef struct capdec_clip_block {
+    const float *ln_1_w, *ln_1_b;            /* [w] */
+    const float *in_proj_w, *in_proj_b;      /* [3w, w], [3w] */
+    const float *out_proj_w, *out_proj_b;    /* [w, w], [w] */
+    const float *ln_2_w, *ln_2_b;            /* [w] */
+    const float *c_fc_w, *c_fc_b;            /* [4w, w], [4w] */
+    const float *c_proj_w, *c_proj_b;        /* [w, 4w], [w] */
+} capdec_clip_block;
+
+typedef struct capdec_clip_text_weights {
+    int context_length, vocab, width, heads, layers, embed_dim;
+    const float *token_embedding;            /* [vocab, w] */
+    const float *positional_embedding;       /* [context_length, w] */
+    const capdec_clip_block *blocks;         /* [layers] */
+    const float *ln_final_w, *ln_final_b;    /* [w] */
+    const float *text_projection;            /* [w, embed_dim] */
+} capdec_clip_text_weights;
+
+typedef struct capdec_clip_vision_weights {
+    int image_size, patch, width, heads, layers, embed_dim;
+    const float *conv1_w;                    /* [w, 3, patch, patch] (no bias) */
+    const float *class_embedding;            /* [w] */
+    const float *positional_embedding;       /* [(image_size/patch)^2 + 1, w] */
+    const float *ln_pre_w, *ln_pre_b;        /* [w] */
+    const capdec_clip_block *blocks;         /* [layers] */
+    const float *ln_post_w, *ln_post_b;      /* [w] */
+    const float *proj;                       /* [w, embed_dim] */
+} capdec_clip_vision_weights;
+
+int capdec_load_clip_text(capdec_ctx *ctx, const capdec_clip_text_weights *h_w);
+int capdec_load_clip_vision(capdec_ctx *ctx, const capdec_clip_vision_weights *h_w);
+/* `clip_model.encode_text(clip.tokenize(caption))`: d_tokens int32 [n, context_length] (SOT ... EOT,
+ * zero padded; the EOT row is found as argmax of the ids) -> d_out [n, embed_dim], NOT normalised */
+int capdec_clip_encode_text(capdec_ctx *ctx, const int32_t *d_tokens, int n, float *d_out);
+/* `clip_model.encode_image(preprocess(image))`: d_pixels fp32 [n, 3, S, S] already resized /
+ * normalised -> d_out [n, embed_dim], NOT normalised */
+int capdec_clip_encode_image(capdec_ctx *ctx, const float *d_pixels, int n, float *d_out);
 
 /* ---- GPT-2 --------------------------------------------------------------------------- */
 /* `model.gpt(inputs_embeds=x).logits` (reference gpt2_prefix_eval.py:76-77,163-164).

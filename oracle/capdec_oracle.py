@@ -361,3 +361,61 @@ def beam_cached(sd: SD, prefix: Tensor, beam_size: int = 5, stop_id: int = 13, e
 def beam_output_order(scores: Tensor) -> Tensor:
     """``scores.argsort(descending=True)`` of reference gpt2_prefix_eval.py:113, per caption."""
     return scores.argsort(dim=-1, descending=True)
+
+
+# ----------------------------------------------------------------------------------------
+# CLIP ViT-B/32 towers (third-party `clip` = openai/CLIP, un-vendored and NOT installed here;
+# reference call sites embeddings_generator.py:86,89, predictions_runner.py:218,220).  Restated
+# from the published model (clip/model.py: Transformer / ResidualAttentionBlock / QuickGELU /
+# VisionTransformer / CLIP.encode_text / encode_image) on OpenAI state-dict names.  Pinned only
+# against the independent HF `CLIPModel` stand-in (tests/golden/clip_*.npz): PARITY UNPINNED
+# with respect to the reference's own dependency.
+# ----------------------------------------------------------------------------------------
+def _clip_resblocks(x: Tensor, sd: SD, prefix: str, n_head: int, causal: bool) -> Tensor:
+    N, L, d = x.shape
+    hd = d // n_head
+    i = 0
+    while f"{prefix}transformer.resblocks.{i}.ln_1.weight" in sd:
+        b = f"{prefix}transformer.resblocks.{i}."
+        a = F.layer_norm(x, (d,), sd[b + "ln_1.weight"], sd[b + "ln_1.bias"], 1e-5)
+        qkv = F.linear(a, sd[b + "attn.in_proj_weight"], sd[b + "attn.in_proj_bias"])
+        q, k, v = qkv.split(d, dim=2)
+        q = q.view(N, L, n_head, hd).transpose(1, 2) * (hd ** -0.5)     # nn.MultiheadAttention scales q
+        k = k.view(N, L, n_head, hd).transpose(1, 2)
+        v = v.view(N, L, n_head, hd).transpose(1, 2)
+        w = torch.matmul(q, k.transpose(-1, -2))
+        if causal:                                                        # build_attention_mask: -inf above the diagonal
+            w = w + torch.full((L, L), float("-inf")).triu_(1)
+        o = torch.matmul(w.softmax(dim=-1), v).transpose(1, 2).reshape(N, L, d)
+        x = x + F.linear(o, sd[b + "attn.out_proj.weight"], sd[b + "attn.out_proj.bias"])
+        m = F.layer_norm(x, (d,), sd[b + "ln_2.weight"], sd[b + "ln_2.bias"], 1e-5)
+        m = F.linear(m, sd[b + "mlp.c_fc.weight"], sd[b + "mlp.c_fc.bias"])
+        m = m * torch.sigmoid(1.702 * m)                                  # QuickGELU
+        x = x + F.linear(m, sd[b + "mlp.c_proj.weight"], sd[b + "mlp.c_proj.bias"])
+        i += 1
+    return x
+
+
+def clip_encode_text(text: Tensor, sd: SD, n_head: int = 8) -> Tensor:
+    """CLIP.encode_text: token ids int [N, 77] -> [N, embed_dim] (NOT normalised, like
+    reference embeddings_generator.py:86-87)."""
+    x = sd["token_embedding.weight"][text] + sd["positional_embedding"]
+    x = _clip_resblocks(x, sd, "", n_head, causal=True)
+    d = x.shape[-1]
+    x = F.layer_norm(x, (d,), sd["ln_final.weight"], sd["ln_final.bias"], 1e-5)
+    x = x[torch.arange(x.shape[0]), text.argmax(dim=-1)]                  # EOT token = highest id
+    return x @ sd["text_projection"]
+
+
+def clip_encode_image(image: Tensor, sd: SD, n_head: int = 12) -> Tensor:
+    """CLIP.encode_image (VisionTransformer): pixels fp32 [N, 3, 224, 224] -> [N, embed_dim]."""
+    w = sd["visual.conv1.weight"]
+    x = F.conv2d(image, w, stride=w.shape[-1])                            # [N, width, 7, 7]
+    x = x.reshape(x.shape[0], x.shape[1], -1).permute(0, 2, 1)            # [N, 49, width]
+    cls = sd["visual.class_embedding"].expand(x.shape[0], 1, -1)
+    x = torch.cat([cls, x], dim=1) + sd["visual.positional_embedding"]
+    d = x.shape[-1]
+    x = F.layer_norm(x, (d,), sd["visual.ln_pre.weight"], sd["visual.ln_pre.bias"], 1e-5)
+    x = _clip_resblocks(x, sd, "visual.", n_head, causal=False)
+    x = F.layer_norm(x[:, 0, :], (d,), sd["visual.ln_post.weight"], sd["visual.ln_post.bias"], 1e-5)
+    return x @ sd["visual.proj"]

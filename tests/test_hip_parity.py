@@ -331,3 +331,53 @@ def test_full_size_properties():
     ids_c, lens_c = E.decode_greedy_ids(model, pe[:1], first, 67)
     k = int((ids[0] == first).nonzero()[0])
     assert int(lens_c[0]) == k + 1 and torch.equal(ids_c[0, :k + 1], ids[0, :k + 1])
+
+
+# ----------------------------------------------------------------------------------- CLIP ViT-B/32 towers
+def _check_clip(g, dims):
+    from capdec_amd import clip as cclip
+    from oracle import capdec_oracle as O
+    sd = synth.hot_clip_state_dict(43, dims)
+    assert synth.state_dict_checksum(sd) == int(g["crc"]), "RNG drift"
+    model, _ = cclip.load(sd, device=0)
+    toks = T(g["tokens"])
+    tf = model.encode_text(toks).cpu()
+    np.testing.assert_allclose(tf.numpy(), g["text_features"], atol=5e-4)          # HF stand-in fixture
+    np.testing.assert_allclose(tf.numpy(), O.clip_encode_text(toks, sd).numpy(), atol=5e-4)
+    imgs = synth.synthetic_images(g["image_features"].shape[0], seed=int(g["image_seed"]))
+    vf = model.encode_image(imgs).cpu()
+    np.testing.assert_allclose(vf.numpy(), g["image_features"], atol=5e-4)
+    return model, sd
+
+
+def test_clip_tiny_towers(golden):
+    model, sd = _check_clip(golden("clip_tiny"), synth.CLIP_TINY)
+    from oracle import capdec_oracle as O
+    # ragged batch (not a multiple of anything), every row a different EOT position
+    toks = synth.synthetic_clip_tokens(37, seed=9, min_len=1, max_len=75)
+    np.testing.assert_allclose(model.encode_text(toks).cpu().numpy(), O.clip_encode_text(toks, sd).numpy(), atol=5e-4)
+    assert model.encode_text(toks[:0]).shape == (0, 512)
+
+
+def test_clip_b32_towers(golden):
+    _check_clip(golden("clip_b32"), synth.CLIP_VIT_B32)
+
+
+def test_text_to_prefix_pipeline():
+    """config-4 chain: encode_text -> noise_injection -> clip_project, vs the oracle with the same injected noise"""
+    from capdec_amd import clip as cclip, embeddings_generator as eg
+    from oracle import capdec_oracle as O
+    dims = synth.CLIP_TINY
+    csd = synth.hot_clip_state_dict(43, dims)
+    cm, _ = cclip.load(csd, device=0)
+    model, sd = _model(synth.GPT2_TINY, "mlp", 512, seed=7)
+    toks = synth.synthetic_clip_tokens(9, seed=5)
+    emb = eg.encode_captions(cm, toks)
+    assert emb.shape == (9, 512)
+    noise = torch.randn(9, 512, generator=torch.Generator().manual_seed(3))
+    from capdec_amd import train as ct
+    x = ct.noise_injection(emb, 0.016, noise=noise)
+    pe = model.clip_project(x).reshape(9, 10, -1).cpu()
+    ref = O.clip_project(O.noise_injection(O.clip_encode_text(toks, csd), 0.016, noise=noise), sd, "mlp", 10)
+    np.testing.assert_allclose(pe.numpy(), ref.numpy(), atol=1e-3)
+    assert eg.text_to_prefix(cm, model, toks, noise_variance=0.016, seed=1).shape == (9, 10, 768)

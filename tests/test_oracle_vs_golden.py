@@ -148,3 +148,25 @@ def test_decode_tiny(golden):
 @pytest.mark.slow
 def test_decode_small(golden):
     _check_decode(golden("decode_small"), synth.GPT2_SMALL, 1, 1)
+
+
+# ------------------------------------------------------------------ CLIP ViT-B/32 (HF stand-in pin)
+def _check_clip(g, dims):
+    sd = synth.hot_clip_state_dict(43, dims)
+    assert synth.state_dict_checksum(sd) == int(g["crc"]), "RNG drift"
+    toks = T(g["tokens"])
+    np.testing.assert_array_equal(toks.numpy(), synth.synthetic_clip_tokens(toks.shape[0], seed=2).numpy())
+    tf = O.clip_encode_text(toks, sd)
+    np.testing.assert_allclose(tf.numpy(), g["text_features"], atol=2e-4)
+    imgs = synth.synthetic_images(g["image_features"].shape[0], seed=int(g["image_seed"]))
+    vf = O.clip_encode_image(imgs, sd)
+    np.testing.assert_allclose(vf.numpy(), g["image_features"], atol=2e-4)
+
+
+def test_clip_tiny(golden):
+    _check_clip(golden("clip_tiny"), synth.CLIP_TINY)
+
+
+@pytest.mark.slow
+def test_clip_b32(golden):
+    _check_clip(golden("clip_b32"), synth.CLIP_VIT_B32)

@@ -251,6 +251,64 @@ def gen_decode(refs, dims, tag, n_greedy, n_beam, lengths):
     print(f"decode_{tag}.npz written; greedy stop {out['greedy_stop_id']}, beam stop {out['beam_stop_id']}")
 
 
+def openai_to_hf_clip(sd, dims):
+    """Map an OpenAI-CLIP-named state dict onto transformers.CLIPModel names (the independent
+    stand-in used to pin the CLIP kernels: the reference's own `clip` package is not installed)."""
+    out = {"logit_scale": sd["logit_scale"],
+           "text_model.embeddings.token_embedding.weight": sd["token_embedding.weight"],
+           "text_model.embeddings.position_embedding.weight": sd["positional_embedding"],
+           "text_model.final_layer_norm.weight": sd["ln_final.weight"],
+           "text_model.final_layer_norm.bias": sd["ln_final.bias"],
+           "text_projection.weight": sd["text_projection"].t().contiguous(),
+           "vision_model.embeddings.class_embedding": sd["visual.class_embedding"],
+           "vision_model.embeddings.patch_embedding.weight": sd["visual.conv1.weight"],
+           "vision_model.embeddings.position_embedding.weight": sd["visual.positional_embedding"],
+           "vision_model.pre_layrnorm.weight": sd["visual.ln_pre.weight"],
+           "vision_model.pre_layrnorm.bias": sd["visual.ln_pre.bias"],
+           "vision_model.post_layernorm.weight": sd["visual.ln_post.weight"],
+           "vision_model.post_layernorm.bias": sd["visual.ln_post.bias"],
+           "visual_projection.weight": sd["visual.proj"].t().contiguous()}
+    for tower, pfx, width, layers in (("text_model", "", dims.text_width, dims.text_layers),
+                                      ("vision_model", "visual.", dims.vision_width, dims.vision_layers)):
+        for i in range(layers):
+            b, h = f"{pfx}transformer.resblocks.{i}.", f"{tower}.encoder.layers.{i}."
+            wq, wk, wv = sd[b + "attn.in_proj_weight"].split(width, dim=0)
+            bq, bk, bv = sd[b + "attn.in_proj_bias"].split(width, dim=0)
+            out.update({h + "self_attn.q_proj.weight": wq, h + "self_attn.k_proj.weight": wk,
+                        h + "self_attn.v_proj.weight": wv, h + "self_attn.q_proj.bias": bq,
+                        h + "self_attn.k_proj.bias": bk, h + "self_attn.v_proj.bias": bv,
+                        h + "self_attn.out_proj.weight": sd[b + "attn.out_proj.weight"],
+                        h + "self_attn.out_proj.bias": sd[b + "attn.out_proj.bias"],
+                        h + "layer_norm1.weight": sd[b + "ln_1.weight"], h + "layer_norm1.bias": sd[b + "ln_1.bias"],
+                        h + "layer_norm2.weight": sd[b + "ln_2.weight"], h + "layer_norm2.bias": sd[b + "ln_2.bias"],
+                        h + "mlp.fc1.weight": sd[b + "mlp.c_fc.weight"], h + "mlp.fc1.bias": sd[b + "mlp.c_fc.bias"],
+                        h + "mlp.fc2.weight": sd[b + "mlp.c_proj.weight"], h + "mlp.fc2.bias": sd[b + "mlp.c_proj.bias"]})
+    return out
+
+
+def gen_clip(dims, tag, n_text, n_img):
+    """CLIP ViT-B/32 text / image features from transformers.CLIPModel (random 'hot' weights)."""
+    from transformers import CLIPConfig, CLIPModel
+    cfg = CLIPConfig()
+    cfg.text_config.num_hidden_layers = dims.text_layers
+    cfg.vision_config.num_hidden_layers = dims.vision_layers
+    model = CLIPModel(cfg).eval()
+    sd = synth.hot_clip_state_dict(43, dims)
+    missing, unexpected = model.load_state_dict(openai_to_hf_clip(sd, dims), strict=False)
+    assert not unexpected and all("position_ids" in m for m in missing), (missing, unexpected)
+    toks = synth.synthetic_clip_tokens(n_text, seed=2)
+    imgs = synth.synthetic_images(n_img, seed=4)
+    with torch.no_grad():
+        tf = model.get_text_features(input_ids=toks)
+        vf = model.get_image_features(pixel_values=imgs)
+    tf = getattr(tf, "pooler_output", tf)
+    vf = getattr(vf, "pooler_output", vf)
+    out = {"crc": np.uint32(synth.state_dict_checksum(sd)), "tokens": toks.numpy(), "text_features": tf.numpy(),
+           "image_seed": np.int64(4), "image_features": vf.numpy()}
+    np.savez_compressed(os.path.join(OUT, f"clip_{tag}.npz"), **out)
+    print(f"clip_{tag}.npz", tf.shape, vf.shape, float(tf.norm(dim=1).mean()), float(vf.norm(dim=1).mean()))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", nargs="*", default=None)
@@ -265,6 +323,8 @@ def main():
         "logits_small": lambda: gen_gpt2_logits(refs, synth.GPT2_SMALL, "small"),
         "decode_tiny": lambda: gen_decode(refs, synth.GPT2_TINY, "tiny", 8, 6, (12, 67)),
         "decode_small": lambda: gen_decode(refs, synth.GPT2_SMALL, "small", 8, 4, (12, 67)),
+        "clip_tiny": lambda: gen_clip(synth.CLIP_TINY, "tiny", 6, 3),
+        "clip_b32": lambda: gen_clip(synth.CLIP_VIT_B32, "b32", 6, 3),
     }
     for name, fn in jobs.items():
         if args.only and name not in args.only:
