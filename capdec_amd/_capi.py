@@ -75,6 +75,8 @@ SIGNATURES = {
     "capdec_set_stream": (C.c_int, [_VP, _VP]),
     "capdec_use_own_stream": (C.c_int, [_VP]),
     "capdec_synchronize": (C.c_int, [_VP]),
+    "capdec_set_gemm_mode": (C.c_int, [_VP, C.c_int]),
+    "capdec_get_gemm_mode": (C.c_int, [_VP]),
     "capdec_set_kv_budget": (C.c_int, [_VP, C.c_size_t]),
     "capdec_malloc": (C.c_int, [_VP, C.c_size_t, C.POINTER(_VP)]),
     "capdec_free": (C.c_int, [_VP, _VP]),

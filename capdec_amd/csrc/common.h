@@ -68,6 +68,15 @@ int launch_gemm_f32_topk(hipStream_t st, const float *A, int lda, const float *B
                          int k, float inv_temp, float *tile_max, float *tile_sum, float *cand_val, int *cand_idx);
 inline int gemm_tiles_n(int N) { return (N + GEMM_BN - 1) / GEMM_BN; }
 
+// gemm_bf16x3.hip: the same two GEMMs on the bf16 matrix cores with operands split into three bf16
+// planes (fp32-accurate, 6 MFMA terms).  Bpacked = tile-major planes made by launch_pack_planes.
+size_t packed_planes_bytes(int N, int K);
+int launch_pack_planes(hipStream_t st, const float *w, int N, int K, void *out);
+int launch_gemm_bf16x3(hipStream_t st, const float *A, int lda, const void *Bpacked, float *C, int ldc, int M, int N,
+                       int K, const GemmEpilogue &epi);
+int launch_gemm_bf16x3_topk(hipStream_t st, const float *A, int lda, const void *Bpacked, int M, int N, int K, int k,
+                            float inv_temp, float *tile_max, float *tile_sum, float *cand_val, int *cand_idx);
+
 // elementwise.hip
 int launch_layernorm(hipStream_t st, const float *x, int ldx, const float *w, const float *b, float eps, float *y,
                      int ldy, int rows, int d);

@@ -1,0 +1,294 @@
+// fp32-accurate GEMM on the bf16 matrix cores:  C[M,N] = epi( A[M,K] . Bt[N,K]^T )
+//
+// gfx950's fp32-input MFMA runs at 1/16 of the bf16 MFMA rate (157 vs 2500 TFLOP/s).  Every fp32
+// value is exactly a sum of three bf16 values  a = a1 + a2 + a3  (8 + 8 + 8 mantissa bits), so
+//     a . b  =  a1 b1 + (a1 b2 + a2 b1) + (a2 b2 + a1 b3 + a3 b1) + O(2^-27 |a b|)
+// and six v_mfma_f32_32x32x16_bf16 (products exact, fp32 accumulate) reproduce an fp32 dot product
+// to fp32 round-off at 16/6 = 2.7x the throughput of the native fp32 MFMA.  The dropped terms
+// (a2 b3 + a3 b2 + a3 b3) are below half an fp32 ulp of the product.
+//
+// Weights are split once at load time into three bf16 planes, packed tile-major; activations stay fp32 in
+// HBM and are split on the fly while they are staged into LDS (6 VALU ops per element, hidden
+// under 24 MFMAs per k-step).  Tiling as the fp32 kernel: 128x128 block, 4 wavefronts x (2x2)
+// 32x32 accumulators; BK = 16 (one MFMA k-step) per LDS stage, three-stage ring (72 KB, 2 blocks/CU).
+#include <cstdlib>
+
+#include "gemm_epilogue.h"
+
+namespace capdec {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+constexpr int X3_BK = 16;
+constexpr int X3_ROW_B = 32;                         // bytes per LDS row: 16 bf16, unpadded, 16-B halves XOR-swizzled
+constexpr int X3_PLANE_B = GEMM_BM * X3_ROW_B;       // 4096: one plane of one operand of a stage
+constexpr int X3_OPER_B = 3 * X3_PLANE_B;            // 12288
+constexpr int X3_STAGE_B = 2 * X3_OPER_B;            // 24576
+constexpr int X3_STAGES = 3;
+constexpr int X3_SMEM_B = X3_STAGES * X3_STAGE_B;    // 73728 -> 2 blocks per CU
+
+__device__ __forceinline__ void split3(const float4 v, bf16x4 &h, bf16x4 &m, bf16x4 &l) {
+    const float a[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const __bf16 hh = (__bf16)a[e];
+        const float r1 = a[e] - (float)hh;            // exact
+        const __bf16 mm = (__bf16)r1;
+        const float r2 = r1 - (float)mm;              // exact
+        h[e] = hh;
+        m[e] = mm;
+        l[e] = (__bf16)r2;
+    }
+}
+
+// Weight pre-pack: fp32 W [N, K] -> bf16 planes in TILE-MAJOR order
+//     Bpk[tile_n][k_step][plane][row 0..127][16 bf16]      (rows past N are zero)
+// i.e. exactly the LDS image of one B stage (3 planes x 128 rows x 32 B, 16-B halves swapped when bit
+// 3 of the row is set), so a block's B tile of one k-step is 12 KB of CONTIGUOUS memory: every
+// global load uses whole 128-B lines and the LDS write is a linear copy.
+__global__ void pack_planes_kernel(const float *__restrict__ w, __bf16 *__restrict__ out, int N, int K, int nk) {
+    // one thread per (tile, k_step, row, half): 8 consecutive k
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int tiles = (N + GEMM_BN - 1) / GEMM_BN;
+    if (i >= (size_t)tiles * nk * 256) return;
+    const int hk = i & 1, r = (i >> 1) & 127;
+    const size_t tk = i >> 8;                       // tile * nk + k_step
+    const int ks = (int)(tk % nk), tile = (int)(tk / nk);
+    const int n = tile * GEMM_BN + r;
+    bf16x4 h0, m0, l0, h1, m1, l1;
+    float4 v0 = make_float4(0.f, 0.f, 0.f, 0.f), v1 = v0;
+    if (n < N) {
+        const float *src = w + (size_t)n * K + ks * 16 + hk * 8;
+        v0 = reinterpret_cast<const float4 *>(src)[0];
+        v1 = reinterpret_cast<const float4 *>(src)[1];
+    }
+    split3(v0, h0, m0, l0);
+    split3(v1, h1, m1, l1);
+    __bf16 *dst = out + tk * (3 * 128 * 16) + r * 16 + ((hk ^ ((r >> 3) & 1)) << 3);
+    reinterpret_cast<bf16x4 *>(dst)[0] = h0;
+    reinterpret_cast<bf16x4 *>(dst)[1] = h1;
+    reinterpret_cast<bf16x4 *>(dst + 2048)[0] = m0;
+    reinterpret_cast<bf16x4 *>(dst + 2048)[1] = m1;
+    reinterpret_cast<bf16x4 *>(dst + 4096)[0] = l0;
+    reinterpret_cast<bf16x4 *>(dst + 4096)[1] = l1;
+}
+
+size_t packed_planes_bytes(int N, int K) {
+    return (size_t)((N + GEMM_BN - 1) / GEMM_BN) * GEMM_BN * K * 3 * sizeof(uint16_t);
+}
+
+int launch_pack_planes(hipStream_t st, const float *w, int N, int K, void *out) {
+    CAPDEC_CHECK(K % 64 == 0, "pack_planes: K must be a multiple of 64");
+    const int nk = K / X3_BK;
+    const size_t tot = (size_t)((N + GEMM_BN - 1) / GEMM_BN) * nk * 256;
+    hipLaunchKernelGGL(pack_planes_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, w, (__bf16 *)out, N, K, nk);
+    CAPDEC_HIP(hipGetLastError());
+    return 0;
+}
+
+// Main loop.  LDS: 3-stage ring, rows of 32 B (16 bf16) whose two 16-B halves are swapped when bit 3
+// of the row index is set (conflict-free ds_read_b128 without padding; 3 x 24 KB = 72 KB, 2 blocks/CU).
+// Global loads run TWO k-steps ahead of their LDS store (L2 misses served by the Infinity Cache take
+// longer than one 24-MFMA k-step), through alternating register sets; the loop is unrolled by 4 so
+// every register set has a static name.  In k-step kt a wavefront
+//   reads the fragments of tile kt from stage kt%3,
+//   issues its 24 MFMAs with the split + LDS store of tile kt+2 (stage (kt+2)%3) interleaved between
+//   the six MFMA groups (VALU / LDS work overlaps the matrix pipe inside the wavefront),
+//   re-issues the global loads of tile kt+4 into the registers it just drained (unconditionally, with a
+//   clamped tile index past the end: a load under a branch would force the compiler to wait vmcnt(0)
+//   instead of a counted wait); one barrier per k-step.
+// A: thread (row = t>>2 [+64], quad = t&3) owns 4 k of each k-step; an (even, odd) k-step pair is loaded
+//    together so the 4 threads of a row fetch one whole 128-B line.  B: packed tile, 12 KB contiguous.
+template <int ABL = 0>
+__device__ __forceinline__ void x3_mainloop(const float *__restrict__ A, int lda, const __bf16 *__restrict__ Bpk,
+                                            int M, int K, int m0, int tn, char *smem, f32x16 (&acc)[2][2]) {
+    const int t = threadIdx.x;
+    const int lane = t & 63, wave = t >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int half = lane >> 5, l32 = lane & 31;
+    const int nk = K / X3_BK;                     // multiple of 4 (K % 64 == 0)
+
+    const int arow = t >> 2, akq = t & 3;
+    const float *ap0 = A + (size_t)min(m0 + arow, M - 1) * lda + akq * 4;
+    const float *ap1 = A + (size_t)min(m0 + arow + 64, M - 1) * lda + akq * 4;
+    const int a_st = arow * X3_ROW_B + (((akq >> 1) ^ ((arow >> 3) & 1)) << 4) + ((akq & 1) << 3);
+    const __bf16 *bp = Bpk + (size_t)tn * nk * 6144 + t * 8;
+    const int b_st = X3_OPER_B + t * 16;
+
+    // staging registers: A pairs P0 / P1 (even + odd k-step of a pair), B sets B0 / B1
+    float4 p0_0e, p0_1e, p0_0o, p0_1o, p1_0e, p1_1e, p1_0o, p1_1o;
+    uint4 b0_0, b0_1, b0_2, b1_0, b1_1, b1_2;
+#define X3_GLOAD_A(P, kp)   /* kp = even k-step of the pair */                       \
+    P##_0e = *reinterpret_cast<const float4 *>(ap0 + (kp) * X3_BK);                  \
+    P##_0o = *reinterpret_cast<const float4 *>(ap0 + (kp) * X3_BK + X3_BK);          \
+    P##_1e = *reinterpret_cast<const float4 *>(ap1 + (kp) * X3_BK);                  \
+    P##_1o = *reinterpret_cast<const float4 *>(ap1 + (kp) * X3_BK + X3_BK);
+#define X3_GLOAD_B(S, ks)                                                            \
+    S##_0 = *reinterpret_cast<const uint4 *>(bp + (size_t)(ks) * 6144);              \
+    S##_1 = *reinterpret_cast<const uint4 *>(bp + (size_t)(ks) * 6144 + 2048);       \
+    S##_2 = *reinterpret_cast<const uint4 *>(bp + (size_t)(ks) * 6144 + 4096);
+#define X3_STORE_A(sb, RA, off)                                                                   \
+    {                                                                                             \
+        bf16x4 h, m, l;                                                                           \
+        if (ABL == 2) { h = m = l = __builtin_bit_cast(bf16x4, make_uint2(__float_as_uint(RA.x), __float_as_uint(RA.y))); } \
+        else split3(RA, h, m, l);                                                                 \
+        *reinterpret_cast<bf16x4 *>((sb) + a_st + (off)) = h;                                     \
+        *reinterpret_cast<bf16x4 *>((sb) + X3_PLANE_B + a_st + (off)) = m;                        \
+        *reinterpret_cast<bf16x4 *>((sb) + 2 * X3_PLANE_B + a_st + (off)) = l;                    \
+    }
+#define X3_STORE_B(sb, S)                                                                         \
+    *reinterpret_cast<uint4 *>((sb) + b_st) = S##_0;                                              \
+    *reinterpret_cast<uint4 *>((sb) + X3_PLANE_B + b_st) = S##_1;                                 \
+    *reinterpret_cast<uint4 *>((sb) + 2 * X3_PLANE_B + b_st) = S##_2;
+
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int swz = ((half ^ ((l32 >> 3) & 1)) << 4);
+    const int a_rd = (wm * 64 + l32) * X3_ROW_B + swz;
+    const int b_rd = X3_OPER_B + (wn * 64 + l32) * X3_ROW_B + swz;
+
+    bf16x8 fa0[3], fa1[3], fb0[3], fb1[3];
+    // smallest terms first: (a3 b1), (a1 b3), (a2 b2), (a2 b1), (a1 b2), (a1 b1)
+#define X3_TERM(pa, pb)                                                                            \
+    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa0[pa], fb0[pb], acc[0][0], 0, 0, 0);     \
+    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa0[pa], fb1[pb], acc[0][1], 0, 0, 0);     \
+    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa1[pa], fb0[pb], acc[1][0], 0, 0, 0);     \
+    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa1[pa], fb1[pb], acc[1][1], 0, 0, 0);
+    // one k-step: RA0/RA1 = A registers of tile kt+2 (two row passes), SB = its B set, LOADS = re-issue
+#define X3_STEP(kt, RA0, RA1, SB, LOADS)                                                           \
+    {                                                                                              \
+        const char *rs = smem + ((kt) % X3_STAGES) * X3_STAGE_B;                                   \
+        char *ws = smem + (((kt) + 2) % X3_STAGES) * X3_STAGE_B;                                   \
+        const bool st = (kt) + 2 < nk;                                                             \
+        _Pragma("unroll") for (int p = 0; p < 3; ++p) {                                            \
+            fa0[p] = *reinterpret_cast<const bf16x8 *>(rs + p * X3_PLANE_B + a_rd);                \
+            fa1[p] = *reinterpret_cast<const bf16x8 *>(rs + p * X3_PLANE_B + a_rd + 32 * X3_ROW_B); \
+            fb0[p] = *reinterpret_cast<const bf16x8 *>(rs + p * X3_PLANE_B + b_rd);                \
+            fb1[p] = *reinterpret_cast<const bf16x8 *>(rs + p * X3_PLANE_B + b_rd + 32 * X3_ROW_B); \
+        }                                                                                          \
+        X3_TERM(2, 0)                                                                              \
+        if (st) X3_STORE_A(ws, RA0, 0)                                                             \
+        X3_TERM(0, 2)                                                                              \
+        X3_TERM(1, 1)                                                                              \
+        if (st) X3_STORE_A(ws, RA1, 64 * X3_ROW_B)                                                 \
+        X3_TERM(1, 0)                                                                              \
+        X3_TERM(0, 1)                                                                              \
+        if (st) { X3_STORE_B(ws, SB) }                                                             \
+        X3_TERM(0, 0)                                                                              \
+        if (ABL != 1) { LOADS }                                                                    \
+        __syncthreads();                                                                           \
+    }
+
+    // prologue: tiles 0, 1 staged synchronously; tiles 2, 3 (pair P1, B0, B1) put in flight
+    X3_GLOAD_A(p0, 0)
+    X3_GLOAD_B(b0, 0)
+    X3_GLOAD_B(b1, 1)
+    X3_STORE_A(smem, p0_0e, 0)
+    X3_STORE_A(smem, p0_1e, 64 * X3_ROW_B)
+    X3_STORE_B(smem, b0)
+    X3_STORE_A(smem + X3_STAGE_B, p0_0o, 0)
+    X3_STORE_A(smem + X3_STAGE_B, p0_1o, 64 * X3_ROW_B)
+    X3_STORE_B(smem + X3_STAGE_B, b1)
+    X3_GLOAD_A(p1, 2)
+    X3_GLOAD_B(b0, 2)
+    X3_GLOAD_B(b1, 3)
+    __syncthreads();
+    for (int kt = 0; kt < nk; kt += 4) {
+        // tile kt+2 = even half of pair P1; afterwards B0 <- tile kt+4, P0 <- pair (kt+4, kt+5)
+        X3_STEP(kt, p1_0e, p1_1e, b0, X3_GLOAD_B(b0, min(kt + 4, nk - 1)) X3_GLOAD_A(p0, min(kt + 4, nk - 2)))
+        // tile kt+3 = odd half of P1; B1 <- tile kt+5
+        X3_STEP(kt + 1, p1_0o, p1_1o, b1, X3_GLOAD_B(b1, min(kt + 5, nk - 1)))
+        // tile kt+4 = even half of P0; B0 <- tile kt+6, P1 <- pair (kt+6, kt+7)
+        X3_STEP(kt + 2, p0_0e, p0_1e, b0, X3_GLOAD_B(b0, min(kt + 6, nk - 1)) X3_GLOAD_A(p1, min(kt + 6, nk - 2)))
+        // tile kt+5 = odd half of P0; B1 <- tile kt+7
+        X3_STEP(kt + 3, p0_0o, p0_1o, b1, X3_GLOAD_B(b1, min(kt + 7, nk - 1)))
+    }
+#undef X3_GLOAD_A
+#undef X3_GLOAD_B
+#undef X3_STORE_A
+#undef X3_STORE_B
+#undef X3_TERM
+#undef X3_STEP
+}
+
+template <int ABL>
+__global__ __launch_bounds__(256, 2) void gemm_bf16x3_kernel(const float *__restrict__ A, int lda,
+                                                             const __bf16 *__restrict__ Bpk, float *C, int ldc,
+                                                             int M, int N, int K,
+                                                             const float *__restrict__ bias, const float *resid,
+                                                             int ldr, int act, int tiles_m, int tiles_n, int gm) {
+    __shared__ __attribute__((aligned(16))) char smem[X3_SMEM_B];
+    int tm, tn;
+    tile_coords(tiles_m, tiles_n, tm, tn, gm);
+    const int m0 = tm * GEMM_BM, n0 = tn * GEMM_BN;
+    f32x16 acc[2][2];
+    x3_mainloop<ABL>(A, lda, Bpk, M, K, m0, tn, smem, acc);
+    epilogue_store(acc, C, ldc, M, N, m0, n0, bias, resid, ldr, act);
+}
+
+template <int KSEL>
+__global__ __launch_bounds__(256, 2) void gemm_bf16x3_topk_kernel(const float *__restrict__ A, int lda,
+                                                                  const __bf16 *__restrict__ Bpk, int M, int N,
+                                                                  int K, float inv_temp,
+                                                                  float *tile_max, float *tile_sum, float *cand_val,
+                                                                  int *cand_idx, int tiles_m, int tiles_n) {
+    __shared__ __attribute__((aligned(16))) char smem[X3_SMEM_B];
+    static_assert(64 * CT_LD * 4 <= X3_SMEM_B, "64 rows of the epilogue tile must fit the staging buffers");
+    int tm, tn;
+    tile_coords(tiles_m, tiles_n, tm, tn);
+    const int m0 = tm * GEMM_BM, n0 = tn * GEMM_BN;
+    f32x16 acc[2][2];
+    x3_mainloop<0>(A, lda, Bpk, M, K, m0, tn, smem, acc);   // ends with a barrier
+    epilogue_topk<KSEL>(acc, reinterpret_cast<float *>(smem), M, N, m0, n0, tn, tiles_n, inv_temp, tile_max, tile_sum,
+                        cand_val, cand_idx);
+}
+
+int launch_gemm_bf16x3(hipStream_t st, const float *A, int lda, const void *Bpacked, float *C, int ldc, int M, int N,
+                       int K, const GemmEpilogue &epi) {
+    CAPDEC_CHECK(M > 0 && N > 0 && K > 0, "gemm: empty problem");
+    CAPDEC_CHECK(K % 64 == 0 && lda % 4 == 0, "gemm_bf16x3: K must be a multiple of 64");
+    CAPDEC_CHECK((((uintptr_t)A | (uintptr_t)Bpacked) & 15) == 0, "gemm_bf16x3: operands must be 16-byte aligned");
+    static const int abl = [] { const char *e = getenv("CAPDEC_GEMM_ABL"); return e ? atoi(e) : 0; }();
+    const int tiles_m = (M + GEMM_BM - 1) / GEMM_BM, tiles_n = (N + GEMM_BN - 1) / GEMM_BN;
+#define X3_LAUNCH(AB)                                                                                                \
+    hipLaunchKernelGGL(gemm_bf16x3_kernel<AB>, dim3(tiles_m * tiles_n), dim3(256), 0, st, A, lda, (const __bf16 *)Bpacked, \
+                       C, ldc, M, N, K, epi.bias, epi.resid, epi.ldr, epi.act, tiles_m, tiles_n, gm)
+    static const int gm = [] { const char *e = getenv("CAPDEC_GEMM_GM"); return e ? atoi(e) : 8; }();
+    if (abl == 1) X3_LAUNCH(1); else if (abl == 2) X3_LAUNCH(2); else X3_LAUNCH(0);
+#undef X3_LAUNCH
+    CAPDEC_HIP(hipGetLastError());
+    return 0;
+}
+
+int launch_gemm_bf16x3_topk(hipStream_t st, const float *A, int lda, const void *Bpacked, int M, int N, int K, int k,
+                            float inv_temp, float *tile_max, float *tile_sum, float *cand_val, int *cand_idx) {
+    CAPDEC_CHECK(M > 0 && N > 0 && K > 0, "gemm_topk: empty problem");
+    CAPDEC_CHECK(K % 64 == 0 && lda % 4 == 0, "gemm_bf16x3_topk: K must be a multiple of 64");
+    const int tiles_m = (M + GEMM_BM - 1) / GEMM_BM, tiles_n = (N + GEMM_BN - 1) / GEMM_BN;
+    dim3 grid(tiles_m * tiles_n), block(256);
+#define LAUNCH_TOPK(KS)                                                                                          \
+    hipLaunchKernelGGL(gemm_bf16x3_topk_kernel<KS>, grid, block, 0, st, A, lda, (const __bf16 *)Bpacked, M, N, K, \
+                       inv_temp, tile_max, tile_sum, cand_val, cand_idx, tiles_m, tiles_n)
+    switch (k) {
+        case 1: LAUNCH_TOPK(1); break;
+        case 2: LAUNCH_TOPK(2); break;
+        case 3: LAUNCH_TOPK(3); break;
+        case 4: LAUNCH_TOPK(4); break;
+        case 5: LAUNCH_TOPK(5); break;
+        case 6: LAUNCH_TOPK(6); break;
+        case 7: LAUNCH_TOPK(7); break;
+        case 8: LAUNCH_TOPK(8); break;
+        default: CAPDEC_CHECK(false, "gemm_topk: k must be in 1..8");
+    }
+#undef LAUNCH_TOPK
+    CAPDEC_HIP(hipGetLastError());
+    return 0;
+}
+
+}  // namespace capdec

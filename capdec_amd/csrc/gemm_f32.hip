@@ -16,45 +16,9 @@
 // per tile.
 #include <cstdlib>
 
-#include "common.h"
+#include "gemm_epilogue.h"
 
 namespace capdec {
-
-using f32x16 = __attribute__((ext_vector_type(16))) float;
-
-constexpr int CT_LD = 129;                            // epilogue tile row stride (top-k variant)
-
-__device__ __forceinline__ float act_apply(float v, int act) {
-    switch (act) {
-        case CAPDEC_ACT_TANH: return tanhf(v);
-        case CAPDEC_ACT_RELU: return fmaxf(v, 0.f);
-        case CAPDEC_ACT_GELU_NEW: {
-            // transformers NewGELUActivation: 0.5 x (1 + tanh(sqrt(2/pi) (x + 0.044715 x^3)))
-            const float c = 0.7978845608028654f;
-            return 0.5f * v * (1.f + tanhf(c * (v + 0.044715f * v * v * v)));
-        }
-        case CAPDEC_ACT_QUICK_GELU: return v / (1.f + __expf(-1.702f * v));   // x * sigmoid(1.702 x)
-        default: return v;
-    }
-}
-
-// XCD-aware, L2-friendly tile order: consecutive ids of one XCD walk 8 M-tiles per N-tile.
-__device__ __forceinline__ void tile_coords(int tiles_m, int tiles_n, int &tm, int &tn) {
-    const int nwg = tiles_m * tiles_n;
-    int id = blockIdx.x;
-    {   // bijective XCD remap: blocks b, b+8, b+16.. (same XCD) get contiguous ids
-        const int q = nwg >> 3, r = nwg & 7, xcd = id & 7, idx = id >> 3;
-        id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    }
-    constexpr int GM = 8;
-    const int per_group = GM * tiles_n;
-    const int group = id / per_group;
-    const int first_m = group * GM;
-    const int gsz = min(tiles_m - first_m, GM);
-    const int in_g = id - group * per_group;
-    tm = first_m + in_g % gsz;
-    tn = in_g / gsz;
-}
 
 // Shared main loop: accumulates the 128x128 tile at (m0, n0) into per-wave accumulators.
 // BK = k-depth of one LDS stage (32: 72 KB LDS, 2 blocks/CU; 16: 40 KB, 3 blocks/CU).
@@ -181,26 +145,7 @@ __global__ __launch_bounds__(256, OCC) void gemm_f32_kernel(const float *__restr
     f32x16 acc[2][2];
     gemm_mainloop<BK, ABL>(A, lda, Bt, ldb, M, N, K, m0, n0, smem, acc);
 
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int wm = wave >> 1, wn = wave & 1, half = lane >> 5, l32 = lane & 31;
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int col = n0 + wn * 64 + j * 32 + l32;
-        if (col >= N) continue;
-        const float bv = bias ? bias[col] : 0.f;
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                if (row < M) {
-                    float v = act_apply(acc[i][j][r] + bv, act);
-                    if (resid) v += resid[(size_t)row * ldr + col];
-                    C[(size_t)row * ldc + col] = v;
-                }
-            }
-        }
-    }
+    epilogue_store(acc, C, ldc, M, N, m0, n0, bias, resid, ldr, act);
 }
 
 // lm_head variant: per (row, 128-col tile) max, sum exp(x - max) and top-k (value, column).
@@ -220,77 +165,7 @@ __global__ __launch_bounds__(256, OCC) void gemm_f32_topk_kernel(const float *__
     f32x16 acc[2][2];
     gemm_mainloop<BK>(A, lda, Bt, ldb, M, N, K, m0, n0, smem, acc);   // ends with a barrier
 
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int wm = wave >> 1, wn = wave & 1, half = lane >> 5, l32 = lane & 31;
-    const int grp = lane >> 4, sub = lane & 15;
-    float *Ct = smem;                                   // [64][CT_LD]: one 64-row half of the tile at a time
-    for (int hh = 0; hh < 2; ++hh) {
-        if (wm == hh) {
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int row = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                        Ct[row * CT_LD + wn * 64 + j * 32 + l32] = acc[i][j][r] * inv_temp;
-                    }
-        }
-        __syncthreads();
-        for (int it = 0; it < 4; ++it) {
-            const int rl = wave * 16 + it * 4 + grp;       // row within the half
-            const int row = m0 + hh * 64 + rl;
-            float v[8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int cl = sub + 16 * j;
-                v[j] = (n0 + cl < N) ? Ct[rl * CT_LD + cl] : -INFINITY;
-            }
-            float mx = v[0];
-#pragma unroll
-            for (int j = 1; j < 8; ++j) mx = fmaxf(mx, v[j]);
-#pragma unroll
-            for (int o = 8; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
-            float se = 0.f;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) se += __expf(v[j] - mx);
-#pragma unroll
-            for (int o = 8; o > 0; o >>= 1) se += __shfl_xor(se, o, 64);
-            const size_t tbase = (size_t)row * tiles_n + tn;
-            if (row < M && sub == 0) {
-                tile_max[tbase] = mx;
-                tile_sum[tbase] = se;
-            }
-#pragma unroll
-            for (int kk = 0; kk < KSEL; ++kk) {
-                // lane-local best (lowest column wins ties: columns ascend with j)
-                float bv = v[0];
-                int bj = 0;
-#pragma unroll
-                for (int j = 1; j < 8; ++j)
-                    if (v[j] > bv) { bv = v[j]; bj = j; }
-                const int bc = sub + 16 * bj;   // local column
-                float gv = bv;
-                int gc = bc;
-#pragma unroll
-                for (int o = 8; o > 0; o >>= 1) {
-                    const float ov = __shfl_xor(gv, o, 64);
-                    const int oc = __shfl_xor(gc, o, 64);
-                    if (ov > gv || (ov == gv && oc < gc)) { gv = ov; gc = oc; }
-                }
-                if (gc == bc) {           // this lane owned the winner: retire it
-#pragma unroll
-                    for (int j = 0; j < 8; ++j)
-                        if (j == bj) v[j] = -INFINITY;
-                }
-                if (row < M && sub == kk) {
-                    cand_val[tbase * KSEL + kk] = gv;
-                    cand_idx[tbase * KSEL + kk] = n0 + gc;
-                }
-            }
-        }
-        __syncthreads();
-    }
+    epilogue_topk<KSEL>(acc, smem, M, N, m0, n0, tn, tiles_n, inv_temp, tile_max, tile_sum, cand_val, cand_idx);
 }
 
 int launch_gemm_f32(hipStream_t st, const float *A, int lda, const float *Bt, int ldb, float *C, int ldc, int M,

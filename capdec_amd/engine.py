@@ -317,6 +317,13 @@ class Engine:
                                        r.data_ptr() if r is not None else None, N, act), "capdec_gemm_f32")
         return out
 
+    def set_gemm_mode(self, mode: str):
+        """'f32' (native fp32 MFMA) or 'bf16x3' (fp32-accurate split-bf16 MFMA)"""
+        check(self.lib.capdec_set_gemm_mode(self._h, {"f32": 0, "bf16x3": 1}[mode]), "set_gemm_mode")
+
+    def gemm_mode(self) -> str:
+        return ["f32", "bf16x3"][self.lib.capdec_get_gemm_mode(self._h)]
+
     def profile_enable(self, on: bool = True):
         check(self.lib.capdec_profile_enable(self._h, int(on)), "profile_enable")
 

@@ -243,9 +243,30 @@ def test_decode_tiny_vs_reference_golden(golden):
     _check_decode(golden("decode_tiny"), synth.GPT2_TINY)
 
 
-def test_decode_small_vs_reference_golden(golden):
-    """full GPT-2 small geometry (12 layers, V = 50257): greedy ids bit-identical to the reference"""
+@pytest.mark.parametrize("mode", ["bf16x3", "f32"])
+def test_decode_small_vs_reference_golden(golden, mode, monkeypatch):
+    """full GPT-2 small geometry (12 layers, V = 50257): greedy ids bit-identical to the reference, with the
+    projections on the split-bf16 MFMA path (default) and on the native fp32 MFMA path"""
+    monkeypatch.setenv("CAPDEC_GEMM_MODE", mode)
     _check_decode(golden("decode_small"), synth.GPT2_SMALL)
+
+
+@pytest.mark.parametrize("mode", ["bf16x3", "f32"])
+def test_gemm_modes_vs_fp64(mode):
+    """both GEMM back-ends stay in the fp32 round-off class (error relative to sum |a||b|)"""
+    from capdec_amd.engine import Engine
+    e = Engine(0)
+    e.set_gemm_mode(mode)
+    assert e.gemm_mode() == mode
+    g = torch.Generator().manual_seed(5)
+    for (M, N, K) in [(300, 1531, 768), (129, 257, 3072), (64, 64, 64), (1000, 768, 640)]:
+        a = torch.randn(M, K, generator=g) * torch.logspace(-3, 3, K)       # wide dynamic range across k
+        bt = torch.randn(N, K, generator=g) * 0.1
+        ref = a.double() @ bt.double().t()
+        scale = a.abs().double() @ bt.abs().double().t()
+        out = e.gemm(a, bt).cpu().double()
+        assert float(((out - ref).abs() / scale).max()) < 5e-7, (mode, M, N, K)
+    e.close()
 
 
 # ----------------------------------------------------------------------------------- decode vs oracle, bigger batches
