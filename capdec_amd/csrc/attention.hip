@@ -16,9 +16,11 @@ constexpr int ATT_CTX_MAX = 256;
 __device__ __forceinline__ float dot4(const float4 &a, const float4 &b) {
     return (a.x * b.x + a.y * b.y) + (a.z * b.z + a.w * b.w);
 }
-__device__ __forceinline__ float group16_sum(float v) {
-#pragma unroll
-    for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+__device__ __forceinline__ float group16_sum(float v) { return row16_sum(v); }
+// lane l (0..15 of every row) <- sum over the four rows of lane l: row_bcast-free, two ds_swizzle-free steps
+__device__ __forceinline__ float groups4_sum(float v) {
+    v += __shfl_xor(v, 16, 64);
+    v += __shfl_xor(v, 32, 64);
     return v;
 }
 
@@ -108,17 +110,134 @@ __global__ __launch_bounds__(256) void attn_gpt2_kernel(const float *__restrict_
         const float w = sc[wave][L - 1];
         acc.x += w * vcur.x; acc.y += w * vcur.y; acc.z += w * vcur.z; acc.w += w * vcur.w;
     }
-#pragma unroll
-    for (int o = 16; o <= 32; o <<= 1) {
-        acc.x += __shfl_xor(acc.x, o, 64);
-        acc.y += __shfl_xor(acc.y, o, 64);
-        acc.z += __shfl_xor(acc.z, o, 64);
-        acc.w += __shfl_xor(acc.w, o, 64);
-    }
+    acc.x = groups4_sum(acc.x); acc.y = groups4_sum(acc.y); acc.z = groups4_sum(acc.z); acc.w = groups4_sum(acc.w);
     if (active && grp == 0) {
         const float inv = 1.0f / sum;
         reinterpret_cast<float4 *>(out + (size_t)row * d + head * 64)[sub] =
             make_float4(acc.x * inv, acc.y * inv, acc.z * inv, acc.w * inv);
+    }
+}
+
+// Beam-shared decode attention: one wavefront per (caption, head) serves all BEAM rows of the caption.
+// The beams of a caption mostly share their ancestors (the whole prefix, and usually all but the last
+// few generated positions), so K/V of position p are loaded once per DISTINCT physical slot among
+// consecutive beams instead of once per row: the 5 q vectors / 5 accumulators live in registers, a
+// loaded key or value is reused while anc[b][p] does not change from beam b-1 to beam b.
+template <int BEAM>
+__global__ __launch_bounds__(256) void attn_decode_beams_kernel(const float *__restrict__ qkv, float *__restrict__ kc,
+                                                                float *__restrict__ vc, int total, int heads,
+                                                                int ctx, int d, int L,
+                                                                const uint8_t *__restrict__ anc, int anc_stride,
+                                                                float *__restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) float sc_all[];      // [4 waves][BEAM][L] scores + [4][BEAM][L] slots
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int grp = lane >> 4, sub = lane & 15;
+    const int gw = blockIdx.x * 4 + wave;
+    const bool active = gw < total;
+    const int cap = active ? gw / heads : 0;
+    const int head = active ? gw - cap * heads : 0;
+    float *sc = sc_all + (size_t)wave * BEAM * L;
+    int *sl = reinterpret_cast<int *>(sc_all + (size_t)4 * BEAM * L) + (size_t)wave * BEAM * L;
+    const size_t hstride = (size_t)ctx * 64;
+    const int row0 = cap * BEAM;
+    const int Lpast = L - 1;
+
+    // ancestor slots of this caption -> LDS (removes the dependent byte load in front of every K/V load)
+    for (int i = lane; i < BEAM * Lpast; i += 64) {
+        const int b = i / Lpast, p = i - b * Lpast;
+        sl[b * L + p] = anc[(size_t)(row0 + b) * anc_stride + p];
+    }
+
+    float4 q[BEAM];
+#pragma unroll
+    for (int b = 0; b < BEAM; ++b) {
+        const float *qrow = qkv + (size_t)(row0 + b) * 3 * d;
+        q[b] = reinterpret_cast<const float4 *>(qrow + head * 64)[sub];
+        q[b].x *= 0.125f; q[b].y *= 0.125f; q[b].z *= 0.125f; q[b].w *= 0.125f;
+        // the row's own key / value: score from registers, appended to the cache at its own slot
+        const float4 kcur = reinterpret_cast<const float4 *>(qrow + d + head * 64)[sub];
+        const float4 vcur = reinterpret_cast<const float4 *>(qrow + 2 * d + head * 64)[sub];
+        if (active && grp == 0) {
+            const size_t o = ((size_t)(row0 + b) * heads + head) * hstride + (size_t)Lpast * 64;
+            reinterpret_cast<float4 *>(kc + o)[sub] = kcur;
+            reinterpret_cast<float4 *>(vc + o)[sub] = vcur;
+        }
+        const float s = group16_sum(dot4(q[b], kcur));
+        if (lane == 0) sc[b * L + Lpast] = s;
+    }
+    __syncthreads();
+    const float *kbase = kc + ((size_t)row0 * heads + head) * hstride + sub * 4;
+    const float *vbase = vc + ((size_t)row0 * heads + head) * hstride + sub * 4;
+    const size_t slot_stride = (size_t)heads * hstride;
+    // ---- scores over the cached positions: two positions per 16-lane group per iteration
+    for (int p0 = 0; p0 < Lpast; p0 += 8) {
+        const int pa = p0 + grp, pb = p0 + 4 + grp;
+        const bool va = pa < Lpast, vb = pb < Lpast;
+        int preva = -1, prevb = -1;
+        float4 ka = make_float4(0.f, 0.f, 0.f, 0.f), kb = ka;
+#pragma unroll
+        for (int b = 0; b < BEAM; ++b) {
+            const int sa = va ? sl[b * L + pa] : 0, sb = vb ? sl[b * L + pb] : 0;
+            if (va && sa != preva) ka = *reinterpret_cast<const float4 *>(kbase + sa * slot_stride + (size_t)pa * 64);
+            if (vb && sb != prevb) kb = *reinterpret_cast<const float4 *>(kbase + sb * slot_stride + (size_t)pb * 64);
+            preva = sa; prevb = sb;
+            const float s0 = group16_sum(dot4(q[b], ka));
+            const float s1 = group16_sum(dot4(q[b], kb));
+            if (sub == 0) {
+                if (va) sc[b * L + pa] = s0;
+                if (vb) sc[b * L + pb] = s1;
+            }
+        }
+    }
+    __syncthreads();
+    // ---- softmax statistics per beam
+    float inv[BEAM];
+#pragma unroll
+    for (int b = 0; b < BEAM; ++b) {
+        float mx = -INFINITY;
+        for (int p = lane; p < L; p += 64) mx = fmaxf(mx, sc[b * L + p]);
+        mx = wave_max(mx);
+        float sum = 0.f;
+        for (int p = lane; p < L; p += 64) {
+            const float e = expf(sc[b * L + p] - mx);
+            sc[b * L + p] = e;
+            sum += e;
+        }
+        inv[b] = 1.0f / wave_sum(sum);
+    }
+    __syncthreads();
+    // ---- P.V
+    float4 acc[BEAM];
+#pragma unroll
+    for (int b = 0; b < BEAM; ++b) acc[b] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int p0 = 0; p0 < Lpast; p0 += 8) {
+        const int pa = p0 + grp, pb = p0 + 4 + grp;
+        const bool va = pa < Lpast, vb = pb < Lpast;
+        int preva = -1, prevb = -1;
+        float4 xa = make_float4(0.f, 0.f, 0.f, 0.f), xb = xa;
+#pragma unroll
+        for (int b = 0; b < BEAM; ++b) {
+            const int sa = va ? sl[b * L + pa] : 0, sb = vb ? sl[b * L + pb] : 0;
+            if (va && sa != preva) xa = *reinterpret_cast<const float4 *>(vbase + sa * slot_stride + (size_t)pa * 64);
+            if (vb && sb != prevb) xb = *reinterpret_cast<const float4 *>(vbase + sb * slot_stride + (size_t)pb * 64);
+            preva = sa; prevb = sb;
+            const float wa = va ? sc[b * L + pa] : 0.f, wb = vb ? sc[b * L + pb] : 0.f;
+            acc[b].x += wa * xa.x + wb * xb.x; acc[b].y += wa * xa.y + wb * xb.y;
+            acc[b].z += wa * xa.z + wb * xb.z; acc[b].w += wa * xa.w + wb * xb.w;
+        }
+    }
+#pragma unroll
+    for (int b = 0; b < BEAM; ++b) {
+        if (grp == 0) {   // own token
+            const float4 vcur = reinterpret_cast<const float4 *>(qkv + (size_t)(row0 + b) * 3 * d + 2 * d + head * 64)[sub];
+            const float w = sc[b * L + Lpast];
+            acc[b].x += w * vcur.x; acc[b].y += w * vcur.y; acc[b].z += w * vcur.z; acc[b].w += w * vcur.w;
+        }
+        acc[b].x = groups4_sum(acc[b].x); acc[b].y = groups4_sum(acc[b].y);
+        acc[b].z = groups4_sum(acc[b].z); acc[b].w = groups4_sum(acc[b].w);
+        if (active && grp == 0)
+            reinterpret_cast<float4 *>(out + (size_t)(row0 + b) * d + head * 64)[sub] =
+                make_float4(acc[b].x * inv[b], acc[b].y * inv[b], acc[b].z * inv[b], acc[b].w * inv[b]);
     }
 }
 
@@ -167,6 +286,29 @@ int launch_attn_decode(hipStream_t st, const float *qkv, const KvCache &c, int l
                        const uint8_t *anc, int anc_stride, float *out) {
     CAPDEC_CHECK(c.hd == 64, "attention: head_dim must be 64");
     CAPDEC_CHECK(L >= 1 && L <= ATT_CTX_MAX && L <= c.ctx, "attention: context length out of range");
+    if (anc != nullptr && beam > 1) {
+        const int ncap = rows / beam, total = ncap * c.heads;
+        if (total <= 0) return 0;
+        const size_t lds = (size_t)2 * 4 * beam * L * sizeof(float);   // scores + ancestor slots
+        dim3 grid((total + 3) / 4), block(256);
+        float *kl = c.k + layer * c.layer_stride(), *vl = c.v + layer * c.layer_stride();
+#define LAUNCH_BEAMS(B)                                                                                         \
+    hipLaunchKernelGGL(attn_decode_beams_kernel<B>, grid, block, lds, st, qkv, kl, vl, total, c.heads, c.ctx,      \
+                       c.heads * c.hd, L, anc, anc_stride, out)
+        switch (beam) {
+            case 2: LAUNCH_BEAMS(2); break;
+            case 3: LAUNCH_BEAMS(3); break;
+            case 4: LAUNCH_BEAMS(4); break;
+            case 5: LAUNCH_BEAMS(5); break;
+            case 6: LAUNCH_BEAMS(6); break;
+            case 7: LAUNCH_BEAMS(7); break;
+            case 8: LAUNCH_BEAMS(8); break;
+            default: CAPDEC_CHECK(false, "attention: beam must be in 1..8");
+        }
+#undef LAUNCH_BEAMS
+        CAPDEC_HIP(hipGetLastError());
+        return 0;
+    }
     const int total = rows * c.heads;
     if (total <= 0) return 0;
     hipLaunchKernelGGL(attn_gpt2_kernel<true>, dim3((total + 3) / 4), dim3(256), 0, st, qkv,

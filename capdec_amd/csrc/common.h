@@ -38,15 +38,46 @@ void set_error(const std::string &msg);
 constexpr int WAVE = 64;
 
 // ---- wave-level helpers (64-wide wavefronts) ------------------------------------------
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+// Cross-lane traffic goes through DPP (data-parallel primitives: a VALU operand modifier), not
+// through __shfl (which hipcc lowers to ds_bpermute_b32, an LDS-crossbar round trip per step).
+// Within a row of 16 lanes: quad_perm [1,0,3,2] / [2,3,0,1] are the xor-1 / xor-2 butterflies, then
+// row_half_mirror (lane i <- 7-i) and row_mirror (lane i <- 15-i) join the two quads and the two
+// halves: after the four steps every lane of the row holds the reduction of the row's 16 lanes.
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+template <int CTRL>
+__device__ __forceinline__ int dpp_i(int v) {
+    return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, true);
+}
+constexpr int DPP_XOR1 = 0xB1, DPP_XOR2 = 0x4E, DPP_HALF_MIRROR = 0x141, DPP_MIRROR = 0x140;
+
+__device__ __forceinline__ float row16_sum(float v) {
+    v += dpp_f<DPP_XOR1>(v);
+    v += dpp_f<DPP_XOR2>(v);
+    v += dpp_f<DPP_HALF_MIRROR>(v);
+    v += dpp_f<DPP_MIRROR>(v);
     return v;
 }
-__device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+__device__ __forceinline__ float row16_max(float v) {
+    v = fmaxf(v, dpp_f<DPP_XOR1>(v));
+    v = fmaxf(v, dpp_f<DPP_XOR2>(v));
+    v = fmaxf(v, dpp_f<DPP_HALF_MIRROR>(v));
+    v = fmaxf(v, dpp_f<DPP_MIRROR>(v));
     return v;
+}
+__device__ __forceinline__ float lane_bcast(float v, int l) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
+}
+// full-wave reductions (all 64 lanes must be active): four row reductions + four scalar reads
+__device__ __forceinline__ float wave_sum(float v) {
+    v = row16_sum(v);
+    return (lane_bcast(v, 0) + lane_bcast(v, 16)) + (lane_bcast(v, 32) + lane_bcast(v, 48));
+}
+__device__ __forceinline__ float wave_max(float v) {
+    v = row16_max(v);
+    return fmaxf(fmaxf(lane_bcast(v, 0), lane_bcast(v, 16)), fmaxf(lane_bcast(v, 32), lane_bcast(v, 48)));
 }
 
 // ---- launch geometry of the f32 MFMA GEMM ----------------------------------------------

@@ -102,13 +102,11 @@ __device__ __forceinline__ void epilogue_topk(const f32x16 (&acc)[2][2], float *
             float mx = v[0];
 #pragma unroll
             for (int j = 1; j < 8; ++j) mx = fmaxf(mx, v[j]);
-#pragma unroll
-            for (int o = 8; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+            mx = row16_max(mx);
             float se = 0.f;
 #pragma unroll
             for (int j = 0; j < 8; ++j) se += __expf(v[j] - mx);
-#pragma unroll
-            for (int o = 8; o > 0; o >>= 1) se += __shfl_xor(se, o, 64);
+            se = row16_sum(se);
             const size_t tbase = (size_t)row * tiles_n + tn;
             if (row < M && sub == 0) {
                 tile_max[tbase] = mx;
@@ -125,12 +123,14 @@ __device__ __forceinline__ void epilogue_topk(const f32x16 (&acc)[2][2], float *
                 const int bc = sub + 16 * bj;   // local column
                 float gv = bv;
                 int gc = bc;
-#pragma unroll
-                for (int o = 8; o > 0; o >>= 1) {
-                    const float ov = __shfl_xor(gv, o, 64);
-                    const int oc = __shfl_xor(gc, o, 64);
-                    if (ov > gv || (ov == gv && oc < gc)) { gv = ov; gc = oc; }
-                }
+#define TOPK_STEP(CTRL)                                                       \
+    {                                                                          \
+        const float ov = dpp_f<CTRL>(gv);                                      \
+        const int oc = dpp_i<CTRL>(gc);                                        \
+        if (ov > gv || (ov == gv && oc < gc)) { gv = ov; gc = oc; }            \
+    }
+                TOPK_STEP(DPP_XOR1) TOPK_STEP(DPP_XOR2) TOPK_STEP(DPP_HALF_MIRROR) TOPK_STEP(DPP_MIRROR)
+#undef TOPK_STEP
                 if (gc == bc) {           // this lane owned the winner: retire it
 #pragma unroll
                     for (int j = 0; j < 8; ++j)
