@@ -29,7 +29,8 @@ if ROOT not in sys.path:
 
 from capdec_amd import synth  # noqa: E402
 
-PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+PEAK_F32_MFMA_TFLOPS = 157.3    # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+PEAK_BF16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA (not the 2:1-sparse marketing figure)
 STOP_ID, D_EMB = 13, 768
 
 
@@ -175,7 +176,22 @@ def main():
 
     if rank == 0:
         value = n_global * args.steps / dt
-        fam = prof["gemm_f32"]
+        mode = eng.gemm_mode()
+        if mode == "bf16x3":
+            # every fp32 product is six bf16 MFMA products: the kernel's ceiling in fp32-equivalent FLOP/s is
+            # the dense bf16 peak / 6; achieved = algorithmic (2*M*N*K) FLOPs / measured kernel time
+            fam, kname, peak = prof["gemm_bf16x3"], "gemm_bf16x3_kernel", PEAK_BF16_MFMA_TFLOPS / 6.0
+            peak_note = "fp32-equivalent TFLOP/s: dense bf16 MFMA peak 2500 / 6 products per fp32 product"
+        else:
+            fam, kname, peak = prof["gemm_f32"], "gemm_f32_kernel", PEAK_F32_MFMA_TFLOPS
+            peak_note = "dense fp32-input MFMA peak"
+        traffic = None
+        try:   # HBM-side bytes per launch of the dominant kernel, from the committed rocprofv3 --pmc passes
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")))
+            if beam and args.captions == 5000 and kname in pmc:
+                traffic = pmc[kname]["traffic_bytes_per_launch"]
+        except (OSError, ValueError, KeyError):
+            pass
         gemm_ms = fam["ms"] / max(fam["launches"], 1)
         achieved = fam["flops"] / (fam["ms"] * 1e-3) / 1e12 if fam["ms"] > 0 else 0.0
         n_local = args.captions if args.scaling == "weak" else cdist.shard_size(args.captions, world)
@@ -184,7 +200,9 @@ def main():
             "metric": "captions/sec (whole node), COCO-val 5k, prefix_len=10 beam=5, 1/2/4/8 GPUs",
             "value": round(value, 2), "unit": "captions/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True,
-            "scaling": args.scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": args.scaling, "vs_baseline": None,
+            "dtype": "f32" if mode == "f32" else "f32 (operands split into 3 bf16 planes, 6 bf16 MFMAs per product, fp32 accumulate)",
+            "data": "synthetic",
             "config": {"workload": ("COCO-val-5k-shaped: %d x 512-d synthetic CLIP embeddings per GPU -> normalise -> "
                                     "%s -> GPT-2 small KV-cached %s, prefix_len %d, entry_length %d, hot-init seeded "
                                     "weights (never emit the stop id: all %d steps run)")
@@ -193,12 +211,16 @@ def main():
                           "beam-5 decode" if beam else "greedy decode", P, T, T),
                        "captions_per_step": n_global, "beam": B, "parallelism": f"caption-shard dp{world}",
                        "tokens_per_s": round(value * T, 1)},
-            "roofline": {"bound": "mfma", "kernel": "gemm_f32_kernel (all GPT-2 / mapper projections; the fused "
-                         "lm_head variant is listed in `kernels`)",
-                         "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+            "roofline": {"bound": "mfma", "kernel": kname + " (every GPT-2 / mapper projection; the fused lm_head variant "
+                         "is listed in `kernels`)",
+                         "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
+                         "frac": round(achieved / peak, 4), "traffic": traffic, "peak_note": peak_note,
+                         "traffic_note": "bytes per launch at the L2<->fabric boundary (2 x FETCH_SIZE + WRITE_SIZE, "
+                                         "profiles/r1_pmc_traffic.json; Infinity-Cache hits are counted)",
                          "avg_launch_ms": round(gemm_ms, 4), "launches": fam["launches"],
-                         "whole_path_frac": round(alg / dt / 1e12 / PEAK_F32_MFMA_TFLOPS, 4)},
+                         "bf16_mfma_tflops_executed": round(achieved * 6, 1) if mode == "bf16x3" else None,
+                         "vs_native_f32_mfma_peak": round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
+                         "whole_path_tflops": round(alg / dt / 1e12, 2)},
             "kernels": {k: {"ms": round(v["ms"], 2), "launches": v["launches"],
                             **({"tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2)} if v["flops"] and v["ms"] else {})}
                         for k, v in prof.items() if v["launches"]},

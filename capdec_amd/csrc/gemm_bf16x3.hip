@@ -100,7 +100,6 @@ int launch_pack_planes(hipStream_t st, const float *w, int N, int K, void *out) 
 //   instead of a counted wait); one barrier per k-step.
 // A: thread (row = t>>2 [+64], quad = t&3) owns 4 k of each k-step; an (even, odd) k-step pair is loaded
 //    together so the 4 threads of a row fetch one whole 128-B line.  B: packed tile, 12 KB contiguous.
-template <int ABL = 0>
 __device__ __forceinline__ void x3_mainloop(const float *__restrict__ A, int lda, const __bf16 *__restrict__ Bpk,
                                             int M, int K, int m0, int tn, char *smem, f32x16 (&acc)[2][2]) {
     const int t = threadIdx.x;
@@ -131,8 +130,7 @@ __device__ __forceinline__ void x3_mainloop(const float *__restrict__ A, int lda
 #define X3_STORE_A(sb, RA, off)                                                                   \
     {                                                                                             \
         bf16x4 h, m, l;                                                                           \
-        if (ABL == 2) { h = m = l = __builtin_bit_cast(bf16x4, make_uint2(__float_as_uint(RA.x), __float_as_uint(RA.y))); } \
-        else split3(RA, h, m, l);                                                                 \
+        split3(RA, h, m, l);                                                                      \
         *reinterpret_cast<bf16x4 *>((sb) + a_st + (off)) = h;                                     \
         *reinterpret_cast<bf16x4 *>((sb) + X3_PLANE_B + a_st + (off)) = m;                        \
         *reinterpret_cast<bf16x4 *>((sb) + 2 * X3_PLANE_B + a_st + (off)) = l;                    \
@@ -181,7 +179,7 @@ __device__ __forceinline__ void x3_mainloop(const float *__restrict__ A, int lda
         X3_TERM(0, 1)                                                                              \
         if (st) { X3_STORE_B(ws, SB) }                                                             \
         X3_TERM(0, 0)                                                                              \
-        if (ABL != 1) { LOADS }                                                                    \
+        LOADS                                                                                      \
         __syncthreads();                                                                           \
     }
 
@@ -217,18 +215,17 @@ __device__ __forceinline__ void x3_mainloop(const float *__restrict__ A, int lda
 #undef X3_STEP
 }
 
-template <int ABL>
 __global__ __launch_bounds__(256, 2) void gemm_bf16x3_kernel(const float *__restrict__ A, int lda,
                                                              const __bf16 *__restrict__ Bpk, float *C, int ldc,
                                                              int M, int N, int K,
                                                              const float *__restrict__ bias, const float *resid,
-                                                             int ldr, int act, int tiles_m, int tiles_n, int gm) {
+                                                             int ldr, int act, int tiles_m, int tiles_n) {
     __shared__ __attribute__((aligned(16))) char smem[X3_SMEM_B];
     int tm, tn;
-    tile_coords(tiles_m, tiles_n, tm, tn, gm);
+    tile_coords(tiles_m, tiles_n, tm, tn);
     const int m0 = tm * GEMM_BM, n0 = tn * GEMM_BN;
     f32x16 acc[2][2];
-    x3_mainloop<ABL>(A, lda, Bpk, M, K, m0, tn, smem, acc);
+    x3_mainloop(A, lda, Bpk, M, K, m0, tn, smem, acc);
     epilogue_store(acc, C, ldc, M, N, m0, n0, bias, resid, ldr, act);
 }
 
@@ -244,7 +241,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x3_topk_kernel(const float *_
     tile_coords(tiles_m, tiles_n, tm, tn);
     const int m0 = tm * GEMM_BM, n0 = tn * GEMM_BN;
     f32x16 acc[2][2];
-    x3_mainloop<0>(A, lda, Bpk, M, K, m0, tn, smem, acc);   // ends with a barrier
+    x3_mainloop(A, lda, Bpk, M, K, m0, tn, smem, acc);   // ends with a barrier
     epilogue_topk<KSEL>(acc, reinterpret_cast<float *>(smem), M, N, m0, n0, tn, tiles_n, inv_temp, tile_max, tile_sum,
                         cand_val, cand_idx);
 }
@@ -254,14 +251,9 @@ int launch_gemm_bf16x3(hipStream_t st, const float *A, int lda, const void *Bpac
     CAPDEC_CHECK(M > 0 && N > 0 && K > 0, "gemm: empty problem");
     CAPDEC_CHECK(K % 64 == 0 && lda % 4 == 0, "gemm_bf16x3: K must be a multiple of 64");
     CAPDEC_CHECK((((uintptr_t)A | (uintptr_t)Bpacked) & 15) == 0, "gemm_bf16x3: operands must be 16-byte aligned");
-    static const int abl = [] { const char *e = getenv("CAPDEC_GEMM_ABL"); return e ? atoi(e) : 0; }();
     const int tiles_m = (M + GEMM_BM - 1) / GEMM_BM, tiles_n = (N + GEMM_BN - 1) / GEMM_BN;
-#define X3_LAUNCH(AB)                                                                                                \
-    hipLaunchKernelGGL(gemm_bf16x3_kernel<AB>, dim3(tiles_m * tiles_n), dim3(256), 0, st, A, lda, (const __bf16 *)Bpacked, \
-                       C, ldc, M, N, K, epi.bias, epi.resid, epi.ldr, epi.act, tiles_m, tiles_n, gm)
-    static const int gm = [] { const char *e = getenv("CAPDEC_GEMM_GM"); return e ? atoi(e) : 8; }();
-    if (abl == 1) X3_LAUNCH(1); else if (abl == 2) X3_LAUNCH(2); else X3_LAUNCH(0);
-#undef X3_LAUNCH
+    hipLaunchKernelGGL(gemm_bf16x3_kernel, dim3(tiles_m * tiles_n), dim3(256), 0, st, A, lda, (const __bf16 *)Bpacked, C, ldc,
+                       M, N, K, epi.bias, epi.resid, epi.ldr, epi.act, tiles_m, tiles_n);
     CAPDEC_HIP(hipGetLastError());
     return 0;
 }

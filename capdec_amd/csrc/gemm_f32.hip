@@ -33,7 +33,7 @@ struct Tile {
     static constexpr int SMEM_FLOATS = 4 * TILE;
 };
 
-template <int BK, int ABL = 0>
+template <int BK>
 __device__ __forceinline__ void gemm_mainloop(const float *__restrict__ A, int lda, const float *__restrict__ Bt,
                                               int ldb, int M, int N, int K, int m0, int n0, float *smem,
                                               f32x16 (&acc)[2][2]) {
@@ -106,7 +106,7 @@ __device__ __forceinline__ void gemm_mainloop(const float *__restrict__ A, int l
     for (int kt = 0; kt < nk; ++kt) {
         const int buf = kt & 1;
         const bool more = kt + 1 < nk;
-        if (more && (ABL < 1)) { GLOAD((kt + 1) * BK) }
+        if (more) { GLOAD((kt + 1) * BK) }
         const float *Ab = As + buf * TILE + a_off;
         const float *Bb = Bs + buf * TILE + b_off;
 #pragma unroll
@@ -123,16 +123,14 @@ __device__ __forceinline__ void gemm_mainloop(const float *__restrict__ A, int l
             MFMA4(x) MFMA4(y) MFMA4(z) MFMA4(w)
 #undef MFMA4
         }
-        if (ABL < 2) {
-            if (more) { LSTORE(buf ^ 1) }
-            __syncthreads();
-        }
+        if (more) { LSTORE(buf ^ 1) }
+        __syncthreads();
     }
 #undef GLOAD
 #undef LSTORE
 }
 
-template <int BK, int OCC, int ABL = 0>
+template <int BK, int OCC>
 __global__ __launch_bounds__(256, OCC) void gemm_f32_kernel(const float *__restrict__ A, int lda,
                                                           const float *__restrict__ Bt, int ldb, float *C, int ldc,
                                                           int M, int N, int K, const float *__restrict__ bias,
@@ -143,7 +141,7 @@ __global__ __launch_bounds__(256, OCC) void gemm_f32_kernel(const float *__restr
     tile_coords(tiles_m, tiles_n, tm, tn);
     const int m0 = tm * GEMM_BM, n0 = tn * GEMM_BN;
     f32x16 acc[2][2];
-    gemm_mainloop<BK, ABL>(A, lda, Bt, ldb, M, N, K, m0, n0, smem, acc);
+    gemm_mainloop<BK>(A, lda, Bt, ldb, M, N, K, m0, n0, smem, acc);
 
     epilogue_store(acc, C, ldc, M, N, m0, n0, bias, resid, ldr, act);
 }
@@ -179,14 +177,7 @@ int launch_gemm_f32(hipStream_t st, const float *A, int lda, const float *Bt, in
     // N = K = 768 ones; CAPDEC_GEMM_BK overrides (tuning knob)
     static const int bk_env = [] { const char *e = getenv("CAPDEC_GEMM_BK"); return e ? atoi(e) : 0; }();
     const int bk = bk_env ? bk_env : ((N >= 3072 || K >= 2048) ? 16 : 32);
-    static const int abl = [] { const char *e = getenv("CAPDEC_GEMM_ABL"); return e ? atoi(e) : 0; }();
-    if (abl == 1)
-        hipLaunchKernelGGL((gemm_f32_kernel<32, 2, 1>), dim3(tiles_m * tiles_n), dim3(256), 0, st, A, lda, Bt, ldb, C, ldc,
-                           M, N, K, epi.bias, epi.resid, epi.ldr, epi.act, tiles_m, tiles_n);
-    else if (abl == 2)
-        hipLaunchKernelGGL((gemm_f32_kernel<32, 2, 2>), dim3(tiles_m * tiles_n), dim3(256), 0, st, A, lda, Bt, ldb, C, ldc,
-                           M, N, K, epi.bias, epi.resid, epi.ldr, epi.act, tiles_m, tiles_n);
-    else if (bk == 16)
+    if (bk == 16)
         hipLaunchKernelGGL((gemm_f32_kernel<16, 3>), dim3(tiles_m * tiles_n), dim3(256), 0, st, A, lda, Bt, ldb, C, ldc, M,
                            N, K, epi.bias, epi.resid, epi.ldr, epi.act, tiles_m, tiles_n);
     else
