@@ -22,11 +22,16 @@ typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
 constexpr int X3_BK = 16;
 constexpr int X3_ROW_B = 32;                         // bytes per LDS row: 16 bf16, unpadded, 16-B halves XOR-swizzled
-constexpr int X3_PLANE_B = GEMM_BM * X3_ROW_B;       // 4096: one plane of one operand of a stage
-constexpr int X3_OPER_B = 3 * X3_PLANE_B;            // 12288
-constexpr int X3_STAGE_B = 2 * X3_OPER_B;            // 24576
+constexpr int X3_BPLANE_B = GEMM_BN * X3_ROW_B;      // 4096: one B plane of a stage (128 columns)
 constexpr int X3_STAGES = 3;
-constexpr int X3_SMEM_B = X3_STAGES * X3_STAGE_B;    // 73728 -> 2 blocks per CU
+// WMG = 2: 128x128 tile (72 KB LDS, 2 blocks/CU); WMG = 1: 64x128 tile for small M (54 KB, twice the blocks)
+template <int WMG> struct X3Geo {
+    static constexpr int BM = 64 * WMG;
+    static constexpr int APLANE_B = BM * X3_ROW_B;
+    static constexpr int AOPER_B = 3 * APLANE_B;
+    static constexpr int STAGE_B = AOPER_B + 3 * X3_BPLANE_B;
+    static constexpr int SMEM_B = X3_STAGES * STAGE_B > 64 * CT_LD * 4 ? X3_STAGES * STAGE_B : 64 * CT_LD * 4;
+};
 
 __device__ __forceinline__ void split3(const float4 v, bf16x4 &h, bf16x4 &m, bf16x4 &l) {
     const float a[4] = {v.x, v.y, v.z, v.w};
@@ -100,29 +105,37 @@ int launch_pack_planes(hipStream_t st, const float *w, int N, int K, void *out) 
 //   instead of a counted wait); one barrier per k-step.
 // A: thread (row = t>>2 [+64], quad = t&3) owns 4 k of each k-step; an (even, odd) k-step pair is loaded
 //    together so the 4 threads of a row fetch one whole 128-B line.  B: packed tile, 12 KB contiguous.
+template <int WMG>
 __device__ __forceinline__ void x3_mainloop(const float *__restrict__ A, int lda, const __bf16 *__restrict__ Bpk,
-                                            int M, int K, int m0, int tn, char *smem, f32x16 (&acc)[2][2]) {
+                                            int M, int K, int m0, int tn, char *smem,
+                                            f32x16 (&acc)[2][WaveGrid<WMG>::NJ]) {
+    using G = X3Geo<WMG>;
+    constexpr int NJ = WaveGrid<WMG>::NJ;
+    constexpr int X3_PLANE_B = G::APLANE_B, X3_OPER_B = G::AOPER_B, X3_STAGE_B = G::STAGE_B;
     const int t = threadIdx.x;
     const int lane = t & 63, wave = t >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = WaveGrid<WMG>::wm(wave), wn = WaveGrid<WMG>::wn(wave);
     const int half = lane >> 5, l32 = lane & 31;
     const int nk = K / X3_BK;                     // multiple of 4 (K % 64 == 0)
 
     const int arow = t >> 2, akq = t & 3;
     const float *ap0 = A + (size_t)min(m0 + arow, M - 1) * lda + akq * 4;
-    const float *ap1 = A + (size_t)min(m0 + arow + 64, M - 1) * lda + akq * 4;
+    const float *ap1 = A + (size_t)min(m0 + arow + (WMG == 2 ? 64 : 0), M - 1) * lda + akq * 4;   // second 64 rows (WMG 2)
     const int a_st = arow * X3_ROW_B + (((akq >> 1) ^ ((arow >> 3) & 1)) << 4) + ((akq & 1) << 3);
     const __bf16 *bp = Bpk + (size_t)tn * nk * 6144 + t * 8;
     const int b_st = X3_OPER_B + t * 16;
 
     // staging registers: A pairs P0 / P1 (even + odd k-step of a pair), B sets B0 / B1
     float4 p0_0e, p0_1e, p0_0o, p0_1o, p1_0e, p1_1e, p1_0o, p1_1o;
+    p0_1e = p0_1o = p1_1e = p1_1o = make_float4(0.f, 0.f, 0.f, 0.f);
     uint4 b0_0, b0_1, b0_2, b1_0, b1_1, b1_2;
 #define X3_GLOAD_A(P, kp)   /* kp = even k-step of the pair */                       \
     P##_0e = *reinterpret_cast<const float4 *>(ap0 + (kp) * X3_BK);                  \
     P##_0o = *reinterpret_cast<const float4 *>(ap0 + (kp) * X3_BK + X3_BK);          \
-    P##_1e = *reinterpret_cast<const float4 *>(ap1 + (kp) * X3_BK);                  \
-    P##_1o = *reinterpret_cast<const float4 *>(ap1 + (kp) * X3_BK + X3_BK);
+    if constexpr (WMG == 2) {                                                        \
+        P##_1e = *reinterpret_cast<const float4 *>(ap1 + (kp) * X3_BK);              \
+        P##_1o = *reinterpret_cast<const float4 *>(ap1 + (kp) * X3_BK + X3_BK);      \
+    }
 #define X3_GLOAD_B(S, ks)                                                            \
     S##_0 = *reinterpret_cast<const uint4 *>(bp + (size_t)(ks) * 6144);              \
     S##_1 = *reinterpret_cast<const uint4 *>(bp + (size_t)(ks) * 6144 + 2048);       \
@@ -137,27 +150,27 @@ __device__ __forceinline__ void x3_mainloop(const float *__restrict__ A, int lda
     }
 #define X3_STORE_B(sb, S)                                                                         \
     *reinterpret_cast<uint4 *>((sb) + b_st) = S##_0;                                              \
-    *reinterpret_cast<uint4 *>((sb) + X3_PLANE_B + b_st) = S##_1;                                 \
-    *reinterpret_cast<uint4 *>((sb) + 2 * X3_PLANE_B + b_st) = S##_2;
+    *reinterpret_cast<uint4 *>((sb) + X3_BPLANE_B + b_st) = S##_1;                                \
+    *reinterpret_cast<uint4 *>((sb) + 2 * X3_BPLANE_B + b_st) = S##_2;
 
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < NJ; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     const int swz = ((half ^ ((l32 >> 3) & 1)) << 4);
     const int a_rd = (wm * 64 + l32) * X3_ROW_B + swz;
-    const int b_rd = X3_OPER_B + (wn * 64 + l32) * X3_ROW_B + swz;
+    const int b_rd = X3_OPER_B + (wn * 32 * NJ + l32) * X3_ROW_B + swz;
 
     bf16x8 fa0[3], fa1[3], fb0[3], fb1[3];
     // smallest terms first: (a3 b1), (a1 b3), (a2 b2), (a2 b1), (a1 b2), (a1 b1)
-#define X3_TERM(pa, pb)                                                                            \
-    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa0[pa], fb0[pb], acc[0][0], 0, 0, 0);     \
-    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa0[pa], fb1[pb], acc[0][1], 0, 0, 0);     \
-    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa1[pa], fb0[pb], acc[1][0], 0, 0, 0);     \
-    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa1[pa], fb1[pb], acc[1][1], 0, 0, 0);
+#define X3_TERM(pa, pb)                                                                                \
+    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa0[pa], fb0[pb], acc[0][0], 0, 0, 0);         \
+    if constexpr (NJ == 2) acc[0][NJ - 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa0[pa], fb1[pb], acc[0][NJ - 1], 0, 0, 0); \
+    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa1[pa], fb0[pb], acc[1][0], 0, 0, 0);         \
+    if constexpr (NJ == 2) acc[1][NJ - 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa1[pa], fb1[pb], acc[1][NJ - 1], 0, 0, 0);
     // one k-step: RA0/RA1 = A registers of tile kt+2 (two row passes), SB = its B set, LOADS = re-issue
 #define X3_STEP(kt, RA0, RA1, SB, LOADS)                                                           \
     {                                                                                              \
@@ -167,14 +180,14 @@ __device__ __forceinline__ void x3_mainloop(const float *__restrict__ A, int lda
         _Pragma("unroll") for (int p = 0; p < 3; ++p) {                                            \
             fa0[p] = *reinterpret_cast<const bf16x8 *>(rs + p * X3_PLANE_B + a_rd);                \
             fa1[p] = *reinterpret_cast<const bf16x8 *>(rs + p * X3_PLANE_B + a_rd + 32 * X3_ROW_B); \
-            fb0[p] = *reinterpret_cast<const bf16x8 *>(rs + p * X3_PLANE_B + b_rd);                \
-            fb1[p] = *reinterpret_cast<const bf16x8 *>(rs + p * X3_PLANE_B + b_rd + 32 * X3_ROW_B); \
+            fb0[p] = *reinterpret_cast<const bf16x8 *>(rs + p * X3_BPLANE_B + b_rd);               \
+            if constexpr (NJ == 2) fb1[p] = *reinterpret_cast<const bf16x8 *>(rs + p * X3_BPLANE_B + b_rd + 32 * X3_ROW_B); \
         }                                                                                          \
         X3_TERM(2, 0)                                                                              \
         if (st) X3_STORE_A(ws, RA0, 0)                                                             \
         X3_TERM(0, 2)                                                                              \
         X3_TERM(1, 1)                                                                              \
-        if (st) X3_STORE_A(ws, RA1, 64 * X3_ROW_B)                                                 \
+        if constexpr (WMG == 2) { if (st) X3_STORE_A(ws, RA1, 64 * X3_ROW_B) }                     \
         X3_TERM(1, 0)                                                                              \
         X3_TERM(0, 1)                                                                              \
         if (st) { X3_STORE_B(ws, SB) }                                                             \
@@ -188,10 +201,10 @@ __device__ __forceinline__ void x3_mainloop(const float *__restrict__ A, int lda
     X3_GLOAD_B(b0, 0)
     X3_GLOAD_B(b1, 1)
     X3_STORE_A(smem, p0_0e, 0)
-    X3_STORE_A(smem, p0_1e, 64 * X3_ROW_B)
+    if constexpr (WMG == 2) X3_STORE_A(smem, p0_1e, 64 * X3_ROW_B)
     X3_STORE_B(smem, b0)
     X3_STORE_A(smem + X3_STAGE_B, p0_0o, 0)
-    X3_STORE_A(smem + X3_STAGE_B, p0_1o, 64 * X3_ROW_B)
+    if constexpr (WMG == 2) X3_STORE_A(smem + X3_STAGE_B, p0_1o, 64 * X3_ROW_B)
     X3_STORE_B(smem + X3_STAGE_B, b1)
     X3_GLOAD_A(p1, 2)
     X3_GLOAD_B(b0, 2)
@@ -215,35 +228,44 @@ __device__ __forceinline__ void x3_mainloop(const float *__restrict__ A, int lda
 #undef X3_STEP
 }
 
+template <int WMG>
 __global__ __launch_bounds__(256, 2) void gemm_bf16x3_kernel(const float *__restrict__ A, int lda,
                                                              const __bf16 *__restrict__ Bpk, float *C, int ldc,
                                                              int M, int N, int K,
                                                              const float *__restrict__ bias, const float *resid,
                                                              int ldr, int act, int tiles_m, int tiles_n) {
-    __shared__ __attribute__((aligned(16))) char smem[X3_SMEM_B];
+    __shared__ __attribute__((aligned(16))) char smem[X3Geo<WMG>::SMEM_B];
     int tm, tn;
     tile_coords(tiles_m, tiles_n, tm, tn);
-    const int m0 = tm * GEMM_BM, n0 = tn * GEMM_BN;
-    f32x16 acc[2][2];
-    x3_mainloop(A, lda, Bpk, M, K, m0, tn, smem, acc);
-    epilogue_store(acc, C, ldc, M, N, m0, n0, bias, resid, ldr, act);
+    const int m0 = tm * X3Geo<WMG>::BM, n0 = tn * GEMM_BN;
+    f32x16 acc[2][WaveGrid<WMG>::NJ];
+    x3_mainloop<WMG>(A, lda, Bpk, M, K, m0, tn, smem, acc);
+    epilogue_store<WMG>(acc, C, ldc, M, N, m0, n0, bias, resid, ldr, act);
 }
 
-template <int KSEL>
+template <int KSEL, int WMG>
 __global__ __launch_bounds__(256, 2) void gemm_bf16x3_topk_kernel(const float *__restrict__ A, int lda,
                                                                   const __bf16 *__restrict__ Bpk, int M, int N,
                                                                   int K, float inv_temp,
                                                                   float *tile_max, float *tile_sum, float *cand_val,
                                                                   int *cand_idx, int tiles_m, int tiles_n) {
-    __shared__ __attribute__((aligned(16))) char smem[X3_SMEM_B];
-    static_assert(64 * CT_LD * 4 <= X3_SMEM_B, "64 rows of the epilogue tile must fit the staging buffers");
+    __shared__ __attribute__((aligned(16))) char smem[X3Geo<WMG>::SMEM_B];
     int tm, tn;
     tile_coords(tiles_m, tiles_n, tm, tn);
-    const int m0 = tm * GEMM_BM, n0 = tn * GEMM_BN;
-    f32x16 acc[2][2];
-    x3_mainloop(A, lda, Bpk, M, K, m0, tn, smem, acc);   // ends with a barrier
-    epilogue_topk<KSEL>(acc, reinterpret_cast<float *>(smem), M, N, m0, n0, tn, tiles_n, inv_temp, tile_max, tile_sum,
+    const int m0 = tm * X3Geo<WMG>::BM, n0 = tn * GEMM_BN;
+    f32x16 acc[2][WaveGrid<WMG>::NJ];
+    x3_mainloop<WMG>(A, lda, Bpk, M, K, m0, tn, smem, acc);   // ends with a barrier
+    epilogue_topk<KSEL, WMG>(acc, reinterpret_cast<float *>(smem), M, N, m0, n0, tn, tiles_n, inv_temp, tile_max, tile_sum,
                         cand_val, cand_idx);
+}
+
+static bool x3_use_small_tile(int M, int tiles_n) {
+    static const int force = [] { const char *e = getenv("CAPDEC_X3_TILE_M"); return e ? atoi(e) : 0; }();
+    // Measured on MI355X (M = 3125 / 5000 decode rows): the 64-row tile doubles the blocks of an under-filled
+    // grid but also doubles the B bytes per FLOP, and comes out 6-10 % SLOWER than 128-row tiles even at
+    // 150 blocks on 256 CUs -- so it is opt-in only (CAPDEC_X3_TILE_M=64), e.g. for M <= 64.
+    (void)M; (void)tiles_n;
+    return force == 64;
 }
 
 int launch_gemm_bf16x3(hipStream_t st, const float *A, int lda, const void *Bpacked, float *C, int ldc, int M, int N,
@@ -251,9 +273,16 @@ int launch_gemm_bf16x3(hipStream_t st, const float *A, int lda, const void *Bpac
     CAPDEC_CHECK(M > 0 && N > 0 && K > 0, "gemm: empty problem");
     CAPDEC_CHECK(K % 64 == 0 && lda % 4 == 0, "gemm_bf16x3: K must be a multiple of 64");
     CAPDEC_CHECK((((uintptr_t)A | (uintptr_t)Bpacked) & 15) == 0, "gemm_bf16x3: operands must be 16-byte aligned");
-    const int tiles_m = (M + GEMM_BM - 1) / GEMM_BM, tiles_n = (N + GEMM_BN - 1) / GEMM_BN;
-    hipLaunchKernelGGL(gemm_bf16x3_kernel, dim3(tiles_m * tiles_n), dim3(256), 0, st, A, lda, (const __bf16 *)Bpacked, C, ldc,
-                       M, N, K, epi.bias, epi.resid, epi.ldr, epi.act, tiles_m, tiles_n);
+    // 64-row tiles when the 128-row grid would leave the chip (256 CUs x 2 blocks) under-filled
+    const int tiles_n = (N + GEMM_BN - 1) / GEMM_BN;
+    const bool small = x3_use_small_tile(M, tiles_n);
+    const int bm = small ? 64 : 128, tiles_m = (M + bm - 1) / bm;
+    if (small)
+        hipLaunchKernelGGL(gemm_bf16x3_kernel<1>, dim3(tiles_m * tiles_n), dim3(256), 0, st, A, lda, (const __bf16 *)Bpacked,
+                           C, ldc, M, N, K, epi.bias, epi.resid, epi.ldr, epi.act, tiles_m, tiles_n);
+    else
+        hipLaunchKernelGGL(gemm_bf16x3_kernel<2>, dim3(tiles_m * tiles_n), dim3(256), 0, st, A, lda, (const __bf16 *)Bpacked,
+                           C, ldc, M, N, K, epi.bias, epi.resid, epi.ldr, epi.act, tiles_m, tiles_n);
     CAPDEC_HIP(hipGetLastError());
     return 0;
 }
@@ -262,11 +291,17 @@ int launch_gemm_bf16x3_topk(hipStream_t st, const float *A, int lda, const void 
                             float inv_temp, float *tile_max, float *tile_sum, float *cand_val, int *cand_idx) {
     CAPDEC_CHECK(M > 0 && N > 0 && K > 0, "gemm_topk: empty problem");
     CAPDEC_CHECK(K % 64 == 0 && lda % 4 == 0, "gemm_bf16x3_topk: K must be a multiple of 64");
-    const int tiles_m = (M + GEMM_BM - 1) / GEMM_BM, tiles_n = (N + GEMM_BN - 1) / GEMM_BN;
+    const int tiles_n = (N + GEMM_BN - 1) / GEMM_BN;
+    const bool small = x3_use_small_tile(M, tiles_n);
+    const int bm = small ? 64 : 128, tiles_m = (M + bm - 1) / bm;
     dim3 grid(tiles_m * tiles_n), block(256);
-#define LAUNCH_TOPK(KS)                                                                                          \
-    hipLaunchKernelGGL(gemm_bf16x3_topk_kernel<KS>, grid, block, 0, st, A, lda, (const __bf16 *)Bpacked, M, N, K, \
-                       inv_temp, tile_max, tile_sum, cand_val, cand_idx, tiles_m, tiles_n)
+#define LAUNCH_TOPK(KS)                                                                                               \
+    if (small)                                                                                                        \
+        hipLaunchKernelGGL((gemm_bf16x3_topk_kernel<KS, 1>), grid, block, 0, st, A, lda, (const __bf16 *)Bpacked, M, N, K, \
+                           inv_temp, tile_max, tile_sum, cand_val, cand_idx, tiles_m, tiles_n);                       \
+    else                                                                                                              \
+        hipLaunchKernelGGL((gemm_bf16x3_topk_kernel<KS, 2>), grid, block, 0, st, A, lda, (const __bf16 *)Bpacked, M, N, K, \
+                           inv_temp, tile_max, tile_sum, cand_val, cand_idx, tiles_m, tiles_n)
     switch (k) {
         case 1: LAUNCH_TOPK(1); break;
         case 2: LAUNCH_TOPK(2); break;

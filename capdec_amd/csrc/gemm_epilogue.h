@@ -41,15 +41,26 @@ __device__ __forceinline__ void tile_coords(int tiles_m, int tiles_n, int &tm, i
     tn = in_g / gsz;
 }
 
-// C = act(acc + bias) + resid for the 128x128 tile at (m0, n0)
-__device__ __forceinline__ void epilogue_store(const f32x16 (&acc)[2][2], float *C, int ldc, int M, int N, int m0,
-                                               int n0, const float *__restrict__ bias, const float *resid, int ldr,
-                                               int act) {
+// Wave layouts of the 4-wavefront block: WMG = 2 -> 2x2 waves, 128x128 tile, 64x64 per wave (NJ = 2 column
+// blocks); WMG = 1 -> 1x4 waves, 64x128 tile, 64x32 per wave (NJ = 1): twice the blocks for small M.
+template <int WMG> struct WaveGrid {
+    static constexpr int NJ = WMG;                 // 32-column blocks per wave
+    static constexpr int BM = 64 * WMG;
+    __device__ static int wm(int wave) { return WMG == 2 ? wave >> 1 : 0; }
+    __device__ static int wn(int wave) { return WMG == 2 ? wave & 1 : wave; }
+};
+
+// C = act(acc + bias) + resid for the tile at (m0, n0)
+template <int WMG = 2>
+__device__ __forceinline__ void epilogue_store(const f32x16 (&acc)[2][WaveGrid<WMG>::NJ], float *C, int ldc, int M,
+                                               int N, int m0, int n0, const float *__restrict__ bias,
+                                               const float *resid, int ldr, int act) {
+    constexpr int NJ = WaveGrid<WMG>::NJ;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int wm = wave >> 1, wn = wave & 1, half = lane >> 5, l32 = lane & 31;
+    const int wm = WaveGrid<WMG>::wm(wave), wn = WaveGrid<WMG>::wn(wave), half = lane >> 5, l32 = lane & 31;
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int col = n0 + wn * 64 + j * 32 + l32;
+    for (int j = 0; j < NJ; ++j) {
+        const int col = n0 + wn * 32 * NJ + j * 32 + l32;
         if (col >= N) continue;
         const float bv = bias ? bias[col] : 0.f;
 #pragma unroll
@@ -71,28 +82,29 @@ __device__ __forceinline__ void epilogue_store(const f32x16 (&acc)[2][2], float 
 // logits tile goes accumulators -> LDS (`Ct`, >= 64 x CT_LD floats, reusing the staging buffers;
 // the caller's main loop must have ended with a barrier) -> 16-lane groups, one row per group, 8
 // columns per lane; only (2 + 2k) words per (row, tile) reach HBM.
-template <int KSEL, int NW = 4>
-__device__ __forceinline__ void epilogue_topk(const f32x16 (&acc)[2][2], float *Ct, int M, int N, int m0, int n0,
-                                              int tn, int tiles_n, float inv_temp, float *tile_max, float *tile_sum,
-                                              float *cand_val, int *cand_idx) {
+template <int KSEL, int WMG = 2>
+__device__ __forceinline__ void epilogue_topk(const f32x16 (&acc)[2][WaveGrid<WMG>::NJ], float *Ct, int M, int N,
+                                              int m0, int n0, int tn, int tiles_n, float inv_temp, float *tile_max,
+                                              float *tile_sum, float *cand_val, int *cand_idx) {
+    constexpr int NJ = WaveGrid<WMG>::NJ;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int wm = wave >> 1, wn = wave & 1, half = lane >> 5, l32 = lane & 31;
+    const int wm = WaveGrid<WMG>::wm(wave), wn = WaveGrid<WMG>::wn(wave), half = lane >> 5, l32 = lane & 31;
     const int grp = lane >> 4, sub = lane & 15;
-    for (int hh = 0; hh < NW / 2; ++hh) {         // 64 rows of the tile at a time
+    for (int hh = 0; hh < WMG; ++hh) {            // 64 rows of the tile at a time
         if (wm == hh) {
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j)
+                for (int j = 0; j < NJ; ++j)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const int row = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                        Ct[row * CT_LD + wn * 64 + j * 32 + l32] = acc[i][j][r] * inv_temp;
+                        Ct[row * CT_LD + wn * 32 * NJ + j * 32 + l32] = acc[i][j][r] * inv_temp;
                     }
         }
         __syncthreads();
-        for (int it = 0; it < 16 / NW; ++it) {
-            const int rl = wave * (64 / NW) + it * 4 + grp;   // row within the half
+        for (int it = 0; it < 4; ++it) {
+            const int rl = wave * 16 + it * 4 + grp;   // row within the 64-row slab
             const int row = m0 + hh * 64 + rl;
             float v[8];
 #pragma unroll

@@ -402,3 +402,27 @@ def test_text_to_prefix_pipeline():
     ref = O.clip_project(O.noise_injection(O.clip_encode_text(toks, csd), 0.016, noise=noise), sd, "mlp", 10)
     np.testing.assert_allclose(pe.numpy(), ref.numpy(), atol=1e-3)
     assert eg.text_to_prefix(cm, model, toks, noise_variance=0.016, seed=1).shape == (9, 10, 768)
+
+
+def test_decode_p40_notebook_geometry(golden):
+    """prefix_length 40 / 640-d (others/CapDec_inference.ipynb): contexts up to 106 tokens, 80-token mapper sequences"""
+    from capdec_amd import gpt2_prefix_eval as E
+    g = golden("decode_p40_tiny")
+    dims = synth.GPT2_TINY
+    for mapping in ("mlp", "transformer_encoder"):
+        model, sd = _model(dims, mapping, 640, seed=11, P=40, clip_length=40, num_layers=2)
+        assert synth.state_dict_checksum(sd) == int(g[f"{mapping}_crc"]), "RNG drift"
+        n = g[f"{mapping}_x"].shape[0]
+        pe = model.clip_project(T(g[f"{mapping}_x"])).reshape(n, 40, -1)
+        np.testing.assert_allclose(pe.cpu().numpy(), g[f"{mapping}_prefix_embed"], atol=3e-4)
+        pe = T(g[f"{mapping}_prefix_embed"])
+        ids, lens = E.decode_greedy_ids(model, pe, dims.vocab + 5, 67)
+        np.testing.assert_array_equal(ids.cpu().numpy(), g[f"{mapping}_greedy_ids"])
+        np.testing.assert_array_equal(lens.cpu().numpy(), g[f"{mapping}_greedy_lens"])
+        bi, bl, bs, bo = (t.cpu().numpy() for t in E.decode_beam_ids(model, pe, int(g[f"{mapping}_beam_stop_id"]), 5, 67))
+        go = g[f"{mapping}_beam_order"]
+        np.testing.assert_array_equal(bo, go)
+        for r in range(n):
+            np.testing.assert_array_equal(bi[r], g[f"{mapping}_beam_tokens"][r][go[r]])
+            np.testing.assert_array_equal(bl[r], g[f"{mapping}_beam_seqlen"][r][go[r]].astype(np.int32))
+            np.testing.assert_allclose(bs[r], g[f"{mapping}_beam_scores"][r][go[r]], atol=1e-4)

@@ -170,3 +170,22 @@ def test_clip_tiny(golden):
 @pytest.mark.slow
 def test_clip_b32(golden):
     _check_clip(golden("clip_b32"), synth.CLIP_VIT_B32)
+
+
+# ------------------------------------------------------------------ notebook geometry: prefix_length 40, 640-d
+def test_decode_p40_tiny(golden):
+    g = golden("decode_p40_tiny")
+    dims = synth.GPT2_TINY
+    for mapping in ("mlp", "transformer_encoder"):
+        sd = synth.hot_state_dict(11, mapping, 640, 40, 40, 2, dims)
+        assert synth.state_dict_checksum(sd) == int(g[f"{mapping}_crc"]), "RNG drift"
+        pe = O.clip_project(T(g[f"{mapping}_x"]), sd, mapping, 40, 40, 2)
+        np.testing.assert_allclose(pe.numpy(), g[f"{mapping}_prefix_embed"], atol=3e-4)
+        pe = T(g[f"{mapping}_prefix_embed"])
+        ids, lens = O.greedy_cached(sd, pe, stop_id=dims.vocab + 5, entry_length=67, alt_stop_id=764)
+        np.testing.assert_array_equal(ids.numpy(), g[f"{mapping}_greedy_ids"])
+        np.testing.assert_array_equal(lens.numpy(), g[f"{mapping}_greedy_lens"])
+        tok, seq, sc = O.beam_cached(sd, pe, 5, int(g[f"{mapping}_beam_stop_id"]), 67)
+        np.testing.assert_array_equal(tok.numpy(), g[f"{mapping}_beam_tokens"])
+        np.testing.assert_array_equal(seq.numpy(), g[f"{mapping}_beam_seqlen"].astype(np.int32))
+        np.testing.assert_allclose(sc.numpy(), g[f"{mapping}_beam_scores"], atol=1e-4)

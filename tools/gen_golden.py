@@ -251,6 +251,38 @@ def gen_decode(refs, dims, tag, n_greedy, n_beam, lengths):
     print(f"decode_{tag}.npz written; greedy stop {out['greedy_stop_id']}, beam stop {out['beam_stop_id']}")
 
 
+def gen_decode_p40(refs, dims, tag):
+    """the notebook's geometry (others/CapDec_inference.ipynb: prefix_length 40, RN50x4 640-d): contexts up to
+    P + T - 1 = 106 tokens; MLP mapper 640 -> 15360 -> 30720, TransformerMapper with 80-token sequences"""
+    gpt2_prefix, gpt2_prefix_eval = refs[0], refs[1]
+    out = {}
+    for mapping, n in (("mlp", 3), ("transformer_encoder", 3)):
+        model, sd = build_ref_model(gpt2_prefix, dims, mapping, 640, 40, clip_length=40, num_layers=2, seed=11)
+        out[f"{mapping}_crc"] = np.uint32(synth.state_dict_checksum(sd))
+        x = synth.synthetic_clip_embeddings(n, 640, seed=21)
+        with torch.no_grad():
+            pe = model.clip_project(x).reshape(n, 40, -1)
+            out[f"{mapping}_x"], out[f"{mapping}_prefix_embed"] = x.numpy(), pe.numpy()
+            ids = np.zeros((n, 67), np.int64)
+            lens = np.zeros(n, np.int64)
+            for r in range(n):
+                t = [int(v) for v in gpt2_prefix_eval.generate2(model, FakeTok(stop=dims.vocab + 5), embed=pe[r:r + 1]).split()]
+                ids[r, :len(t)], lens[r] = t, len(t)
+            out[f"{mapping}_greedy_ids"], out[f"{mapping}_greedy_lens"] = ids, lens
+            toks = np.zeros((n, 5, 67), np.int64); seql = np.zeros((n, 5), np.float32)
+            scs = np.zeros((n, 5), np.float32); order = np.zeros((n, 5), np.int64)
+            stop = int(ids[0, 5])
+            out[f"{mapping}_beam_stop_id"] = np.int64(stop)
+            for r in range(n):
+                got = capture_beam(gpt2_prefix_eval, model, FakeTok(stop=stop), pe[r:r + 1], 67)
+                toks[r] = pad_tokens(got["tokens"], 67)
+                seql[r], scs[r], order[r] = got["seq_lengths"], got["scores"], got["order"]
+            out[f"{mapping}_beam_tokens"], out[f"{mapping}_beam_seqlen"] = toks, seql
+            out[f"{mapping}_beam_scores"], out[f"{mapping}_beam_order"] = scs, order
+    np.savez_compressed(os.path.join(OUT, f"decode_p40_{tag}.npz"), **out)
+    print(f"decode_p40_{tag}.npz written")
+
+
 def openai_to_hf_clip(sd, dims):
     """Map an OpenAI-CLIP-named state dict onto transformers.CLIPModel names (the independent
     stand-in used to pin the CLIP kernels: the reference's own `clip` package is not installed)."""
@@ -323,6 +355,7 @@ def main():
         "logits_small": lambda: gen_gpt2_logits(refs, synth.GPT2_SMALL, "small"),
         "decode_tiny": lambda: gen_decode(refs, synth.GPT2_TINY, "tiny", 8, 6, (12, 67)),
         "decode_small": lambda: gen_decode(refs, synth.GPT2_SMALL, "small", 8, 4, (12, 67)),
+        "decode_p40_tiny": lambda: gen_decode_p40(refs, synth.GPT2_TINY, "tiny"),
         "clip_tiny": lambda: gen_clip(synth.CLIP_TINY, "tiny", 6, 3),
         "clip_b32": lambda: gen_clip(synth.CLIP_VIT_B32, "b32", 6, 3),
     }
