@@ -104,12 +104,58 @@ def cpu_baseline(mapper, beam, P, T, budget_s=20.0, D=512):
                       f"thread count chosen by a 1.5 s probe, warm-up discarded"}
 
 
+def side_workload(args, world, rank, dev):
+    """configs[3] / configs[4] of BASELINE.json: parity-test cases, measured here for DESIGN.md (not the metric line)."""
+    from capdec_amd import clip as cclip, distributed as cdist, embeddings_generator as eg
+    from capdec_amd.gpt2_prefix import ClipCaptionModel, MappingType
+    from capdec_amd.predictions_runner import caption_ids
+    P, T = args.prefix_length, args.entry_length
+    cm, _ = cclip.load(synth.hot_clip_state_dict(43), device=dev.index or 0)
+    text = args.workload == "text_embed"
+    mt = MappingType.MLP if text else MappingType.TransformerEncoder
+    model = ClipCaptionModel(P, clip_length=10, prefix_dim=512, num_layers=8, mapping_type=mt).to(dev).eval()
+    model.load_state_dict(synth.hot_state_dict(42, "mlp" if text else "transformer_encoder", 512, P))
+    n_global = args.captions * world
+    if text:
+        inp = synth.synthetic_clip_tokens(n_global, seed=2).to(dev)
+    else:
+        inp = synth.synthetic_images(n_global, seed=4).to(dev)
+
+    def step():
+        if text:     # embeddings_generator.py:58-101 + train.py:347,253-254
+            return eg.text_to_prefix(cm, model, inp, noise_variance=0.016, seed=3, rank=rank, world=world)
+        emb = eg.encode_images(cm, inp, rank, world, gather=False)      # predictions_runner.py:220-232
+        full = torch.zeros(n_global, 512, device=dev)
+        lo, hi = cdist.shard_bounds(n_global, rank, world)
+        full[lo:hi] = emb
+        ids, lens, sc = caption_ids(model, full, STOP_ID, beam=True, entry_length=T, rank=rank, world=world)
+        return cdist.gather_ids(ids, lens, n_global, sc)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if rank == 0:
+        print(json.dumps({"metric": f"{'captions' if text else 'images'}/sec, side workload {args.workload}",
+                          "value": round(n_global * args.steps / dt, 2), "unit": "items/s", "n_gpus": world,
+                          "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 2),
+                          "config": {"workload": args.workload, "items_per_step": n_global}}), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", choices=["beam_transformer", "greedy_mlp"], default="beam_transformer")
+    ap.add_argument("--workload", choices=["beam_transformer", "greedy_mlp", "text_embed", "image_beam"],
+                    default="beam_transformer",
+                    help="beam_transformer = BASELINE metric config (default); greedy_mlp = configs[1] shape; "
+                         "text_embed = configs[3] (CLIP ViT-B/32 encode_text + noise + mapper); "
+                         "image_beam = configs[4] (ViT-B/32 encode_image + TransformerMapper + beam 5)")
     ap.add_argument("--captions", type=int, default=5000, help="captions per GPU per step (weak scaling)")
     ap.add_argument("--entry-length", type=int, default=67)
     ap.add_argument("--prefix-length", type=int, default=10)
@@ -134,6 +180,8 @@ def main():
     from capdec_amd.gpt2_prefix import ClipCaptionModel, MappingType
     from capdec_amd.predictions_runner import caption_ids
 
+    if args.workload in ("text_embed", "image_beam"):
+        return side_workload(args, world, rank, dev)
     beam = args.workload == "beam_transformer"
     mapper = "transformer_encoder" if beam else "mlp"
     P, T, B = args.prefix_length, args.entry_length, (5 if beam else 1)

@@ -426,3 +426,25 @@ def test_decode_p40_notebook_geometry(golden):
             np.testing.assert_array_equal(bi[r], g[f"{mapping}_beam_tokens"][r][go[r]])
             np.testing.assert_array_equal(bl[r], g[f"{mapping}_beam_seqlen"][r][go[r]].astype(np.int32))
             np.testing.assert_allclose(bs[r], g[f"{mapping}_beam_scores"][r][go[r]], atol=1e-4)
+
+
+def test_long_context_vs_oracle():
+    """near the supported maxima (context 209 of 256, entry_length 120 of 128): softmax over > 3 x 64 positions,
+    beam token history / ancestor tables at full length"""
+    from capdec_amd import gpt2_prefix_eval as E
+    from capdec_amd.gpt2_prefix import ClipCaptionModel, MappingType
+    from oracle import capdec_oracle as O
+    dims = synth.GPT2Dims(n_layer=2, vocab=1531, n_pos=256)
+    sd = synth.hot_state_dict(5, "mlp", 512, 10, dims=dims)
+    model = ClipCaptionModel(10, prefix_dim=512, mapping_type=MappingType.MLP, gpt2_dims=dims).to("cuda:0").eval()
+    model.load_state_dict(sd)
+    pe = torch.randn(3, 90, 768, generator=torch.Generator().manual_seed(1)) * 0.5      # prefix of 90 positions
+    ids_o, lens_o = O.greedy_cached(sd, pe, stop_id=10 ** 6, entry_length=120, alt_stop_id=-1)
+    ids, lens = E.decode_greedy_ids(model, pe, 10 ** 6, 120, alt_stop_id=-1)
+    np.testing.assert_array_equal(ids.cpu().numpy(), ids_o.numpy())
+    tok_o, seq_o, sc_o = O.beam_cached(sd, pe, 3, 10 ** 6, 120)
+    od = O.beam_output_order(sc_o)
+    bi, bl, bs, bo = E.decode_beam_ids(model, pe, 10 ** 6, 3, 120)
+    for r in range(3):
+        np.testing.assert_array_equal(bi[r].cpu().numpy(), tok_o[r][od[r]].numpy())
+        np.testing.assert_allclose(bs[r].cpu().numpy(), sc_o[r][od[r]].numpy(), atol=1e-4)
