@@ -166,7 +166,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    force_dist = os.environ.get("CAPDEC_FORCE_DIST") == "1" and "RANK" in os.environ   # exercise RCCL with 1 rank
+    if world > 1 or force_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -278,7 +279,7 @@ def main():
         else:
             rec["cpu_baseline"] = None
         print(json.dumps(rec), flush=True)
-    if world > 1:
+    if world > 1 or force_dist:
         import torch.distributed as dist
         dist.destroy_process_group()
 

@@ -5,6 +5,7 @@ lengths (+ fp32 beam scores) over RCCL (torch.distributed backend "nccl"; "gloo"
 Rank order preserves caption order, so the gathered matrix equals the 1-GPU result."""
 from __future__ import annotations
 
+import os
 from typing import List, Optional, Sequence, Tuple
 
 import torch
@@ -24,7 +25,9 @@ def shard_size(n: int, world: int) -> int:
 def gather_rows(local: torch.Tensor, n_total: int, group=None) -> torch.Tensor:
     """all-gather row blocks produced under :func:`shard_bounds`: every rank pads its block to
     ceil(N/R) rows, one all_gather_into_tensor moves them, the padding is cut off again."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    if not (dist.is_available() and dist.is_initialized()):
+        return local[:n_total]
+    if dist.get_world_size(group) == 1 and os.environ.get("CAPDEC_FORCE_DIST") != "1":
         return local[:n_total]
     world = dist.get_world_size(group)
     per = shard_size(n_total, world)
