@@ -61,6 +61,19 @@ def preprocess_tensor(image: torch.Tensor) -> torch.Tensor:
     return (image - mean) / std
 
 
+_tokenizer = None
+
+
 def tokenize(texts, context_length: int = 77, truncate: bool = False):
-    raise CapdecError("clip.tokenize needs the CLIP BPE vocabulary (bpe_simple_vocab_16e6.txt.gz), which is not "
-                      "available offline; pass pre-tokenised int [N, 77] rows to encode_text")
+    """``clip.tokenize`` (reference embeddings_generator.py:81, predictions_runner.py:217).  The BPE vocabulary
+    (bpe_simple_vocab_16e6.txt.gz) is not shipped and not downloadable here: point CAPDEC_CLIP_BPE at it."""
+    global _tokenizer
+    if _tokenizer is None:
+        import os
+        path = os.environ.get("CAPDEC_CLIP_BPE")
+        if not path or not os.path.exists(path):
+            raise CapdecError("clip.tokenize needs the CLIP BPE vocabulary: set CAPDEC_CLIP_BPE to "
+                              "bpe_simple_vocab_16e6.txt.gz, or pass pre-tokenised int [N, 77] rows to encode_text")
+        from .bpe import ClipBPE
+        _tokenizer = ClipBPE(path)
+    return _tokenizer.tokenize(texts, context_length, truncate)

@@ -174,3 +174,121 @@ def test_gather_ids_gloo_world_size_2(tmp_path):
     outs = [p.communicate(timeout=180)[0] for p in procs]
     assert all(p.returncode == 0 for p in procs), outs
     assert all("OK" in o for o in outs)
+
+
+def test_formats_round_trip(tmp_path):
+    import pickle
+    from capdec_amd import formats, synth
+    caps = [{"image_id": 7, "caption": "A dog.", "id": 0}, {"image_id": 9, "caption": "Two cats", "id": 1, "filename": "x.jpg"}]
+    txt = synth.synthetic_clip_embeddings(2, 512, seed=1, normalize=False)
+    p = tmp_path / "emb.pkl"
+    formats.save_embeddings_pickle(str(p), caps, text_embeddings=txt, half=True)        # fp16 like a GPU run
+    raw = pickle.load(open(p, "rb"))
+    assert set(raw) == {"clip_embedding", "captions", "clip_embedding_text_dave"}
+    assert raw["clip_embedding_text_dave"].dtype == torch.float16 and raw["captions"][1]["clip_embedding"] == 1
+    img, t2, c2 = formats.load_embeddings_pickle(str(p))
+    assert img.shape == (0, 512) and t2.dtype == torch.float32 and t2.shape == (2, 512)
+    np.testing.assert_allclose(t2.numpy(), txt.half().float().numpy())
+    assert c2[0]["caption"] == "A dog."
+    # the reference's real modality-offset pickle layout
+    off = {k: torch.randn(1, 640) for k in ("center_text", "center_image", "offset_to_add_in_training", "offset_to_add_in_inference")}
+    q = tmp_path / "centers.pkl"
+    pickle.dump(off, open(q, "wb"))
+    o = formats.load_modality_offset(str(q))
+    assert o.shape == (1, 640) and torch.equal(o, off["offset_to_add_in_inference"])
+    with pytest.raises(KeyError):
+        formats.load_modality_offset(str(q), "nope")
+    sd = synth.hot_mlp_mapper_state_dict(1, 512, 10)
+    ck = tmp_path / "m.pt"
+    torch.save(sd, ck)
+    assert set(formats.load_checkpoint(str(ck))) == set(sd)
+    torch.save({"state_dict": sd, "epoch": 3}, ck)
+    assert set(formats.load_checkpoint(str(ck))) == set(sd)
+    js = formats.write_predictions_json(str(tmp_path / "p.json"), ["A Dog.", "CATS"], [7, 9])
+    assert js == [{"caption": "a dog.", "image_id": 7}, {"caption": "cats", "image_id": 9}]
+
+
+def _toy_bpe(corpus_words, n_merges, end_of_word=""):
+    """tiny BPE trainer (test helper): returns the ranked merge list over byte-unicode symbols"""
+    from collections import Counter
+    from capdec_amd.bpe import bytes_to_unicode
+    be = bytes_to_unicode()
+    words = Counter()
+    for w in corpus_words:
+        sym = [be[b] for b in w.encode("utf-8")]
+        if end_of_word:
+            sym[-1] = sym[-1] + end_of_word
+        words[tuple(sym)] += 1
+    merges = []
+    for _ in range(n_merges):
+        pairs = Counter()
+        for w, c in words.items():
+            for a, b in zip(w[:-1], w[1:]):
+                pairs[(a, b)] += c
+        if not pairs:
+            break
+        best = max(sorted(pairs), key=lambda p: pairs[p])
+        merges.append(best)
+        new = Counter()
+        for w, c in words.items():
+            out, i = [], 0
+            while i < len(w):
+                if i < len(w) - 1 and (w[i], w[i + 1]) == best:
+                    out.append(w[i] + w[i + 1]); i += 2
+                else:
+                    out.append(w[i]); i += 1
+            new[tuple(out)] += c
+        words = new
+    return merges
+
+
+_TEXTS = ["A man riding a wave on top of a surfboard.", "two dogs' bowls aren't here,  I'll say!!", "  naïve café déjà-vu ☕ 123 4567",
+          "the the the cat sat on the mat", "don't you've we're he'd", "x", "Ünïcödé and tabs\tand\nnewlines  "]
+
+
+def test_gpt2_bpe_matches_transformers(tmp_path):
+    import json
+    from transformers import GPT2Tokenizer
+    from capdec_amd.bpe import GPT2BPE, bytes_to_unicode
+    corpus = " ".join(_TEXTS).replace("\t", " ").split(" ")
+    corpus = [w for w in corpus if w] + [" " + w for w in corpus if w]
+    merges = _toy_bpe(corpus, 120)
+    vocab = {c: i for i, c in enumerate(bytes_to_unicode().values())}
+    for a, b in merges:
+        vocab.setdefault(a + b, len(vocab))
+    vf, mf = tmp_path / "vocab.json", tmp_path / "merges.txt"
+    vf.write_text(json.dumps(vocab), encoding="utf-8")
+    mf.write_text("#version: 0.2\n" + "\n".join(f"{a} {b}" for a, b in merges) + "\n", encoding="utf-8")
+    ref = GPT2Tokenizer(vocab=str(vf), merges=str(mf))          # transformers >= 5 signature
+    mine = GPT2BPE(str(vf), str(mf))
+    for t in _TEXTS:
+        ids = mine.encode(t)
+        assert ids == ref.encode(t), t
+        assert mine.decode(ids) == t                       # byte-level BPE is lossless
+        assert mine.decode(ids) == ref.decode(ids, clean_up_tokenization_spaces=False)
+    assert mine.encode(".")[0] == ref.encode(".")[0]        # the stop-token lookup the decode functions do
+
+
+def test_clip_bpe_matches_transformers(tmp_path):
+    import json
+    from transformers import CLIPTokenizer
+    from capdec_amd.bpe import ClipBPE
+    words = [w.lower() for t in _TEXTS for w in t.replace("\t", " ").split() if w]
+    merges = _toy_bpe(words, 150, end_of_word="</w>")
+    mine = ClipBPE(merges)
+    vf, mf = tmp_path / "vocab.json", tmp_path / "merges.txt"
+    vf.write_text(json.dumps(mine.encoder), encoding="utf-8")
+    mf.write_text("#version: 0.2\n" + "\n".join(f"{a} {b}" for a, b in merges) + "\n", encoding="utf-8")
+    ref = CLIPTokenizer(vocab=str(vf), merges=str(mf))
+    ascii_texts = [t for t in _TEXTS if t.isascii()]          # non-ascii cleaning differs without ftfy (both sides lack it here)
+    for t in ascii_texts:
+        want = ref(t)["input_ids"]
+        got = [mine.sot] + mine.encode(t) + [mine.eot]
+        assert got == want, t
+    rows = mine.tokenize(ascii_texts)
+    assert rows.shape == (len(ascii_texts), 77) and rows.dtype == torch.int32
+    assert (rows[:, 0] == mine.sot).all() and all(int(r.max()) == mine.eot for r in rows)
+    assert int(rows[0].argmax()) == len(mine.encode(ascii_texts[0])) + 1         # EOT position = argmax (encode_text pooling)
+    with pytest.raises(RuntimeError):
+        mine.tokenize("word " * 100)
+    assert mine.tokenize("word " * 100, truncate=True)[0, 76] == mine.eot
