@@ -1,0 +1,56 @@
+// Split-bf16 ("bf16x3") operand format shared by the GEMM and by the kernels that produce its operands.
+//
+// An fp32 value is exactly a1 + a2 + a3 with three bf16 (8 + 8 + 8 mantissa bits, round-to-nearest at each
+// step).  A matrix [R, K] (rows = GEMM M or N index, K contiguous) is stored as three bf16 planes in
+// TILE-MAJOR order  P[row_tile][k_step][plane][128 rows][16 bf16]  -- one (row_tile, k_step) block is 12 KB of
+// contiguous memory and is byte-for-byte the LDS image of one GEMM stage: rows of 32 B whose two 16-B halves
+// are swapped when bit 3 of the row is set (conflict-free ds_read_b128 without padding).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace capdec {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+constexpr int X3_BK = 16;            // k per step = one v_mfma_f32_32x32x16_bf16
+constexpr int X3_ROW_B = 32;         // bytes per row per plane per k-step
+constexpr int X3_TILE_ROWS = 128;
+constexpr int X3_PLANE_B = X3_TILE_ROWS * X3_ROW_B;   // 4096
+constexpr int X3_BLOCK_B = 3 * X3_PLANE_B;            // 12288: one (row_tile, k_step) block
+
+__device__ __forceinline__ void split3(const float4 v, bf16x4 &h, bf16x4 &m, bf16x4 &l) {
+    const float a[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const __bf16 hh = (__bf16)a[e];
+        const float r1 = a[e] - (float)hh;            // exact
+        const __bf16 mm = (__bf16)r1;
+        const float r2 = r1 - (float)mm;              // exact
+        h[e] = hh;
+        m[e] = mm;
+        l[e] = (__bf16)r2;
+    }
+}
+
+// byte offset of the 8-byte group holding k = 4*quad .. 4*quad+3 (quad 0..3 within the k-step) of row r (0..127)
+__device__ __forceinline__ int x3_group_offset(int r, int quad) {
+    return r * X3_ROW_B + (((quad >> 1) ^ ((r >> 3) & 1)) << 4) + ((quad & 1) << 3);
+}
+
+// store the split of 4 consecutive k (one float4) of matrix row `row`, k-step `ks`, quad `quad`
+__device__ __forceinline__ void x3_store_quad(char *packed, int nk, int row, int ks, int quad, const float4 v) {
+    bf16x4 h, m, l;
+    split3(v, h, m, l);
+    char *p = packed + ((size_t)(row >> 7) * nk + ks) * X3_BLOCK_B + x3_group_offset(row & 127, quad);
+    *reinterpret_cast<bf16x4 *>(p) = h;
+    *reinterpret_cast<bf16x4 *>(p + X3_PLANE_B) = m;
+    *reinterpret_cast<bf16x4 *>(p + 2 * X3_PLANE_B) = l;
+}
+
+inline size_t x3_packed_bytes(int rows, int K) {
+    return (size_t)((rows + X3_TILE_ROWS - 1) / X3_TILE_ROWS) * X3_TILE_ROWS * K * 3 * sizeof(uint16_t);
+}
+
+}  // namespace capdec

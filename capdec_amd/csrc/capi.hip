@@ -105,7 +105,8 @@ struct capdec_ctx {
     Prof prof;
     int gemm_mode = GEMM_BF16X3;
     std::unordered_map<const void *, std::pair<void *, size_t>> planes;   // fp32 weight -> (three bf16 planes, elements)
-    DBuf x3_tmp;
+    DBuf x3_tmp, xpk;          // scratch planes for un-cached matrices; packed split-bf16 LayerNorm output
+    bool pack_a = true;        // bf16x3 mode: LayerNorm emits the packed A operand, GEMM moves both operands by LDS-DMA
     hipEvent_t t0 = nullptr, t1 = nullptr;
     // workspaces
     DBuf h, x, qkv, att, ff, xl, tmax, tsum, cval, cidx, lse, topv, topi, kc, vc;
@@ -246,6 +247,23 @@ static int gemm(capdec_ctx *c, const float *A, int lda, const float *Bt, int ldb
     return launch_gemm_f32(c->stream, A, lda, Bt, ldb, C, ldc, M, N, K, e);
 }
 
+// LayerNorm -> GEMM with the normalised rows handed over in packed split-bf16 form (never fp32 in HBM).
+// Returns 1 in *done when the packed path ran; otherwise the caller runs the fp32-activation path.
+static bool use_packed_a(capdec_ctx *c, int K) { return c->gemm_mode == GEMM_BF16X3 && c->pack_a && K % 64 == 0; }
+
+static int ln_gemm_packed(capdec_ctx *c, const float *h, int ldh, const float *lnw, const float *lnb, float eps,
+                          const float *W, float *C, int ldc, int M, int N, int K, const float *bias, int act) {
+    CAPDEC_TRY(c->xpk.ensure(x3_packed_bytes_host(M, K)));
+    { ProfScope ps(c, F_LN); CAPDEC_TRY(launch_layernorm_packed(c->stream, h, ldh, lnw, lnb, eps, c->xpk.p, M, K)); }
+    const void *pl = nullptr;
+    CAPDEC_TRY(planes_of(c, W, N, K, true, &pl));
+    GemmEpilogue e;
+    e.bias = bias;
+    e.act = act;
+    ProfScope ps(c, F_GEMM_X3, 2.0 * M * (double)N * K);
+    return launch_gemm_bf16x3p(c->stream, c->xpk.p, pl, C, ldc, M, N, K, e);
+}
+
 // ---------------------------------------------------------------------------- GPT-2 body
 struct StepShape {
     bool prefill;
@@ -281,8 +299,12 @@ static int stack_body(capdec_ctx *c, const StackCfg &g, const StepShape &s, cons
     for (int l = 0; l < g.n_layer; ++l) {
         const Gpt2Layer &w = (*g.layers)[l];
         const int kl = g.keep_kv ? l : 0;
-        { ProfScope ps(c, F_LN); CAPDEC_TRY(launch_layernorm(c->stream, h, d, w.ln1w, w.ln1b, g.eps, x, d, M, d)); }
-        CAPDEC_TRY(gemm(c, x, d, w.wqkv, d, qkv, 3 * d, M, 3 * d, d, w.bqkv, CAPDEC_ACT_NONE));
+        if (use_packed_a(c, d)) {
+            CAPDEC_TRY(ln_gemm_packed(c, h, d, w.ln1w, w.ln1b, g.eps, w.wqkv, qkv, 3 * d, M, 3 * d, d, w.bqkv, CAPDEC_ACT_NONE));
+        } else {
+            { ProfScope ps(c, F_LN); CAPDEC_TRY(launch_layernorm(c->stream, h, d, w.ln1w, w.ln1b, g.eps, x, d, M, d)); }
+            CAPDEC_TRY(gemm(c, x, d, w.wqkv, d, qkv, 3 * d, M, 3 * d, d, w.bqkv, CAPDEC_ACT_NONE));
+        }
         if (s.prefill) {
             ProfScope ps(c, F_ATTN_PRE);
             CAPDEC_TRY(launch_kv_scatter_prefill(c->stream, qkv, kv, kl, s.ncap, s.P, s.beam));
@@ -292,8 +314,12 @@ static int stack_body(capdec_ctx *c, const StackCfg &g, const StepShape &s, cons
             CAPDEC_TRY(launch_attn_decode(c->stream, qkv, kv, kl, s.rows, s.beam, s.L, s.anc, s.anc_stride, att));
         }
         CAPDEC_TRY(gemm(c, att, d, w.wproj, d, h, d, M, d, d, w.bproj, CAPDEC_ACT_NONE, h, d));
-        { ProfScope ps(c, F_LN); CAPDEC_TRY(launch_layernorm(c->stream, h, d, w.ln2w, w.ln2b, g.eps, x, d, M, d)); }
-        CAPDEC_TRY(gemm(c, x, d, w.wfc, d, ff, 4 * d, M, 4 * d, d, w.bfc, g.act));
+        if (use_packed_a(c, d)) {
+            CAPDEC_TRY(ln_gemm_packed(c, h, d, w.ln2w, w.ln2b, g.eps, w.wfc, ff, 4 * d, M, 4 * d, d, w.bfc, g.act));
+        } else {
+            { ProfScope ps(c, F_LN); CAPDEC_TRY(launch_layernorm(c->stream, h, d, w.ln2w, w.ln2b, g.eps, x, d, M, d)); }
+            CAPDEC_TRY(gemm(c, x, d, w.wfc, d, ff, 4 * d, M, 4 * d, d, w.bfc, g.act));
+        }
         CAPDEC_TRY(gemm(c, ff, 4 * d, w.wproj2, 4 * d, h, d, M, d, 4 * d, w.bproj2, CAPDEC_ACT_NONE, h, d));
     }
     return 0;
@@ -318,8 +344,16 @@ static int lm_head_select(capdec_ctx *c, const float *h0, int ldh, int R, int k,
     CAPDEC_TRY(c->lse.ensure((size_t)R * 4));
     CAPDEC_TRY(c->topv.ensure((size_t)R * k * 4));
     CAPDEC_TRY(c->topi.ensure((size_t)R * k * 4));
-    { ProfScope ps(c, F_LN); CAPDEC_TRY(launch_layernorm(c->stream, h0, ldh, g.lnfw, g.lnfb, g.eps, c->xl.as<float>(), d, R, d)); }
-    if (c->gemm_mode == GEMM_BF16X3) {
+    if (use_packed_a(c, d)) {
+        CAPDEC_TRY(c->xpk.ensure(x3_packed_bytes_host(R, d)));
+        { ProfScope ps(c, F_LN); CAPDEC_TRY(launch_layernorm_packed(c->stream, h0, ldh, g.lnfw, g.lnfb, g.eps, c->xpk.p, R, d)); }
+        const void *pl = nullptr;
+        CAPDEC_TRY(planes_of(c, g.wte, g.vocab, d, true, &pl));
+        ProfScope ps(c, F_LMHEAD_X3, 2.0 * R * (double)g.vocab * d);
+        CAPDEC_TRY(launch_gemm_bf16x3p_topk(c->stream, c->xpk.p, pl, R, g.vocab, d, k, inv_temp, c->tmax.as<float>(),
+                                            c->tsum.as<float>(), c->cval.as<float>(), c->cidx.as<int>()));
+    } else if (c->gemm_mode == GEMM_BF16X3) {
+        { ProfScope ps(c, F_LN); CAPDEC_TRY(launch_layernorm(c->stream, h0, ldh, g.lnfw, g.lnfb, g.eps, c->xl.as<float>(), d, R, d)); }
         const void *pl = nullptr;
         CAPDEC_TRY(planes_of(c, g.wte, g.vocab, d, true, &pl));
         ProfScope ps(c, F_LMHEAD_X3, 2.0 * R * (double)g.vocab * d);
@@ -327,6 +361,7 @@ static int lm_head_select(capdec_ctx *c, const float *h0, int ldh, int R, int k,
                                            c->tmax.as<float>(), c->tsum.as<float>(), c->cval.as<float>(),
                                            c->cidx.as<int>()));
     } else {
+        { ProfScope ps(c, F_LN); CAPDEC_TRY(launch_layernorm(c->stream, h0, ldh, g.lnfw, g.lnfb, g.eps, c->xl.as<float>(), d, R, d)); }
         ProfScope ps(c, F_LMHEAD, 2.0 * R * (double)g.vocab * d);
         CAPDEC_TRY(launch_gemm_f32_topk(c->stream, c->xl.as<float>(), d, g.wte, d, R, g.vocab, d, k, inv_temp,
                                         c->tmax.as<float>(), c->tsum.as<float>(), c->cval.as<float>(),
@@ -630,6 +665,7 @@ int capdec_create(int device_id, capdec_ctx **out) {
     }
     std::unique_ptr<capdec_ctx> c(new capdec_ctx());
     c->device = device_id;
+    if (const char *e = getenv("CAPDEC_X3_PACKA")) c->pack_a = atoi(e) != 0;
     if (const char *e = getenv("CAPDEC_GEMM_MODE")) c->gemm_mode = (std::string(e) == "f32") ? GEMM_F32 : GEMM_BF16X3;
     CAPDEC_HIP(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
     c->stream = c->own_stream;
@@ -653,7 +689,7 @@ void capdec_destroy(capdec_ctx *c) {
     DBuf *bufs[] = {&c->h, &c->x, &c->qkv, &c->att, &c->ff, &c->xl, &c->tmax, &c->tsum, &c->cval, &c->cidx,
                     &c->lse, &c->topv, &c->topi, &c->kc, &c->vc, &c->tokens, &c->scores, &c->seq, &c->stopped,
                     &c->done, &c->anc, &c->next_tok, &c->alive, &c->gids, &c->glens, &c->m_hid, &c->m_lin, &c->m_seq,
-                    &c->m_x, &c->m_qkv, &c->m_att, &c->m_ff, &c->t_idx, &c->t_patch, &c->t_pout};
+                    &c->m_x, &c->m_qkv, &c->m_att, &c->m_ff, &c->t_idx, &c->t_patch, &c->t_pout, &c->xpk};
     for (DBuf *b : bufs) b->release();
     for (auto &r : c->prof.recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
     for (auto e : c->prof.pool) (void)hipEventDestroy(e);

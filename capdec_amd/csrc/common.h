@@ -102,11 +102,21 @@ inline int gemm_tiles_n(int N) { return (N + GEMM_BN - 1) / GEMM_BN; }
 // gemm_bf16x3.hip: the same two GEMMs on the bf16 matrix cores with operands split into three bf16
 // planes (fp32-accurate, 6 MFMA terms).  Bpacked = tile-major planes made by launch_pack_planes.
 size_t packed_planes_bytes(int N, int K);
+inline size_t x3_packed_bytes_host(int rows, int K) { return (size_t)((rows + 127) / 128) * 128 * K * 3 * sizeof(uint16_t); }
 int launch_pack_planes(hipStream_t st, const float *w, int N, int K, void *out);
 int launch_gemm_bf16x3(hipStream_t st, const float *A, int lda, const void *Bpacked, float *C, int ldc, int M, int N,
                        int K, const GemmEpilogue &epi);
 int launch_gemm_bf16x3_topk(hipStream_t st, const float *A, int lda, const void *Bpacked, int M, int N, int K, int k,
                             float inv_temp, float *tile_max, float *tile_sum, float *cand_val, int *cand_idx);
+// packed-A variants: A already split / tile-major (written by launch_layernorm_packed, launch_pack_planes): both
+// operands move by LDS-DMA
+int launch_gemm_bf16x3p(hipStream_t st, const void *Apacked, const void *Bpacked, float *C, int ldc, int M, int N, int K,
+                        const GemmEpilogue &epi);
+int launch_gemm_bf16x3p_topk(hipStream_t st, const void *Apacked, const void *Bpacked, int M, int N, int K, int k,
+                             float inv_temp, float *tile_max, float *tile_sum, float *cand_val, int *cand_idx);
+// LayerNorm whose output goes straight into the packed split-bf16 A format of the next GEMM (d % 16 == 0)
+int launch_layernorm_packed(hipStream_t st, const float *x, int ldx, const float *w, const float *b, float eps,
+                            void *packed, int rows, int d);
 
 // elementwise.hip
 int launch_layernorm(hipStream_t st, const float *x, int ldx, const float *w, const float *b, float eps, float *y,

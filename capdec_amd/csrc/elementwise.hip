@@ -1,6 +1,7 @@
 // Memory-bound row kernels: LayerNorm, embedding gathers, prefix normalise / noise injection,
 // TransformerMapper sequence assembly, weight transposes.  One wavefront per row wherever a
 // row reduction is needed (64-lane shuffle reductions, float4 accesses).
+#include "bf16x3.h"
 #include "common.h"
 
 namespace capdec {
@@ -62,6 +63,65 @@ int launch_layernorm(hipStream_t st, const float *x, int ldx, const float *w, co
     CAPDEC_CHECK(d % 4 == 0 && d <= 256 * LN_MAXV && ldx % 4 == 0 && ldy % 4 == 0, "layernorm: unsupported width");
     if (rows <= 0) return 0;
     hipLaunchKernelGGL(layernorm_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, x, ldx, w, b, eps, y, ldy, rows, d);
+    CAPDEC_HIP(hipGetLastError());
+    return 0;
+}
+
+// Same LayerNorm, output written as the packed split-bf16 A operand of the next GEMM (bf16x3.h): the fp32
+// normalised row never goes to HBM; float4 index idx of the row is k-step idx/4, quad idx%4.
+__global__ __launch_bounds__(256) void layernorm_packed_kernel(const float *__restrict__ x, int ldx,
+                                                               const float *__restrict__ w, const float *__restrict__ b,
+                                                               float eps, char *__restrict__ packed, int rows, int d) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float *xr = x + (size_t)row * ldx;
+    const int nv = d >> 2, nk = d / X3_BK;
+    float4 v[LN_MAXV];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+        const int idx = lane + 64 * i;
+        if (idx < nv) {
+            v[i] = reinterpret_cast<const float4 *>(xr)[idx];
+            s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+        } else {
+            v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
+    const float mean = wave_sum(s) / (float)d;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+        const int idx = lane + 64 * i;
+        if (idx < nv) {
+            const float a = v[i].x - mean, bb = v[i].y - mean, c = v[i].z - mean, e = v[i].w - mean;
+            q += (a * a + bb * bb) + (c * c + e * e);
+        }
+    }
+    const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)d + eps);
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+        const int idx = lane + 64 * i;
+        if (idx < nv) {
+            const float4 ww = reinterpret_cast<const float4 *>(w)[idx];
+            const float4 bb = reinterpret_cast<const float4 *>(b)[idx];
+            float4 o;
+            o.x = (v[i].x - mean) * rstd * ww.x + bb.x;
+            o.y = (v[i].y - mean) * rstd * ww.y + bb.y;
+            o.z = (v[i].z - mean) * rstd * ww.z + bb.z;
+            o.w = (v[i].w - mean) * rstd * ww.w + bb.w;
+            x3_store_quad(packed, nk, row, idx >> 2, idx & 3, o);
+        }
+    }
+}
+
+int launch_layernorm_packed(hipStream_t st, const float *x, int ldx, const float *w, const float *b, float eps,
+                            void *packed, int rows, int d) {
+    CAPDEC_CHECK(d % 16 == 0 && d <= 256 * LN_MAXV && ldx % 4 == 0, "layernorm_packed: unsupported width");
+    if (rows <= 0) return 0;
+    hipLaunchKernelGGL(layernorm_packed_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, x, ldx, w, b, eps, (char *)packed,
+                       rows, d);
     CAPDEC_HIP(hipGetLastError());
     return 0;
 }

@@ -13,16 +13,12 @@
 // 32x32 accumulators; BK = 16 (one MFMA k-step) per LDS stage, three-stage ring (72 KB, 2 blocks/CU).
 #include <cstdlib>
 
+#include "bf16x3.h"
 #include "gemm_epilogue.h"
 
 namespace capdec {
 
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
-
-constexpr int X3_BK = 16;
-constexpr int X3_ROW_B = 32;                         // bytes per LDS row: 16 bf16, unpadded, 16-B halves XOR-swizzled
-constexpr int X3_BPLANE_B = GEMM_BN * X3_ROW_B;      // 4096: one B plane of a stage (128 columns)
+constexpr int X3_BPLANE_B = X3_PLANE_B;      // 4096: one B plane of a stage (128 columns)
 constexpr int X3_STAGES = 3;
 // WMG = 2: 128x128 tile (72 KB LDS, 2 blocks/CU); WMG = 1: 64x128 tile for small M (54 KB, twice the blocks)
 template <int WMG> struct X3Geo {
@@ -32,20 +28,6 @@ template <int WMG> struct X3Geo {
     static constexpr int STAGE_B = AOPER_B + 3 * X3_BPLANE_B;
     static constexpr int SMEM_B = X3_STAGES * STAGE_B > 64 * CT_LD * 4 ? X3_STAGES * STAGE_B : 64 * CT_LD * 4;
 };
-
-__device__ __forceinline__ void split3(const float4 v, bf16x4 &h, bf16x4 &m, bf16x4 &l) {
-    const float a[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        const __bf16 hh = (__bf16)a[e];
-        const float r1 = a[e] - (float)hh;            // exact
-        const __bf16 mm = (__bf16)r1;
-        const float r2 = r1 - (float)mm;              // exact
-        h[e] = hh;
-        m[e] = mm;
-        l[e] = (__bf16)r2;
-    }
-}
 
 // Weight pre-pack: fp32 W [N, K] -> bf16 planes in TILE-MAJOR order
 //     Bpk[tile_n][k_step][plane][row 0..127][16 bf16]      (rows past N are zero)
@@ -79,9 +61,7 @@ __global__ void pack_planes_kernel(const float *__restrict__ w, __bf16 *__restri
     reinterpret_cast<bf16x4 *>(dst + 4096)[1] = l1;
 }
 
-size_t packed_planes_bytes(int N, int K) {
-    return (size_t)((N + GEMM_BN - 1) / GEMM_BN) * GEMM_BN * K * 3 * sizeof(uint16_t);
-}
+size_t packed_planes_bytes(int N, int K) { return x3_packed_bytes(N, K); }
 
 int launch_pack_planes(hipStream_t st, const float *w, int N, int K, void *out) {
     CAPDEC_CHECK(K % 64 == 0, "pack_planes: K must be a multiple of 64");
@@ -257,6 +237,143 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x3_topk_kernel(const float *_
     x3_mainloop<WMG>(A, lda, Bpk, M, K, m0, tn, smem, acc);   // ends with a barrier
     epilogue_topk<KSEL, WMG>(acc, reinterpret_cast<float *>(smem), M, N, m0, n0, tn, tiles_n, inv_temp, tile_max, tile_sum,
                         cand_val, cand_idx);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Packed-A variant: when the producer of A (LayerNorm, ...) already emits the split, tile-major planes, both
+// operands of a k-step are 12 KB contiguous LDS images and the main loop moves them with LDS-DMA
+// (global_load_lds_dwordx4: no VGPR round trip, no ds_write, no split VALU): per k-step a wavefront issues
+// 12 ds_read_b128, 24 MFMAs and 6 DMA pieces (tile kt+2 -> stage (kt+2)%3), and one counted s_waitcnt
+// vmcnt(6) in front of a raw s_barrier retires the pieces of tile kt+1.  Every vector-memory operation of the
+// loop is a DMA, so the in-order vmcnt count is exact.
+typedef __attribute__((address_space(3))) void lds_void;
+typedef const __attribute__((address_space(1))) void glb_void;
+
+__device__ __forceinline__ void x3p_mainloop(const __bf16 *__restrict__ Apk, const __bf16 *__restrict__ Bpk, int K,
+                                             int tm, int tn, char *smem, f32x16 (&acc)[2][2]) {
+    constexpr int STAGE_B = 2 * X3_BLOCK_B;                  // A block + B block = 24 KB
+    const int t = threadIdx.x;
+    const int lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int half = lane >> 5, l32 = lane & 31;
+    const int nk = K / X3_BK;
+    const __bf16 *ap = Apk + (size_t)tm * nk * (X3_BLOCK_B / 2) + t * 8;       // this thread's 16-B piece of a block
+    const __bf16 *bp = Bpk + (size_t)tn * nk * (X3_BLOCK_B / 2) + t * 8;
+    char *dst0 = smem + wave * 1024;                                           // wave-uniform LDS base of its pieces
+#define X3P_DMA(stage, ks)                                                                                     \
+    {                                                                                                          \
+        const __bf16 *sa = ap + (size_t)(ks) * (X3_BLOCK_B / 2), *sb = bp + (size_t)(ks) * (X3_BLOCK_B / 2);   \
+        char *d = dst0 + (stage) * STAGE_B;                                                                    \
+        _Pragma("unroll") for (int p = 0; p < 3; ++p) {                                                        \
+            __builtin_amdgcn_global_load_lds((glb_void *)(sa + p * 2048), (lds_void *)(d + p * X3_PLANE_B), 16, 0, 0); \
+            __builtin_amdgcn_global_load_lds((glb_void *)(sb + p * 2048), (lds_void *)(d + X3_BLOCK_B + p * X3_PLANE_B), 16, 0, 0); \
+        }                                                                                                      \
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int swz = ((half ^ ((l32 >> 3) & 1)) << 4);
+    const int a_rd = (wm * 64 + l32) * X3_ROW_B + swz;
+    const int b_rd = X3_BLOCK_B + (wn * 64 + l32) * X3_ROW_B + swz;
+
+    X3P_DMA(0, 0)
+    X3P_DMA(1, min(1, nk - 1))
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    bf16x8 fa0[3], fa1[3], fb0[3], fb1[3];
+    for (int kt = 0; kt < nk; ++kt) {
+        const char *rs = smem + (kt % X3_STAGES) * STAGE_B;
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+            fa0[p] = *reinterpret_cast<const bf16x8 *>(rs + p * X3_PLANE_B + a_rd);
+            fa1[p] = *reinterpret_cast<const bf16x8 *>(rs + p * X3_PLANE_B + a_rd + 32 * X3_ROW_B);
+            fb0[p] = *reinterpret_cast<const bf16x8 *>(rs + p * X3_PLANE_B + b_rd);
+            fb1[p] = *reinterpret_cast<const bf16x8 *>(rs + p * X3_PLANE_B + b_rd + 32 * X3_ROW_B);
+        }
+        X3P_DMA((kt + 2) % X3_STAGES, min(kt + 2, nk - 1))       // unconditional (clamped) so the count below is exact
+#define X3P_TERM(pa, pb)                                                                            \
+    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa0[pa], fb0[pb], acc[0][0], 0, 0, 0);      \
+    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa0[pa], fb1[pb], acc[0][1], 0, 0, 0);      \
+    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa1[pa], fb0[pb], acc[1][0], 0, 0, 0);      \
+    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa1[pa], fb1[pb], acc[1][1], 0, 0, 0);
+        X3P_TERM(2, 0) X3P_TERM(0, 2) X3P_TERM(1, 1) X3P_TERM(1, 0) X3P_TERM(0, 1) X3P_TERM(0, 0)
+#undef X3P_TERM
+        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");         // tile kt+1 has landed (only tile kt+2's 6 pieces pending)
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // clamped tail pieces must land before LDS is reused
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+#undef X3P_DMA
+}
+
+__global__ __launch_bounds__(256, 2) void gemm_bf16x3p_kernel(const __bf16 *__restrict__ Apk,
+                                                              const __bf16 *__restrict__ Bpk, float *C, int ldc, int M,
+                                                              int N, int K, const float *__restrict__ bias,
+                                                              const float *resid, int ldr, int act, int tiles_m,
+                                                              int tiles_n) {
+    __shared__ __attribute__((aligned(16))) char smem[X3_STAGES * 2 * X3_BLOCK_B];
+    int tm, tn;
+    tile_coords(tiles_m, tiles_n, tm, tn);
+    f32x16 acc[2][2];
+    x3p_mainloop(Apk, Bpk, K, tm, tn, smem, acc);
+    epilogue_store<2>(acc, C, ldc, M, N, tm * GEMM_BM, tn * GEMM_BN, bias, resid, ldr, act);
+}
+
+template <int KSEL>
+__global__ __launch_bounds__(256, 2) void gemm_bf16x3p_topk_kernel(const __bf16 *__restrict__ Apk,
+                                                                   const __bf16 *__restrict__ Bpk, int M, int N, int K,
+                                                                   float inv_temp, float *tile_max, float *tile_sum,
+                                                                   float *cand_val, int *cand_idx, int tiles_m,
+                                                                   int tiles_n) {
+    __shared__ __attribute__((aligned(16))) char smem[X3_STAGES * 2 * X3_BLOCK_B];
+    static_assert(64 * CT_LD * 4 <= X3_STAGES * 2 * X3_BLOCK_B, "epilogue slab must fit the staging ring");
+    int tm, tn;
+    tile_coords(tiles_m, tiles_n, tm, tn);
+    f32x16 acc[2][2];
+    x3p_mainloop(Apk, Bpk, K, tm, tn, smem, acc);      // ends with a barrier
+    epilogue_topk<KSEL, 2>(acc, reinterpret_cast<float *>(smem), M, N, tm * GEMM_BM, tn * GEMM_BN, tn, tiles_n, inv_temp,
+                           tile_max, tile_sum, cand_val, cand_idx);
+}
+
+int launch_gemm_bf16x3p(hipStream_t st, const void *Apacked, const void *Bpacked, float *C, int ldc, int M, int N, int K,
+                        const GemmEpilogue &epi) {
+    CAPDEC_CHECK(M > 0 && N > 0 && K > 0 && K % 64 == 0, "gemm_bf16x3p: K must be a multiple of 64");
+    const int tiles_m = (M + GEMM_BM - 1) / GEMM_BM, tiles_n = (N + GEMM_BN - 1) / GEMM_BN;
+    hipLaunchKernelGGL(gemm_bf16x3p_kernel, dim3(tiles_m * tiles_n), dim3(256), 0, st, (const __bf16 *)Apacked,
+                       (const __bf16 *)Bpacked, C, ldc, M, N, K, epi.bias, epi.resid, epi.ldr, epi.act, tiles_m, tiles_n);
+    CAPDEC_HIP(hipGetLastError());
+    return 0;
+}
+
+int launch_gemm_bf16x3p_topk(hipStream_t st, const void *Apacked, const void *Bpacked, int M, int N, int K, int k,
+                             float inv_temp, float *tile_max, float *tile_sum, float *cand_val, int *cand_idx) {
+    CAPDEC_CHECK(M > 0 && N > 0 && K > 0 && K % 64 == 0, "gemm_bf16x3p_topk: K must be a multiple of 64");
+    const int tiles_m = (M + GEMM_BM - 1) / GEMM_BM, tiles_n = (N + GEMM_BN - 1) / GEMM_BN;
+    dim3 grid(tiles_m * tiles_n), block(256);
+#define LAUNCH_TOPKP(KS)                                                                                          \
+    hipLaunchKernelGGL(gemm_bf16x3p_topk_kernel<KS>, grid, block, 0, st, (const __bf16 *)Apacked,                  \
+                       (const __bf16 *)Bpacked, M, N, K, inv_temp, tile_max, tile_sum, cand_val, cand_idx, tiles_m, tiles_n)
+    switch (k) {
+        case 1: LAUNCH_TOPKP(1); break;
+        case 2: LAUNCH_TOPKP(2); break;
+        case 3: LAUNCH_TOPKP(3); break;
+        case 4: LAUNCH_TOPKP(4); break;
+        case 5: LAUNCH_TOPKP(5); break;
+        case 6: LAUNCH_TOPKP(6); break;
+        case 7: LAUNCH_TOPKP(7); break;
+        case 8: LAUNCH_TOPKP(8); break;
+        default: CAPDEC_CHECK(false, "gemm_topk: k must be in 1..8");
+    }
+#undef LAUNCH_TOPKP
+    CAPDEC_HIP(hipGetLastError());
+    return 0;
 }
 
 static bool x3_use_small_tile(int M, int tiles_n) {
