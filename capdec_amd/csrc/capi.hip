@@ -1012,6 +1012,16 @@ int capdec_gemm_f32(capdec_ctx *c, const float *a, int lda, const float *bt, int
     CAPDEC_CHECK(c && a && bt && cc, "gemm: null argument");
     CAPDEC_HIP(hipSetDevice(c->device));
     static const bool cache = getenv("CAPDEC_HOOK_CACHE") != nullptr;   // benchmarking: treat Bt as a resident weight
+    static const bool packa = getenv("CAPDEC_HOOK_PACKA") != nullptr;   // benchmarking: pre-packed A (the LayerNorm -> GEMM path)
+    if (packa && c->gemm_mode == GEMM_BF16X3 && lda == K && ldb == K && K % 64 == 0) {
+        const void *pa = nullptr, *pb = nullptr;
+        CAPDEC_TRY(planes_of(c, a, M, K, true, &pa));
+        CAPDEC_TRY(planes_of(c, bt, N, K, true, &pb));
+        GemmEpilogue e;
+        e.bias = bias; e.act = act; e.resid = resid; e.ldr = ldr;
+        ProfScope ps(c, F_GEMM_X3, 2.0 * M * (double)N * K);
+        return launch_gemm_bf16x3p(c->stream, pa, pb, cc, ldc, M, N, K, e);
+    }
     return gemm(c, a, lda, bt, ldb, cc, ldc, M, N, K, bias, act, resid, ldr, /*weight=*/cache);
 }
 
