@@ -76,10 +76,10 @@ struct Tower {
 };
 
 enum Family { F_GEMM = 0, F_LMHEAD, F_ATTN_DEC, F_ATTN_PRE, F_LN, F_EMBED, F_SELECT, F_MAP_ATTN, F_OTHER, F_GEMM_X3,
-              F_LMHEAD_X3, F_COUNT };
+              F_LMHEAD_X3, F_GEMM_X3P, F_COUNT };
 static const char *kFamilyNames[F_COUNT] = {"gemm_f32", "gemm_f32_lmhead_topk", "attn_decode", "attn_prefill",
                                             "layernorm", "embed", "select", "attn_mapper", "other", "gemm_bf16x3",
-                                            "gemm_bf16x3_lmhead_topk"};
+                                            "gemm_bf16x3_lmhead_topk", "gemm_bf16x3p"};
 enum GemmMode { GEMM_F32 = 0, GEMM_BF16X3 = 1 };
 
 struct Prof {
@@ -260,7 +260,7 @@ static int ln_gemm_packed(capdec_ctx *c, const float *h, int ldh, const float *l
     GemmEpilogue e;
     e.bias = bias;
     e.act = act;
-    ProfScope ps(c, F_GEMM_X3, 2.0 * M * (double)N * K);
+    ProfScope ps(c, F_GEMM_X3P, 2.0 * M * (double)N * K);
     return launch_gemm_bf16x3p(c->stream, c->xpk.p, pl, C, ldc, M, N, K, e);
 }
 
@@ -1019,7 +1019,7 @@ int capdec_gemm_f32(capdec_ctx *c, const float *a, int lda, const float *bt, int
         CAPDEC_TRY(planes_of(c, bt, N, K, true, &pb));
         GemmEpilogue e;
         e.bias = bias; e.act = act; e.resid = resid; e.ldr = ldr;
-        ProfScope ps(c, F_GEMM_X3, 2.0 * M * (double)N * K);
+        ProfScope ps(c, F_GEMM_X3P, 2.0 * M * (double)N * K);
         return launch_gemm_bf16x3p(c->stream, pa, pb, cc, ldc, M, N, K, e);
     }
     return gemm(c, a, lda, bt, ldb, cc, ldc, M, N, K, bias, act, resid, ldr, /*weight=*/cache);
