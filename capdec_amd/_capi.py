@@ -105,7 +105,7 @@ SIGNATURES = {
     "capdec_profile_enable": (C.c_int, [_VP, C.c_int]),
     "capdec_profile_reset": (C.c_int, [_VP]),
     "capdec_profile_get": (C.c_int, [_VP, C.POINTER(C.c_int), C.POINTER(C.c_char_p), c_float_p,
-                                     C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
+                                     C.POINTER(C.c_int64), C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
 }
 
 _lib: Optional[C.CDLL] = None

@@ -7,6 +7,7 @@
 // The KV cache is [layer][phys_row][head][ctx][64]: consecutive positions of a head are
 // contiguous.  Beam search never copies K/V: row r reads position p from physical row
 // caption*beam + anc[r][p] (ancestor table maintained by the beam-step kernel).
+#include "bf16x3.h"
 #include "common.h"
 
 namespace capdec {
@@ -33,7 +34,7 @@ __global__ __launch_bounds__(256) void attn_gpt2_kernel(const float *__restrict_
                                                         float *__restrict__ vc, int total, int heads, int ctx,
                                                         int d, int beam, int Lparam, int P, int causal,
                                                         const uint8_t *__restrict__ anc, int anc_stride,
-                                                        float *__restrict__ out) {
+                                                        float *__restrict__ out, char *__restrict__ packed_out) {
     __shared__ float sc[4][ATT_CTX_MAX];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int grp = lane >> 4, sub = lane & 15;
@@ -113,8 +114,9 @@ __global__ __launch_bounds__(256) void attn_gpt2_kernel(const float *__restrict_
     acc.x = groups4_sum(acc.x); acc.y = groups4_sum(acc.y); acc.z = groups4_sum(acc.z); acc.w = groups4_sum(acc.w);
     if (active && grp == 0) {
         const float inv = 1.0f / sum;
-        reinterpret_cast<float4 *>(out + (size_t)row * d + head * 64)[sub] =
-            make_float4(acc.x * inv, acc.y * inv, acc.z * inv, acc.w * inv);
+        const float4 o = make_float4(acc.x * inv, acc.y * inv, acc.z * inv, acc.w * inv);
+        if (packed_out) x3_store_quad(packed_out, d >> 4, row, head * 4 + (sub >> 2), sub & 3, o);   // A operand of c_proj
+        else reinterpret_cast<float4 *>(out + (size_t)row * d + head * 64)[sub] = o;
     }
 }
 
@@ -128,7 +130,8 @@ __global__ __launch_bounds__(256) void attn_decode_beams_kernel(const float *__r
                                                                 float *__restrict__ vc, int total, int heads,
                                                                 int ctx, int d, int L,
                                                                 const uint8_t *__restrict__ anc, int anc_stride,
-                                                                float *__restrict__ out) {
+                                                                float *__restrict__ out,
+                                                                char *__restrict__ packed_out) {
     extern __shared__ __attribute__((aligned(16))) float sc_all[];      // [4 waves][BEAM][L] scores + [4][BEAM][L] slots
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int grp = lane >> 4, sub = lane & 15;
@@ -235,9 +238,11 @@ __global__ __launch_bounds__(256) void attn_decode_beams_kernel(const float *__r
         }
         acc[b].x = groups4_sum(acc[b].x); acc[b].y = groups4_sum(acc[b].y);
         acc[b].z = groups4_sum(acc[b].z); acc[b].w = groups4_sum(acc[b].w);
-        if (active && grp == 0)
-            reinterpret_cast<float4 *>(out + (size_t)(row0 + b) * d + head * 64)[sub] =
-                make_float4(acc[b].x * inv[b], acc[b].y * inv[b], acc[b].z * inv[b], acc[b].w * inv[b]);
+        if (active && grp == 0) {
+            const float4 o = make_float4(acc[b].x * inv[b], acc[b].y * inv[b], acc[b].z * inv[b], acc[b].w * inv[b]);
+            if (packed_out) x3_store_quad(packed_out, d >> 4, row0 + b, head * 4 + (sub >> 2), sub & 3, o);
+            else reinterpret_cast<float4 *>(out + (size_t)(row0 + b) * d + head * 64)[sub] = o;
+        }
     }
 }
 
@@ -270,20 +275,20 @@ int launch_kv_scatter_prefill(hipStream_t st, const float *qkv, const KvCache &c
 }
 
 int launch_attn_prefill(hipStream_t st, const float *qkv, const KvCache &c, int layer, int ncap, int P, int beam,
-                        float *out, bool causal) {
+                        float *out, bool causal, void *packed_out) {
     CAPDEC_CHECK(c.hd == 64, "attention: head_dim must be 64");
     CAPDEC_CHECK(P <= ATT_CTX_MAX && P <= c.ctx, "attention: prefix longer than the supported context");
     const int total = ncap * P * c.heads;
     if (total <= 0) return 0;
     hipLaunchKernelGGL(attn_gpt2_kernel<false>, dim3((total + 3) / 4), dim3(256), 0, st, qkv,
                        c.k + layer * c.layer_stride(), c.v + layer * c.layer_stride(), total, c.heads, c.ctx,
-                       c.heads * c.hd, beam, 0, P, causal ? 1 : 0, (const uint8_t *)nullptr, 0, out);
+                       c.heads * c.hd, beam, 0, P, causal ? 1 : 0, (const uint8_t *)nullptr, 0, out, (char *)packed_out);
     CAPDEC_HIP(hipGetLastError());
     return 0;
 }
 
 int launch_attn_decode(hipStream_t st, const float *qkv, const KvCache &c, int layer, int rows, int beam, int L,
-                       const uint8_t *anc, int anc_stride, float *out) {
+                       const uint8_t *anc, int anc_stride, float *out, void *packed_out) {
     CAPDEC_CHECK(c.hd == 64, "attention: head_dim must be 64");
     CAPDEC_CHECK(L >= 1 && L <= ATT_CTX_MAX && L <= c.ctx, "attention: context length out of range");
     if (anc != nullptr && beam > 1) {
@@ -294,7 +299,7 @@ int launch_attn_decode(hipStream_t st, const float *qkv, const KvCache &c, int l
         float *kl = c.k + layer * c.layer_stride(), *vl = c.v + layer * c.layer_stride();
 #define LAUNCH_BEAMS(B)                                                                                         \
     hipLaunchKernelGGL(attn_decode_beams_kernel<B>, grid, block, lds, st, qkv, kl, vl, total, c.heads, c.ctx,      \
-                       c.heads * c.hd, L, anc, anc_stride, out)
+                       c.heads * c.hd, L, anc, anc_stride, out, (char *)packed_out)
         switch (beam) {
             case 2: LAUNCH_BEAMS(2); break;
             case 3: LAUNCH_BEAMS(3); break;
@@ -313,7 +318,7 @@ int launch_attn_decode(hipStream_t st, const float *qkv, const KvCache &c, int l
     if (total <= 0) return 0;
     hipLaunchKernelGGL(attn_gpt2_kernel<true>, dim3((total + 3) / 4), dim3(256), 0, st, qkv,
                        c.k + layer * c.layer_stride(), c.v + layer * c.layer_stride(), total, c.heads, c.ctx,
-                       c.heads * c.hd, beam, L, 0, 1, anc, anc_stride, out);
+                       c.heads * c.hd, beam, L, 0, 1, anc, anc_stride, out, (char *)packed_out);
     CAPDEC_HIP(hipGetLastError());
     return 0;
 }

@@ -84,6 +84,8 @@ enum GemmMode { GEMM_F32 = 0, GEMM_BF16X3 = 1 };
 
 struct Prof {
     bool on = false;
+    int every = 1;                       // time every `every`-th launch of each family (1 = all)
+    int64_t calls[16] = {0};             // launches seen per family (timed or not)
     struct Rec { int fam; hipEvent_t a, b; double flops; };
     std::vector<Rec> recs;
     std::vector<hipEvent_t> pool;
@@ -105,7 +107,8 @@ struct capdec_ctx {
     Prof prof;
     int gemm_mode = GEMM_BF16X3;
     std::unordered_map<const void *, std::pair<void *, size_t>> planes;   // fp32 weight -> (three bf16 planes, elements)
-    DBuf x3_tmp, xpk;          // scratch planes for un-cached matrices; packed split-bf16 LayerNorm output
+    DBuf x3_tmp, xpk, apk, fpk;          // scratch planes for un-cached matrices; packed split-bf16 LayerNorm output
+    bool pack_chain = true;    // ... and attention / the fc GEMM epilogue emit the packed A operand of the GEMM that follows
     bool pack_a = true;        // bf16x3 mode: LayerNorm emits the packed A operand, GEMM moves both operands by LDS-DMA
     hipEvent_t t0 = nullptr, t1 = nullptr;
     // workspaces
@@ -134,6 +137,7 @@ struct ProfScope {
     int idx = -1;
     ProfScope(capdec_ctx *ctx, int fam, double flops = 0.0) : c(ctx) {
         if (!c->prof.on) return;
+        if (c->prof.calls[fam]++ % c->prof.every != 0) return;
         Prof::Rec r{fam, prof_event(c), prof_event(c), flops};
         (void)hipEventRecord(r.a, c->stream);
         c->prof.recs.push_back(r);
@@ -251,17 +255,29 @@ static int gemm(capdec_ctx *c, const float *A, int lda, const float *Bt, int ldb
 // Returns 1 in *done when the packed path ran; otherwise the caller runs the fp32-activation path.
 static bool use_packed_a(capdec_ctx *c, int K) { return c->gemm_mode == GEMM_BF16X3 && c->pack_a && K % 64 == 0; }
 
-static int ln_gemm_packed(capdec_ctx *c, const float *h, int ldh, const float *lnw, const float *lnb, float eps,
-                          const float *W, float *C, int ldc, int M, int N, int K, const float *bias, int act) {
-    CAPDEC_TRY(c->xpk.ensure(x3_packed_bytes_host(M, K)));
-    { ProfScope ps(c, F_LN); CAPDEC_TRY(launch_layernorm_packed(c->stream, h, ldh, lnw, lnb, eps, c->xpk.p, M, K)); }
+// C = act(Apk . W^T + bias) + resid with A already packed; packed_out != nullptr: the result is written as the
+// packed A operand of the next GEMM instead of fp32 C
+static int gemm_packed(capdec_ctx *c, const void *Apk, const float *W, float *C, int ldc, int M, int N, int K,
+                       const float *bias, int act, const float *resid = nullptr, int ldr = 0,
+                       void *packed_out = nullptr) {
     const void *pl = nullptr;
     CAPDEC_TRY(planes_of(c, W, N, K, true, &pl));
     GemmEpilogue e;
     e.bias = bias;
     e.act = act;
+    e.resid = resid;
+    e.ldr = ldr;
+    e.packed_out = packed_out;
     ProfScope ps(c, F_GEMM_X3P, 2.0 * M * (double)N * K);
-    return launch_gemm_bf16x3p(c->stream, c->xpk.p, pl, C, ldc, M, N, K, e);
+    return launch_gemm_bf16x3p(c->stream, Apk, pl, C, ldc, M, N, K, e);
+}
+
+static int ln_gemm_packed(capdec_ctx *c, const float *h, int ldh, const float *lnw, const float *lnb, float eps,
+                          const float *W, float *C, int ldc, int M, int N, int K, const float *bias, int act,
+                          void *packed_out = nullptr) {
+    CAPDEC_TRY(c->xpk.ensure(x3_packed_bytes_host(M, K)));
+    { ProfScope ps(c, F_LN); CAPDEC_TRY(launch_layernorm_packed(c->stream, h, ldh, lnw, lnb, eps, c->xpk.p, M, K)); }
+    return gemm_packed(c, c->xpk.p, W, C, ldc, M, N, K, bias, act, nullptr, 0, packed_out);
 }
 
 // ---------------------------------------------------------------------------- GPT-2 body
@@ -296,6 +312,17 @@ static int stack_body(capdec_ctx *c, const StackCfg &g, const StepShape &s, cons
     const int d = g.d, M = s.prefill ? s.ncap * s.P : s.rows;
     float *h = c->h.as<float>(), *x = c->x.as<float>(), *qkv = c->qkv.as<float>(), *att = c->att.as<float>(),
           *ff = c->ff.as<float>();
+    // packed chain (bf16x3 mode): LN1 -> [packed] -> qkv GEMM -> attention -> [packed] -> c_proj (+h) -> LN2 ->
+    // [packed] -> fc GEMM + act -> [packed] -> mlp c_proj (+h): every GEMM operand moves by LDS-DMA, and the
+    // attention / MLP intermediates never exist in fp32 in HBM.
+    const bool chain = use_packed_a(c, d) && c->pack_chain;
+    void *apk = nullptr, *fpk = nullptr;
+    if (chain) {
+        CAPDEC_TRY(c->apk.ensure(x3_packed_bytes_host(M, d)));
+        CAPDEC_TRY(c->fpk.ensure(x3_packed_bytes_host(M, 4 * d)));
+        apk = c->apk.p;
+        fpk = c->fpk.p;
+    }
     for (int l = 0; l < g.n_layer; ++l) {
         const Gpt2Layer &w = (*g.layers)[l];
         const int kl = g.keep_kv ? l : 0;
@@ -308,12 +335,18 @@ static int stack_body(capdec_ctx *c, const StackCfg &g, const StepShape &s, cons
         if (s.prefill) {
             ProfScope ps(c, F_ATTN_PRE);
             CAPDEC_TRY(launch_kv_scatter_prefill(c->stream, qkv, kv, kl, s.ncap, s.P, s.beam));
-            CAPDEC_TRY(launch_attn_prefill(c->stream, qkv, kv, kl, s.ncap, s.P, s.beam, att, g.causal));
+            CAPDEC_TRY(launch_attn_prefill(c->stream, qkv, kv, kl, s.ncap, s.P, s.beam, att, g.causal, apk));
         } else {
             ProfScope ps(c, F_ATTN_DEC);
-            CAPDEC_TRY(launch_attn_decode(c->stream, qkv, kv, kl, s.rows, s.beam, s.L, s.anc, s.anc_stride, att));
+            CAPDEC_TRY(launch_attn_decode(c->stream, qkv, kv, kl, s.rows, s.beam, s.L, s.anc, s.anc_stride, att, apk));
         }
-        CAPDEC_TRY(gemm(c, att, d, w.wproj, d, h, d, M, d, d, w.bproj, CAPDEC_ACT_NONE, h, d));
+        if (chain) CAPDEC_TRY(gemm_packed(c, apk, w.wproj, h, d, M, d, d, w.bproj, CAPDEC_ACT_NONE, h, d));
+        else CAPDEC_TRY(gemm(c, att, d, w.wproj, d, h, d, M, d, d, w.bproj, CAPDEC_ACT_NONE, h, d));
+        if (chain) {
+            CAPDEC_TRY(ln_gemm_packed(c, h, d, w.ln2w, w.ln2b, g.eps, w.wfc, ff, 4 * d, M, 4 * d, d, w.bfc, g.act, fpk));
+            CAPDEC_TRY(gemm_packed(c, fpk, w.wproj2, h, d, M, d, 4 * d, w.bproj2, CAPDEC_ACT_NONE, h, d));
+            continue;
+        }
         if (use_packed_a(c, d)) {
             CAPDEC_TRY(ln_gemm_packed(c, h, d, w.ln2w, w.ln2b, g.eps, w.wfc, ff, 4 * d, M, 4 * d, d, w.bfc, g.act));
         } else {
@@ -666,6 +699,7 @@ int capdec_create(int device_id, capdec_ctx **out) {
     std::unique_ptr<capdec_ctx> c(new capdec_ctx());
     c->device = device_id;
     if (const char *e = getenv("CAPDEC_X3_PACKA")) c->pack_a = atoi(e) != 0;
+    if (const char *e = getenv("CAPDEC_X3_CHAIN")) c->pack_chain = atoi(e) != 0;
     if (const char *e = getenv("CAPDEC_GEMM_MODE")) c->gemm_mode = (std::string(e) == "f32") ? GEMM_F32 : GEMM_BF16X3;
     CAPDEC_HIP(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
     c->stream = c->own_stream;
@@ -689,7 +723,7 @@ void capdec_destroy(capdec_ctx *c) {
     DBuf *bufs[] = {&c->h, &c->x, &c->qkv, &c->att, &c->ff, &c->xl, &c->tmax, &c->tsum, &c->cval, &c->cidx,
                     &c->lse, &c->topv, &c->topi, &c->kc, &c->vc, &c->tokens, &c->scores, &c->seq, &c->stopped,
                     &c->done, &c->anc, &c->next_tok, &c->alive, &c->gids, &c->glens, &c->m_hid, &c->m_lin, &c->m_seq,
-                    &c->m_x, &c->m_qkv, &c->m_att, &c->m_ff, &c->t_idx, &c->t_patch, &c->t_pout, &c->xpk};
+                    &c->m_x, &c->m_qkv, &c->m_att, &c->m_ff, &c->t_idx, &c->t_patch, &c->t_pout, &c->xpk, &c->apk, &c->fpk};
     for (DBuf *b : bufs) b->release();
     for (auto &r : c->prof.recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
     for (auto e : c->prof.pool) (void)hipEventDestroy(e);
@@ -1039,16 +1073,18 @@ int capdec_timer_stop_ms(capdec_ctx *c, float *ms) {
 }
 int capdec_profile_enable(capdec_ctx *c, int on) {
     CAPDEC_CHECK(c, "null context");
-    c->prof.on = on != 0;
+    c->prof.on = on != 0;       // on = N > 1: time every N-th launch of each family (sampling keeps the event
+    c->prof.every = on > 1 ? on : 1;   // overhead out of a timed region; pick N coprime to the per-layer launch cycle)
     return 0;
 }
 int capdec_profile_reset(capdec_ctx *c) {
     CAPDEC_CHECK(c, "null context");
     CAPDEC_TRY(prof_collect(c));
-    for (int f = 0; f < F_COUNT; ++f) { c->prof.ms[f] = 0; c->prof.flops[f] = 0; c->prof.launches[f] = 0; }
+    for (int f = 0; f < F_COUNT; ++f) { c->prof.ms[f] = 0; c->prof.flops[f] = 0; c->prof.launches[f] = 0; c->prof.calls[f] = 0; }
     return 0;
 }
-int capdec_profile_get(capdec_ctx *c, int *count, const char **names, float *ms, int64_t *launches, double *flops) {
+int capdec_profile_get(capdec_ctx *c, int *count, const char **names, float *ms, int64_t *launches, double *flops,
+                       int64_t *calls) {
     CAPDEC_CHECK(c && count, "null argument");
     CAPDEC_TRY(prof_collect(c));
     *count = F_COUNT;
@@ -1057,6 +1093,7 @@ int capdec_profile_get(capdec_ctx *c, int *count, const char **names, float *ms,
         if (ms) ms[f] = (float)c->prof.ms[f];
         if (launches) launches[f] = c->prof.launches[f];
         if (flops) flops[f] = c->prof.flops[f];
+        if (calls) calls[f] = c->prof.calls[f];
     }
     return 0;
 }

@@ -90,6 +90,8 @@ struct GemmEpilogue {
     const float *resid = nullptr;  // [M, ldr] added after the activation
     int ldr = 0;
     int act = CAPDEC_ACT_NONE;
+    void *packed_out = nullptr;    // bf16x3p only: write act(acc + bias) as the packed split-bf16 A operand (K = N)
+                                   // of the next GEMM instead of fp32 C
 };
 int launch_gemm_f32(hipStream_t st, const float *A, int lda, const float *Bt, int ldb, float *C, int ldc,
                     int M, int N, int K, const GemmEpilogue &epi);
@@ -154,11 +156,13 @@ int launch_kv_scatter_prefill(hipStream_t st, const float *qkv, const KvCache &c
                               int beam);
 // prefill: query row (caption, i) attends cache positions 0..i of phys row caption*beam
 int launch_attn_prefill(hipStream_t st, const float *qkv, const KvCache &c, int layer, int ncap, int P, int beam,
-                        float *out, bool causal = true);
+                        float *out, bool causal = true, void *packed_out = nullptr);
 // decode: row r (caption = r / beam) at position L-1: its own k/v come from qkv (and are written to the cache
 // at phys row r), positions p < L-1 from phys row caption*beam + anc[r][p] (anc == nullptr -> r itself)
 int launch_attn_decode(hipStream_t st, const float *qkv, const KvCache &c, int layer, int rows, int beam, int L,
-                       const uint8_t *anc, int anc_stride, float *out);
+                       const uint8_t *anc, int anc_stride, float *out, void *packed_out = nullptr);
+// (packed_out != nullptr: the attention rows are written as the packed split-bf16 A operand of c_proj, K = d,
+//  instead of fp32 `out`)
 // TransformerMapper self-attention (no mask): q / k / v rows of n*seq tokens (row strides ldq, ldkv), head-major
 int launch_attn_mapper(hipStream_t st, const float *q, int ldq, const float *k, const float *v, int ldkv, float *out,
                        int n, int seq, int heads, int hd);

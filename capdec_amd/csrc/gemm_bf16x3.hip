@@ -317,13 +317,18 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x3p_kernel(const __bf16 *__re
                                                               const __bf16 *__restrict__ Bpk, float *C, int ldc, int M,
                                                               int N, int K, const float *__restrict__ bias,
                                                               const float *resid, int ldr, int act, int tiles_m,
-                                                              int tiles_n) {
+                                                              int tiles_n, char *packed_out) {
     __shared__ __attribute__((aligned(16))) char smem[X3_STAGES * 2 * X3_BLOCK_B];
+    static_assert(128 * CP_LD * 4 <= X3_STAGES * 2 * X3_BLOCK_B, "packed epilogue tile must fit the staging ring");
     int tm, tn;
     tile_coords(tiles_m, tiles_n, tm, tn);
     f32x16 acc[2][2];
-    x3p_mainloop(Apk, Bpk, K, tm, tn, smem, acc);
-    epilogue_store<2>(acc, C, ldc, M, N, tm * GEMM_BM, tn * GEMM_BN, bias, resid, ldr, act);
+    x3p_mainloop(Apk, Bpk, K, tm, tn, smem, acc);      // ends with a barrier
+    if (packed_out)
+        epilogue_store_packed(acc, reinterpret_cast<float *>(smem), packed_out, N >> 4, M, N, tm * GEMM_BM, tn * GEMM_BN,
+                              bias, act);
+    else
+        epilogue_store<2>(acc, C, ldc, M, N, tm * GEMM_BM, tn * GEMM_BN, bias, resid, ldr, act);
 }
 
 template <int KSEL>
@@ -345,9 +350,12 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x3p_topk_kernel(const __bf16 
 int launch_gemm_bf16x3p(hipStream_t st, const void *Apacked, const void *Bpacked, float *C, int ldc, int M, int N, int K,
                         const GemmEpilogue &epi) {
     CAPDEC_CHECK(M > 0 && N > 0 && K > 0 && K % 64 == 0, "gemm_bf16x3p: K must be a multiple of 64");
+    CAPDEC_CHECK(epi.packed_out == nullptr || (N % 64 == 0 && epi.resid == nullptr),
+                 "gemm_bf16x3p: packed output needs N % 64 == 0 and no residual");
     const int tiles_m = (M + GEMM_BM - 1) / GEMM_BM, tiles_n = (N + GEMM_BN - 1) / GEMM_BN;
     hipLaunchKernelGGL(gemm_bf16x3p_kernel, dim3(tiles_m * tiles_n), dim3(256), 0, st, (const __bf16 *)Apacked,
-                       (const __bf16 *)Bpacked, C, ldc, M, N, K, epi.bias, epi.resid, epi.ldr, epi.act, tiles_m, tiles_n);
+                       (const __bf16 *)Bpacked, C, ldc, M, N, K, epi.bias, epi.resid, epi.ldr, epi.act, tiles_m, tiles_n,
+                       (char *)epi.packed_out);
     CAPDEC_HIP(hipGetLastError());
     return 0;
 }

@@ -2,6 +2,7 @@
 // activations, and the two epilogues operating on the 2x2 x (32x32) accumulator layout of one
 // wavefront (C/D layout of v_mfma_*_32x32: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)).
 #pragma once
+#include "bf16x3.h"
 #include "common.h"
 
 namespace capdec {
@@ -74,6 +75,39 @@ __device__ __forceinline__ void epilogue_store(const f32x16 (&acc)[2][WaveGrid<W
                     C[(size_t)row * ldc + col] = v;
                 }
             }
+        }
+    }
+}
+
+// Packed-output epilogue (128x128 tile): act(acc + bias) goes accumulators -> LDS (`Ct`, 128 x CP_LD floats, the
+// caller's main loop must have ended with a barrier) -> float4 per thread along the row -> split3 -> the
+// tile-major planes of the NEXT GEMM's A operand (its K = this GEMM's N).  The fp32 tile never reaches HBM.
+constexpr int CP_LD = 132;
+__device__ __forceinline__ void epilogue_store_packed(const f32x16 (&acc)[2][2], float *Ct, char *packed, int nk_out,
+                                                      int M, int N, int m0, int n0, const float *__restrict__ bias,
+                                                      int act) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wm = wave >> 1, wn = wave & 1, half = lane >> 5, l32 = lane & 31;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int cl = wn * 64 + j * 32 + l32;
+        const float bv = (bias && n0 + cl < N) ? bias[n0 + cl] : 0.f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int rl = wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                Ct[rl * CP_LD + cl] = (n0 + cl < N) ? act_apply(acc[i][j][r] + bv, act) : 0.f;
+            }
+    }
+    __syncthreads();
+#pragma unroll 4
+    for (int it = 0; it < 16; ++it) {
+        const int u = threadIdx.x + 256 * it, rl = u >> 5, qc = u & 31;
+        const int row = m0 + rl, col = n0 + 4 * qc;
+        if (row < M && col < N) {
+            const float4 v = *reinterpret_cast<const float4 *>(Ct + rl * CP_LD + 4 * qc);
+            x3_store_quad(packed, nk_out, row, col >> 4, qc & 3, v);
         }
     }
 }

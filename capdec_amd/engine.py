@@ -324,7 +324,8 @@ class Engine:
     def gemm_mode(self) -> str:
         return ["f32", "bf16x3"][self.lib.capdec_get_gemm_mode(self._h)]
 
-    def profile_enable(self, on: bool = True):
+    def profile_enable(self, on=True):
+        """True / 1: time every launch; N > 1: every N-th launch of each kernel family (sampling); False: off"""
         check(self.lib.capdec_profile_enable(self._h, int(on)), "profile_enable")
 
     def profile_reset(self):
@@ -336,8 +337,10 @@ class Engine:
         ms = (C.c_float * 16)()
         launches = (C.c_int64 * 16)()
         flops = (C.c_double * 16)()
-        check(self.lib.capdec_profile_get(self._h, C.byref(cnt), names, ms, launches, flops), "profile_get")
-        return {names[i].decode(): dict(ms=float(ms[i]), launches=int(launches[i]), flops=float(flops[i]))
+        calls = (C.c_int64 * 16)()
+        check(self.lib.capdec_profile_get(self._h, C.byref(cnt), names, ms, launches, flops, calls), "profile_get")
+        return {names[i].decode(): dict(ms=float(ms[i]), launches=int(launches[i]), flops=float(flops[i]),
+                                        calls=int(calls[i]))
                 for i in range(cnt.value)}
 
 

@@ -214,11 +214,14 @@ int capdec_gemm_f32(capdec_ctx *ctx, const float *d_a, int lda, const float *d_b
 /* hipEvent timers on the context's stream -- the reference's Timer (predictions_runner.py:125-150) */
 int capdec_timer_start(capdec_ctx *ctx);
 int capdec_timer_stop_ms(capdec_ctx *ctx, float *ms);   /* records, synchronises, returns elapsed */
-/* per-kernel-family accumulated device time of the last decode call (hipEvents around every
- * launch when profiling is enabled): caller arrays of capacity 16, *count entries are filled */
+/* per-kernel-family accumulated device time since the last reset (hipEvents around the timed launches).
+ * on = 0: off; 1: every launch is timed; N > 1: every N-th launch of each family is timed (sampling: the
+ * events of the other launches are skipped, so a timed region is barely perturbed).
+ * get: caller arrays of capacity 16, *count entries are filled; ms / launches / flops cover the TIMED launches
+ * (flops: algorithmic FLOPs issued, 0 for non-GEMM families), calls = all launches of the family. */
 int capdec_profile_enable(capdec_ctx *ctx, int on);
 int capdec_profile_get(capdec_ctx *ctx, int *count, const char **names, float *ms, int64_t *launches,
-                       double *flops);   /* flops: algorithmic FLOPs issued by the family (0 for non-GEMM) */
+                       double *flops, int64_t *calls);
 int capdec_profile_reset(capdec_ctx *ctx);
 
 #ifdef __cplusplus
