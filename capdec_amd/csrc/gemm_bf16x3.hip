@@ -256,7 +256,7 @@ __device__ __forceinline__ void x3p_mainloop(const __bf16 *__restrict__ Apk, con
     const int lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int wm = wave >> 1, wn = wave & 1;
     const int half = lane >> 5, l32 = lane & 31;
-    const int nk = K / X3_BK;
+    const int nk = K / X3_BK;                                                  // even (K % 64 == 0)
     const __bf16 *ap = Apk + (size_t)tm * nk * (X3_BLOCK_B / 2) + t * 8;       // this thread's 16-B piece of a block
     const __bf16 *bp = Bpk + (size_t)tn * nk * (X3_BLOCK_B / 2) + t * 8;
     char *dst0 = smem + wave * 1024;                                           // wave-uniform LDS base of its pieces
@@ -280,37 +280,81 @@ __device__ __forceinline__ void x3p_mainloop(const __bf16 *__restrict__ Apk, con
     const int a_rd = (wm * 64 + l32) * X3_ROW_B + swz;
     const int b_rd = X3_BLOCK_B + (wn * 64 + l32) * X3_ROW_B + swz;
 
+    // Fragment sets F0 / F1: the 12 ds_read_b128 of tile kt+1 are issued at the top of k-step kt and land under its
+    // 24 MFMAs (which run from the other set), so no LDS latency sits in front of an MFMA.  Ring of 3 stages:
+    // in k-step kt  stage kt%3 (its fragments were read during kt-1) receives tile kt+3 by DMA, stage (kt+1)%3 is
+    // read, tile kt+2 is in flight.  End of k-step: vmcnt(6) = tile kt+2 landed (only tile kt+3's 6 pieces pending),
+    // lgkmcnt(0) = this wave's fragment reads are complete, then the barrier frees stage (kt+1)%3 for the next DMA.
+    bf16x8 f0a0[3], f0a1[3], f0b0[3], f0b1[3], f1a0[3], f1a1[3], f1b0[3], f1b1[3];
+#define X3P_READ(F, stage)                                                                          \
+    {                                                                                               \
+        const char *rs = smem + (stage) * STAGE_B;                                                  \
+        _Pragma("unroll") for (int p = 0; p < 3; ++p) {                                             \
+            F##a0[p] = *reinterpret_cast<const bf16x8 *>(rs + p * X3_PLANE_B + a_rd);                \
+            F##a1[p] = *reinterpret_cast<const bf16x8 *>(rs + p * X3_PLANE_B + a_rd + 32 * X3_ROW_B); \
+            F##b0[p] = *reinterpret_cast<const bf16x8 *>(rs + p * X3_PLANE_B + b_rd);                \
+            F##b1[p] = *reinterpret_cast<const bf16x8 *>(rs + p * X3_PLANE_B + b_rd + 32 * X3_ROW_B); \
+        }                                                                                           \
+    }
+#define X3P_TERM(F, pa, pb)                                                                         \
+    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F##a0[pa], F##b0[pb], acc[0][0], 0, 0, 0);  \
+    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F##a0[pa], F##b1[pb], acc[0][1], 0, 0, 0);  \
+    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F##a1[pa], F##b0[pb], acc[1][0], 0, 0, 0);  \
+    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F##a1[pa], F##b1[pb], acc[1][1], 0, 0, 0);
+#define X3P_MFMAS(F) X3P_TERM(F, 2, 0) X3P_TERM(F, 0, 2) X3P_TERM(F, 1, 1) X3P_TERM(F, 1, 0) X3P_TERM(F, 0, 1) X3P_TERM(F, 0, 0)
+    // (the s_waitcnt builtin, not inline asm: the compiler's own waitcnt pass must see that the fragment reads
+    //  have completed, or it puts an lgkmcnt(0) in front of the next MFMAs -- behind the freshly issued reads)
+#define X3P_SYNC()                                                                      \
+    asm volatile("" ::: "memory");                                                      \
+    __builtin_amdgcn_s_waitcnt(0x0076); /* vmcnt(6) expcnt(7 = none) lgkmcnt(0) */      \
+    __builtin_amdgcn_s_barrier();                                                       \
+    asm volatile("" ::: "memory");
+
+    // issue order inside a k-step: one memory operation in the shadow of each MFMA (12 fragment reads, then the 6
+    // DMA pieces), the last 6 MFMAs bare; without this hipcc sinks the reads next to their uses
+#define X3P_INTERLEAVE()                                                                   \
+    _Pragma("unroll") for (int i_ = 0; i_ < 12; ++i_) {                                    \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   /* 1 MFMA    */               \
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   /* 1 DS read */               \
+    }                                                                                      \
+    _Pragma("unroll") for (int i_ = 0; i_ < 6; ++i_) {                                     \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                 \
+        __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);   /* 1 VMEM (LDS-DMA piece) */  \
+    }                                                                                      \
+    __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);                                     \
+    __builtin_amdgcn_sched_barrier(0);
     X3P_DMA(0, 0)
     X3P_DMA(1, min(1, nk - 1))
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    X3P_DMA(2, min(2, nk - 1))
+    asm volatile("s_waitcnt vmcnt(12)" ::: "memory");            // tile 0 landed
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-    bf16x8 fa0[3], fa1[3], fb0[3], fb1[3];
-    for (int kt = 0; kt < nk; ++kt) {
-        const char *rs = smem + (kt % X3_STAGES) * STAGE_B;
-#pragma unroll
-        for (int p = 0; p < 3; ++p) {
-            fa0[p] = *reinterpret_cast<const bf16x8 *>(rs + p * X3_PLANE_B + a_rd);
-            fa1[p] = *reinterpret_cast<const bf16x8 *>(rs + p * X3_PLANE_B + a_rd + 32 * X3_ROW_B);
-            fb0[p] = *reinterpret_cast<const bf16x8 *>(rs + p * X3_PLANE_B + b_rd);
-            fb1[p] = *reinterpret_cast<const bf16x8 *>(rs + p * X3_PLANE_B + b_rd + 32 * X3_ROW_B);
-        }
-        X3P_DMA((kt + 2) % X3_STAGES, min(kt + 2, nk - 1))       // unconditional (clamped) so the count below is exact
-#define X3P_TERM(pa, pb)                                                                            \
-    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa0[pa], fb0[pb], acc[0][0], 0, 0, 0);      \
-    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa0[pa], fb1[pb], acc[0][1], 0, 0, 0);      \
-    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa1[pa], fb0[pb], acc[1][0], 0, 0, 0);      \
-    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa1[pa], fb1[pb], acc[1][1], 0, 0, 0);
-        X3P_TERM(2, 0) X3P_TERM(0, 2) X3P_TERM(1, 1) X3P_TERM(1, 0) X3P_TERM(0, 1) X3P_TERM(0, 0)
-#undef X3P_TERM
-        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");         // tile kt+1 has landed (only tile kt+2's 6 pieces pending)
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
+    X3P_READ(f0, 0)
+    X3P_SYNC()                                                   // tile 1 landed, stage 0 free
+    int s0 = 0;                                                  // kt % 3
+    for (int kt = 0; kt < nk; kt += 2) {
+        const int s1 = s0 == 2 ? 0 : s0 + 1, s2 = s1 == 2 ? 0 : s1 + 1;
+        X3P_READ(f1, s1)                                         // tile kt+1
+        X3P_DMA(s0, min(kt + 3, nk - 1))                         // unconditional (clamped) so the vmcnt count is exact
+        X3P_MFMAS(f0)                                            // tile kt
+        X3P_INTERLEAVE()
+        X3P_SYNC()
+        X3P_READ(f0, s2)                                         // tile kt+2
+        X3P_DMA(s1, min(kt + 4, nk - 1))
+        X3P_MFMAS(f1)                                            // tile kt+1
+        X3P_INTERLEAVE()
+        X3P_SYNC()
+        s0 = s2;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // clamped tail pieces must land before LDS is reused
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
 #undef X3P_DMA
+#undef X3P_READ
+#undef X3P_TERM
+#undef X3P_MFMAS
+#undef X3P_SYNC
+#undef X3P_INTERLEAVE
 }
 
 __global__ __launch_bounds__(256, 2) void gemm_bf16x3p_kernel(const __bf16 *__restrict__ Apk,
