@@ -1045,12 +1045,18 @@ int capdec_gemm_f32(capdec_ctx *c, const float *a, int lda, const float *bt, int
                     int K, const float *bias, const float *resid, int ldr, int act) {
     CAPDEC_CHECK(c && a && bt && cc, "gemm: null argument");
     CAPDEC_HIP(hipSetDevice(c->device));
-    static const bool cache = getenv("CAPDEC_HOOK_CACHE") != nullptr;   // benchmarking: treat Bt as a resident weight
-    static const bool packa = getenv("CAPDEC_HOOK_PACKA") != nullptr;   // benchmarking: pre-packed A (the LayerNorm -> GEMM path)
+    const bool cache = getenv("CAPDEC_HOOK_CACHE") != nullptr;   // benchmarking: treat Bt as a resident weight
+    const bool packa = getenv("CAPDEC_HOOK_PACKA") != nullptr;   // tests / benchmarking: pre-packed A (the LayerNorm -> GEMM path)
     if (packa && c->gemm_mode == GEMM_BF16X3 && lda == K && ldb == K && K % 64 == 0) {
         const void *pa = nullptr, *pb = nullptr;
-        CAPDEC_TRY(planes_of(c, a, M, K, true, &pa));
-        CAPDEC_TRY(planes_of(c, bt, N, K, true, &pb));
+        if (cache) {
+            CAPDEC_TRY(planes_of(c, a, M, K, true, &pa));
+        } else {   // tests: always re-pack A (the plane cache is keyed by address, torch recycles addresses)
+            CAPDEC_TRY(c->xpk.ensure(x3_packed_bytes_host(M, K)));
+            CAPDEC_TRY(launch_pack_planes(c->stream, a, M, K, c->xpk.p));
+            pa = c->xpk.p;
+        }
+        CAPDEC_TRY(planes_of(c, bt, N, K, cache, &pb));
         GemmEpilogue e;
         e.bias = bias; e.act = act; e.resid = resid; e.ldr = ldr;
         ProfScope ps(c, F_GEMM_X3P, 2.0 * M * (double)N * K);

@@ -249,6 +249,10 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x3_topk_kernel(const float *_
 typedef __attribute__((address_space(3))) void lds_void;
 typedef const __attribute__((address_space(1))) void glb_void;
 
+// TR: the MFMA operands are swapped (D^T = B^T-fragment x A-fragment), so a lane ends up with FOUR CONSECUTIVE COLUMNS
+// of one output row (row = lane & 31, columns 8 (r >> 2) + 4 (lane >> 5) + (r & 3)) instead of four consecutive
+// rows of one column: the epilogue stores float4 / whole split quads straight from the accumulators.
+template <bool TR>
 __device__ __forceinline__ void x3p_mainloop(const __bf16 *__restrict__ Apk, const __bf16 *__restrict__ Bpk, int K,
                                              int tm, int tn, char *smem, f32x16 (&acc)[2][2]) {
     constexpr int STAGE_B = 2 * X3_BLOCK_B;                  // A block + B block = 24 KB
@@ -296,11 +300,13 @@ __device__ __forceinline__ void x3p_mainloop(const __bf16 *__restrict__ Apk, con
             F##b1[p] = *reinterpret_cast<const bf16x8 *>(rs + p * X3_PLANE_B + b_rd + 32 * X3_ROW_B); \
         }                                                                                           \
     }
-#define X3P_TERM(F, pa, pb)                                                                         \
-    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F##a0[pa], F##b0[pb], acc[0][0], 0, 0, 0);  \
-    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F##a0[pa], F##b1[pb], acc[0][1], 0, 0, 0);  \
-    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F##a1[pa], F##b0[pb], acc[1][0], 0, 0, 0);  \
-    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F##a1[pa], F##b1[pb], acc[1][1], 0, 0, 0);
+#define X3P_MM(x, y, c) (TR ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(y, x, c, 0, 0, 0)                \
+                            : __builtin_amdgcn_mfma_f32_32x32x16_bf16(x, y, c, 0, 0, 0))
+#define X3P_TERM(F, pa, pb)                                      \
+    acc[0][0] = X3P_MM(F##a0[pa], F##b0[pb], acc[0][0]);         \
+    acc[0][1] = X3P_MM(F##a0[pa], F##b1[pb], acc[0][1]);         \
+    acc[1][0] = X3P_MM(F##a1[pa], F##b0[pb], acc[1][0]);         \
+    acc[1][1] = X3P_MM(F##a1[pa], F##b1[pb], acc[1][1]);
 #define X3P_MFMAS(F) X3P_TERM(F, 2, 0) X3P_TERM(F, 0, 2) X3P_TERM(F, 1, 1) X3P_TERM(F, 1, 0) X3P_TERM(F, 0, 1) X3P_TERM(F, 0, 0)
     // (the s_waitcnt builtin, not inline asm: the compiler's own waitcnt pass must see that the fragment reads
     //  have completed, or it puts an lgkmcnt(0) in front of the next MFMAs -- behind the freshly issued reads)
@@ -352,27 +358,27 @@ __device__ __forceinline__ void x3p_mainloop(const __bf16 *__restrict__ Apk, con
 #undef X3P_DMA
 #undef X3P_READ
 #undef X3P_TERM
+#undef X3P_MM
 #undef X3P_MFMAS
 #undef X3P_SYNC
 #undef X3P_INTERLEAVE
 }
 
+template <bool VEC4>
 __global__ __launch_bounds__(256, 2) void gemm_bf16x3p_kernel(const __bf16 *__restrict__ Apk,
                                                               const __bf16 *__restrict__ Bpk, float *C, int ldc, int M,
                                                               int N, int K, const float *__restrict__ bias,
                                                               const float *resid, int ldr, int act, int tiles_m,
                                                               int tiles_n, char *packed_out) {
     __shared__ __attribute__((aligned(16))) char smem[X3_STAGES * 2 * X3_BLOCK_B];
-    static_assert(128 * CP_LD * 4 <= X3_STAGES * 2 * X3_BLOCK_B, "packed epilogue tile must fit the staging ring");
     int tm, tn;
     tile_coords(tiles_m, tiles_n, tm, tn);
     f32x16 acc[2][2];
-    x3p_mainloop(Apk, Bpk, K, tm, tn, smem, acc);      // ends with a barrier
+    x3p_mainloop<true>(Apk, Bpk, K, tm, tn, smem, acc);
     if (packed_out)
-        epilogue_store_packed(acc, reinterpret_cast<float *>(smem), packed_out, N >> 4, M, N, tm * GEMM_BM, tn * GEMM_BN,
-                              bias, act);
+        epilogue_store_packed_t(acc, packed_out, N >> 4, M, N, tm * GEMM_BM, tn * GEMM_BN, bias, act);
     else
-        epilogue_store<2>(acc, C, ldc, M, N, tm * GEMM_BM, tn * GEMM_BN, bias, resid, ldr, act);
+        epilogue_store_t<VEC4>(acc, C, ldc, M, N, tm * GEMM_BM, tn * GEMM_BN, bias, resid, ldr, act);
 }
 
 template <int KSEL>
@@ -386,7 +392,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x3p_topk_kernel(const __bf16 
     int tm, tn;
     tile_coords(tiles_m, tiles_n, tm, tn);
     f32x16 acc[2][2];
-    x3p_mainloop(Apk, Bpk, K, tm, tn, smem, acc);      // ends with a barrier
+    x3p_mainloop<false>(Apk, Bpk, K, tm, tn, smem, acc);      // ends with a barrier
     epilogue_topk<KSEL, 2>(acc, reinterpret_cast<float *>(smem), M, N, tm * GEMM_BM, tn * GEMM_BN, tn, tiles_n, inv_temp,
                            tile_max, tile_sum, cand_val, cand_idx);
 }
@@ -394,12 +400,22 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x3p_topk_kernel(const __bf16 
 int launch_gemm_bf16x3p(hipStream_t st, const void *Apacked, const void *Bpacked, float *C, int ldc, int M, int N, int K,
                         const GemmEpilogue &epi) {
     CAPDEC_CHECK(M > 0 && N > 0 && K > 0 && K % 64 == 0, "gemm_bf16x3p: K must be a multiple of 64");
-    CAPDEC_CHECK(epi.packed_out == nullptr || (N % 64 == 0 && epi.resid == nullptr),
-                 "gemm_bf16x3p: packed output needs N % 64 == 0 and no residual");
+    CAPDEC_CHECK(epi.packed_out == nullptr ||
+                     (N % 64 == 0 && epi.resid == nullptr && ((uintptr_t)epi.bias & 15) == 0),
+                 "gemm_bf16x3p: packed output needs N % 64 == 0, a 16-byte aligned bias and no residual");
     const int tiles_m = (M + GEMM_BM - 1) / GEMM_BM, tiles_n = (N + GEMM_BN - 1) / GEMM_BN;
-    hipLaunchKernelGGL(gemm_bf16x3p_kernel, dim3(tiles_m * tiles_n), dim3(256), 0, st, (const __bf16 *)Apacked,
-                       (const __bf16 *)Bpacked, C, ldc, M, N, K, epi.bias, epi.resid, epi.ldr, epi.act, tiles_m, tiles_n,
-                       (char *)epi.packed_out);
+    // float4 epilogue when every row segment is 16-byte aligned (always the case on the decode path)
+    const bool vec4 = N % 4 == 0 && ldc % 4 == 0 && ((uintptr_t)C & 15) == 0 &&
+                      (epi.bias == nullptr || ((uintptr_t)epi.bias & 15) == 0) &&
+                      (epi.resid == nullptr || (epi.ldr % 4 == 0 && ((uintptr_t)epi.resid & 15) == 0));
+    if (vec4)
+        hipLaunchKernelGGL(gemm_bf16x3p_kernel<true>, dim3(tiles_m * tiles_n), dim3(256), 0, st, (const __bf16 *)Apacked,
+                           (const __bf16 *)Bpacked, C, ldc, M, N, K, epi.bias, epi.resid, epi.ldr, epi.act, tiles_m,
+                           tiles_n, (char *)epi.packed_out);
+    else
+        hipLaunchKernelGGL(gemm_bf16x3p_kernel<false>, dim3(tiles_m * tiles_n), dim3(256), 0, st, (const __bf16 *)Apacked,
+                           (const __bf16 *)Bpacked, C, ldc, M, N, K, epi.bias, epi.resid, epi.ldr, epi.act, tiles_m,
+                           tiles_n, (char *)epi.packed_out);
     CAPDEC_HIP(hipGetLastError());
     return 0;
 }

@@ -79,36 +79,84 @@ __device__ __forceinline__ void epilogue_store(const f32x16 (&acc)[2][WaveGrid<W
     }
 }
 
-// Packed-output epilogue (128x128 tile): act(acc + bias) goes accumulators -> LDS (`Ct`, 128 x CP_LD floats, the
-// caller's main loop must have ended with a barrier) -> float4 per thread along the row -> split3 -> the
-// tile-major planes of the NEXT GEMM's A operand (its K = this GEMM's N).  The fp32 tile never reaches HBM.
-constexpr int CP_LD = 132;
-__device__ __forceinline__ void epilogue_store_packed(const f32x16 (&acc)[2][2], float *Ct, char *packed, int nk_out,
-                                                      int M, int N, int m0, int n0, const float *__restrict__ bias,
-                                                      int act) {
+// ---- epilogues of the TRANSPOSED accumulator layout (packed-A kernel: MFMA operands swapped, 128x128 tile, 2x2
+// waves): acc[i][j][r] = C[m0 + wm 64 + i 32 + (lane & 31)][n0 + wn 64 + j 32 + 8 (r >> 2) + 4 (lane >> 5) + (r & 3)],
+// i.e. four consecutive columns per (lane, r >> 2).
+__device__ __forceinline__ float4 acc_quad(const f32x16 &a, int g) {
+    return make_float4(a[4 * g], a[4 * g + 1], a[4 * g + 2], a[4 * g + 3]);
+}
+
+// C = act(acc + bias) + resid, 16 float4 stores per lane (vec4: every row segment 16-byte aligned, N % 4 == 0)
+template <bool VEC4>
+__device__ __forceinline__ void epilogue_store_t(const f32x16 (&acc)[2][2], float *C, int ldc, int M, int N, int m0,
+                                                 int n0, const float *__restrict__ bias, const float *resid, int ldr,
+                                                 int act) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wm = wave >> 1, wn = wave & 1, half = lane >> 5, l32 = lane & 31;
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int cl = wn * 64 + j * 32 + l32;
-        const float bv = (bias && n0 + cl < N) ? bias[n0 + cl] : 0.f;
+    for (int i = 0; i < 2; ++i) {
+        const int row = m0 + wm * 64 + i * 32 + l32;
+        if (row >= M) continue;
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int rl = wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                Ct[rl * CP_LD + cl] = (n0 + cl < N) ? act_apply(acc[i][j][r] + bv, act) : 0.f;
+            for (int g = 0; g < 4; ++g) {
+                const int col = n0 + wn * 64 + j * 32 + 8 * g + 4 * half;
+                if (col >= N) continue;
+                float4 v = acc_quad(acc[i][j], g);
+                if constexpr (VEC4) {
+                    if (bias) {
+                        const float4 b = *reinterpret_cast<const float4 *>(bias + col);
+                        v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
+                    }
+                    v.x = act_apply(v.x, act); v.y = act_apply(v.y, act);
+                    v.z = act_apply(v.z, act); v.w = act_apply(v.w, act);
+                    if (resid) {
+                        const float4 r4 = *reinterpret_cast<const float4 *>(resid + (size_t)row * ldr + col);
+                        v.x += r4.x; v.y += r4.y; v.z += r4.z; v.w += r4.w;
+                    }
+                    *reinterpret_cast<float4 *>(C + (size_t)row * ldc + col) = v;
+                } else {
+                    const float e[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        if (col + q < N) {
+                            float x = act_apply(e[q] + (bias ? bias[col + q] : 0.f), act);
+                            if (resid) x += resid[(size_t)row * ldr + col + q];
+                            C[(size_t)row * ldc + col + q] = x;
+                        }
+                }
             }
     }
-    __syncthreads();
-#pragma unroll 4
-    for (int it = 0; it < 16; ++it) {
-        const int u = threadIdx.x + 256 * it, rl = u >> 5, qc = u & 31;
-        const int row = m0 + rl, col = n0 + 4 * qc;
-        if (row < M && col < N) {
-            const float4 v = *reinterpret_cast<const float4 *>(Ct + rl * CP_LD + 4 * qc);
-            x3_store_quad(packed, nk_out, row, col >> 4, qc & 3, v);
-        }
+}
+
+// act(acc + bias) written as the packed split-bf16 A operand of the NEXT GEMM (its K = this GEMM's N, N % 16 == 0):
+// a lane's four consecutive columns are exactly one quad of that operand -- split3 and three 8-byte stores, the fp32
+// tile never reaches HBM (or LDS).
+__device__ __forceinline__ void epilogue_store_packed_t(const f32x16 (&acc)[2][2], char *packed, int nk_out, int M,
+                                                        int N, int m0, int n0, const float *__restrict__ bias,
+                                                        int act) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wm = wave >> 1, wn = wave & 1, half = lane >> 5, l32 = lane & 31;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int row = m0 + wm * 64 + i * 32 + l32;
+        if (row >= M) continue;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int col = n0 + wn * 64 + j * 32 + 8 * g + 4 * half;
+                if (col >= N) continue;
+                float4 v = acc_quad(acc[i][j], g);
+                if (bias) {
+                    const float4 b = *reinterpret_cast<const float4 *>(bias + col);
+                    v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
+                }
+                v.x = act_apply(v.x, act); v.y = act_apply(v.y, act);
+                v.z = act_apply(v.z, act); v.w = act_apply(v.w, act);
+                x3_store_quad(packed, nk_out, row, col >> 4, (col >> 2) & 3, v);
+            }
     }
 }
 

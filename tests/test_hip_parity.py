@@ -269,6 +269,25 @@ def test_gemm_modes_vs_fp64(mode):
     e.close()
 
 
+@pytest.mark.parametrize("N", [1024, 1001, 130])
+def test_gemm_packed_a_path(eng, N, monkeypatch):
+    """the packed-A LDS-DMA kernel (both operands pre-split, transposed accumulator layout) through the test hook:
+    float4 epilogue (N % 4 == 0) and the scalar tail path, bias + activation + residual, ragged M"""
+    from oracle import capdec_oracle as O
+    monkeypatch.setenv("CAPDEC_HOOK_PACKA", "1")
+    g = torch.Generator().manual_seed(N)
+    M, K = 333, 256
+    a, bt = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g) * 0.2
+    bias, resid = torch.randn(N, generator=g), torch.randn(M, N, generator=g)
+    ref = a.double() @ bt.double().t()
+    scale = a.abs().double() @ bt.abs().double().t()
+    out = eng.gemm(a, bt).cpu().double()
+    assert float(((out - ref).abs() / scale).max()) < 5e-7
+    y = O.gelu_new(a @ bt.t() + bias) + resid
+    out = eng.gemm(a, bt, bias=bias, resid=resid, act=3).cpu()
+    np.testing.assert_allclose(out.numpy(), y.numpy(), atol=2e-5, rtol=1e-5)
+
+
 # ----------------------------------------------------------------------------------- decode vs oracle, bigger batches
 def test_batched_decode_vs_oracle_and_chunking():
     from capdec_amd import gpt2_prefix_eval as E
