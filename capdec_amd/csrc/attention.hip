@@ -172,20 +172,34 @@ __global__ __launch_bounds__(256) void attn_decode_beams_kernel(const float *__r
     const float *kbase = kc + ((size_t)row0 * heads + head) * hstride + sub * 4;
     const float *vbase = vc + ((size_t)row0 * heads + head) * hstride + sub * 4;
     const size_t slot_stride = (size_t)heads * hstride;
-    // ---- scores over the cached positions: two positions per 16-lane group per iteration
+    // ---- scores over the cached positions: two positions per 16-lane group per iteration.  All 2 x BEAM loads of an
+    // iteration are issued back to back (no branch, no wait between them): a beam whose slot equals the previous
+    // beam's re-reads a line that is already hot in L1 (the wavefront's own q row) and takes the previous beam's
+    // registers instead, so HBM traffic stays one load per DISTINCT consecutive slot while the wavefront keeps
+    // 2 x BEAM requests in flight (the kernel is latency-bound: a dependent load -> use chain per beam was 2x slower).
+    const float *dummy = qkv + (size_t)row0 * 3 * d + head * 64 + sub * 4;
     for (int p0 = 0; p0 < Lpast; p0 += 8) {
         const int pa = p0 + grp, pb = p0 + 4 + grp;
         const bool va = pa < Lpast, vb = pb < Lpast;
-        int preva = -1, prevb = -1;
-        float4 ka = make_float4(0.f, 0.f, 0.f, 0.f), kb = ka;
+        int sa[BEAM], sb[BEAM];
+        float4 ka[BEAM], kb[BEAM];
 #pragma unroll
         for (int b = 0; b < BEAM; ++b) {
-            const int sa = va ? sl[b * L + pa] : 0, sb = vb ? sl[b * L + pb] : 0;
-            if (va && sa != preva) ka = *reinterpret_cast<const float4 *>(kbase + sa * slot_stride + (size_t)pa * 64);
-            if (vb && sb != prevb) kb = *reinterpret_cast<const float4 *>(kbase + sb * slot_stride + (size_t)pb * 64);
-            preva = sa; prevb = sb;
-            const float s0 = group16_sum(dot4(q[b], ka));
-            const float s1 = group16_sum(dot4(q[b], kb));
+            sa[b] = va ? sl[b * L + pa] : 0;
+            sb[b] = vb ? sl[b * L + pb] : 0;
+        }
+#pragma unroll
+        for (int b = 0; b < BEAM; ++b) {
+            const bool na = va && (b == 0 || sa[b] != sa[b - 1]), nb = vb && (b == 0 || sb[b] != sb[b - 1]);
+            ka[b] = *reinterpret_cast<const float4 *>(na ? kbase + sa[b] * slot_stride + (size_t)pa * 64 : dummy);
+            kb[b] = *reinterpret_cast<const float4 *>(nb ? kbase + sb[b] * slot_stride + (size_t)pb * 64 : dummy);
+        }
+#pragma unroll
+        for (int b = 0; b < BEAM; ++b) {
+            if (b > 0 && sa[b] == sa[b - 1]) ka[b] = ka[b - 1];
+            if (b > 0 && sb[b] == sb[b - 1]) kb[b] = kb[b - 1];
+            const float s0 = group16_sum(dot4(q[b], ka[b]));
+            const float s1 = group16_sum(dot4(q[b], kb[b]));
             if (sub == 0) {
                 if (va) sc[b * L + pa] = s0;
                 if (vb) sc[b * L + pb] = s1;
@@ -216,17 +230,26 @@ __global__ __launch_bounds__(256) void attn_decode_beams_kernel(const float *__r
     for (int p0 = 0; p0 < Lpast; p0 += 8) {
         const int pa = p0 + grp, pb = p0 + 4 + grp;
         const bool va = pa < Lpast, vb = pb < Lpast;
-        int preva = -1, prevb = -1;
-        float4 xa = make_float4(0.f, 0.f, 0.f, 0.f), xb = xa;
+        int sa[BEAM], sb[BEAM];
+        float4 xa[BEAM], xb[BEAM];
 #pragma unroll
         for (int b = 0; b < BEAM; ++b) {
-            const int sa = va ? sl[b * L + pa] : 0, sb = vb ? sl[b * L + pb] : 0;
-            if (va && sa != preva) xa = *reinterpret_cast<const float4 *>(vbase + sa * slot_stride + (size_t)pa * 64);
-            if (vb && sb != prevb) xb = *reinterpret_cast<const float4 *>(vbase + sb * slot_stride + (size_t)pb * 64);
-            preva = sa; prevb = sb;
+            sa[b] = va ? sl[b * L + pa] : 0;
+            sb[b] = vb ? sl[b * L + pb] : 0;
+        }
+#pragma unroll
+        for (int b = 0; b < BEAM; ++b) {
+            const bool na = va && (b == 0 || sa[b] != sa[b - 1]), nb = vb && (b == 0 || sb[b] != sb[b - 1]);
+            xa[b] = *reinterpret_cast<const float4 *>(na ? vbase + sa[b] * slot_stride + (size_t)pa * 64 : dummy);
+            xb[b] = *reinterpret_cast<const float4 *>(nb ? vbase + sb[b] * slot_stride + (size_t)pb * 64 : dummy);
+        }
+#pragma unroll
+        for (int b = 0; b < BEAM; ++b) {
+            if (b > 0 && sa[b] == sa[b - 1]) xa[b] = xa[b - 1];
+            if (b > 0 && sb[b] == sb[b - 1]) xb[b] = xb[b - 1];
             const float wa = va ? sc[b * L + pa] : 0.f, wb = vb ? sc[b * L + pb] : 0.f;
-            acc[b].x += wa * xa.x + wb * xb.x; acc[b].y += wa * xa.y + wb * xb.y;
-            acc[b].z += wa * xa.z + wb * xb.z; acc[b].w += wa * xa.w + wb * xb.w;
+            acc[b].x += wa * xa[b].x + wb * xb[b].x; acc[b].y += wa * xa[b].y + wb * xb[b].y;
+            acc[b].z += wa * xa[b].z + wb * xb[b].z; acc[b].w += wa * xa[b].w + wb * xb[b].w;
         }
     }
 #pragma unroll
