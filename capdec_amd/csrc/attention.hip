@@ -126,7 +126,7 @@ __global__ __launch_bounds__(256) void attn_gpt2_kernel(const float *__restrict_
 // consecutive beams instead of once per row: the 5 q vectors / 5 accumulators live in registers, a
 // loaded key or value is reused while anc[b][p] does not change from beam b-1 to beam b.
 template <int BEAM>
-__global__ __launch_bounds__(256) void attn_decode_beams_kernel(const float *__restrict__ qkv, float *__restrict__ kc,
+__global__ __launch_bounds__(256, 4) void attn_decode_beams_kernel(const float *__restrict__ qkv, float *__restrict__ kc,
                                                                 float *__restrict__ vc, int total, int heads,
                                                                 int ctx, int d, int L,
                                                                 const uint8_t *__restrict__ anc, int anc_stride,
@@ -188,6 +188,23 @@ __global__ __launch_bounds__(256) void attn_decode_beams_kernel(const float *__r
             sa[b] = va ? sl[b * L + pa] : 0;
             sb[b] = vb ? sl[b * L + pb] : 0;
         }
+        bool same = true;
+#pragma unroll
+        for (int b = 1; b < BEAM; ++b) same = same && sa[b] == sa[0] && sb[b] == sb[0];
+        if (__all(same)) {   // wave-uniform: every beam reads the same slot at these 8 positions (prefix, converged history)
+            const float4 k0 = *reinterpret_cast<const float4 *>(va ? kbase + sa[0] * slot_stride + (size_t)pa * 64 : dummy);
+            const float4 k1 = *reinterpret_cast<const float4 *>(vb ? kbase + sb[0] * slot_stride + (size_t)pb * 64 : dummy);
+#pragma unroll
+            for (int b = 0; b < BEAM; ++b) {
+                const float s0 = group16_sum(dot4(q[b], k0));
+                const float s1 = group16_sum(dot4(q[b], k1));
+                if (sub == 0) {
+                    if (va) sc[b * L + pa] = s0;
+                    if (vb) sc[b * L + pb] = s1;
+                }
+            }
+            continue;
+        }
 #pragma unroll
         for (int b = 0; b < BEAM; ++b) {
             const bool na = va && (b == 0 || sa[b] != sa[b - 1]), nb = vb && (b == 0 || sb[b] != sb[b - 1]);
@@ -236,6 +253,20 @@ __global__ __launch_bounds__(256) void attn_decode_beams_kernel(const float *__r
         for (int b = 0; b < BEAM; ++b) {
             sa[b] = va ? sl[b * L + pa] : 0;
             sb[b] = vb ? sl[b * L + pb] : 0;
+        }
+        bool same = true;
+#pragma unroll
+        for (int b = 1; b < BEAM; ++b) same = same && sa[b] == sa[0] && sb[b] == sb[0];
+        if (__all(same)) {
+            const float4 x0 = *reinterpret_cast<const float4 *>(va ? vbase + sa[0] * slot_stride + (size_t)pa * 64 : dummy);
+            const float4 x1 = *reinterpret_cast<const float4 *>(vb ? vbase + sb[0] * slot_stride + (size_t)pb * 64 : dummy);
+#pragma unroll
+            for (int b = 0; b < BEAM; ++b) {
+                const float wa = va ? sc[b * L + pa] : 0.f, wb = vb ? sc[b * L + pb] : 0.f;
+                acc[b].x += wa * x0.x + wb * x1.x; acc[b].y += wa * x0.y + wb * x1.y;
+                acc[b].z += wa * x0.z + wb * x1.z; acc[b].w += wa * x0.w + wb * x1.w;
+            }
+            continue;
         }
 #pragma unroll
         for (int b = 0; b < BEAM; ++b) {
