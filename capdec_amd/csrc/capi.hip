@@ -76,11 +76,12 @@ struct Tower {
 };
 
 enum Family { F_GEMM = 0, F_LMHEAD, F_ATTN_DEC, F_ATTN_PRE, F_LN, F_EMBED, F_SELECT, F_MAP_ATTN, F_OTHER, F_GEMM_X3,
-              F_LMHEAD_X3, F_GEMM_X3P, F_COUNT };
+              F_LMHEAD_X3, F_GEMM_X3P, F_GEMM_BF16P, F_LMHEAD_BF16, F_COUNT };
 static const char *kFamilyNames[F_COUNT] = {"gemm_f32", "gemm_f32_lmhead_topk", "attn_decode", "attn_prefill",
                                             "layernorm", "embed", "select", "attn_mapper", "other", "gemm_bf16x3",
-                                            "gemm_bf16x3_lmhead_topk", "gemm_bf16x3p"};
-enum GemmMode { GEMM_F32 = 0, GEMM_BF16X3 = 1 };
+                                            "gemm_bf16x3_lmhead_topk", "gemm_bf16x3p", "gemm_bf16p",
+                                            "gemm_bf16p_lmhead_topk"};
+enum GemmMode { GEMM_F32 = 0, GEMM_BF16X3 = 1, GEMM_BF16 = 2 };
 
 struct Prof {
     bool on = false;
@@ -241,7 +242,8 @@ static int gemm(capdec_ctx *c, const float *A, int lda, const float *Bt, int ldb
     e.act = act;
     e.resid = resid;
     e.ldr = ldr;
-    if (c->gemm_mode == GEMM_BF16X3 && ldb == K && K % 64 == 0) {   // other K: native fp32 MFMA
+    // (bf16 mode: GEMMs whose A operand is fp32 in HBM -- mapper, patch embedding -- keep the split kernel)
+    if (c->gemm_mode != GEMM_F32 && ldb == K && K % 64 == 0) {   // other K: native fp32 MFMA
         const void *pl = nullptr;
         CAPDEC_TRY(planes_of(c, Bt, N, K, weight, &pl));
         ProfScope ps(c, F_GEMM_X3, 2.0 * M * (double)N * K);
@@ -253,7 +255,9 @@ static int gemm(capdec_ctx *c, const float *A, int lda, const float *Bt, int ldb
 
 // LayerNorm -> GEMM with the normalised rows handed over in packed split-bf16 form (never fp32 in HBM).
 // Returns 1 in *done when the packed path ran; otherwise the caller runs the fp32-activation path.
-static bool use_packed_a(capdec_ctx *c, int K) { return c->gemm_mode == GEMM_BF16X3 && c->pack_a && K % 64 == 0; }
+static bool use_packed_a(capdec_ctx *c, int K) {
+    return (c->gemm_mode == GEMM_BF16 || (c->gemm_mode == GEMM_BF16X3 && c->pack_a)) && K % 64 == 0;
+}
 
 // C = act(Apk . W^T + bias) + resid with A already packed; packed_out != nullptr: the result is written as the
 // packed A operand of the next GEMM instead of fp32 C
@@ -268,6 +272,10 @@ static int gemm_packed(capdec_ctx *c, const void *Apk, const float *W, float *C,
     e.resid = resid;
     e.ldr = ldr;
     e.packed_out = packed_out;
+    if (c->gemm_mode == GEMM_BF16) {   // plane 0 only: bf16 operands, one MFMA per product
+        ProfScope ps(c, F_GEMM_BF16P, 2.0 * M * (double)N * K);
+        return launch_gemm_bf16p(c->stream, Apk, pl, C, ldc, M, N, K, e);
+    }
     ProfScope ps(c, F_GEMM_X3P, 2.0 * M * (double)N * K);
     return launch_gemm_bf16x3p(c->stream, Apk, pl, C, ldc, M, N, K, e);
 }
@@ -382,10 +390,17 @@ static int lm_head_select(capdec_ctx *c, const float *h0, int ldh, int R, int k,
         { ProfScope ps(c, F_LN); CAPDEC_TRY(launch_layernorm_packed(c->stream, h0, ldh, g.lnfw, g.lnfb, g.eps, c->xpk.p, R, d)); }
         const void *pl = nullptr;
         CAPDEC_TRY(planes_of(c, g.wte, g.vocab, d, true, &pl));
-        ProfScope ps(c, F_LMHEAD_X3, 2.0 * R * (double)g.vocab * d);
-        CAPDEC_TRY(launch_gemm_bf16x3p_topk(c->stream, c->xpk.p, pl, R, g.vocab, d, k, inv_temp, c->tmax.as<float>(),
-                                            c->tsum.as<float>(), c->cval.as<float>(), c->cidx.as<int>()));
-    } else if (c->gemm_mode == GEMM_BF16X3) {
+        if (c->gemm_mode == GEMM_BF16) {
+            ProfScope ps(c, F_LMHEAD_BF16, 2.0 * R * (double)g.vocab * d);
+            CAPDEC_TRY(launch_gemm_bf16p_topk(c->stream, c->xpk.p, pl, R, g.vocab, d, k, inv_temp, c->tmax.as<float>(),
+                                              c->tsum.as<float>(), c->cval.as<float>(), c->cidx.as<int>()));
+        } else {
+            ProfScope ps(c, F_LMHEAD_X3, 2.0 * R * (double)g.vocab * d);
+            CAPDEC_TRY(launch_gemm_bf16x3p_topk(c->stream, c->xpk.p, pl, R, g.vocab, d, k, inv_temp,
+                                                c->tmax.as<float>(), c->tsum.as<float>(), c->cval.as<float>(),
+                                                c->cidx.as<int>()));
+        }
+    } else if (c->gemm_mode != GEMM_F32) {
         { ProfScope ps(c, F_LN); CAPDEC_TRY(launch_layernorm(c->stream, h0, ldh, g.lnfw, g.lnfb, g.eps, c->xl.as<float>(), d, R, d)); }
         const void *pl = nullptr;
         CAPDEC_TRY(planes_of(c, g.wte, g.vocab, d, true, &pl));
@@ -700,7 +715,8 @@ int capdec_create(int device_id, capdec_ctx **out) {
     c->device = device_id;
     if (const char *e = getenv("CAPDEC_X3_PACKA")) c->pack_a = atoi(e) != 0;
     if (const char *e = getenv("CAPDEC_X3_CHAIN")) c->pack_chain = atoi(e) != 0;
-    if (const char *e = getenv("CAPDEC_GEMM_MODE")) c->gemm_mode = (std::string(e) == "f32") ? GEMM_F32 : GEMM_BF16X3;
+    if (const char *e = getenv("CAPDEC_GEMM_MODE"))
+        c->gemm_mode = std::string(e) == "f32" ? GEMM_F32 : std::string(e) == "bf16" ? GEMM_BF16 : GEMM_BF16X3;
     CAPDEC_HIP(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
     c->stream = c->own_stream;
     CAPDEC_HIP(hipEventCreate(&c->t0));
@@ -750,7 +766,8 @@ int capdec_synchronize(capdec_ctx *c) {
     return 0;
 }
 int capdec_set_gemm_mode(capdec_ctx *c, int mode) {
-    CAPDEC_CHECK(c && (mode == GEMM_F32 || mode == GEMM_BF16X3), "set_gemm_mode: mode must be 0 (f32 MFMA) or 1 (bf16x3)");
+    CAPDEC_CHECK(c && (mode == GEMM_F32 || mode == GEMM_BF16X3 || mode == GEMM_BF16),
+                 "set_gemm_mode: mode must be 0 (f32 MFMA), 1 (bf16x3, fp32-accurate) or 2 (bf16 operands)");
     c->gemm_mode = mode;
     return 0;
 }
@@ -1014,6 +1031,9 @@ int capdec_gpt2_logits(capdec_ctx *c, const float *embeds, int n, int L, int all
     CAPDEC_TRY(c->xl.ensure((size_t)R * d * 4));
     const float *h0 = all_positions ? c->h.as<float>() : c->h.as<float>() + (size_t)(L - 1) * d;
     const int ldh = all_positions ? d : L * d;
+    if (use_packed_a(c, d))   // same operand path as the decode loop's fused lm_head (bf16 mode: bf16 operands)
+        return ln_gemm_packed(c, h0, ldh, g.lnfw, g.lnfb, g.eps, g.wte, logits, g.vocab, R, g.vocab, d, nullptr,
+                              CAPDEC_ACT_NONE);
     { ProfScope ps(c, F_LN); CAPDEC_TRY(launch_layernorm(c->stream, h0, ldh, g.lnfw, g.lnfb, g.eps, c->xl.as<float>(), d, R, d)); }
     CAPDEC_TRY(gemm(c, c->xl.as<float>(), d, g.wte, d, logits, g.vocab, R, g.vocab, d, nullptr, CAPDEC_ACT_NONE));
     return 0;
@@ -1047,7 +1067,7 @@ int capdec_gemm_f32(capdec_ctx *c, const float *a, int lda, const float *bt, int
     CAPDEC_HIP(hipSetDevice(c->device));
     const bool cache = getenv("CAPDEC_HOOK_CACHE") != nullptr;   // benchmarking: treat Bt as a resident weight
     const bool packa = getenv("CAPDEC_HOOK_PACKA") != nullptr;   // tests / benchmarking: pre-packed A (the LayerNorm -> GEMM path)
-    if (packa && c->gemm_mode == GEMM_BF16X3 && lda == K && ldb == K && K % 64 == 0) {
+    if ((packa || c->gemm_mode == GEMM_BF16) && c->gemm_mode != GEMM_F32 && lda == K && ldb == K && K % 64 == 0) {
         const void *pa = nullptr, *pb = nullptr;
         if (cache) {
             CAPDEC_TRY(planes_of(c, a, M, K, true, &pa));
@@ -1059,6 +1079,10 @@ int capdec_gemm_f32(capdec_ctx *c, const float *a, int lda, const float *bt, int
         CAPDEC_TRY(planes_of(c, bt, N, K, cache, &pb));
         GemmEpilogue e;
         e.bias = bias; e.act = act; e.resid = resid; e.ldr = ldr;
+        if (c->gemm_mode == GEMM_BF16) {
+            ProfScope ps(c, F_GEMM_BF16P, 2.0 * M * (double)N * K);
+            return launch_gemm_bf16p(c->stream, pa, pb, cc, ldc, M, N, K, e);
+        }
         ProfScope ps(c, F_GEMM_X3P, 2.0 * M * (double)N * K);
         return launch_gemm_bf16x3p(c->stream, pa, pb, cc, ldc, M, N, K, e);
     }

@@ -116,6 +116,11 @@ int launch_gemm_bf16x3p(hipStream_t st, const void *Apacked, const void *Bpacked
                         const GemmEpilogue &epi);
 int launch_gemm_bf16x3p_topk(hipStream_t st, const void *Apacked, const void *Bpacked, int M, int N, int K, int k,
                              float inv_temp, float *tile_max, float *tile_sum, float *cand_val, int *cand_idx);
+// bf16 mode (gemm_bf16.hip): same packed operands, plane 0 only -- one bf16 MFMA per product, fp32 accumulate
+int launch_gemm_bf16p(hipStream_t st, const void *Apacked, const void *Bpacked, float *C, int ldc, int M, int N, int K,
+                      const GemmEpilogue &epi);
+int launch_gemm_bf16p_topk(hipStream_t st, const void *Apacked, const void *Bpacked, int M, int N, int K, int k,
+                           float inv_temp, float *tile_max, float *tile_sum, float *cand_val, int *cand_idx);
 // LayerNorm whose output goes straight into the packed split-bf16 A format of the next GEMM (d % 16 == 0)
 int launch_layernorm_packed(hipStream_t st, const float *x, int ldx, const float *w, const float *b, float eps,
                             void *packed, int rows, int d);

@@ -319,10 +319,10 @@ class Engine:
 
     def set_gemm_mode(self, mode: str):
         """'f32' (native fp32 MFMA) or 'bf16x3' (fp32-accurate split-bf16 MFMA)"""
-        check(self.lib.capdec_set_gemm_mode(self._h, {"f32": 0, "bf16x3": 1}[mode]), "set_gemm_mode")
+        check(self.lib.capdec_set_gemm_mode(self._h, {"f32": 0, "bf16x3": 1, "bf16": 2}[mode]), "set_gemm_mode")
 
     def gemm_mode(self) -> str:
-        return ["f32", "bf16x3"][self.lib.capdec_get_gemm_mode(self._h)]
+        return ["f32", "bf16x3", "bf16"][self.lib.capdec_get_gemm_mode(self._h)]
 
     def profile_enable(self, on=True):
         """True / 1: time every launch; N > 1: every N-th launch of each kernel family (sampling); False: off"""

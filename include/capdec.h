@@ -54,9 +54,12 @@ int capdec_synchronize(capdec_ctx *ctx);
 /* how the dense projections run: 0 = native fp32 MFMA (v_mfma_f32_32x32x2_f32, exact fma chain);
  * 1 = fp32-accurate split-bf16 ("bf16x3": operands split into three bf16 planes, six
  * v_mfma_f32_32x32x16_bf16 per product, fp32 accumulate; 2.7x the MFMA throughput, same fp32
- * round-off class: every parity test passes in both modes).  Default 1; the environment variable
- * CAPDEC_GEMM_MODE=f32|bf16x3 overrides it at capdec_create. */
-enum { CAPDEC_GEMM_F32 = 0, CAPDEC_GEMM_BF16X3 = 1 };
+ * round-off class: every parity test passes in both modes);
+ * 2 = bf16 operands (BASELINE configs[1]): weights and GEMM-input activations of the GPT-2 / CLIP block stacks and
+ * the lm_head rounded to bf16 (RNE), ONE MFMA per product, fp32 accumulate; residual stream, LayerNorm, softmax, KV
+ * cache and the mapper GEMMs stay fp32-accurate.  Not bit-comparable with the fp32 reference (tolerance tests).
+ * Default 1; the environment variable CAPDEC_GEMM_MODE=f32|bf16x3|bf16 overrides it at capdec_create. */
+enum { CAPDEC_GEMM_F32 = 0, CAPDEC_GEMM_BF16X3 = 1, CAPDEC_GEMM_BF16 = 2 };
 int capdec_set_gemm_mode(capdec_ctx *ctx, int mode);
 int capdec_get_gemm_mode(capdec_ctx *ctx);
 /* cap on bytes the decode KV cache may take (captions are processed in chunks that fit);

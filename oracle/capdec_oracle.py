@@ -22,6 +22,7 @@ against outputs of the reference itself, imported in the build container by
 """
 from __future__ import annotations
 
+import contextlib
 import math
 from typing import Dict, List, Optional, Sequence, Tuple
 
@@ -136,6 +137,27 @@ def gelu_new(x: Tensor) -> Tensor:
     return 0.5 * x * (1.0 + torch.tanh(math.sqrt(2.0 / math.pi) * (x + 0.044715 * torch.pow(x, 3.0))))
 
 
+# bf16 GEMM-operand mode (BASELINE configs[1]; include/capdec.h CAPDEC_GEMM_BF16): inside ``bf16_gemm_operands()`` both
+# operands of every GPT-2 projection and of the lm_head are rounded to bf16 (round-to-nearest-even) before an fp32
+# matmul -- the arithmetic of the HIP bf16 mode (one bf16 MFMA per product, fp32 accumulate; residual stream,
+# LayerNorm, softmax, KV cache fp32).  Default: no rounding, the reference's fp32 path.
+_GEMM_BF16 = False
+
+
+@contextlib.contextmanager
+def bf16_gemm_operands():
+    global _GEMM_BF16
+    old, _GEMM_BF16 = _GEMM_BF16, True
+    try:
+        yield
+    finally:
+        _GEMM_BF16 = old
+
+
+def _r(x: Tensor) -> Tensor:
+    return x.to(torch.bfloat16).to(torch.float32) if _GEMM_BF16 else x
+
+
 def _n_layer(sd: SD, g: str) -> int:
     n = 0
     while f"{g}transformer.h.{n}.ln_1.weight" in sd:
@@ -157,7 +179,7 @@ def gpt2_hidden(embeds: Tensor, sd: SD, n_head: int = 12, g: str = "gpt.", pos0:
     for i in range(_n_layer(sd, g)):
         b = f"{t}h.{i}."
         a = F.layer_norm(h, (d,), sd[b + "ln_1.weight"], sd[b + "ln_1.bias"], 1e-5)
-        qkv = torch.addmm(sd[b + "attn.c_attn.bias"], a.reshape(-1, d), sd[b + "attn.c_attn.weight"]).view(N, L, 3 * d)
+        qkv = torch.addmm(sd[b + "attn.c_attn.bias"], _r(a.reshape(-1, d)), _r(sd[b + "attn.c_attn.weight"])).view(N, L, 3 * d)
         q, k, v = qkv.split(d, dim=2)
         q = q.view(N, L, n_head, hd).transpose(1, 2)
         k = k.view(N, L, n_head, hd).transpose(1, 2)
@@ -173,12 +195,12 @@ def gpt2_hidden(embeds: Tensor, sd: SD, n_head: int = 12, g: str = "gpt.", pos0:
         w = torch.where(causal, w, torch.full((), torch.finfo(w.dtype).min))
         w = w.softmax(dim=-1)
         o = torch.matmul(w, v).transpose(1, 2).reshape(N, L, d)
-        o = torch.addmm(sd[b + "attn.c_proj.bias"], o.reshape(-1, d), sd[b + "attn.c_proj.weight"]).view(N, L, d)
+        o = torch.addmm(sd[b + "attn.c_proj.bias"], _r(o.reshape(-1, d)), _r(sd[b + "attn.c_proj.weight"])).view(N, L, d)
         h = h + o
         m = F.layer_norm(h, (d,), sd[b + "ln_2.weight"], sd[b + "ln_2.bias"], 1e-5)
-        m = torch.addmm(sd[b + "mlp.c_fc.bias"], m.reshape(-1, d), sd[b + "mlp.c_fc.weight"])
+        m = torch.addmm(sd[b + "mlp.c_fc.bias"], _r(m.reshape(-1, d)), _r(sd[b + "mlp.c_fc.weight"]))
         m = gelu_new(m)
-        m = torch.addmm(sd[b + "mlp.c_proj.bias"], m, sd[b + "mlp.c_proj.weight"]).view(N, L, d)
+        m = torch.addmm(sd[b + "mlp.c_proj.bias"], _r(m), _r(sd[b + "mlp.c_proj.weight"])).view(N, L, d)
         h = h + m
     return F.layer_norm(h, (d,), sd[t + "ln_f.weight"], sd[t + "ln_f.bias"], 1e-5)
 
@@ -187,7 +209,7 @@ def gpt2_logits(embeds: Tensor, sd: SD, n_head: int = 12, g: str = "gpt.") -> Te
     """``model.gpt(inputs_embeds=x).logits`` -- ALL positions [N, L, V], tied lm_head
     (what the reference computes every step, gpt2_prefix_eval.py:76-77,163-164)."""
     h = gpt2_hidden(embeds, sd, n_head, g)
-    return torch.matmul(h, sd[g + "transformer.wte.weight"].t())
+    return torch.matmul(_r(h), _r(sd[g + "transformer.wte.weight"]).t())
 
 
 def wte(ids: Tensor, sd: SD, g: str = "gpt.") -> Tensor:
@@ -285,12 +307,13 @@ def greedy_cached(sd: SD, prefix: Tensor, stop_id: int = 13, entry_length: int =
     g = "gpt."
     cache: list = [None] * _n_layer(sd, g)
     W = sd[g + "transformer.wte.weight"]
+    Wr = _r(W)
     ids = torch.zeros(N, entry_length, dtype=torch.int32)
     lens = torch.zeros(N, dtype=torch.int32)
     done = torch.zeros(N, dtype=torch.bool)
     h = gpt2_hidden(prefix, sd, n_head, g, 0, cache)[:, -1]
     for i in range(entry_length):
-        nxt = torch.argmax(h @ W.t(), -1)
+        nxt = torch.argmax(_r(h) @ Wr.t(), -1)
         ids[~done, i] = nxt[~done].to(torch.int32)
         lens[~done] += 1
         done = done | (nxt == stop_id) | (nxt == alt_stop_id)
@@ -316,7 +339,8 @@ def beam_cached(sd: SD, prefix: Tensor, beam_size: int = 5, stop_id: int = 13, e
     V = W.shape[0]
     temp = temperature if temperature > 0 else 1.0
     h = gpt2_hidden(prefix, sd, n_head, g, 0, cache)[:, -1]
-    logp = ((h @ W.t()) / temp).softmax(-1).log()
+    Wr = _r(W)
+    logp = ((_r(h) @ Wr.t()) / temp).softmax(-1).log()
     scores, nxt = logp.topk(B, -1)                      # [N, B]
     tokens = torch.zeros(N, B, entry_length, dtype=torch.int64)
     tokens[:, :, 0] = nxt
@@ -330,7 +354,7 @@ def beam_cached(sd: SD, prefix: Tensor, beam_size: int = 5, stop_id: int = 13, e
             break
         x = W[nxt.reshape(-1)].unsqueeze(1)
         h = gpt2_hidden(x, sd, n_head, g, P + i - 1, cache)[:, -1]
-        logp = ((h @ W.t()) / temp).softmax(-1).log().view(N, B, V)
+        logp = ((_r(h) @ Wr.t()) / temp).softmax(-1).log().view(N, B, V)
         logp[stopped] = -float("inf")
         logp[stopped, 0] = 0
         ssum = scores[:, :, None] + logp
