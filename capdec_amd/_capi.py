@@ -100,6 +100,7 @@ SIGNATURES = {
                                      _VP, _VP]),
     "capdec_gemm_f32": (C.c_int, [_VP, _VP, C.c_int, _VP, C.c_int, _VP, C.c_int, C.c_int, C.c_int, C.c_int, _VP,
                                   _VP, C.c_int, C.c_int]),
+    "capdec_decode_stats": (C.c_int, [_VP, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_longlong)]),
     "capdec_timer_start": (C.c_int, [_VP]),
     "capdec_timer_stop_ms": (C.c_int, [_VP, c_float_p]),
     "capdec_profile_enable": (C.c_int, [_VP, C.c_int]),

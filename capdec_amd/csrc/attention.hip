@@ -34,7 +34,8 @@ __global__ __launch_bounds__(256) void attn_gpt2_kernel(const float *__restrict_
                                                         float *__restrict__ vc, int total, int heads, int ctx,
                                                         int d, int beam, int Lparam, int P, int causal,
                                                         const uint8_t *__restrict__ anc, int anc_stride,
-                                                        float *__restrict__ out, char *__restrict__ packed_out) {
+                                                        float *__restrict__ out, char *__restrict__ packed_out,
+                                                        const int *__restrict__ cmap) {
     __shared__ float sc[4][ATT_CTX_MAX];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int grp = lane >> 4, sub = lane & 15;
@@ -42,16 +43,19 @@ __global__ __launch_bounds__(256) void attn_gpt2_kernel(const float *__restrict_
     const bool active = gw < total;
     const int row = active ? gw / heads : 0;
     const int head = active ? gw - row * heads : 0;
+    // state row: after finished captions were compacted away, activation row r belongs to caption cmap[r / beam]
+    // (KV cache, ancestor table and beam state keep the ORIGINAL caption indexing)
+    const int srow = (DECODE && cmap) ? cmap[row / beam] * beam + row % beam : row;
     int L, phys_self;
     if (DECODE) {
         L = Lparam;
-        phys_self = row;
+        phys_self = srow;
     } else {
         const int cap = row / P, i = row - cap * P;
         L = causal ? i + 1 : P;                  // CLIP's vision tower attends to the whole sequence
         phys_self = cap * beam;
     }
-    const int cap_base = DECODE ? (row / beam) * beam : phys_self;
+    const int cap_base = DECODE ? (srow / beam) * beam : phys_self;
     const size_t hstride = (size_t)ctx * 64;
     const float *qrow = qkv + (size_t)row * 3 * d;
     float4 q = reinterpret_cast<const float4 *>(qrow + head * 64)[sub];
@@ -72,7 +76,7 @@ __global__ __launch_bounds__(256) void attn_gpt2_kernel(const float *__restrict_
         const int p = p0 + grp;
         if (p < Lpast) {
             int phys = phys_self;
-            if (DECODE && anc) phys = cap_base + anc[(size_t)row * anc_stride + p];
+            if (DECODE && anc) phys = cap_base + anc[(size_t)srow * anc_stride + p];
             const float4 k = reinterpret_cast<const float4 *>(kc + ((size_t)phys * heads + head) * hstride + (size_t)p * 64)[sub];
             const float s = group16_sum(dot4(q, k));
             if (sub == 0) sc[wave][p] = s;
@@ -101,7 +105,7 @@ __global__ __launch_bounds__(256) void attn_gpt2_kernel(const float *__restrict_
         const int p = p0 + grp;
         if (p < Lpast) {
             int phys = phys_self;
-            if (DECODE && anc) phys = cap_base + anc[(size_t)row * anc_stride + p];
+            if (DECODE && anc) phys = cap_base + anc[(size_t)srow * anc_stride + p];
             const float4 v = reinterpret_cast<const float4 *>(vc + ((size_t)phys * heads + head) * hstride + (size_t)p * 64)[sub];
             const float w = sc[wave][p];
             acc.x += w * v.x; acc.y += w * v.y; acc.z += w * v.z; acc.w += w * v.w;
@@ -131,7 +135,8 @@ __global__ __launch_bounds__(256, 4) void attn_decode_beams_kernel(const float *
                                                                 int ctx, int d, int L,
                                                                 const uint8_t *__restrict__ anc, int anc_stride,
                                                                 float *__restrict__ out,
-                                                                char *__restrict__ packed_out) {
+                                                                char *__restrict__ packed_out,
+                                                                const int *__restrict__ cmap) {
     extern __shared__ __attribute__((aligned(16))) float sc_all[];      // [4 waves][BEAM][L] scores + [4][BEAM][L] slots
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int grp = lane >> 4, sub = lane & 15;
@@ -142,13 +147,14 @@ __global__ __launch_bounds__(256, 4) void attn_decode_beams_kernel(const float *
     float *sc = sc_all + (size_t)wave * BEAM * L;
     int *sl = reinterpret_cast<int *>(sc_all + (size_t)4 * BEAM * L) + (size_t)wave * BEAM * L;
     const size_t hstride = (size_t)ctx * 64;
-    const int row0 = cap * BEAM;
+    const int row0 = cap * BEAM;                                   // activation rows (compact)
+    const int srow0 = (cmap ? cmap[cap] : cap) * BEAM;             // state rows: KV cache / ancestor table (original)
     const int Lpast = L - 1;
 
     // ancestor slots of this caption -> LDS (removes the dependent byte load in front of every K/V load)
     for (int i = lane; i < BEAM * Lpast; i += 64) {
         const int b = i / Lpast, p = i - b * Lpast;
-        sl[b * L + p] = anc[(size_t)(row0 + b) * anc_stride + p];
+        sl[b * L + p] = anc[(size_t)(srow0 + b) * anc_stride + p];
     }
 
     float4 q[BEAM];
@@ -161,7 +167,7 @@ __global__ __launch_bounds__(256, 4) void attn_decode_beams_kernel(const float *
         const float4 kcur = reinterpret_cast<const float4 *>(qrow + d + head * 64)[sub];
         const float4 vcur = reinterpret_cast<const float4 *>(qrow + 2 * d + head * 64)[sub];
         if (active && grp == 0) {
-            const size_t o = ((size_t)(row0 + b) * heads + head) * hstride + (size_t)Lpast * 64;
+            const size_t o = ((size_t)(srow0 + b) * heads + head) * hstride + (size_t)Lpast * 64;
             reinterpret_cast<float4 *>(kc + o)[sub] = kcur;
             reinterpret_cast<float4 *>(vc + o)[sub] = vcur;
         }
@@ -169,8 +175,8 @@ __global__ __launch_bounds__(256, 4) void attn_decode_beams_kernel(const float *
         if (lane == 0) sc[b * L + Lpast] = s;
     }
     __syncthreads();
-    const float *kbase = kc + ((size_t)row0 * heads + head) * hstride + sub * 4;
-    const float *vbase = vc + ((size_t)row0 * heads + head) * hstride + sub * 4;
+    const float *kbase = kc + ((size_t)srow0 * heads + head) * hstride + sub * 4;
+    const float *vbase = vc + ((size_t)srow0 * heads + head) * hstride + sub * 4;
     const size_t slot_stride = (size_t)heads * hstride;
     // ---- scores over the cached positions: two positions per 16-lane group per iteration.  All 2 x BEAM loads of an
     // iteration are issued back to back (no branch, no wait between them): a beam whose slot equals the previous
@@ -336,13 +342,13 @@ int launch_attn_prefill(hipStream_t st, const float *qkv, const KvCache &c, int 
     if (total <= 0) return 0;
     hipLaunchKernelGGL(attn_gpt2_kernel<false>, dim3((total + 3) / 4), dim3(256), 0, st, qkv,
                        c.k + layer * c.layer_stride(), c.v + layer * c.layer_stride(), total, c.heads, c.ctx,
-                       c.heads * c.hd, beam, 0, P, causal ? 1 : 0, (const uint8_t *)nullptr, 0, out, (char *)packed_out);
+                       c.heads * c.hd, beam, 0, P, causal ? 1 : 0, (const uint8_t *)nullptr, 0, out, (char *)packed_out, (const int *)nullptr);
     CAPDEC_HIP(hipGetLastError());
     return 0;
 }
 
 int launch_attn_decode(hipStream_t st, const float *qkv, const KvCache &c, int layer, int rows, int beam, int L,
-                       const uint8_t *anc, int anc_stride, float *out, void *packed_out) {
+                       const uint8_t *anc, int anc_stride, float *out, void *packed_out, const int *cmap) {
     CAPDEC_CHECK(c.hd == 64, "attention: head_dim must be 64");
     CAPDEC_CHECK(L >= 1 && L <= ATT_CTX_MAX && L <= c.ctx, "attention: context length out of range");
     if (anc != nullptr && beam > 1) {
@@ -353,7 +359,7 @@ int launch_attn_decode(hipStream_t st, const float *qkv, const KvCache &c, int l
         float *kl = c.k + layer * c.layer_stride(), *vl = c.v + layer * c.layer_stride();
 #define LAUNCH_BEAMS(B)                                                                                         \
     hipLaunchKernelGGL(attn_decode_beams_kernel<B>, grid, block, lds, st, qkv, kl, vl, total, c.heads, c.ctx,      \
-                       c.heads * c.hd, L, anc, anc_stride, out, (char *)packed_out)
+                       c.heads * c.hd, L, anc, anc_stride, out, (char *)packed_out, cmap)
         switch (beam) {
             case 2: LAUNCH_BEAMS(2); break;
             case 3: LAUNCH_BEAMS(3); break;
@@ -372,7 +378,7 @@ int launch_attn_decode(hipStream_t st, const float *qkv, const KvCache &c, int l
     if (total <= 0) return 0;
     hipLaunchKernelGGL(attn_gpt2_kernel<true>, dim3((total + 3) / 4), dim3(256), 0, st, qkv,
                        c.k + layer * c.layer_stride(), c.v + layer * c.layer_stride(), total, c.heads, c.ctx,
-                       c.heads * c.hd, beam, L, 0, 1, anc, anc_stride, out, (char *)packed_out);
+                       c.heads * c.hd, beam, L, 0, 1, anc, anc_stride, out, (char *)packed_out, cmap);
     CAPDEC_HIP(hipGetLastError());
     return 0;
 }

@@ -109,12 +109,15 @@ struct capdec_ctx {
     int gemm_mode = GEMM_BF16X3;
     std::unordered_map<const void *, std::pair<void *, size_t>> planes;   // fp32 weight -> (three bf16 planes, elements)
     DBuf x3_tmp, xpk, apk, fpk;          // scratch planes for un-cached matrices; packed split-bf16 LayerNorm output
+    int stat_steps = 0, stat_compactions = 0;      // last decode call: steps run, compactions done,
+    long long stat_row_steps = 0;                  // activation rows pushed through the GPT-2 body (prefill excluded)
+    bool compact = true;       // decode: drop finished captions from the batch at the poll points (CAPDEC_COMPACT=0: off)
     bool pack_chain = true;    // ... and attention / the fc GEMM epilogue emit the packed A operand of the GEMM that follows
     bool pack_a = true;        // bf16x3 mode: LayerNorm emits the packed A operand, GEMM moves both operands by LDS-DMA
     hipEvent_t t0 = nullptr, t1 = nullptr;
     // workspaces
     DBuf h, x, qkv, att, ff, xl, tmax, tsum, cval, cidx, lse, topv, topi, kc, vc;
-    DBuf tokens, scores, seq, stopped, done, anc, next_tok, alive, gids, glens;
+    DBuf tokens, scores, seq, stopped, done, anc, next_tok, alive, gids, glens, cmap;
     DBuf m_hid, m_lin, m_seq, m_x, m_qkv, m_att, m_ff;
     DBuf t_idx, t_patch, t_pout;
     int *alive_host = nullptr;   // pinned
@@ -295,6 +298,7 @@ struct StepShape {
     int rows, L;            // decode: rows at context length L
     const uint8_t *anc;
     int anc_stride;
+    const int *cmap;        // decode after compaction: activation row r -> caption cmap[r / beam] (nullptr: identity)
 };
 
 static int ensure_body_ws(capdec_ctx *c, int M, int d) {
@@ -346,7 +350,7 @@ static int stack_body(capdec_ctx *c, const StackCfg &g, const StepShape &s, cons
             CAPDEC_TRY(launch_attn_prefill(c->stream, qkv, kv, kl, s.ncap, s.P, s.beam, att, g.causal, apk));
         } else {
             ProfScope ps(c, F_ATTN_DEC);
-            CAPDEC_TRY(launch_attn_decode(c->stream, qkv, kv, kl, s.rows, s.beam, s.L, s.anc, s.anc_stride, att, apk));
+            CAPDEC_TRY(launch_attn_decode(c->stream, qkv, kv, kl, s.rows, s.beam, s.L, s.anc, s.anc_stride, att, apk, s.cmap));
         }
         if (chain) CAPDEC_TRY(gemm_packed(c, apk, w.wproj, h, d, M, d, d, w.bproj, CAPDEC_ACT_NONE, h, d));
         else CAPDEC_TRY(gemm(c, att, d, w.wproj, d, h, d, M, d, d, w.bproj, CAPDEC_ACT_NONE, h, d));
@@ -511,37 +515,54 @@ static int decode_chunk(capdec_ctx *c, const float *prefix, int nc, int P, int b
         CAPDEC_TRY(launch_beam_init(c->stream, bs, c->lse.as<float>(), c->topv.as<float>(), c->topi.as<int>(), nc,
                                     beam, k, T, ctx, P, stop_id));
     }
-    // ---- steps 1..T-1: one token per row per step
+    // ---- steps 1..T-1: one token per row per step.  Finished captions (stop token on every beam) are dropped from
+    // the batch at the poll points: `cmap` lists the captions still generating, the activations of a step are the
+    // na * beam rows of those captions only, while KV cache / ancestor table / beam state keep their original rows.
     const int poll_every = 8;
+    int na = nc;
+    const int *cmap = nullptr;
+    CAPDEC_TRY(c->cmap.ensure(((size_t)nc + 1) * 4));
     for (int i = 1; i < T; ++i) {
         if ((i - 1) % poll_every == 0) {
             int alive = 0;
             CAPDEC_TRY(poll_alive(c, &alive));
             if (alive == 0) break;
+            if (c->compact && alive <= na - std::max(1, na / 32)) {
+                ProfScope ps(c, F_SELECT);
+                CAPDEC_TRY(launch_compact_alive(c->stream, c->done.as<uint8_t>(), nc, c->cmap.as<int>(),
+                                                c->cmap.as<int>() + nc));
+                na = alive;
+                cmap = c->cmap.as<int>();
+                c->stat_compactions += 1;
+            }
         }
         const int pos = P + i - 1;   // position of the token fed this step
+        const int arows = na * beam;
+        c->stat_steps = std::max(c->stat_steps, i + 1);
+        c->stat_row_steps += arows;
         CAPDEC_HIP(hipMemsetAsync(c->alive.p, 0, sizeof(int), c->stream));
         {
             ProfScope ps(c, F_EMBED);
             CAPDEC_TRY(launch_embed_tokens(c->stream, c->next_tok.as<int>(), g.wte, g.wpe + (size_t)pos * d,
-                                           c->h.as<float>(), rows, d));
+                                           c->h.as<float>(), arows, d, cmap, beam));
         }
         StepShape sd{};
         sd.prefill = false;
-        sd.rows = rows;
+        sd.rows = arows;
         sd.beam = beam;
         sd.L = pos + 1;
         sd.anc = greedy ? nullptr : bs.anc;
         sd.anc_stride = ctx;
+        sd.cmap = cmap;
         CAPDEC_TRY(gpt2_body(c, sd, kv));
-        CAPDEC_TRY(lm_head_select(c, c->h.as<float>(), d, rows, k, inv_temp));
+        CAPDEC_TRY(lm_head_select(c, c->h.as<float>(), d, arows, k, inv_temp));
         ProfScope ps(c, F_SELECT);
         if (greedy) {
-            CAPDEC_TRY(launch_greedy_step(c->stream, c->topi.as<int>(), rows, i, T, stop_id, alt_stop_id, ids, lens,
-                                          c->done.as<uint8_t>(), c->next_tok.as<int>(), c->alive.as<int>()));
+            CAPDEC_TRY(launch_greedy_step(c->stream, c->topi.as<int>(), arows, i, T, stop_id, alt_stop_id, ids, lens,
+                                          c->done.as<uint8_t>(), c->next_tok.as<int>(), c->alive.as<int>(), cmap));
         } else {
-            CAPDEC_TRY(launch_beam_step(c->stream, bs, c->lse.as<float>(), c->topv.as<float>(), c->topi.as<int>(), nc,
-                                        beam, k, T, ctx, i, pos, g.vocab, stop_id));
+            CAPDEC_TRY(launch_beam_step(c->stream, bs, c->lse.as<float>(), c->topv.as<float>(), c->topi.as<int>(), na,
+                                        beam, k, T, ctx, i, pos, g.vocab, stop_id, cmap));
         }
     }
     if (!greedy) {
@@ -561,6 +582,9 @@ static int decode_common(capdec_ctx *c, const float *prefix, int n, int P, int b
     CAPDEC_CHECK(beam >= 1 && beam <= 8, "decode: beam size must be in 1..8");
     CAPDEC_CHECK(c->gpt.d / c->gpt.n_head == 64, "decode: head_dim must be 64");
     CAPDEC_HIP(hipSetDevice(c->device));
+    c->stat_steps = n > 0 ? 1 : 0;
+    c->stat_compactions = 0;
+    c->stat_row_steps = 0;
     if (n == 0) return 0;
     const int ctx = P + T - 1;
     const int chunk = chunk_captions(c, n, beam, ctx);
@@ -715,6 +739,7 @@ int capdec_create(int device_id, capdec_ctx **out) {
     c->device = device_id;
     if (const char *e = getenv("CAPDEC_X3_PACKA")) c->pack_a = atoi(e) != 0;
     if (const char *e = getenv("CAPDEC_X3_CHAIN")) c->pack_chain = atoi(e) != 0;
+    if (const char *e = getenv("CAPDEC_COMPACT")) c->compact = atoi(e) != 0;
     if (const char *e = getenv("CAPDEC_GEMM_MODE"))
         c->gemm_mode = std::string(e) == "f32" ? GEMM_F32 : std::string(e) == "bf16" ? GEMM_BF16 : GEMM_BF16X3;
     CAPDEC_HIP(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
@@ -739,7 +764,7 @@ void capdec_destroy(capdec_ctx *c) {
     DBuf *bufs[] = {&c->h, &c->x, &c->qkv, &c->att, &c->ff, &c->xl, &c->tmax, &c->tsum, &c->cval, &c->cidx,
                     &c->lse, &c->topv, &c->topi, &c->kc, &c->vc, &c->tokens, &c->scores, &c->seq, &c->stopped,
                     &c->done, &c->anc, &c->next_tok, &c->alive, &c->gids, &c->glens, &c->m_hid, &c->m_lin, &c->m_seq,
-                    &c->m_x, &c->m_qkv, &c->m_att, &c->m_ff, &c->t_idx, &c->t_patch, &c->t_pout, &c->xpk, &c->apk, &c->fpk};
+                    &c->m_x, &c->m_qkv, &c->m_att, &c->m_ff, &c->t_idx, &c->t_patch, &c->t_pout, &c->xpk, &c->apk, &c->fpk, &c->cmap};
     for (DBuf *b : bufs) b->release();
     for (auto &r : c->prof.recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
     for (auto e : c->prof.pool) (void)hipEventDestroy(e);
@@ -1087,6 +1112,14 @@ int capdec_gemm_f32(capdec_ctx *c, const float *a, int lda, const float *bt, int
         return launch_gemm_bf16x3p(c->stream, pa, pb, cc, ldc, M, N, K, e);
     }
     return gemm(c, a, lda, bt, ldb, cc, ldc, M, N, K, bias, act, resid, ldr, /*weight=*/cache);
+}
+
+int capdec_decode_stats(capdec_ctx *c, int *steps, int *compactions, long long *row_steps) {
+    CAPDEC_CHECK(c, "null context");
+    if (steps) *steps = c->stat_steps;
+    if (compactions) *compactions = c->stat_compactions;
+    if (row_steps) *row_steps = c->stat_row_steps;
+    return 0;
 }
 
 int capdec_timer_start(capdec_ctx *c) {

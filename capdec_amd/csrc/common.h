@@ -129,7 +129,7 @@ int launch_layernorm_packed(hipStream_t st, const float *x, int ldx, const float
 int launch_layernorm(hipStream_t st, const float *x, int ldx, const float *w, const float *b, float eps, float *y,
                      int ldy, int rows, int d);
 int launch_embed_tokens(hipStream_t st, const int *tok, const float *wte, const float *wpe_row, float *h, int rows,
-                        int d);
+                        int d, const int *cmap = nullptr, int beam = 1);
 int launch_embed_prefix(hipStream_t st, const float *prefix, const float *wpe, float *h, int n, int P, int pos0,
                         int d);
 int launch_gather_rows(hipStream_t st, const float *table, const int *ids, float *out, int rows, int d);
@@ -165,7 +165,10 @@ int launch_attn_prefill(hipStream_t st, const float *qkv, const KvCache &c, int 
 // decode: row r (caption = r / beam) at position L-1: its own k/v come from qkv (and are written to the cache
 // at phys row r), positions p < L-1 from phys row caption*beam + anc[r][p] (anc == nullptr -> r itself)
 int launch_attn_decode(hipStream_t st, const float *qkv, const KvCache &c, int layer, int rows, int beam, int L,
-                       const uint8_t *anc, int anc_stride, float *out, void *packed_out = nullptr);
+                       const uint8_t *anc, int anc_stride, float *out, void *packed_out = nullptr,
+                       const int *cmap = nullptr);
+// (cmap != nullptr: finished captions were compacted away -- activation row r belongs to caption cmap[r / beam];
+//  KV cache, ancestor table and beam state stay indexed by the original caption)
 // (packed_out != nullptr: the attention rows are written as the packed split-bf16 A operand of c_proj, K = d,
 //  instead of fp32 `out`)
 // TransformerMapper self-attention (no mask): q / k / v rows of n*seq tokens (row strides ldq, ldkv), head-major
@@ -188,10 +191,14 @@ struct BeamState {
 int launch_beam_init(hipStream_t st, const BeamState &s, const float *lse, const float *top_val, const int *top_idx,
                      int ncap, int beam, int k, int T, int ctx, int P, int stop_id);
 int launch_beam_step(hipStream_t st, const BeamState &s, const float *lse, const float *top_val, const int *top_idx,
-                     int ncap, int beam, int k, int T, int ctx, int step, int pos_new, int vocab, int stop_id);
+                     int ncap, int beam, int k, int T, int ctx, int step, int pos_new, int vocab, int stop_id,
+                     const int *cmap = nullptr);
 int launch_beam_finalize(hipStream_t st, const BeamState &s, int ncap, int beam, int T, int *ids, int *lens,
                          float *scores, int *order);
 int launch_greedy_step(hipStream_t st, const int *top_idx, int rows, int step, int T, int stop_id, int alt_stop_id,
-                       int *ids, int *lens, uint8_t *done, int *next_tok, int *alive_count);
+                       int *ids, int *lens, uint8_t *done, int *next_tok, int *alive_count,
+                       const int *cmap = nullptr);
+// cmap[0..count) = indices of the captions with done[c] == 0, ascending; *count = how many (one block)
+int launch_compact_alive(hipStream_t st, const uint8_t *done, int ncap, int *cmap, int *count);
 
 }  // namespace capdec

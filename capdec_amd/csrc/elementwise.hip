@@ -128,21 +128,24 @@ int launch_layernorm_packed(hipStream_t st, const float *x, int ldx, const float
 
 // ---------------------------------------------------------------------------- embeddings
 // h[row] = wte[tok[row]] + wpe_row   (all rows of a decode step share one position)
+// (cmap: compact activation row -> the original caption whose token it carries, see launch_attn_decode)
 __global__ void embed_tokens_kernel(const int *__restrict__ tok, const float *__restrict__ wte,
-                                    const float *__restrict__ wpe_row, float *__restrict__ h, int rows, int nv) {
+                                    const float *__restrict__ wpe_row, float *__restrict__ h, int rows, int nv,
+                                    const int *__restrict__ cmap, int beam) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= rows * nv) return;
     const int row = i / nv, c = i - row * nv;
-    const float4 a = reinterpret_cast<const float4 *>(wte + (size_t)tok[row] * nv * 4)[c];
+    const int srow = cmap ? cmap[row / beam] * beam + row % beam : row;
+    const float4 a = reinterpret_cast<const float4 *>(wte + (size_t)tok[srow] * nv * 4)[c];
     const float4 p = reinterpret_cast<const float4 *>(wpe_row)[c];
     reinterpret_cast<float4 *>(h)[i] = make_float4(a.x + p.x, a.y + p.y, a.z + p.z, a.w + p.w);
 }
 int launch_embed_tokens(hipStream_t st, const int *tok, const float *wte, const float *wpe_row, float *h, int rows,
-                        int d) {
+                        int d, const int *cmap, int beam) {
     if (rows <= 0) return 0;
     const int n = rows * (d / 4);
     hipLaunchKernelGGL(embed_tokens_kernel, dim3((n + 255) / 256), dim3(256), 0, st, tok, wte, wpe_row, h, rows,
-                       d / 4);
+                       d / 4, cmap, beam);
     CAPDEC_HIP(hipGetLastError());
     return 0;
 }

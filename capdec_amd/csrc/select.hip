@@ -95,10 +95,11 @@ int launch_topk_merge(hipStream_t st, const float *tile_max, const float *tile_s
 __global__ void greedy_step_kernel(const int *__restrict__ top_idx, int rows, int step, int T, int stop_id,
                                    int alt_stop_id, int *__restrict__ ids, int *__restrict__ lens,
                                    uint8_t *__restrict__ done, int *__restrict__ next_tok,
-                                   int *__restrict__ alive_count) {
-    const int row = blockIdx.x * blockDim.x + threadIdx.x;
-    if (row >= rows) return;
-    const int tok = top_idx[row];
+                                   int *__restrict__ alive_count, const int *__restrict__ cmap) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;       // activation row (compact)
+    if (r >= rows) return;
+    const int row = cmap ? cmap[r] : r;                        // caption
+    const int tok = top_idx[r];
     next_tok[row] = tok;
     if (done[row]) return;
     ids[(size_t)row * T + step] = tok;
@@ -108,10 +109,10 @@ __global__ void greedy_step_kernel(const int *__restrict__ top_idx, int rows, in
 }
 
 int launch_greedy_step(hipStream_t st, const int *top_idx, int rows, int step, int T, int stop_id, int alt_stop_id,
-                       int *ids, int *lens, uint8_t *done, int *next_tok, int *alive_count) {
+                       int *ids, int *lens, uint8_t *done, int *next_tok, int *alive_count, const int *cmap) {
     if (rows <= 0) return 0;
     hipLaunchKernelGGL(greedy_step_kernel, dim3((rows + 255) / 256), dim3(256), 0, st, top_idx, rows, step, T,
-                       stop_id, alt_stop_id, ids, lens, done, next_tok, alive_count);
+                       stop_id, alt_stop_id, ids, lens, done, next_tok, alive_count, cmap);
     CAPDEC_HIP(hipGetLastError());
     return 0;
 }
@@ -160,15 +161,17 @@ __global__ __launch_bounds__(64) void beam_step_kernel(BeamState s, const float 
                                                        const float *__restrict__ top_val,
                                                        const int *__restrict__ top_idx, int ncap, int beam, int k,
                                                        int T, int ctx, int step, int pos_cur, int vocab,
-                                                       int stop_id) {
+                                                       int stop_id, const int *__restrict__ cmap) {
     __shared__ int tok_old[SEL_BEAM_MAX * SEL_T_MAX];
     __shared__ uint8_t anc_old[SEL_BEAM_MAX * SEL_CTX_MAX];
     __shared__ int w_src[SEL_BEAM_MAX], w_tok[SEL_BEAM_MAX];
     __shared__ float w_key[SEL_BEAM_MAX], seq_new[SEL_BEAM_MAX];
     __shared__ uint8_t st_old[SEL_BEAM_MAX];
-    const int cap = blockIdx.x, lane = threadIdx.x;
+    const int lane = threadIdx.x;
+    const int cap = cmap ? cmap[blockIdx.x] : blockIdx.x;       // state (tokens, scores, anc ...) by original caption
     if (s.done[cap]) return;
     const size_t cb0 = (size_t)cap * beam;
+    const size_t ab0 = (size_t)blockIdx.x * beam;               // lm_head outputs by (compact) activation row
     // stage the state that is permuted in place
     for (int i = lane; i < beam * step; i += 64) {
         const int b = i / step, t = i - b * step;
@@ -190,12 +193,12 @@ __global__ __launch_bounds__(64) void beam_step_kernel(BeamState s, const float 
     if (lane < beam * k) {
         cb = lane / k;
         const int j = lane - cb * k;
-        const size_t row = cb0 + cb;
+        const size_t row = cb0 + cb, arow = ab0 + cb;
         if (st_old[cb]) {
             if (j == 0) { ctok = 0; key = (s.scores[row] + 0.0f) / seq_new[cb]; }
         } else {
-            ctok = top_idx[row * k + j];
-            const float logp = top_val[row * k + j] - lse[row];
+            ctok = top_idx[arow * k + j];
+            const float logp = top_val[arow * k + j] - lse[arow];
             key = (s.scores[row] + logp) / seq_new[cb];
         }
         if (key > -INFINITY || (st_old[cb] && j == 0)) flat = cb * vocab + ctok;
@@ -243,13 +246,14 @@ __global__ __launch_bounds__(64) void beam_step_kernel(BeamState s, const float 
 }
 
 int launch_beam_step(hipStream_t st, const BeamState &s, const float *lse, const float *top_val, const int *top_idx,
-                     int ncap, int beam, int k, int T, int ctx, int step, int pos_cur, int vocab, int stop_id) {
+                     int ncap, int beam, int k, int T, int ctx, int step, int pos_cur, int vocab, int stop_id,
+                     const int *cmap) {
     CAPDEC_CHECK(beam * k <= 64, "beam: beam*k must fit one wavefront");
     CAPDEC_CHECK(T <= SEL_T_MAX && ctx <= SEL_CTX_MAX, "beam: entry_length / context too long");
     CAPDEC_CHECK((long long)beam * vocab < 0x7fffffffLL, "beam: beam*vocab overflows int");
     if (ncap <= 0) return 0;
     hipLaunchKernelGGL(beam_step_kernel, dim3(ncap), dim3(64), 0, st, s, lse, top_val, top_idx, ncap, beam, k, T, ctx,
-                       step, pos_cur, vocab, stop_id);
+                       step, pos_cur, vocab, stop_id, cmap);
     CAPDEC_HIP(hipGetLastError());
     return 0;
 }
@@ -284,6 +288,43 @@ int launch_beam_finalize(hipStream_t st, const BeamState &s, int ncap, int beam,
                          float *scores, int *order) {
     if (ncap <= 0) return 0;
     hipLaunchKernelGGL(beam_finalize_kernel, dim3(ncap), dim3(64), 0, st, s, ncap, beam, T, ids, lens, scores, order);
+    CAPDEC_HIP(hipGetLastError());
+    return 0;
+}
+
+// ---- finished-caption compaction: the captions that still generate, in ascending order.  One block; every
+// 1024-caption slab is ranked with a wavefront ballot + a 16-entry scan of the wavefront totals.
+__global__ __launch_bounds__(1024) void compact_alive_kernel(const uint8_t *__restrict__ done, int ncap,
+                                                             int *__restrict__ cmap, int *__restrict__ count) {
+    __shared__ int wtot[16];
+    __shared__ int base;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    if (t == 0) base = 0;
+    __syncthreads();
+    for (int c0 = 0; c0 < ncap; c0 += 1024) {
+        const int c = c0 + t;
+        const bool alive = c < ncap && !done[c];
+        const unsigned long long m = __ballot(alive);
+        const int before = __popcll(m & ((1ull << lane) - 1ull));
+        if (lane == 0) wtot[wave] = __popcll(m);
+        __syncthreads();
+        int off = base;
+        for (int w = 0; w < wave; ++w) off += wtot[w];
+        if (alive) cmap[off + before] = c;
+        __syncthreads();
+        if (t == 0) {
+            int tot = 0;
+            for (int w = 0; w < 16; ++w) tot += wtot[w];
+            base += tot;
+        }
+        __syncthreads();
+    }
+    if (t == 0) *count = base;
+}
+
+int launch_compact_alive(hipStream_t st, const uint8_t *done, int ncap, int *cmap, int *count) {
+    if (ncap <= 0) return 0;
+    hipLaunchKernelGGL(compact_alive_kernel, dim3(1), dim3(1024), 0, st, done, ncap, cmap, count);
     CAPDEC_HIP(hipGetLastError());
     return 0;
 }

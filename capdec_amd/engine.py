@@ -303,6 +303,12 @@ class Engine:
                                           order.data_ptr()), "capdec_decode_beam")
         return ids, lens, scores, order
 
+    def decode_stats(self) -> Dict[str, int]:
+        """steps run / compactions / activation row-steps of the last decode call"""
+        a, b, r = C.c_int(0), C.c_int(0), C.c_longlong(0)
+        check(self.lib.capdec_decode_stats(self._h, C.byref(a), C.byref(b), C.byref(r)), "decode_stats")
+        return dict(steps=a.value, compactions=b.value, row_steps=r.value)
+
     # ------------------------------------------------------------------ hooks
     def gemm(self, a: torch.Tensor, bt: torch.Tensor, bias=None, resid=None, act: int = 0) -> torch.Tensor:
         a, bt = self._dev(a), self._dev(bt)

@@ -207,6 +207,10 @@ int capdec_decode_greedy(capdec_ctx *ctx, const float *d_prefix, int n, int P, i
 int capdec_decode_beam(capdec_ctx *ctx, const float *d_prefix, int n, int P, int beam, int stop_id,
                        int entry_length, float temperature, int32_t *d_ids, int32_t *d_lens,
                        float *d_scores, int32_t *d_order);
+/* what the last decode call did: decode steps run (<= entry_length: the loop ends when every caption has stopped),
+ * how many times finished captions were compacted out of the batch, and the activation rows pushed through the
+ * GPT-2 body after the prefill (n * beam * (steps - 1) without early stopping).  CAPDEC_COMPACT=0 disables compaction. */
+int capdec_decode_stats(capdec_ctx *ctx, int *steps, int *compactions, long long *row_steps);
 
 /* ---- measurement / test hooks -------------------------------------------------------- */
 /* C[M,N] = act(A[M,K] . Bt[N,K]^T + bias[N]) + resid[M,N]; bias / resid may be NULL.

@@ -399,6 +399,49 @@ def test_batched_decode_vs_oracle_and_chunking():
             np.testing.assert_array_equal(i.cpu().numpy()[r], tok_o[r][od[r]].numpy())
 
 
+def test_finished_caption_compaction(monkeypatch):
+    """captions that stop early leave the batch at the poll points (activation rows are compacted, KV / beam state stay
+    in place): with a stop id that fires at staggered steps the results still equal the oracle token for token, the
+    decode really ran on fewer rows, and CAPDEC_COMPACT=0 gives the same answer"""
+    from capdec_amd.engine import Engine
+    from oracle import capdec_oracle as O
+    dims, stop, T, n = synth.GPT2_TINY, 1344, 34, 48
+    sd = synth.hot_state_dict(7, "mlp", 512, 10, dims=dims)
+    x = synth.synthetic_clip_embeddings(n, 512, seed=21)
+    pe = O.clip_project(x, sd, "mlp", 10).reshape(n, 10, -1)
+    gi, gl = O.greedy_cached(sd, pe, stop_id=stop, entry_length=T, alt_stop_id=-1, n_head=dims.n_head)
+    assert int((gl < T - 8).sum()) >= 20 and int((gl == T).sum()) >= 5           # staggered finishing, some never stop
+    bt, bq, bs_ = O.beam_cached(sd, pe, 5, stop, T, n_head=dims.n_head)
+    order = O.beam_output_order(bs_)
+    outs = {}
+    for compact in ("1", "0"):
+        monkeypatch.setenv("CAPDEC_COMPACT", compact)
+        e = Engine(0)
+        e.load_gpt2(sd)
+        ids, lens = e.decode_greedy(pe, stop, T, alt_stop_id=-1)
+        st = e.decode_stats()
+        np.testing.assert_array_equal(ids.cpu().numpy(), gi.numpy())
+        np.testing.assert_array_equal(lens.cpu().numpy(), gl.numpy())
+        if compact == "1":
+            assert st["compactions"] >= 2 and st["row_steps"] < 0.8 * n * (st["steps"] - 1), st
+        else:
+            assert st["compactions"] == 0 and st["row_steps"] == n * (st["steps"] - 1), st
+        i, l, s_, o = e.decode_beam(pe, stop, 5, T)
+        st = e.decode_stats()
+        i, l, s_, o = (t.cpu().numpy() for t in (i, l, s_, o))
+        np.testing.assert_array_equal(o, order.numpy())
+        for r in range(n):
+            np.testing.assert_array_equal(i[r], bt[r][order[r]].numpy())
+            np.testing.assert_array_equal(l[r], bq[r][order[r]].numpy())
+            np.testing.assert_allclose(s_[r], bs_[r][order[r]].numpy(), atol=1e-4)
+        if compact == "1":
+            assert st["compactions"] >= 1 and st["row_steps"] < 5 * n * (st["steps"] - 1), st
+        outs[compact] = (ids.cpu().numpy(), i, s_)
+        e.close()
+    np.testing.assert_array_equal(outs["1"][1], outs["0"][1])
+    np.testing.assert_array_equal(outs["1"][2], outs["0"][2])          # scores bit-identical with and without compaction
+
+
 def test_decode_edge_cases():
     from capdec_amd import gpt2_prefix_eval as E
     from capdec_amd._capi import CapdecError
