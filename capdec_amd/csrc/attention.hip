@@ -178,13 +178,48 @@ __global__ __launch_bounds__(256, 4) void attn_decode_beams_kernel(const float *
     const float *kbase = kc + ((size_t)srow0 * heads + head) * hstride + sub * 4;
     const float *vbase = vc + ((size_t)srow0 * heads + head) * hstride + sub * 4;
     const size_t slot_stride = (size_t)heads * hstride;
-    // ---- scores over the cached positions: two positions per 16-lane group per iteration.  All 2 x BEAM loads of an
-    // iteration are issued back to back (no branch, no wait between them): a beam whose slot equals the previous
-    // beam's re-reads a line that is already hot in L1 (the wavefront's own q row) and takes the previous beam's
-    // registers instead, so HBM traffic stays one load per DISTINCT consecutive slot while the wavefront keeps
-    // 2 x BEAM requests in flight (the kernel is latency-bound: a dependent load -> use chain per beam was 2x slower).
-    const float *dummy = qkv + (size_t)row0 * 3 * d + head * 64 + sub * 4;
-    for (int p0 = 0; p0 < Lpast; p0 += 8) {
+    // The beams of a caption are paths of one tree: if they all sit on the same node at position p they share every
+    // earlier position too, so "all beams read the same slot" holds exactly on a PREFIX [0, nconv) of the history
+    // (the CLIP prefix and the converged part of the generated text).  Phase A streams that prefix without any
+    // per-beam slot logic, four positions per 16-lane group per iteration (4 KB per wavefront in flight); phase B
+    // handles the diverged tail.
+    int nconv = Lpast;
+    for (int base = 0; base < Lpast; base += 64) {
+        const int p = base + lane;
+        bool differs = false;
+        if (p < Lpast) {
+#pragma unroll
+            for (int b = 1; b < BEAM; ++b) differs = differs || sl[b * L + p] != sl[p];
+        }
+        const unsigned long long m = __ballot(differs);
+        if (m) { nconv = base + __ffsll((long long)m) - 1; break; }
+    }
+    const float *dummy = qkv + (size_t)row0 * 3 * d + head * 64 + sub * 4;   // an L1-hot line for masked-off loads
+    // ---- scores, phase A
+    for (int p0 = 0; p0 < nconv; p0 += 16) {
+        int pp[4];
+        float4 kk[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            pp[j] = p0 + 4 * j + grp;
+            const bool v = pp[j] < nconv;
+            const int s0 = v ? sl[pp[j]] : 0;
+            kk[j] = *reinterpret_cast<const float4 *>(v ? kbase + s0 * slot_stride + (size_t)pp[j] * 64 : dummy);
+        }
+#pragma unroll
+        for (int b = 0; b < BEAM; ++b) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float sv = group16_sum(dot4(q[b], kk[j]));
+                if (sub == 0 && pp[j] < nconv) sc[b * L + pp[j]] = sv;
+            }
+        }
+    }
+    // ---- scores, phase B: two positions per group per iteration.  All 2 x BEAM loads are issued back to back (no
+    // branch, no wait between them): a beam whose slot equals the previous beam's re-reads the L1-hot dummy line and
+    // takes the previous beam's registers, so HBM traffic stays one load per DISTINCT consecutive slot while the
+    // wavefront keeps 2 x BEAM requests in flight.
+    for (int p0 = nconv; p0 < Lpast; p0 += 8) {
         const int pa = p0 + grp, pb = p0 + 4 + grp;
         const bool va = pa < Lpast, vb = pb < Lpast;
         int sa[BEAM], sb[BEAM];
@@ -193,23 +228,6 @@ __global__ __launch_bounds__(256, 4) void attn_decode_beams_kernel(const float *
         for (int b = 0; b < BEAM; ++b) {
             sa[b] = va ? sl[b * L + pa] : 0;
             sb[b] = vb ? sl[b * L + pb] : 0;
-        }
-        bool same = true;
-#pragma unroll
-        for (int b = 1; b < BEAM; ++b) same = same && sa[b] == sa[0] && sb[b] == sb[0];
-        if (__all(same)) {   // wave-uniform: every beam reads the same slot at these 8 positions (prefix, converged history)
-            const float4 k0 = *reinterpret_cast<const float4 *>(va ? kbase + sa[0] * slot_stride + (size_t)pa * 64 : dummy);
-            const float4 k1 = *reinterpret_cast<const float4 *>(vb ? kbase + sb[0] * slot_stride + (size_t)pb * 64 : dummy);
-#pragma unroll
-            for (int b = 0; b < BEAM; ++b) {
-                const float s0 = group16_sum(dot4(q[b], k0));
-                const float s1 = group16_sum(dot4(q[b], k1));
-                if (sub == 0) {
-                    if (va) sc[b * L + pa] = s0;
-                    if (vb) sc[b * L + pb] = s1;
-                }
-            }
-            continue;
         }
 #pragma unroll
         for (int b = 0; b < BEAM; ++b) {
@@ -250,7 +268,28 @@ __global__ __launch_bounds__(256, 4) void attn_decode_beams_kernel(const float *
     float4 acc[BEAM];
 #pragma unroll
     for (int b = 0; b < BEAM; ++b) acc[b] = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int p0 = 0; p0 < Lpast; p0 += 8) {
+    // phase A: converged prefix, four positions per group per iteration
+    for (int p0 = 0; p0 < nconv; p0 += 16) {
+        int pp[4];
+        float4 xx[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            pp[j] = p0 + 4 * j + grp;
+            const bool v = pp[j] < nconv;
+            const int s0 = v ? sl[pp[j]] : 0;
+            xx[j] = *reinterpret_cast<const float4 *>(v ? vbase + s0 * slot_stride + (size_t)pp[j] * 64 : dummy);
+        }
+#pragma unroll
+        for (int b = 0; b < BEAM; ++b) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float w = pp[j] < nconv ? sc[b * L + pp[j]] : 0.f;
+                acc[b].x += w * xx[j].x; acc[b].y += w * xx[j].y; acc[b].z += w * xx[j].z; acc[b].w += w * xx[j].w;
+            }
+        }
+    }
+    // phase B: diverged tail
+    for (int p0 = nconv; p0 < Lpast; p0 += 8) {
         const int pa = p0 + grp, pb = p0 + 4 + grp;
         const bool va = pa < Lpast, vb = pb < Lpast;
         int sa[BEAM], sb[BEAM];
@@ -259,20 +298,6 @@ __global__ __launch_bounds__(256, 4) void attn_decode_beams_kernel(const float *
         for (int b = 0; b < BEAM; ++b) {
             sa[b] = va ? sl[b * L + pa] : 0;
             sb[b] = vb ? sl[b * L + pb] : 0;
-        }
-        bool same = true;
-#pragma unroll
-        for (int b = 1; b < BEAM; ++b) same = same && sa[b] == sa[0] && sb[b] == sb[0];
-        if (__all(same)) {
-            const float4 x0 = *reinterpret_cast<const float4 *>(va ? vbase + sa[0] * slot_stride + (size_t)pa * 64 : dummy);
-            const float4 x1 = *reinterpret_cast<const float4 *>(vb ? vbase + sb[0] * slot_stride + (size_t)pb * 64 : dummy);
-#pragma unroll
-            for (int b = 0; b < BEAM; ++b) {
-                const float wa = va ? sc[b * L + pa] : 0.f, wb = vb ? sc[b * L + pb] : 0.f;
-                acc[b].x += wa * x0.x + wb * x1.x; acc[b].y += wa * x0.y + wb * x1.y;
-                acc[b].z += wa * x0.z + wb * x1.z; acc[b].w += wa * x0.w + wb * x1.w;
-            }
-            continue;
         }
 #pragma unroll
         for (int b = 0; b < BEAM; ++b) {
