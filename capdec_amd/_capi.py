@@ -100,6 +100,8 @@ SIGNATURES = {
                                      _VP, _VP]),
     "capdec_gemm_f32": (C.c_int, [_VP, _VP, C.c_int, _VP, C.c_int, _VP, C.c_int, C.c_int, C.c_int, C.c_int, _VP,
                                   _VP, C.c_int, C.c_int]),
+    "capdec_preprocess_images": (C.c_int, [_VP, _VP, C.POINTER(C.c_int64), C.POINTER(C.c_int32), C.POINTER(C.c_int32),
+                                           C.c_int, C.c_int, C.c_int, c_float_p, c_float_p, _VP]),
     "capdec_decode_stats": (C.c_int, [_VP, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_longlong)]),
     "capdec_timer_start": (C.c_int, [_VP]),
     "capdec_timer_stop_ms": (C.c_int, [_VP, c_float_p]),

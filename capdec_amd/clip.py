@@ -26,6 +26,7 @@ class ClipModel:
         self.has_vision = "visual.conv1.weight" in sd
         self._engine.load_clip(sd, text=True, vision=self.has_vision)
         self.context_length = self._engine.clip_text["context_length"]
+        self.input_resolution = self._engine.clip_vision["image_size"] if self.has_vision else 224
         self.device = self._engine.device
 
     def eval(self):
@@ -49,7 +50,33 @@ def load(name_or_state_dict: Union[str, Dict[str, torch.Tensor]], device=0, jit:
         sd = obj.state_dict() if hasattr(obj, "state_dict") else obj
     else:
         sd = name_or_state_dict
-    return ClipModel(sd, device), preprocess_tensor
+    model = ClipModel(sd, device)
+    return model, Preprocess(model._engine, model.input_resolution)
+
+
+class Preprocess:
+    """The ``preprocess`` callable ``clip.load`` returns (reference predictions_runner.py:212
+    ``preprocess(image_raw).unsqueeze(0).to(device)``, embeddings_generator.py:72): Resize(n_px, BICUBIC) ->
+    CenterCrop(n_px) -> RGB -> ToTensor -> Normalize, bit-identical to the PIL / torchvision pipeline but computed by
+    the HIP kernels of ``preprocess.hip``.  Accepts a PIL image (anything with ``.convert``), a uint8 [H, W, 3] numpy
+    array or torch tensor; returns fp32 [3, n_px, n_px] on the device.  ``batch(images)`` does a whole list in one launch
+    pair -> [N, 3, n_px, n_px]; ``stretch=True`` is the reference's ``clip_transform_full`` (:116-122)."""
+
+    def __init__(self, engine: Engine, n_px: int = 224, stretch: bool = False):
+        self._engine, self.n_px, self.stretch = engine, int(n_px), bool(stretch)
+
+    @staticmethod
+    def _rgb(image):
+        if hasattr(image, "convert"):                      # PIL.Image: `lambda image: image.convert("RGB")`
+            import numpy as np
+            return np.asarray(image.convert("RGB"))
+        return image
+
+    def batch(self, images) -> torch.Tensor:
+        return self._engine.preprocess_images([self._rgb(im) for im in images], self.n_px, self.stretch)
+
+    def __call__(self, image) -> torch.Tensor:
+        return self.batch([image])[0]
 
 
 def preprocess_tensor(image: torch.Tensor) -> torch.Tensor:

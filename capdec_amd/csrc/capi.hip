@@ -119,7 +119,7 @@ struct capdec_ctx {
     DBuf h, x, qkv, att, ff, xl, tmax, tsum, cval, cidx, lse, topv, topi, kc, vc;
     DBuf tokens, scores, seq, stopped, done, anc, next_tok, alive, gids, glens, cmap;
     DBuf m_hid, m_lin, m_seq, m_x, m_qkv, m_att, m_ff;
-    DBuf t_idx, t_patch, t_pout;
+    DBuf t_idx, t_patch, t_pout, p_desc, p_inter;
     int *alive_host = nullptr;   // pinned
 };
 
@@ -764,7 +764,7 @@ void capdec_destroy(capdec_ctx *c) {
     DBuf *bufs[] = {&c->h, &c->x, &c->qkv, &c->att, &c->ff, &c->xl, &c->tmax, &c->tsum, &c->cval, &c->cidx,
                     &c->lse, &c->topv, &c->topi, &c->kc, &c->vc, &c->tokens, &c->scores, &c->seq, &c->stopped,
                     &c->done, &c->anc, &c->next_tok, &c->alive, &c->gids, &c->glens, &c->m_hid, &c->m_lin, &c->m_seq,
-                    &c->m_x, &c->m_qkv, &c->m_att, &c->m_ff, &c->t_idx, &c->t_patch, &c->t_pout, &c->xpk, &c->apk, &c->fpk, &c->cmap};
+                    &c->m_x, &c->m_qkv, &c->m_att, &c->m_ff, &c->t_idx, &c->t_patch, &c->t_pout, &c->xpk, &c->apk, &c->fpk, &c->cmap, &c->p_desc, &c->p_inter};
     for (DBuf *b : bufs) b->release();
     for (auto &r : c->prof.recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
     for (auto e : c->prof.pool) (void)hipEventDestroy(e);
@@ -1112,6 +1112,51 @@ int capdec_gemm_f32(capdec_ctx *c, const float *a, int lda, const float *bt, int
         return launch_gemm_bf16x3p(c->stream, pa, pb, cc, ldc, M, N, K, e);
     }
     return gemm(c, a, lda, bt, ldb, cc, ldc, M, N, K, bias, act, resid, ldr, /*weight=*/cache);
+}
+
+int capdec_preprocess_images(capdec_ctx *c, const uint8_t *d_rgb, const int64_t *offsets, const int32_t *heights,
+                             const int32_t *widths, int n, int n_px, int stretch, const float *mean, const float *stdv,
+                             float *d_out) {
+    CAPDEC_CHECK(c && (n == 0 || (d_rgb && offsets && heights && widths && mean && stdv && d_out)),
+                 "preprocess_images: null argument");
+    CAPDEC_CHECK(n >= 0 && n_px >= 1 && n_px <= 1024, "preprocess_images: bad sizes");
+    CAPDEC_HIP(hipSetDevice(c->device));
+    if (n == 0) return 0;
+    std::vector<ImageDesc> desc((size_t)n);
+    long long ioff = 0;
+    int max_h = 0;
+    for (int i = 0; i < n; ++i) {
+        const int H = heights[i], W = widths[i];
+        CAPDEC_CHECK(H >= 1 && W >= 1 && H <= 16384 && W <= 16384, "preprocess_images: image size out of range");
+        ImageDesc &d = desc[(size_t)i];
+        d.off = offsets[i];
+        d.ioff = ioff;
+        d.H = H;
+        d.W = W;
+        if (stretch) {               // clip_transform_full (predictions_runner.py:116-122): Resize((n_px, n_px)), no crop
+            d.rh = d.rw = n_px;
+            d.top = d.left = 0;
+        } else {                     // torchvision Resize(n_px): shorter side -> n_px, longer = int(n_px * long / short);
+            if (W <= H) {            // CenterCrop: origin int(round((size - n_px) / 2.0)), round-half-even like Python
+                d.rw = n_px;
+                d.rh = (int)((double)((long long)n_px * H) / (double)W);
+            } else {
+                d.rh = n_px;
+                d.rw = (int)((double)((long long)n_px * W) / (double)H);
+            }
+            d.top = (int)nearbyint((d.rh - n_px) / 2.0);
+            d.left = (int)nearbyint((d.rw - n_px) / 2.0);
+        }
+        ioff += (long long)H * n_px * 3;
+        max_h = std::max(max_h, H);
+    }
+    CAPDEC_TRY(c->p_desc.ensure(desc.size() * sizeof(ImageDesc)));
+    CAPDEC_TRY(c->p_inter.ensure((size_t)ioff));
+    CAPDEC_HIP(hipMemcpyAsync(c->p_desc.p, desc.data(), desc.size() * sizeof(ImageDesc), hipMemcpyHostToDevice, c->stream));
+    CAPDEC_HIP(hipStreamSynchronize(c->stream));      // `desc` is pageable host memory about to go out of scope
+    ProfScope ps(c, F_OTHER);
+    return launch_preprocess(c->stream, d_rgb, c->p_desc.as<ImageDesc>(), n, max_h, n_px, c->p_inter.as<uint8_t>(),
+                             d_out, mean, stdv);
 }
 
 int capdec_decode_stats(capdec_ctx *c, int *steps, int *compactions, long long *row_steps) {

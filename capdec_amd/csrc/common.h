@@ -201,4 +201,15 @@ int launch_greedy_step(hipStream_t st, const int *top_idx, int rows, int step, i
 // cmap[0..count) = indices of the captions with done[c] == 0, ascending; *count = how many (one block)
 int launch_compact_alive(hipStream_t st, const uint8_t *done, int ncap, int *cmap, int *count);
 
+// preprocess.hip: PIL-exact bicubic resize + centre crop + ToTensor + Normalize of a batch of uint8 RGB images
+struct ImageDesc {
+    long long off;     // byte offset of the image (HWC uint8) in the concatenated pixel buffer
+    long long ioff;    // byte offset of its [H][n_px][3] intermediate (after the horizontal pass)
+    int H, W;          // input size
+    int rh, rw;        // size after Resize
+    int top, left;     // crop origin inside the resized image
+};
+int launch_preprocess(hipStream_t st, const uint8_t *rgb, const ImageDesc *desc, int n, int max_h, int n_px,
+                      uint8_t *inter, float *out, const float *mean, const float *stdv);
+
 }  // namespace capdec

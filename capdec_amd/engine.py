@@ -303,6 +303,36 @@ class Engine:
                                           order.data_ptr()), "capdec_decode_beam")
         return ids, lens, scores, order
 
+    # ------------------------------------------------------------------ image preprocessing
+    def preprocess_images(self, images, n_px: int = 224, stretch: bool = False,
+                          mean=(0.48145466, 0.4578275, 0.40821073), std=(0.26862954, 0.26130258, 0.27577711)) -> torch.Tensor:
+        """uint8 RGB images (list of [H, W, 3] numpy arrays / torch tensors, any sizes) -> fp32 [n, 3, n_px, n_px] on the
+        device: PIL-exact bicubic Resize(n_px) + CenterCrop(n_px) (or stretch to n_px x n_px) + ToTensor + Normalize
+        (reference predictions_runner.py:116-122,212; embeddings_generator.py:72), one HIP launch pair per batch."""
+        arrs = []
+        for im in images:
+            a = im.detach().cpu().numpy() if isinstance(im, torch.Tensor) else np.asarray(im)
+            if a.ndim != 3 or a.shape[2] != 3 or a.dtype != np.uint8:
+                raise CapdecError(f"preprocess_images: expected uint8 [H, W, 3], got {a.dtype} {a.shape}")
+            arrs.append(np.ascontiguousarray(a))
+        n = len(arrs)
+        out = torch.empty(n, 3, n_px, n_px, device=self.device, dtype=torch.float32)
+        if n == 0:
+            return out
+        sizes = np.array([a.size for a in arrs], dtype=np.int64)
+        offs = np.concatenate([[0], np.cumsum(sizes)[:-1]]).astype(np.int64)
+        flat = torch.from_numpy(np.concatenate([a.reshape(-1) for a in arrs])).to(self.device)
+        hs = np.array([a.shape[0] for a in arrs], dtype=np.int32)
+        ws = np.array([a.shape[1] for a in arrs], dtype=np.int32)
+        m = np.asarray(mean, dtype=np.float32)
+        sd = np.asarray(std, dtype=np.float32)
+        self._sync_stream()
+        check(self.lib.capdec_preprocess_images(
+            self._h, flat.data_ptr(), offs.ctypes.data_as(C.POINTER(C.c_int64)), hs.ctypes.data_as(C.POINTER(C.c_int32)),
+            ws.ctypes.data_as(C.POINTER(C.c_int32)), n, int(n_px), int(bool(stretch)), _fp(m), _fp(sd), out.data_ptr()),
+            "capdec_preprocess_images")
+        return out
+
     def decode_stats(self) -> Dict[str, int]:
         """steps run / compactions / activation row-steps of the last decode call"""
         a, b, r = C.c_int(0), C.c_int(0), C.c_longlong(0)

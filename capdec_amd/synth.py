@@ -241,3 +241,26 @@ def synthetic_images(n: int, seed: int = 4, size: int = 224) -> torch.Tensor:
     """fp32 [n, 3, size, size] ~ N(0,1): stands for already-preprocessed (normalised) pixels."""
     g = torch.Generator(device="cpu").manual_seed(seed)
     return torch.randn(n, 3, size, size, generator=g, dtype=torch.float32)
+
+
+def synthetic_photo(h: int, w: int, seed: int) -> "np.ndarray":
+    """uint8 RGB test image [h, w, 3]: smooth colour gradients + a few hard edges + noise (exercises both the
+    antialiasing taps and the clipping of the bicubic resampler).  numpy RandomState: stable across versions."""
+    import numpy as np
+    rs = np.random.RandomState(seed)
+    yy, xx = np.mgrid[0:h, 0:w].astype(np.float64)
+    img = np.empty((h, w, 3), np.float64)
+    for c in range(3):
+        fx, fy, ph = rs.uniform(0.5, 4.0), rs.uniform(0.5, 4.0), rs.uniform(0, 6.28)
+        img[..., c] = 127.5 + 110.0 * np.sin(fx * xx / max(w, 1) * 6.28 + fy * yy / max(h, 1) * 6.28 + ph)
+    for _ in range(4):                                   # rectangles with saturated colours (hard edges)
+        y0, x0 = rs.randint(0, h), rs.randint(0, w)
+        y1, x1 = min(h, y0 + rs.randint(1, max(2, h // 3))), min(w, x0 + rs.randint(1, max(2, w // 3)))
+        img[y0:y1, x0:x1] = rs.choice([0.0, 255.0], size=3)
+    img += rs.normal(0.0, 12.0, size=img.shape)
+    return np.clip(np.rint(img), 0, 255).astype(np.uint8)
+
+
+#: (H, W) of the preprocessing fixtures: landscape / portrait / square / tiny (upscale) / extreme aspect / odd sizes
+PREPROCESS_SIZES = [(480, 640), (640, 480), (224, 224), (37, 53), (1000, 130), (333, 500), (500, 333), (17, 17),
+                    (225, 223), (768, 1024)]

@@ -207,6 +207,15 @@ int capdec_decode_greedy(capdec_ctx *ctx, const float *d_prefix, int n, int P, i
 int capdec_decode_beam(capdec_ctx *ctx, const float *d_prefix, int n, int P, int beam, int stop_id,
                        int entry_length, float temperature, int32_t *d_ids, int32_t *d_lens,
                        float *d_scores, int32_t *d_order);
+/* Image preprocessing in front of capdec_clip_encode_image: the `preprocess` transform clip.load returns
+ * (reference predictions_runner.py:212, embeddings_generator.py:72) = Resize(n_px, BICUBIC) -> CenterCrop(n_px) ->
+ * ToTensor -> Normalize(mean, std); stretch != 0 = clip_transform_full (predictions_runner.py:116-122): Resize((n_px,
+ * n_px)), no crop.  Bit-identical to PIL's 8-bit bicubic resampler + torch fp32 ToTensor / Normalize.
+ * d_rgb: device buffer of concatenated uint8 HWC RGB images; offsets / heights / widths: HOST arrays [n] (byte offset
+ * of image i in d_rgb and its size); mean / stdv: HOST float[3]; d_out: device fp32 [n, 3, n_px, n_px]. */
+int capdec_preprocess_images(capdec_ctx *ctx, const uint8_t *d_rgb, const int64_t *offsets, const int32_t *heights,
+                             const int32_t *widths, int n, int n_px, int stretch, const float *mean,
+                             const float *stdv, float *d_out);
 /* what the last decode call did: decode steps run (<= entry_length: the loop ends when every caption has stopped),
  * how many times finished captions were compacted out of the batch, and the activation rows pushed through the
  * GPT-2 body after the prefill (n * beam * (steps - 1) without early stopping).  CAPDEC_COMPACT=0 disables compaction. */

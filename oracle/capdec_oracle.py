@@ -443,3 +443,107 @@ def clip_encode_image(image: Tensor, sd: SD, n_head: int = 12) -> Tensor:
     x = _clip_resblocks(x, sd, "visual.", n_head, causal=False)
     x = F.layer_norm(x[:, 0, :], (d,), sd["visual.ln_post.weight"], sd["visual.ln_post.bias"], 1e-5)
     return x @ sd["visual.proj"]
+
+
+# ----------------------------------------------------------------------------------------
+# Image preprocessing in front of encode_image: the `preprocess` callable that
+# `clip.load` returns and the reference applies to every PIL image (predictions_runner.py:212,
+# embeddings_generator.py:72) = torchvision Compose[Resize(n_px, BICUBIC), CenterCrop(n_px),
+# convert("RGB"), ToTensor(), Normalize(mean, std)]; `clip_transform_full` (predictions_runner.py:116-122)
+# is the stretch-to-square variant.  torchvision is not installed here; on PIL images its Resize is
+# `Image.resize(size, BICUBIC)`, restated below from Pillow's Resample.c (8-bit path: separable two-pass
+# convolution, antialiased support = 2 * max(scale, 1), coefficients in 22-bit fixed point, horizontal
+# pass first, uint8 between the passes).  Pinned against PIL itself (tests/golden/preprocess.npz).
+# ----------------------------------------------------------------------------------------
+CLIP_MEAN = (0.48145466, 0.4578275, 0.40821073)      # predictions_runner.py:121
+CLIP_STD = (0.26862954, 0.26130258, 0.27577711)
+_PIL_PRECISION_BITS = 32 - 8 - 2
+
+
+def _bicubic_filter(x: float) -> float:
+    a = -0.5
+    if x < 0.0:
+        x = -x
+    if x < 1.0:
+        return ((a + 2.0) * x - (a + 3.0)) * x * x + 1
+    if x < 2.0:
+        return (((x - 5) * x + 8) * x - 4) * a
+    return 0.0
+
+
+def pil_resample_coeffs(in_size: int, out_size: int):
+    """Pillow precompute_coeffs + normalize_coeffs_8bpc for the bicubic filter over the whole axis:
+    per output index (xmin, [int coefficients])."""
+    scale = in_size / out_size
+    filterscale = max(scale, 1.0)
+    support = 2.0 * filterscale
+    ss = 1.0 / filterscale
+    out = []
+    for xx in range(out_size):
+        center = (xx + 0.5) * scale
+        xmin = max(int(center - support + 0.5), 0)
+        xmax = min(int(center + support + 0.5), in_size) - xmin
+        w = [_bicubic_filter((x + xmin - center + 0.5) * ss) for x in range(xmax)]
+        ww = 0.0
+        for v in w:
+            ww += v
+        if ww != 0.0:
+            w = [v / ww for v in w]
+        kk = [int(-0.5 + v * (1 << _PIL_PRECISION_BITS)) if v < 0 else int(0.5 + v * (1 << _PIL_PRECISION_BITS)) for v in w]
+        out.append((xmin, kk))
+    return out
+
+
+def pil_bicubic_resize(img, out_w: int, out_h: int):
+    """``Image.fromarray(img).resize((out_w, out_h), Image.BICUBIC)`` for a uint8 [H, W, C] array (numpy)."""
+    import numpy as np
+    img = np.asarray(img)
+    H, W, C = img.shape
+    half = 1 << (_PIL_PRECISION_BITS - 1)
+
+    def clip8(v):
+        return np.clip(v >> _PIL_PRECISION_BITS, 0, 255).astype(np.uint8)
+
+    cur = img
+    if out_w != W:                                            # horizontal pass first
+        co = pil_resample_coeffs(W, out_w)
+        tmp = np.empty((H, out_w, C), np.uint8)
+        for xx, (xmin, kk) in enumerate(co):
+            k = np.asarray(kk, np.int64)
+            acc = half + (cur[:, xmin:xmin + len(kk), :].astype(np.int64) * k[None, :, None]).sum(1)
+            tmp[:, xx, :] = clip8(acc)
+        cur = tmp
+    if out_h != H:
+        co = pil_resample_coeffs(H, out_h)
+        tmp = np.empty((out_h, cur.shape[1], C), np.uint8)
+        for yy, (ymin, kk) in enumerate(co):
+            k = np.asarray(kk, np.int64)
+            acc = half + (cur[ymin:ymin + len(kk), :, :].astype(np.int64) * k[:, None, None]).sum(0)
+            tmp[yy] = clip8(acc)
+        cur = tmp
+    return cur
+
+
+def clip_preprocess_geometry(H: int, W: int, n_px: int = 224, stretch: bool = False):
+    """resized (h, w) and crop origin (top, left) of torchvision Resize(n_px) + CenterCrop(n_px)
+    (functional `_compute_resized_output_size`: the longer side is int(n_px * long / short); center_crop uses
+    int(round((size - n_px) / 2.0)) with Python's round-half-even); stretch = Resize((n_px, n_px)), no crop."""
+    if stretch:
+        return n_px, n_px, 0, 0
+    if W <= H:
+        rw, rh = n_px, int(n_px * H / W)
+    else:
+        rh, rw = n_px, int(n_px * W / H)
+    return rh, rw, int(round((rh - n_px) / 2.0)), int(round((rw - n_px) / 2.0))
+
+
+def clip_preprocess(img, n_px: int = 224, stretch: bool = False) -> Tensor:
+    """uint8 RGB image [H, W, 3] -> fp32 [3, n_px, n_px]: bicubic resize, centre crop, /255, (x - mean) / std."""
+    import numpy as np
+    img = np.asarray(img)
+    rh, rw, top, left = clip_preprocess_geometry(img.shape[0], img.shape[1], n_px, stretch)
+    r = pil_bicubic_resize(img, rw, rh)[top:top + n_px, left:left + n_px]
+    x = torch.from_numpy(np.ascontiguousarray(r)).permute(2, 0, 1).to(torch.float32).div(255)
+    mean = torch.tensor(CLIP_MEAN, dtype=torch.float32).view(3, 1, 1)
+    std = torch.tensor(CLIP_STD, dtype=torch.float32).view(3, 1, 1)
+    return x.sub(mean).div(std)

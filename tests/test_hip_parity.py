@@ -518,6 +518,43 @@ def test_clip_b32_towers(golden):
     _check_clip(golden("clip_b32"), synth.CLIP_VIT_B32)
 
 
+def test_image_preprocess_bit_exact(eng, golden):
+    """HIP preprocess (PIL-exact bicubic Resize + CenterCrop + ToTensor + Normalize) == oracle == PIL fixture, on a
+    ragged batch in ONE call, both geometries; then the façade's `preprocess` feeding encode_image"""
+    from oracle import capdec_oracle as O
+    g = golden("preprocess")
+    imgs = [synth.synthetic_photo(h, w, 100 + i) for i, (h, w) in enumerate(synth.PREPROCESS_SIZES)]
+    for stretch in (False, True):
+        out = eng.preprocess_images(imgs, 224, stretch).cpu()
+        assert out.shape == (len(imgs), 3, 224, 224)
+        for i, im in enumerate(imgs):
+            want = O.clip_preprocess(im, 224, stretch)
+            assert torch.equal(out[i], want), (i, stretch, float((out[i] - want).abs().max()))
+            np.testing.assert_array_equal(out[i].reshape(-1)[::29].numpy(), g[f"sub_{i}_{int(stretch)}"])
+    assert eng.preprocess_images([], 224).shape == (0, 3, 224, 224)
+    small = eng.preprocess_images(imgs[:3], 64).cpu()                  # another n_px
+    for i in range(3):
+        assert torch.equal(small[i], O.clip_preprocess(imgs[i], 64))
+    with pytest.raises(Exception):
+        eng.preprocess_images([np.zeros((4, 4), np.uint8)])
+    # drop-in surface: clip.load -> (model, preprocess); preprocess(image) -> [3, 224, 224] on the device
+    from capdec_amd import clip
+    model, preprocess = clip.load(synth.hot_clip_state_dict(43, synth.CLIP_TINY), device=0)
+    x = preprocess(imgs[0])
+    assert x.shape == (3, model.input_resolution, model.input_resolution) and x.is_cuda
+    want = O.clip_preprocess(imgs[0], model.input_resolution)
+    assert torch.equal(x.cpu(), want)
+    emb = model.encode_image(preprocess.batch(imgs[:4]))
+    ref = O.clip_encode_image(torch.stack([O.clip_preprocess(im, model.input_resolution) for im in imgs[:4]]),
+                              synth.hot_clip_state_dict(43, synth.CLIP_TINY), synth.CLIP_TINY.vision_heads)
+    np.testing.assert_allclose(emb.cpu().numpy(), ref.numpy(), atol=5e-4, rtol=1e-4)
+    try:
+        from PIL import Image
+        assert torch.equal(preprocess(Image.fromarray(imgs[1])).cpu(), O.clip_preprocess(imgs[1], model.input_resolution))
+    except ImportError:
+        pass
+
+
 def test_text_to_prefix_pipeline():
     """config-4 chain: encode_text -> noise_injection -> clip_project, vs the oracle with the same injected noise"""
     from capdec_amd import clip as cclip, embeddings_generator as eg

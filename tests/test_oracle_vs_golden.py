@@ -189,3 +189,33 @@ def test_decode_p40_tiny(golden):
         np.testing.assert_array_equal(tok.numpy(), g[f"{mapping}_beam_tokens"])
         np.testing.assert_array_equal(seq.numpy(), g[f"{mapping}_beam_seqlen"].astype(np.int32))
         np.testing.assert_allclose(sc.numpy(), g[f"{mapping}_beam_scores"], atol=1e-4)
+
+
+# ----------------------------------------------------------------------------------- image preprocessing (F3)
+def test_clip_preprocess_vs_pil_golden(golden):
+    """oracle restatement of Pillow's 8-bit bicubic resampler + torchvision Resize / CenterCrop arithmetic + ToTensor +
+    Normalize against outputs PIL itself produced (tools/gen_golden.py:gen_preprocess): uint8 crop bit-identical (crc32),
+    float tensor equal"""
+    import zlib
+    g = golden("preprocess")
+    mean = torch.tensor(O.CLIP_MEAN).view(3, 1, 1)
+    std = torch.tensor(O.CLIP_STD).view(3, 1, 1)
+    for i, (h, w) in enumerate(synth.PREPROCESS_SIZES):
+        img = synth.synthetic_photo(h, w, 100 + i)
+        for stretch in (0, 1):
+            x = O.clip_preprocess(img, 224, bool(stretch))
+            assert x.shape == (3, 224, 224) and x.dtype == torch.float32
+            u8 = (x * std + mean).mul(255).round().clamp(0, 255).to(torch.uint8).permute(1, 2, 0).contiguous().numpy()
+            assert np.uint32(zlib.crc32(u8.tobytes())) == g[f"crc_{i}_{stretch}"], (h, w, stretch)
+            np.testing.assert_array_equal(x.reshape(-1)[::29].numpy(), g[f"sub_{i}_{stretch}"])
+
+
+def test_clip_preprocess_vs_live_pil():
+    """same check against the PIL installed on this machine, on sizes the fixture does not hold"""
+    Image = pytest.importorskip("PIL.Image")
+    for k, (h, w) in enumerate([(301, 97), (64, 1000), (224, 225), (5, 9), (1200, 800)]):
+        img = synth.synthetic_photo(h, w, 7 + k)
+        rh, rw, top, left = O.clip_preprocess_geometry(h, w, 224)
+        ref = np.asarray(Image.fromarray(img).resize((rw, rh), Image.BICUBIC))
+        np.testing.assert_array_equal(O.pil_bicubic_resize(img, rw, rh), ref)
+        assert ref[top:top + 224, left:left + 224].shape == (224, 224, 3)

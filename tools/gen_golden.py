@@ -341,13 +341,43 @@ def gen_clip(dims, tag, n_text, n_img):
     print(f"clip_{tag}.npz", tf.shape, vf.shape, float(tf.norm(dim=1).mean()), float(vf.norm(dim=1).mean()))
 
 
+def gen_preprocess():
+    """CLIP `preprocess` (Resize(224, BICUBIC) -> CenterCrop(224) -> ToTensor -> Normalize) and the stretch variant
+    `clip_transform_full` (predictions_runner.py:116-122) computed with PIL itself (torchvision is not installed: its
+    Resize / CenterCrop on PIL images are Image.resize / Image.crop with the size arithmetic restated here) on the
+    seeded images of synth.synthetic_photo.  Stored: crc32 of the uint8 crop and every 29th value of the float tensor."""
+    import zlib
+    from PIL import Image
+    mean = torch.tensor((0.48145466, 0.4578275, 0.40821073)).view(3, 1, 1)
+    std = torch.tensor((0.26862954, 0.26130258, 0.27577711)).view(3, 1, 1)
+    n_px, out = 224, {}
+    for i, (h, w) in enumerate(synth.PREPROCESS_SIZES):
+        img = Image.fromarray(synth.synthetic_photo(h, w, 100 + i))
+        for stretch in (0, 1):
+            if stretch:
+                r = img.resize((n_px, n_px), Image.BICUBIC)
+            else:
+                if w <= h:
+                    rw, rh = n_px, int(n_px * h / w)
+                else:
+                    rh, rw = n_px, int(n_px * w / h)
+                top, left = int(round((rh - n_px) / 2.0)), int(round((rw - n_px) / 2.0))
+                r = img.resize((rw, rh), Image.BICUBIC).crop((left, top, left + n_px, top + n_px))
+            u8 = np.ascontiguousarray(np.asarray(r.convert("RGB")))
+            x = torch.from_numpy(u8.copy()).permute(2, 0, 1).to(torch.float32).div(255).sub(mean).div(std)
+            out[f"crc_{i}_{stretch}"] = np.uint32(zlib.crc32(u8.tobytes()))
+            out[f"sub_{i}_{stretch}"] = x.reshape(-1)[::29].numpy()
+    out["pil_version"] = np.array(Image.__version__ if hasattr(Image, "__version__") else "?")
+    np.savez_compressed(os.path.join(OUT, "preprocess.npz"), **out)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", nargs="*", default=None)
     args = ap.parse_args()
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(os.cpu_count() or 8)
-    refs = import_reference()
+    refs = None if args.only == ["preprocess"] else import_reference()
     jobs = {
         "mappers": lambda: gen_mappers(refs),
         "noise": lambda: gen_noise(refs),
@@ -358,6 +388,7 @@ def main():
         "decode_p40_tiny": lambda: gen_decode_p40(refs, synth.GPT2_TINY, "tiny"),
         "clip_tiny": lambda: gen_clip(synth.CLIP_TINY, "tiny", 6, 3),
         "clip_b32": lambda: gen_clip(synth.CLIP_VIT_B32, "b32", 6, 3),
+        "preprocess": gen_preprocess,
     }
     for name, fn in jobs.items():
         if args.only and name not in args.only:
