@@ -388,12 +388,12 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x3p_topk_kernel(const __bf16 
                                                                    float *cand_val, int *cand_idx, int tiles_m,
                                                                    int tiles_n) {
     __shared__ __attribute__((aligned(16))) char smem[X3_STAGES * 2 * X3_BLOCK_B];
-    static_assert(64 * CT_LD * 4 <= X3_STAGES * 2 * X3_BLOCK_B, "epilogue slab must fit the staging ring");
+    static_assert(128 * CT_LD * 4 <= X3_STAGES * 2 * X3_BLOCK_B, "epilogue tile must fit the staging ring");
     int tm, tn;
     tile_coords(tiles_m, tiles_n, tm, tn);
     f32x16 acc[2][2];
     x3p_mainloop<false>(Apk, Bpk, K, tm, tn, smem, acc);      // ends with a barrier
-    epilogue_topk<KSEL, 2>(acc, reinterpret_cast<float *>(smem), M, N, tm * GEMM_BM, tn * GEMM_BN, tn, tiles_n, inv_temp,
+    epilogue_topk<KSEL, 2, true>(acc, reinterpret_cast<float *>(smem), M, N, tm * GEMM_BM, tn * GEMM_BN, tn, tiles_n, inv_temp,
                            tile_max, tile_sum, cand_val, cand_idx);
 }
 

@@ -164,7 +164,7 @@ __device__ __forceinline__ void epilogue_store_packed_t(const f32x16 (&acc)[2][2
 // logits tile goes accumulators -> LDS (`Ct`, >= 64 x CT_LD floats, reusing the staging buffers;
 // the caller's main loop must have ended with a barrier) -> 16-lane groups, one row per group, 8
 // columns per lane; only (2 + 2k) words per (row, tile) reach HBM.
-template <int KSEL, int WMG = 2>
+template <int KSEL, int WMG = 2, bool FULL = false>
 __device__ __forceinline__ void epilogue_topk(const f32x16 (&acc)[2][WaveGrid<WMG>::NJ], float *Ct, int M, int N,
                                               int m0, int n0, int tn, int tiles_n, float inv_temp, float *tile_max,
                                               float *tile_sum, float *cand_val, int *cand_idx) {
@@ -172,21 +172,24 @@ __device__ __forceinline__ void epilogue_topk(const f32x16 (&acc)[2][WaveGrid<WM
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wm = WaveGrid<WMG>::wm(wave), wn = WaveGrid<WMG>::wn(wave), half = lane >> 5, l32 = lane & 31;
     const int grp = lane >> 4, sub = lane & 15;
-    for (int hh = 0; hh < WMG; ++hh) {            // 64 rows of the tile at a time
-        if (wm == hh) {
+    // FULL (WMG == 2, Ct >= 128 x CT_LD floats = 66 KB): the whole 128-row tile goes through LDS at once -- every
+    // wavefront stores its accumulators, one barrier, 32 rows per wavefront; otherwise 64 rows at a time.
+    constexpr int SLABS = FULL ? 1 : WMG, ITERS = FULL ? 8 : 4, ROWS_PER_WAVE = FULL ? 32 : 16;
+    for (int hh = 0; hh < SLABS; ++hh) {
+        if (FULL || wm == hh) {
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int j = 0; j < NJ; ++j)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
-                        const int row = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                        const int row = (FULL ? wm * 64 : 0) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
                         Ct[row * CT_LD + wn * 32 * NJ + j * 32 + l32] = acc[i][j][r] * inv_temp;
                     }
         }
         __syncthreads();
-        for (int it = 0; it < 4; ++it) {
-            const int rl = wave * 16 + it * 4 + grp;   // row within the 64-row slab
+        for (int it = 0; it < ITERS; ++it) {
+            const int rl = wave * ROWS_PER_WAVE + it * 4 + grp;   // row within the slab
             const int row = m0 + hh * 64 + rl;
             float v[8];
 #pragma unroll
@@ -237,7 +240,7 @@ __device__ __forceinline__ void epilogue_topk(const f32x16 (&acc)[2][WaveGrid<WM
                 }
             }
         }
-        __syncthreads();
+        if (!FULL) __syncthreads();
     }
 }
 
