@@ -442,6 +442,60 @@ def test_finished_caption_compaction(monkeypatch):
     np.testing.assert_array_equal(outs["1"][2], outs["0"][2])          # scores bit-identical with and without compaction
 
 
+def test_c_host_without_torch(tmp_path):
+    """the C ABI from a plain C program (examples/c_host_demo.c: gcc, no Python, no torch in the process): same ids as
+    the Python host on the same weights"""
+    import os, shutil, struct, subprocess
+    from capdec_amd.engine import Engine
+    gcc = shutil.which("gcc")
+    if gcc is None:
+        pytest.skip("no gcc on this machine")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "c_host_demo")
+    lib_dir = os.path.join(root, "capdec_amd", "lib")
+    subprocess.check_call([gcc, "-O2", "-I" + os.path.join(root, "include"), os.path.join(root, "examples", "c_host_demo.c"),
+                           "-L" + lib_dir, "-lcapdec_hip", "-Wl,-rpath," + lib_dir, "-o", exe])
+    dims = synth.GPT2_TINY
+    sd = synth.hot_gpt2_state_dict(42, dims)
+    g = torch.Generator().manual_seed(5)
+    n, P, T = 5, 10, 12
+    pe = torch.randn(n, P, dims.n_embd, generator=g) * 0.3
+    path = str(tmp_path / "model.bin")
+    with open(path, "wb") as f:
+        f.write(struct.pack("<6if", 0x43415044, dims.n_layer, dims.n_head, dims.n_embd, dims.vocab, dims.n_pos, dims.ln_eps))
+        t = "gpt.transformer."
+        names = [t + "wte.weight", t + "wpe.weight"]
+        for i in range(dims.n_layer):
+            b = f"{t}h.{i}."
+            names += [b + k for k in ("ln_1.weight", "ln_1.bias", "attn.c_attn.weight", "attn.c_attn.bias",
+                                      "attn.c_proj.weight", "attn.c_proj.bias", "ln_2.weight", "ln_2.bias",
+                                      "mlp.c_fc.weight", "mlp.c_fc.bias", "mlp.c_proj.weight", "mlp.c_proj.bias")]
+        names += [t + "ln_f.weight", t + "ln_f.bias"]
+        for k in names:
+            f.write(sd[k].contiguous().numpy().astype("<f4").tobytes())
+        f.write(struct.pack("<2i", n, P))
+        f.write(pe.numpy().astype("<f4").tobytes())
+    env = dict(os.environ)
+    env.pop("LD_PRELOAD", None)
+    out = subprocess.run([exe, path, str(T), "5"], capture_output=True, text=True, env=env, timeout=300)
+    assert out.returncode == 0, out.stderr
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith(("greedy", "beam"))]
+    assert len(lines) == 2 * n
+    e = Engine(0)
+    e.load_gpt2(sd)
+    ids, lens = e.decode_greedy(pe, 13, T)
+    bi, bl, bs, _ = e.decode_beam(pe, 13, 5, T)
+    for r in range(n):
+        head, toks = lines[2 * r].split(":")
+        assert int(head.split()[1]) == int(lens[r])
+        assert [int(v) for v in toks.split()] == ids[r, :int(lens[r])].tolist()
+        head, toks = lines[2 * r + 1].split(":")
+        assert int(head.split()[1]) == int(bl[r, 0])
+        assert abs(float(head.split()[2]) - float(bs[r, 0])) < 1e-5
+        assert [int(v) for v in toks.split()] == bi[r, 0, :int(bl[r, 0])].tolist()
+    e.close()
+
+
 def test_decode_edge_cases():
     from capdec_amd import gpt2_prefix_eval as E
     from capdec_amd._capi import CapdecError
