@@ -254,18 +254,22 @@ typedef const __attribute__((address_space(1))) void glb_void;
 // rows of one column: the epilogue stores float4 / whole split quads straight from the accumulators.
 template <bool TR>
 __device__ __forceinline__ void x3p_mainloop(const __bf16 *__restrict__ Apk, const __bf16 *__restrict__ Bpk, int K,
-                                             int tm, int tn, char *smem, f32x16 (&acc)[2][2]) {
+                                             int tm, int tn, char *smem, f32x16 (&acc)[2][2], int dbg = 0) {
     constexpr int STAGE_B = 2 * X3_BLOCK_B;                  // A block + B block = 24 KB
     const int t = threadIdx.x;
     const int lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int wm = wave >> 1, wn = wave & 1;
     const int half = lane >> 5, l32 = lane & 31;
     const int nk = K / X3_BK;                                                  // even (K % 64 == 0)
-    const __bf16 *ap = Apk + (size_t)tm * nk * (X3_BLOCK_B / 2) + t * 8;       // this thread's 16-B piece of a block
-    const __bf16 *bp = Bpk + (size_t)tn * nk * (X3_BLOCK_B / 2) + t * 8;
+    // dbg (CAPDEC_ABL_DMA, measurement only -- results are wrong): 1 = every block streams the panels of tile (0, 0)
+    // (L2-resident: what the kernel does without fabric traffic), 2 = every k-step re-reads k-step 0 of its own panels
+    const __bf16 *ap = Apk + (size_t)(dbg == 1 ? 0 : tm) * nk * (X3_BLOCK_B / 2) + t * 8;   // this thread's 16-B piece
+    const __bf16 *bp = Bpk + (size_t)(dbg == 1 ? 0 : tn) * nk * (X3_BLOCK_B / 2) + t * 8;
+    const int ksmask = dbg == 2 ? 0 : -1;
     char *dst0 = smem + wave * 1024;                                           // wave-uniform LDS base of its pieces
-#define X3P_DMA(stage, ks)                                                                                     \
+#define X3P_DMA(stage, ks_)                                                                                    \
     {                                                                                                          \
+        const int ks = (ks_) & ksmask;                                                                         \
         const __bf16 *sa = ap + (size_t)(ks) * (X3_BLOCK_B / 2), *sb = bp + (size_t)(ks) * (X3_BLOCK_B / 2);   \
         char *d = dst0 + (stage) * STAGE_B;                                                                    \
         _Pragma("unroll") for (int p = 0; p < 3; ++p) {                                                        \
@@ -369,12 +373,12 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x3p_kernel(const __bf16 *__re
                                                               const __bf16 *__restrict__ Bpk, float *C, int ldc, int M,
                                                               int N, int K, const float *__restrict__ bias,
                                                               const float *resid, int ldr, int act, int tiles_m,
-                                                              int tiles_n, char *packed_out) {
+                                                              int tiles_n, char *packed_out, int dbg) {
     __shared__ __attribute__((aligned(16))) char smem[X3_STAGES * 2 * X3_BLOCK_B];
     int tm, tn;
     tile_coords(tiles_m, tiles_n, tm, tn);
     f32x16 acc[2][2];
-    x3p_mainloop<true>(Apk, Bpk, K, tm, tn, smem, acc);
+    x3p_mainloop<true>(Apk, Bpk, K, tm, tn, smem, acc, dbg);
     if (packed_out)
         epilogue_store_packed_t(acc, packed_out, N >> 4, M, N, tm * GEMM_BM, tn * GEMM_BN, bias, act);
     else
@@ -408,14 +412,15 @@ int launch_gemm_bf16x3p(hipStream_t st, const void *Apacked, const void *Bpacked
     const bool vec4 = N % 4 == 0 && ldc % 4 == 0 && ((uintptr_t)C & 15) == 0 &&
                       (epi.bias == nullptr || ((uintptr_t)epi.bias & 15) == 0) &&
                       (epi.resid == nullptr || (epi.ldr % 4 == 0 && ((uintptr_t)epi.resid & 15) == 0));
+    static const int dbg = [] { const char *e = getenv("CAPDEC_ABL_DMA"); return e ? atoi(e) : 0; }();
     if (vec4)
         hipLaunchKernelGGL(gemm_bf16x3p_kernel<true>, dim3(tiles_m * tiles_n), dim3(256), 0, st, (const __bf16 *)Apacked,
                            (const __bf16 *)Bpacked, C, ldc, M, N, K, epi.bias, epi.resid, epi.ldr, epi.act, tiles_m,
-                           tiles_n, (char *)epi.packed_out);
+                           tiles_n, (char *)epi.packed_out, dbg);
     else
         hipLaunchKernelGGL(gemm_bf16x3p_kernel<false>, dim3(tiles_m * tiles_n), dim3(256), 0, st, (const __bf16 *)Apacked,
                            (const __bf16 *)Bpacked, C, ldc, M, N, K, epi.bias, epi.resid, epi.ldr, epi.act, tiles_m,
-                           tiles_n, (char *)epi.packed_out);
+                           tiles_n, (char *)epi.packed_out, dbg);
     CAPDEC_HIP(hipGetLastError());
     return 0;
 }
