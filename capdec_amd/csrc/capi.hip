@@ -119,7 +119,7 @@ struct capdec_ctx {
     DBuf h, x, qkv, att, ff, xl, tmax, tsum, cval, cidx, lse, topv, topi, kc, vc;
     DBuf tokens, scores, seq, stopped, done, anc, next_tok, alive, gids, glens, cmap;
     DBuf m_hid, m_lin, m_seq, m_x, m_qkv, m_att, m_ff;
-    DBuf t_idx, t_patch, t_pout, p_desc, p_inter;
+    DBuf t_idx, t_patch, t_pout, p_desc, p_inter, splitk;
     int *alive_host = nullptr;   // pinned
 };
 
@@ -275,6 +275,14 @@ static int gemm_packed(capdec_ctx *c, const void *Apk, const float *W, float *C,
     e.resid = resid;
     e.ldr = ldr;
     e.packed_out = packed_out;
+    if (c->gemm_mode == GEMM_BF16X3) {
+        const size_t wsb = gemm_splitk_ws_bytes(M, N, K);
+        if (wsb) {
+            CAPDEC_TRY(c->splitk.ensure(wsb));
+            e.splitk_ws = c->splitk.p;
+            e.splitk_ws_bytes = c->splitk.cap;
+        }
+    }
     if (c->gemm_mode == GEMM_BF16) {   // plane 0 only: bf16 operands, one MFMA per product
         ProfScope ps(c, F_GEMM_BF16P, 2.0 * M * (double)N * K);
         return launch_gemm_bf16p(c->stream, Apk, pl, C, ldc, M, N, K, e);
@@ -764,7 +772,7 @@ void capdec_destroy(capdec_ctx *c) {
     DBuf *bufs[] = {&c->h, &c->x, &c->qkv, &c->att, &c->ff, &c->xl, &c->tmax, &c->tsum, &c->cval, &c->cidx,
                     &c->lse, &c->topv, &c->topi, &c->kc, &c->vc, &c->tokens, &c->scores, &c->seq, &c->stopped,
                     &c->done, &c->anc, &c->next_tok, &c->alive, &c->gids, &c->glens, &c->m_hid, &c->m_lin, &c->m_seq,
-                    &c->m_x, &c->m_qkv, &c->m_att, &c->m_ff, &c->t_idx, &c->t_patch, &c->t_pout, &c->xpk, &c->apk, &c->fpk, &c->cmap, &c->p_desc, &c->p_inter};
+                    &c->m_x, &c->m_qkv, &c->m_att, &c->m_ff, &c->t_idx, &c->t_patch, &c->t_pout, &c->xpk, &c->apk, &c->fpk, &c->cmap, &c->p_desc, &c->p_inter, &c->splitk};
     for (DBuf *b : bufs) b->release();
     for (auto &r : c->prof.recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
     for (auto e : c->prof.pool) (void)hipEventDestroy(e);

@@ -90,6 +90,8 @@ struct GemmEpilogue {
     const float *resid = nullptr;  // [M, ldr] added after the activation
     int ldr = 0;
     int act = CAPDEC_ACT_NONE;
+    void *splitk_ws = nullptr;     // bf16x3p only: workspace for split-K partial tiles (gemm_splitk_ws_bytes); without it
+    size_t splitk_ws_bytes = 0;    // under-filled grids run unsplit
     void *packed_out = nullptr;    // bf16x3p only: write act(acc + bias) as the packed split-bf16 A operand (K = N)
                                    // of the next GEMM instead of fp32 C
 };
@@ -116,6 +118,9 @@ int launch_gemm_bf16x3p(hipStream_t st, const void *Apacked, const void *Bpacked
                         const GemmEpilogue &epi);
 int launch_gemm_bf16x3p_topk(hipStream_t st, const void *Apacked, const void *Bpacked, int M, int N, int K, int k,
                              float inv_temp, float *tile_max, float *tile_sum, float *cand_val, int *cand_idx);
+// split-K of the packed-A kernel for under-filled grids: number of K slices (1 = none) and the workspace it needs
+int gemm_splitk_slices(int M, int N, int K);
+size_t gemm_splitk_ws_bytes(int M, int N, int K);
 // bf16 mode (gemm_bf16.hip): same packed operands, plane 0 only -- one bf16 MFMA per product, fp32 accumulate
 int launch_gemm_bf16p(hipStream_t st, const void *Apacked, const void *Bpacked, float *C, int ldc, int M, int N, int K,
                       const GemmEpilogue &epi);

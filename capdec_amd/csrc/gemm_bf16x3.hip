@@ -254,17 +254,19 @@ typedef const __attribute__((address_space(1))) void glb_void;
 // rows of one column: the epilogue stores float4 / whole split quads straight from the accumulators.
 template <bool TR>
 __device__ __forceinline__ void x3p_mainloop(const __bf16 *__restrict__ Apk, const __bf16 *__restrict__ Bpk, int K,
-                                             int tm, int tn, char *smem, f32x16 (&acc)[2][2], int dbg = 0) {
+                                             int tm, int tn, char *smem, f32x16 (&acc)[2][2], int dbg = 0,
+                                             int ks0 = 0, int nks = -1) {
     constexpr int STAGE_B = 2 * X3_BLOCK_B;                  // A block + B block = 24 KB
     const int t = threadIdx.x;
     const int lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int wm = wave >> 1, wn = wave & 1;
     const int half = lane >> 5, l32 = lane & 31;
-    const int nk = K / X3_BK;                                                  // even (K % 64 == 0)
+    const int nkf = K / X3_BK;                                                 // k-steps of the whole K (panel stride)
+    const int nk = nks < 0 ? nkf : nks;                                        // k-steps of THIS block: [ks0, ks0 + nk), even
     // dbg (CAPDEC_ABL_DMA, measurement only -- results are wrong): 1 = every block streams the panels of tile (0, 0)
     // (L2-resident: what the kernel does without fabric traffic), 2 = every k-step re-reads k-step 0 of its own panels
-    const __bf16 *ap = Apk + (size_t)(dbg == 1 ? 0 : tm) * nk * (X3_BLOCK_B / 2) + t * 8;   // this thread's 16-B piece
-    const __bf16 *bp = Bpk + (size_t)(dbg == 1 ? 0 : tn) * nk * (X3_BLOCK_B / 2) + t * 8;
+    const __bf16 *ap = Apk + ((size_t)(dbg == 1 ? 0 : tm) * nkf + ks0) * (X3_BLOCK_B / 2) + t * 8;   // this thread's 16-B piece
+    const __bf16 *bp = Bpk + ((size_t)(dbg == 1 ? 0 : tn) * nkf + ks0) * (X3_BLOCK_B / 2) + t * 8;
     const int ksmask = dbg == 2 ? 0 : -1;
     char *dst0 = smem + wave * 1024;                                           // wave-uniform LDS base of its pieces
 #define X3P_DMA(stage, ks_)                                                                                    \
@@ -401,6 +403,71 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x3p_topk_kernel(const __bf16 
                            tile_max, tile_sum, cand_val, cand_idx);
 }
 
+// ---- split-K for under-filled grids (small M: a handful of 128x128 tiles, each walking all of K serially, is
+// latency-bound -- 59 us per GEMM at 40 rows).  The K range is cut into S slices (grid = tiles x S); every block
+// stores its raw fp32 partial tile to a workspace [S][M][N], and a second kernel adds the slices IN A FIXED ORDER
+// (deterministic, unlike atomics) and applies the epilogue: bias, activation, residual, fp32 or packed output.
+__global__ __launch_bounds__(256, 2) void gemm_bf16x3p_splitk_kernel(const __bf16 *__restrict__ Apk,
+                                                                     const __bf16 *__restrict__ Bpk, float *part, int M,
+                                                                     int N, int K, int tiles_m, int tiles_n, int S) {
+    __shared__ __attribute__((aligned(16))) char smem[X3_STAGES * 2 * X3_BLOCK_B];
+    const int ntiles = tiles_m * tiles_n;
+    const int slice = blockIdx.x / ntiles;
+    int tm, tn;
+    tile_coords(tiles_m, tiles_n, tm, tn, blockIdx.x - slice * ntiles);
+    const int nks = K / X3_BK / S;
+    f32x16 acc[2][2];
+    x3p_mainloop<true>(Apk, Bpk, K, tm, tn, smem, acc, 0, slice * nks, nks);
+    epilogue_store_t<true>(acc, part + (size_t)slice * M * N, N, M, N, tm * GEMM_BM, tn * GEMM_BN, nullptr, nullptr, 0,
+                           CAPDEC_ACT_NONE);
+}
+
+__global__ void splitk_reduce_kernel(const float *__restrict__ part, int S, int M, int N, const float *__restrict__ bias,
+                                     int act, const float *resid, int ldr, float *C, int ldc, char *packed_out) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;     // one float4 of the [M, N] result
+    const int nq = N >> 2;
+    if (i >= (size_t)M * nq) return;
+    const int row = (int)(i / nq), col = (int)(i - (size_t)row * nq) * 4;
+    const size_t sl = (size_t)M * N;
+    float4 v = *reinterpret_cast<const float4 *>(part + (size_t)row * N + col);
+    for (int s = 1; s < S; ++s) {
+        const float4 p = *reinterpret_cast<const float4 *>(part + s * sl + (size_t)row * N + col);
+        v.x += p.x; v.y += p.y; v.z += p.z; v.w += p.w;
+    }
+    if (bias) {
+        const float4 b = *reinterpret_cast<const float4 *>(bias + col);
+        v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
+    }
+    v.x = act_apply(v.x, act); v.y = act_apply(v.y, act); v.z = act_apply(v.z, act); v.w = act_apply(v.w, act);
+    if (packed_out) {
+        x3_store_quad(packed_out, N >> 4, row, col >> 4, (col >> 2) & 3, v);
+        return;
+    }
+    if (resid) {
+        const float4 r4 = *reinterpret_cast<const float4 *>(resid + (size_t)row * ldr + col);
+        v.x += r4.x; v.y += r4.y; v.z += r4.z; v.w += r4.w;
+    }
+    *reinterpret_cast<float4 *>(C + (size_t)row * ldc + col) = v;
+}
+
+// slices for a [M, N, K] problem: 1 (no split) unless M <= 512 rows (at most four tile rows: the decode of small
+// batches).  S depends on K ONLY -- the largest divisor of the k-step count that leaves >= 8 (an even number of)
+// k-steps per slice -- so a row's result is bit-identical for every batch size in this regime (and for every batch
+// size in the unsplit regime above it); across the boundary the fp32 summation order differs.
+int gemm_splitk_slices(int M, int N, int K) {
+    static const int off = [] { const char *e = getenv("CAPDEC_SPLITK"); return e && atoi(e) == 0 ? 1 : 0; }();
+    const int nk = K / X3_BK;
+    if (off || M > 4 * GEMM_BM || N % 4 != 0) return 1;
+    int best = 1;
+    for (int s = 2; s <= nk / 8; ++s)
+        if (nk % s == 0 && (nk / s) % 2 == 0) best = s;
+    return best;
+}
+size_t gemm_splitk_ws_bytes(int M, int N, int K) {
+    const int s = gemm_splitk_slices(M, N, K);
+    return s > 1 ? (size_t)s * M * N * sizeof(float) : 0;
+}
+
 int launch_gemm_bf16x3p(hipStream_t st, const void *Apacked, const void *Bpacked, float *C, int ldc, int M, int N, int K,
                         const GemmEpilogue &epi) {
     CAPDEC_CHECK(M > 0 && N > 0 && K > 0 && K % 64 == 0, "gemm_bf16x3p: K must be a multiple of 64");
@@ -412,6 +479,17 @@ int launch_gemm_bf16x3p(hipStream_t st, const void *Apacked, const void *Bpacked
     const bool vec4 = N % 4 == 0 && ldc % 4 == 0 && ((uintptr_t)C & 15) == 0 &&
                       (epi.bias == nullptr || ((uintptr_t)epi.bias & 15) == 0) &&
                       (epi.resid == nullptr || (epi.ldr % 4 == 0 && ((uintptr_t)epi.resid & 15) == 0));
+    const int S = (vec4 && epi.splitk_ws) ? gemm_splitk_slices(M, N, K) : 1;
+    if (S > 1 && epi.splitk_ws_bytes >= (size_t)S * M * N * sizeof(float)) {
+        float *part = (float *)epi.splitk_ws;
+        hipLaunchKernelGGL(gemm_bf16x3p_splitk_kernel, dim3(tiles_m * tiles_n * S), dim3(256), 0, st,
+                           (const __bf16 *)Apacked, (const __bf16 *)Bpacked, part, M, N, K, tiles_m, tiles_n, S);
+        const size_t nq = (size_t)M * (N / 4);
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, st, part, S, M, N,
+                           epi.bias, epi.act, epi.resid, epi.ldr, C, ldc, (char *)epi.packed_out);
+        CAPDEC_HIP(hipGetLastError());
+        return 0;
+    }
     static const int dbg = [] { const char *e = getenv("CAPDEC_ABL_DMA"); return e ? atoi(e) : 0; }();
     if (vec4)
         hipLaunchKernelGGL(gemm_bf16x3p_kernel<true>, dim3(tiles_m * tiles_n), dim3(256), 0, st, (const __bf16 *)Apacked,

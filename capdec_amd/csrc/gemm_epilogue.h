@@ -25,10 +25,10 @@ __device__ __forceinline__ float act_apply(float v, int act) {
 }
 
 // XCD-aware, L2-friendly tile order: consecutive ids of one XCD walk 8 M-tiles per N-tile.
-__device__ __forceinline__ void tile_coords(int tiles_m, int tiles_n, int &tm, int &tn) {
+__device__ __forceinline__ void tile_coords(int tiles_m, int tiles_n, int &tm, int &tn, int block_id = -1) {
     constexpr int GM = 8;   // (2..32 measured within noise: neither panel set fits the 4 MB L2 of an XCD)
     const int nwg = tiles_m * tiles_n;
-    int id = blockIdx.x;
+    int id = block_id < 0 ? (int)blockIdx.x : block_id;
     {   // bijective XCD remap: blocks b, b+8, b+16.. (same XCD) get contiguous ids
         const int q = nwg >> 3, r = nwg & 7, xcd = id & 7, idx = id >> 3;
         id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;

@@ -324,12 +324,15 @@ def greedy_cached(sd: SD, prefix: Tensor, stop_id: int = 13, entry_length: int =
 
 
 def beam_cached(sd: SD, prefix: Tensor, beam_size: int = 5, stop_id: int = 13, entry_length: int = 67,
-                temperature: float = 1.0, n_head: int = 12) -> Tuple[Tensor, Tensor, Tensor]:
+                temperature: float = 1.0, n_head: int = 12, margins: Optional[list] = None) -> Tuple[Tensor, Tensor, Tensor]:
     """Batched beam search with a KV cache, per caption identical in arithmetic to
     ``generate_beam_ref`` (same fp32 op order for sum / mean / sum score juggling).
     prefix [N, P, d] -> tokens int32 [N, beam, entry_length] (zero padded), seq_lengths int32
     [N, beam], scores fp32 [N, beam]; rows in the reference's INTERNAL beam order -- sort by
-    ``scores`` descending (stable) to get the returned order."""
+    ``scores`` descending (stable) to get the returned order.
+    ``margins`` (a list): receives one tensor [N] = the smallest gap, over the caption's live steps, between the
+    last selected and the first rejected candidate key -- a caption whose margin is at fp32 round-off level
+    (< ~1e-5) is a numerical tie: another summation order may legitimately keep a different beam."""
     N, P, d = prefix.shape
     g = "gpt."
     B = beam_size
@@ -342,6 +345,11 @@ def beam_cached(sd: SD, prefix: Tensor, beam_size: int = 5, stop_id: int = 13, e
     Wr = _r(W)
     logp = ((_r(h) @ Wr.t()) / temp).softmax(-1).log()
     scores, nxt = logp.topk(B, -1)                      # [N, B]
+    if margins is not None and V > B:
+        t6 = logp.topk(B + 1, -1).values
+        margin = t6[:, B - 1] - t6[:, B]
+    else:
+        margin = torch.full((N,), float("inf"))
     tokens = torch.zeros(N, B, entry_length, dtype=torch.int64)
     tokens[:, :, 0] = nxt
     seq = torch.ones(N, B)
@@ -361,6 +369,10 @@ def beam_cached(sd: SD, prefix: Tensor, beam_size: int = 5, stop_id: int = 13, e
         seq_new = seq + (~stopped).float()
         avg = ssum / seq_new[:, :, None]
         avg_top, flat = avg.view(N, -1).topk(B, -1)
+        if margins is not None:
+            t6 = avg.view(N, -1).topk(B + 1, -1).values
+            gap = t6[:, B - 1] - t6[:, B]
+            margin = torch.where(alive & (gap < margin), gap, margin)
         src = flat // V
         tok = flat % V
         seq_sel = torch.gather(seq_new, 1, src)
@@ -379,6 +391,8 @@ def beam_cached(sd: SD, prefix: Tensor, beam_size: int = 5, stop_id: int = 13, e
             cache[l] = [c[rows] for c in cache[l]]
         alive = alive & ~stopped.all(dim=1)
     final = scores / seq
+    if margins is not None:
+        margins.append(margin)
     return tokens.to(torch.int32), seq.to(torch.int32), final
 
 

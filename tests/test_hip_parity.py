@@ -372,17 +372,25 @@ def test_batched_decode_vs_oracle_and_chunking():
     ids, lens = E.decode_greedy_ids(model, pe, 443, 20)
     np.testing.assert_array_equal(ids.cpu().numpy(), ids_o.numpy())
     np.testing.assert_array_equal(lens.cpu().numpy(), lens_o.numpy())
-    tok_o, seq_o, sc_o = O.beam_cached(sd, pe, 5, 614, 20)
+    mg = []
+    tok_o, seq_o, sc_o = O.beam_cached(sd, pe, 5, 614, 20, margins=mg)
     order_o = O.beam_output_order(sc_o)
+    # a caption whose selected / rejected candidate keys come within fp32 round-off of each other at some step is a
+    # numerical tie (this 2-layer model has two at 4e-6): which beam survives then depends on the summation order
+    clear = (mg[0] > 1e-4).numpy()
+    assert clear.sum() >= 30
     def run():
         i, l, s, o = E.decode_beam_ids(model, pe, 614, 5, 20)
         return i.cpu().numpy(), l.cpu().numpy(), s.cpu().numpy(), o.cpu().numpy()
     i1, l1, s1, o1 = run()
-    np.testing.assert_array_equal(o1, order_o.numpy())
     for r in range(37):
-        np.testing.assert_array_equal(i1[r], tok_o[r][order_o[r]].numpy())
-        np.testing.assert_array_equal(l1[r], seq_o[r][order_o[r]].numpy())
-        np.testing.assert_allclose(s1[r], sc_o[r][order_o[r]].numpy(), atol=1e-4)
+        if clear[r]:
+            np.testing.assert_array_equal(o1[r], order_o[r].numpy())
+            np.testing.assert_array_equal(i1[r], tok_o[r][order_o[r]].numpy())
+            np.testing.assert_array_equal(l1[r], seq_o[r][order_o[r]].numpy())
+            np.testing.assert_allclose(s1[r], sc_o[r][order_o[r]].numpy(), atol=1e-4)
+        else:
+            assert np.isfinite(s1[r]).all() and (np.diff(s1[r]) <= 0).all()      # a tie: any surviving beam set is valid
     # tiny KV budget -> many chunks; results must not change
     from capdec_amd import _capi
     _capi.check(model.engine.lib.capdec_set_kv_budget(model.engine._h, 3 * 5 * 29 * 768 * 2 * 4 * 2), "budget")
