@@ -133,14 +133,20 @@ def side_workload(args, world, rank, dev):
 
     for _ in range(args.warmup):
         step()
+    cm._engine.profile_enable(max(1, args.profile_every))
+    cm._engine.profile_reset()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    prof = cm._engine.profile_get()
     if rank == 0:
         print(json.dumps({"metric": f"{'captions' if text else 'images'}/sec, side workload {args.workload}",
+                          "clip_tower_kernels": {k: {"ms_est": round(v["ms"] * v["calls"] / v["launches"], 2),
+                                                     "launches": v["calls"], "avg_ms": round(v["ms"] / v["launches"], 4)}
+                                                 for k, v in prof.items() if v["launches"]},
                           "value": round(n_global * args.steps / dt, 2), "unit": "items/s", "n_gpus": world,
                           "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 2),
                           "config": {"workload": args.workload, "items_per_step": n_global}}), flush=True)

@@ -354,7 +354,8 @@ static int stack_body(capdec_ctx *c, const StackCfg &g, const StepShape &s, cons
         }
         if (s.prefill) {
             ProfScope ps(c, F_ATTN_PRE);
-            CAPDEC_TRY(launch_kv_scatter_prefill(c->stream, qkv, kv, kl, s.ncap, s.P, s.beam));
+            if (g.keep_kv)      // the towers never decode: only GPT-2 needs its prefix K/V in the cache
+                CAPDEC_TRY(launch_kv_scatter_prefill(c->stream, qkv, kv, kl, s.ncap, s.P, s.beam));
             CAPDEC_TRY(launch_attn_prefill(c->stream, qkv, kv, kl, s.ncap, s.P, s.beam, att, g.causal, apk));
         } else {
             ProfScope ps(c, F_ATTN_DEC);
