@@ -32,6 +32,36 @@ def test_c_abi_exports_every_header_symbol():
     assert declared <= exported
 
 
+def test_ctypes_signatures_match_header_prototypes():
+    """every prototype of include/capdec.h and its ctypes binding agree on the number of parameters and on which of
+    them are pointers / integers / floats (an ABI drift between header, library and Python host would otherwise only
+    show up as garbage on the GPU box)"""
+    import ctypes as C
+    from capdec_amd import _capi
+    header = open(os.path.join(ROOT, "include", "capdec.h")).read()
+    header = re.sub(r"/\*.*?\*/", " ", header, flags=re.S)                       # strip comments
+    protos = re.findall(r"\b(?:int|void|const char \*)\s*(capdec_[a-z0-9_]+)\s*\(([^;{]*?)\)\s*;", header, flags=re.S)
+    seen = 0
+    for name, params in protos:
+        params = " ".join(params.split())
+        plist = [] if params in ("", "void") else [p.strip() for p in params.split(",")]
+        res, argtypes = _capi.SIGNATURES[name]
+        assert len(plist) == len(argtypes), (name, plist, argtypes)
+        for ptxt, at in zip(plist, argtypes):
+            is_ptr = "*" in ptxt
+            at_ptr = at in (C.c_void_p, C.c_char_p) or hasattr(at, "contents") or issubclass(at, C._Pointer)
+            assert is_ptr == at_ptr, (name, ptxt, at)
+            if not is_ptr:
+                if re.search(r"\bfloat\b", ptxt):
+                    assert at is C.c_float, (name, ptxt, at)
+                elif re.search(r"\bsize_t\b|\buint64_t\b", ptxt):
+                    assert at in (C.c_size_t, C.c_uint64), (name, ptxt, at)
+                else:
+                    assert at in (C.c_int, C.c_int32), (name, ptxt, at)
+        seen += 1
+    assert seen == len(_capi.SIGNATURES), (seen, len(_capi.SIGNATURES))
+
+
 def test_no_cpu_fallback_without_gpu():
     if torch.cuda.is_available():
         pytest.skip("GPU present")
