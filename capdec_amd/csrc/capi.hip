@@ -319,8 +319,8 @@ static int ensure_body_ws(capdec_ctx *c, int M, int d) {
 }
 
 // h [M, d] (in c->h) -> h after all blocks (final LN NOT applied).  The same pre-LN block serves
-// GPT-2 (gelu_new, causal, KV cache kept) and the CLIP towers (QuickGELU; one scratch "layer" of
-// K/V reused by every block; the vision tower is not causal).
+// GPT-2 (gelu_new, causal, KV cache kept for the decode steps) and the CLIP towers (QuickGELU, attention straight from
+// the qkv activations, nothing cached; the vision tower is not causal).
 struct StackCfg {
     const std::vector<Gpt2Layer> *layers;
     int n_layer, d;

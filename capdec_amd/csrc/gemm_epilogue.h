@@ -161,7 +161,7 @@ __device__ __forceinline__ void epilogue_store_packed_t(const f32x16 (&acc)[2][2
 }
 
 // lm_head epilogue: per (row, 128-col tile) max, sum exp(x - max) and top-k (value, column).  The
-// logits tile goes accumulators -> LDS (`Ct`, >= 64 x CT_LD floats, reusing the staging buffers;
+// logits tile goes accumulators -> LDS (`Ct`, >= 64 x CT_LD floats -- 128 x CT_LD with FULL --, reusing the staging buffers;
 // the caller's main loop must have ended with a barrier) -> 16-lane groups, one row per group, 8
 // columns per lane; only (2 + 2k) words per (row, tile) reach HBM.
 template <int KSEL, int WMG = 2, bool FULL = false>
