@@ -142,6 +142,7 @@ def gelu_new(x: Tensor) -> Tensor:
 # matmul -- the arithmetic of the HIP bf16 mode (one bf16 MFMA per product, fp32 accumulate; residual stream,
 # LayerNorm, softmax, KV cache fp32).  Default: no rounding, the reference's fp32 path.
 _GEMM_BF16 = False
+_RW_CACHE: dict = {}       # id(weight) -> (weight, rounded weight): a GPT-2-small step would otherwise re-round 124 M values
 
 
 @contextlib.contextmanager
@@ -152,10 +153,25 @@ def bf16_gemm_operands():
         yield
     finally:
         _GEMM_BF16 = old
+        if not old:
+            _RW_CACHE.clear()
 
 
 def _r(x: Tensor) -> Tensor:
+    """GEMM-input activation: rounded to bf16 inside ``bf16_gemm_operands()``, untouched otherwise"""
     return x.to(torch.bfloat16).to(torch.float32) if _GEMM_BF16 else x
+
+
+def _rw(w: Tensor) -> Tensor:
+    """weight operand: as ``_r`` but cached for the lifetime of the context (the key keeps the tensor alive, so an id
+    cannot be recycled)"""
+    if not _GEMM_BF16:
+        return w
+    hit = _RW_CACHE.get(id(w))
+    if hit is None or hit[0] is not w:
+        hit = (w, w.to(torch.bfloat16).to(torch.float32))
+        _RW_CACHE[id(w)] = hit
+    return hit[1]
 
 
 def _n_layer(sd: SD, g: str) -> int:
@@ -179,7 +195,7 @@ def gpt2_hidden(embeds: Tensor, sd: SD, n_head: int = 12, g: str = "gpt.", pos0:
     for i in range(_n_layer(sd, g)):
         b = f"{t}h.{i}."
         a = F.layer_norm(h, (d,), sd[b + "ln_1.weight"], sd[b + "ln_1.bias"], 1e-5)
-        qkv = torch.addmm(sd[b + "attn.c_attn.bias"], _r(a.reshape(-1, d)), _r(sd[b + "attn.c_attn.weight"])).view(N, L, 3 * d)
+        qkv = torch.addmm(sd[b + "attn.c_attn.bias"], _r(a.reshape(-1, d)), _rw(sd[b + "attn.c_attn.weight"])).view(N, L, 3 * d)
         q, k, v = qkv.split(d, dim=2)
         q = q.view(N, L, n_head, hd).transpose(1, 2)
         k = k.view(N, L, n_head, hd).transpose(1, 2)
@@ -195,12 +211,12 @@ def gpt2_hidden(embeds: Tensor, sd: SD, n_head: int = 12, g: str = "gpt.", pos0:
         w = torch.where(causal, w, torch.full((), torch.finfo(w.dtype).min))
         w = w.softmax(dim=-1)
         o = torch.matmul(w, v).transpose(1, 2).reshape(N, L, d)
-        o = torch.addmm(sd[b + "attn.c_proj.bias"], _r(o.reshape(-1, d)), _r(sd[b + "attn.c_proj.weight"])).view(N, L, d)
+        o = torch.addmm(sd[b + "attn.c_proj.bias"], _r(o.reshape(-1, d)), _rw(sd[b + "attn.c_proj.weight"])).view(N, L, d)
         h = h + o
         m = F.layer_norm(h, (d,), sd[b + "ln_2.weight"], sd[b + "ln_2.bias"], 1e-5)
-        m = torch.addmm(sd[b + "mlp.c_fc.bias"], _r(m.reshape(-1, d)), _r(sd[b + "mlp.c_fc.weight"]))
+        m = torch.addmm(sd[b + "mlp.c_fc.bias"], _r(m.reshape(-1, d)), _rw(sd[b + "mlp.c_fc.weight"]))
         m = gelu_new(m)
-        m = torch.addmm(sd[b + "mlp.c_proj.bias"], _r(m), _r(sd[b + "mlp.c_proj.weight"])).view(N, L, d)
+        m = torch.addmm(sd[b + "mlp.c_proj.bias"], _r(m), _rw(sd[b + "mlp.c_proj.weight"])).view(N, L, d)
         h = h + m
     return F.layer_norm(h, (d,), sd[t + "ln_f.weight"], sd[t + "ln_f.bias"], 1e-5)
 
@@ -209,7 +225,7 @@ def gpt2_logits(embeds: Tensor, sd: SD, n_head: int = 12, g: str = "gpt.") -> Te
     """``model.gpt(inputs_embeds=x).logits`` -- ALL positions [N, L, V], tied lm_head
     (what the reference computes every step, gpt2_prefix_eval.py:76-77,163-164)."""
     h = gpt2_hidden(embeds, sd, n_head, g)
-    return torch.matmul(_r(h), _r(sd[g + "transformer.wte.weight"]).t())
+    return torch.matmul(_r(h), _rw(sd[g + "transformer.wte.weight"]).t())
 
 
 def wte(ids: Tensor, sd: SD, g: str = "gpt.") -> Tensor:
@@ -307,7 +323,7 @@ def greedy_cached(sd: SD, prefix: Tensor, stop_id: int = 13, entry_length: int =
     g = "gpt."
     cache: list = [None] * _n_layer(sd, g)
     W = sd[g + "transformer.wte.weight"]
-    Wr = _r(W)
+    Wr = _rw(W)
     ids = torch.zeros(N, entry_length, dtype=torch.int32)
     lens = torch.zeros(N, dtype=torch.int32)
     done = torch.zeros(N, dtype=torch.bool)
@@ -342,7 +358,7 @@ def beam_cached(sd: SD, prefix: Tensor, beam_size: int = 5, stop_id: int = 13, e
     V = W.shape[0]
     temp = temperature if temperature > 0 else 1.0
     h = gpt2_hidden(prefix, sd, n_head, g, 0, cache)[:, -1]
-    Wr = _r(W)
+    Wr = _rw(W)
     logp = ((_r(h) @ Wr.t()) / temp).softmax(-1).log()
     scores, nxt = logp.topk(B, -1)                      # [N, B]
     if margins is not None and V > B:
