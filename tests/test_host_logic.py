@@ -322,3 +322,30 @@ def test_clip_bpe_matches_transformers(tmp_path):
     with pytest.raises(RuntimeError):
         mine.tokenize("word " * 100)
     assert mine.tokenize("word " * 100, truncate=True)[0, 76] == mine.eot
+
+
+def test_pmc_summary_tool(tmp_path):
+    """tools/pmc_summary.py: per-kernel averages of the two rocprofv3 --pmc passes and the gfx950 FETCH_SIZE correction
+    (traffic = 2 x FETCH_SIZE + WRITE_SIZE, counters in KB)"""
+    import json
+    d = tmp_path / "pmc_FETCH_SIZE" / "box"
+    d.mkdir(parents=True)
+    (d / "1_counter_collection.csv").write_text(
+        '"Kernel_Name","Counter_Name","Counter_Value"\n'
+        '"void capdec::gemm_bf16x3p_kernel<true>(int, float*)","FETCH_SIZE",1000\n'
+        '"void capdec::gemm_bf16x3p_kernel<true>(int, float*)","FETCH_SIZE",3000\n'
+        '"capdec::layernorm_packed_kernel(float const*)","FETCH_SIZE",10\n')
+    d2 = tmp_path / "pmc_WRITE_SIZE" / "box"
+    d2.mkdir(parents=True)
+    (d2 / "2_counter_collection.csv").write_text(
+        '"Kernel_Name","Counter_Name","Counter_Value"\n'
+        '"void capdec::gemm_bf16x3p_kernel<true>(int, float*)","WRITE_SIZE",500\n'
+        '"void capdec::gemm_bf16x3p_kernel<true>(int, float*)","WRITE_SIZE",700\n')
+    out = tmp_path / "traffic.json"
+    subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "pmc_summary.py"), str(tmp_path), str(out), "cmd"])
+    rec = json.load(open(out))
+    k = rec["kernels"]["gemm_bf16x3p_kernel<true>"]
+    assert k["launches"] == 2 and k["fetch_KB_raw"] == 2000.0 and k["write_KB"] == 600.0
+    assert k["traffic_bytes_per_launch"] == (2 * 2000 + 600) * 1024
+    assert rec["gemm_bf16x3p_kernel"] == k                       # alias without template arguments (what bench.py reads)
+    assert rec["kernels"]["layernorm_packed_kernel"]["traffic_bytes_per_launch"] == 20 * 1024
