@@ -3,7 +3,8 @@
 // variable set: fp64 comparison, bias / activation / residual, ragged M, N % 4 != 0) and 224 TFLOP/s fp32-equivalent on
 // 4096^3 (128x128 kernel: 204-208), but on the decode shapes 256-row tiles quantise badly -- M = 25 000 is 98 tile rows
 // x 3 / 9 / 12 tile columns on 256 one-block CUs: 129 / 171 / 180 TFLOP/s vs 180 / 182 / 184 -- so it is NOT the default.
-// Where it should pay: the lm_head (197 tile columns; needs a wide top-k epilogue) or with stream-K scheduling.
+// The fc shape (12 tile columns, 92 % grid efficiency, still 180) shows the second cost: one block per CU leaves the
+// pipeline fill and the epilogue of a 48-k-step tile exposed (~13 %).  Next: persistent / stream-K scheduling.
 //
 // Wide-tile variant of the packed-A split-bf16 GEMM (gemm_bf16x3.hip):  C[M,N] = epi( A[M,K] . Bt[N,K]^T ).
 // The 128x128 kernel issues one LDS-DMA piece per 4 MFMAs and one fragment read per 2 MFMAs, with one barrier per 24
