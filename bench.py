@@ -1,13 +1,20 @@
 #!/usr/bin/env python
 """captions/sec of the CapDec caption hot path on MI355X.
 
-  python bench.py --gpus N --steps K --warmup W            (N > 1: launched by torch.distributed.run)
+  python bench.py --gpus N --steps K --warmup W
+
+With N > 1 and no RANK in the environment the script re-executes itself under
+`python -m torch.distributed.run --nnodes=1 --nproc-per-node N` (one rank per GPU, one RCCL
+communicator); started by torch.distributed.run directly it just joins the group.
 
 A "step" is one pass of the hot path over one batch of synthetic CLIP embeddings resident in
 HBM: normalise -> mapping network -> GPT-2 KV-cached decode -> token ids (+ RCCL all-gather of
 the ids when N > 1).  Default workload = BASELINE.json's metric configuration (configs[2]):
-5000 x 512-d embeddings per GPU, TransformerMapper (8 layers), prefix_len 10, beam 5,
+COCO-val-5k-shaped = 5000 x 512-d embeddings IN TOTAL, sharded over the N ranks (strong scaling,
+625 captions per GPU at N = 8), TransformerMapper (8 layers), prefix_len 10, beam 5,
 entry_length 67, fp32 (the reference's GPT-2 dtype; greedy ids bit-identical to it).
+`--scaling weak` keeps 5000 captions PER GPU instead; at N > 1 the strong-scaling line also
+carries a one-step weak measurement and the 1-GPU rate of the same box (`scaling_check`).
 Weights are the seeded hot-init recipe of capdec_amd/synth.py (no checkpoints offline), which
 never emits the stop token, so every caption runs all 67 steps -- fixed, reproducible work.
 
@@ -32,6 +39,7 @@ from capdec_amd import synth  # noqa: E402
 PEAK_F32_MFMA_TFLOPS = 157.3    # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 PEAK_BF16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA (not the 2:1-sparse marketing figure)
 STOP_ID, D_EMB = 13, 768
+PMC_TRAFFIC_FILE = "r1_pmc_traffic.json"   # rocprofv3 --pmc summary the `roofline.traffic` field is read from
 
 
 def algorithmic_flops_per_caption(P, T, beam, mapper, dims=synth.GPT2_SMALL, D=512, clip_len=10):
@@ -152,6 +160,22 @@ def side_workload(args, world, rank, dev):
                           "config": {"workload": args.workload, "items_per_step": n_global}}), flush=True)
 
 
+def respawn_under_torchrun(n):
+    """`python bench.py --gpus N` without a launcher: start N ranks (one per GPU) with torch.distributed.run and
+    pass the same arguments through; the JSON line is printed by rank 0 of that job."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env["CAPDEC_BENCH_SPAWNED"] = "1"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -162,31 +186,57 @@ def main():
                     help="beam_transformer = BASELINE metric config (default); greedy_mlp = configs[1] shape; "
                          "text_embed = configs[3] (CLIP ViT-B/32 encode_text + noise + mapper); "
                          "image_beam = configs[4] (ViT-B/32 encode_image + TransformerMapper + beam 5)")
-    ap.add_argument("--captions", type=int, default=5000, help="captions per GPU per step (weak scaling)")
+    ap.add_argument("--captions", type=int, default=5000,
+                    help="captions per step: IN TOTAL with --scaling strong (default: COCO-val 5k), PER GPU with --scaling weak")
     ap.add_argument("--entry-length", type=int, default=67)
     ap.add_argument("--prefix-length", type=int, default=10)
-    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
-    ap.add_argument("--gemm-mode", choices=["bf16x3", "f32", "bf16"], default=None,
-                    help="bf16x3 (default): fp32-accurate split-bf16 MFMA GEMMs (parity with the fp32 reference); f32: native "
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="strong",
+                    help="strong (default): the metric's 5000 captions sharded over the ranks; weak: 5000 per GPU")
+    ap.add_argument("--no-scaling-check", action="store_true",
+                    help="N > 1, strong scaling: skip the extra 1-GPU pass (rank 0 alone on all captions) and the one-step "
+                         "weak-scaling pass that fill `scaling_check`")
+    ap.add_argument("--gemm-mode", choices=["bf16x3", "f32", "bf16", "f16x2"], default=None,
+                    help="f16x2 / bf16x3: fp32-accurate split-operand MFMA GEMMs (parity with the fp32 reference); f32: native "
                          "fp32 MFMA; bf16: bf16 GEMM operands, fp32 accumulate (BASELINE configs[1]; NOT the headline: "
                          "token ids are no longer bit-identical to the fp32 reference)")
     ap.add_argument("--profile-every", type=int, default=7,
                     help="hipEvent-time every N-th launch of each kernel family inside the timed region (1 = all; "
                          "7 is coprime to the 4-GEMM / 12-layer launch cycles, so every shape is sampled evenly)")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="wall-clock budget of the CPU baseline (0 = skip)")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="launcher check without a GPU (CPU tests): join a gloo group, all-gather the ranks, print "
+                         "{n_gpus, ranks} and exit")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "RANK" not in os.environ:
+        sys.exit(respawn_under_torchrun(args.gpus))
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     force_dist = os.environ.get("CAPDEC_FORCE_DIST") == "1" and "RANK" in os.environ   # exercise RCCL with 1 rank
-    if world > 1 or force_dist:
+    use_dist = world > 1 or force_dist
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
+    if args.dry_run:
+        import torch.distributed as dist
+        seen = [rank]
+        if world > 1:
+            dist.init_process_group("gloo")
+            parts = [torch.zeros(1, dtype=torch.int64) for _ in range(world)]
+            dist.all_gather(parts, torch.tensor([rank]))
+            seen = [int(p) for p in parts]
+            dist.destroy_process_group()
+        if rank == 0:
+            print(json.dumps({"dry_run": True, "n_gpus": world, "ranks": seen}), flush=True)
+        return
+    if use_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+        assert dist.get_world_size() == args.gpus and dist.get_rank() == rank
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
 
@@ -203,21 +253,33 @@ def main():
     model = ClipCaptionModel(P, clip_length=10, prefix_dim=512, num_layers=8,
                              mapping_type=MappingType.TransformerEncoder if beam else MappingType.MLP).to(dev).eval()
     model.load_state_dict(synth.hot_state_dict(42, mapper, 512, P))
-    emb = synth.synthetic_clip_embeddings(n_global, 512, seed=0, normalize=False).to(dev)   # resident in HBM
+    n_alloc = max(n_global, args.captions * world) if (world > 1 and not args.no_scaling_check) else n_global
+    emb_all = synth.synthetic_clip_embeddings(n_alloc, 512, seed=0, normalize=False).to(dev)   # resident in HBM
+    emb = emb_all[:n_global]
     eng = model.engine
     if args.gemm_mode:
         eng.set_gemm_mode(args.gemm_mode)
 
+    def run_step(e, r, w):
+        ids, lens, scores = caption_ids(model, e, STOP_ID, beam=beam, beam_size=5, entry_length=T, rank=r, world=w)
+        return cdist.gather_ids(ids, lens, e.shape[0], scores) if w > 1 or force_dist else (ids, lens, scores)
+
     def step():
-        ids, lens, scores = caption_ids(model, emb, STOP_ID, beam=beam, beam_size=5, entry_length=T,
-                                        rank=rank, world=world)
-        return cdist.gather_ids(ids, lens, n_global, scores)
+        return run_step(emb, rank, world)
 
     def barrier():
-        if world > 1:
+        if use_dist:
             import torch.distributed as dist
             dist.barrier()
         torch.cuda.synchronize()
+
+    def max_over_ranks(x):
+        if not use_dist:
+            return x
+        import torch.distributed as dist
+        tt = torch.tensor([x], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        return float(tt.item())
 
     for _ in range(args.warmup):
         out = step()
@@ -228,71 +290,108 @@ def main():
     for _ in range(args.steps):
         out = step()
     barrier()
-    dt = time.perf_counter() - t0
+    dt = max_over_ranks(time.perf_counter() - t0)
     prof = eng.profile_get()
     eng.profile_enable(False)
-    if world > 1:
-        import torch.distributed as dist
-        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
     assert out[0].shape[0] == n_global and int(out[1].min()) >= 1
+
+    # ---- N > 1, strong scaling: the 1-GPU rate of this box (rank 0 alone decodes all captions; the other ranks wait
+    # at the barrier) and one weak-scaling step (args.captions per GPU) -- extra fields, outside the timed region
+    scaling_check = None
+    if world > 1 and args.scaling == "strong" and not args.no_scaling_check:
+        barrier()
+        t1 = 0.0
+        if rank == 0:
+            run_step(emb, 0, 1)
+            torch.cuda.synchronize()
+            ta = time.perf_counter()
+            one = run_step(emb, 0, 1)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter() - ta
+            same = bool((one[0] == out[0]).all()) and bool((one[1] == out[1]).all())
+        barrier()
+        run_step(emb_all, rank, world)
+        barrier()
+        tb = time.perf_counter()
+        run_step(emb_all, rank, world)
+        barrier()
+        tw = max_over_ranks(time.perf_counter() - tb)
+        if rank == 0:
+            v1, vs, vw = n_global / t1, n_global * args.steps / dt, emb_all.shape[0] / tw
+            scaling_check = {"n1_value": round(v1, 2), "n1_note": "rank 0 alone, all %d captions, 1 timed step" % n_global,
+                             "ids_equal_to_1gpu": same, "per_gpu_value": round(vs / world, 2),
+                             "strong_efficiency": round(vs / (world * v1), 4),
+                             "weak_value": round(vw, 2), "weak_captions_per_gpu": args.captions,
+                             "weak_efficiency": round(vw / (world * v1), 4)}
 
     if rank == 0:
         value = n_global * args.steps / dt
         mode = eng.gemm_mode()
+        est = lambda f: f["ms"] * f["calls"] / f["launches"] if f and f["launches"] else 0.0
         if mode == "bf16":
             fam, kname, peak = prof["gemm_bf16p"], "gemm_bf16p_kernel", PEAK_BF16_MFMA_TFLOPS
             peak_note = "dense bf16 MFMA peak (bf16 operands, one MFMA per product)"
+            products = 1
         elif mode == "bf16x3":
             # every fp32 product is six bf16 MFMA products: the kernel's ceiling in fp32-equivalent FLOP/s is
             # the dense bf16 peak / 6; achieved = algorithmic (2*M*N*K) FLOPs / measured kernel time.
             # Dominant kernel = the GEMM family with the most device time (packed-A LDS-DMA kernel or the
             # fp32-activation kernel).
             cands = [("gemm_bf16x3p", "gemm_bf16x3p_kernel"), ("gemm_bf16x3", "gemm_bf16x3_kernel")]
-            est = lambda f: f["ms"] * f["calls"] / f["launches"] if f and f["launches"] else 0.0
             fkey, kname = max(cands, key=lambda kv: est(prof.get(kv[0])))
             fam, peak = prof[fkey], PEAK_BF16_MFMA_TFLOPS / 6.0
             peak_note = "fp32-equivalent TFLOP/s: dense bf16 MFMA peak 2500 / 6 products per fp32 product"
+            products = 6
+        elif mode == "f16x2":
+            # every fp32 product is three fp16 MFMA products (hi*hi + hi*lo + lo*hi on two fp16 planes): ceiling =
+            # dense fp16 MFMA peak (= the bf16 peak) / 3
+            fam, kname, peak = prof["gemm_f16x2p"], "gemm_f16x2p_kernel", PEAK_BF16_MFMA_TFLOPS / 3.0
+            peak_note = "fp32-equivalent TFLOP/s: dense fp16 MFMA peak 2500 / 3 products per fp32 product"
+            products = 3
         else:
             fam, kname, peak = prof["gemm_f32"], "gemm_f32_kernel", PEAK_F32_MFMA_TFLOPS
             peak_note = "dense fp32-input MFMA peak"
+            products = None
         traffic = None
         try:   # HBM-side bytes per launch of the dominant kernel, from the committed rocprofv3 --pmc passes
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")))
-            if beam and args.captions == 5000 and kname in pmc:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", PMC_TRAFFIC_FILE)))
+            if beam and n_global // world == pmc.get("captions_per_gpu", 5000) and pmc.get("gemm_mode", "bf16x3") == mode \
+                    and kname in pmc:
                 traffic = pmc[kname]["traffic_bytes_per_launch"]
         except (OSError, ValueError, KeyError):
             pass
         gemm_ms = fam["ms"] / max(fam["launches"], 1)
         achieved = fam["flops"] / (fam["ms"] * 1e-3) / 1e12 if fam["ms"] > 0 else 0.0
-        n_local = args.captions if args.scaling == "weak" else cdist.shard_size(args.captions, world)
+        n_local = cdist.shard_size(n_global, world)
         alg = algorithmic_flops_per_caption(P, T, B, "transformer" if beam else "mlp") * n_local * args.steps
         rec = {
             "metric": "captions/sec (whole node), COCO-val 5k, prefix_len=10 beam=5, 1/2/4/8 GPUs",
             "value": round(value, 2), "unit": "captions/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True,
             "scaling": args.scaling, "vs_baseline": None,
-            "dtype": {"f32": "f32", "bf16": "bf16 (GEMM operands bf16, fp32 accumulate; residual stream / LayerNorm / softmax / KV cache f32)",
-                      "bf16x3": "f32 (operands split into 3 bf16 planes, 6 bf16 MFMAs per product, fp32 accumulate)"}[mode],
+            "dtype": {"f32": "f32", "bf16": "bf16 (GEMM operands bf16, fp32 accumulate; residual stream / LayerNorm / softmax f32)",
+                      "bf16x3": "f32 (operands split into 3 bf16 planes, 6 bf16 MFMAs per product, fp32 accumulate)",
+                      "f16x2": "f32 (operands split into 2 fp16 planes, 3 fp16 MFMAs per product, fp32 accumulate)"}[mode],
             "data": "synthetic",
-            "config": {"workload": ("COCO-val-5k-shaped: %d x 512-d synthetic CLIP embeddings per GPU -> normalise -> "
+            "config": {"workload": ("COCO-val-5k-shaped: %d x 512-d synthetic CLIP embeddings %s -> normalise -> "
                                     "%s -> GPT-2 small KV-cached %s, prefix_len %d, entry_length %d, hot-init seeded "
                                     "weights (never emit the stop id: all %d steps run)")
-                       % (args.captions if args.scaling == "weak" else n_global,
+                       % (args.captions, "per GPU" if args.scaling == "weak" else "in total (sharded over the ranks)",
                           "TransformerMapper(8 layers)" if beam else "MLP mapper",
                           "beam-5 decode" if beam else "greedy decode", P, T, T),
-                       "captions_per_step": n_global, "beam": B, "parallelism": f"caption-shard dp{world}",
-                       "tokens_per_s": round(value * T, 1)},
+                       "captions_per_step": n_global, "captions_per_gpu": n_local, "beam": B,
+                       "parallelism": f"caption-shard dp{world}", "tokens_per_s": round(value * T, 1)},
+            "per_gpu_value": round(value / world, 2),
             "roofline": {"bound": "mfma", "kernel": kname + " (dominant GEMM family; the other projections and the fused "
                          "lm_head variant are listed in `kernels`)",
                          "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
                          "frac": round(achieved / peak, 4), "traffic": traffic, "peak_note": peak_note,
                          "traffic_note": "bytes per launch at the L2<->fabric boundary (2 x FETCH_SIZE + WRITE_SIZE, "
-                                         "profiles/r1_pmc_traffic.json; Infinity-Cache hits are counted)",
+                                         "profiles/%s; Infinity-Cache hits are counted)" % PMC_TRAFFIC_FILE,
                          "avg_launch_ms": round(gemm_ms, 4), "launches_timed": fam["launches"],
                          "launches": fam["calls"],
-                         "bf16_mfma_tflops_executed": round(achieved * 6, 1) if mode == "bf16x3" else None,
+                         "mfma_tflops_executed": round(achieved * products, 1) if products else None,
+                         "mfma_frac_of_dense_peak": round(achieved * products / PEAK_BF16_MFMA_TFLOPS, 4) if products else None,
                          "vs_native_f32_mfma_peak": round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
                          "whole_path_tflops": round(alg / dt / 1e12, 2)},
             # per family: ms_est = hipEvent time of the timed launches scaled to all launches of the timed region
@@ -301,14 +400,16 @@ def main():
                             **({"tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2)} if v["flops"] and v["ms"] else {})}
                         for k, v in prof.items() if v["launches"]},
             "profile_every": max(1, args.profile_every),
+            "scaling_check": scaling_check,
         }
         if world == 1 and args.cpu_seconds > 0:
             rec["cpu_baseline"] = cpu_baseline(mapper, B, P, T, args.cpu_seconds)
         else:
             rec["cpu_baseline"] = None
         print(json.dumps(rec), flush=True)
-    if world > 1 or force_dist:
+    if use_dist:
         import torch.distributed as dist
+        dist.barrier()
         dist.destroy_process_group()
 
 
