@@ -99,9 +99,19 @@ class GPT2BPE:
             ids.extend(self.encoder[t] for t in self.bpe.merge(tuple(tok), tok))
         return ids
 
-    def decode(self, ids: Iterable[int]) -> str:
+    @staticmethod
+    def clean_up_tokenization(out_string: str) -> str:
+        """transformers' ``PreTrainedTokenizerBase.clean_up_tokenization`` (the default of ``tokenizer.decode`` in the
+        pinned 4.24, which the reference calls at gpt2_prefix_eval.py:112,192): spaces before punctuation and
+        abbreviated forms are removed."""
+        return (out_string.replace(" .", ".").replace(" ?", "?").replace(" !", "!").replace(" ,", ",")
+                .replace(" ' ", "'").replace(" n't", "n't").replace(" 'm", "'m").replace(" 's", "'s")
+                .replace(" 've", "'ve").replace(" 're", "'re"))
+
+    def decode(self, ids: Iterable[int], clean_up_tokenization_spaces: bool = True) -> str:
         text = "".join(self.decoder[int(i)] for i in ids)
-        return bytearray(self.byte_decoder[c] for c in text).decode("utf-8", errors="replace")
+        text = bytearray(self.byte_decoder[c] for c in text).decode("utf-8", errors="replace")
+        return self.clean_up_tokenization(text) if clean_up_tokenization_spaces else text
 
 
 class ClipBPE:

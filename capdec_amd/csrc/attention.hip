@@ -35,7 +35,7 @@ __global__ __launch_bounds__(256) void attn_gpt2_kernel(const float *__restrict_
                                                         int d, int beam, int Lparam, int P, int causal,
                                                         const uint8_t *__restrict__ anc, int anc_stride,
                                                         float *__restrict__ out, char *__restrict__ packed_out,
-                                                        const int *__restrict__ cmap) {
+                                                        const int *__restrict__ cmap, int fmt) {
     __shared__ float sc[4][ATT_CTX_MAX];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int grp = lane >> 4, sub = lane & 15;
@@ -119,7 +119,7 @@ __global__ __launch_bounds__(256) void attn_gpt2_kernel(const float *__restrict_
     if (active && grp == 0) {
         const float inv = 1.0f / sum;
         const float4 o = make_float4(acc.x * inv, acc.y * inv, acc.z * inv, acc.w * inv);
-        if (packed_out) x3_store_quad(packed_out, d >> 4, row, head * 4 + (sub >> 2), sub & 3, o);   // A operand of c_proj
+        if (packed_out) x3_store_quad(packed_out, d >> 4, row, head * 4 + (sub >> 2), sub & 3, o, fmt);   // A operand of c_proj
         else reinterpret_cast<float4 *>(out + (size_t)row * d + head * 64)[sub] = o;
     }
 }
@@ -136,7 +136,7 @@ __global__ __launch_bounds__(256, 4) void attn_decode_beams_kernel(const float *
                                                                 const uint8_t *__restrict__ anc, int anc_stride,
                                                                 float *__restrict__ out,
                                                                 char *__restrict__ packed_out,
-                                                                const int *__restrict__ cmap) {
+                                                                const int *__restrict__ cmap, int fmt) {
     extern __shared__ __attribute__((aligned(16))) float sc_all[];      // [4 waves][BEAM][L] scores + [4][BEAM][L] slots
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int grp = lane >> 4, sub = lane & 15;
@@ -325,7 +325,7 @@ __global__ __launch_bounds__(256, 4) void attn_decode_beams_kernel(const float *
         acc[b].z = groups4_sum(acc[b].z); acc[b].w = groups4_sum(acc[b].w);
         if (active && grp == 0) {
             const float4 o = make_float4(acc[b].x * inv[b], acc[b].y * inv[b], acc[b].z * inv[b], acc[b].w * inv[b]);
-            if (packed_out) x3_store_quad(packed_out, d >> 4, row0 + b, head * 4 + (sub >> 2), sub & 3, o);
+            if (packed_out) x3_store_quad(packed_out, d >> 4, row0 + b, head * 4 + (sub >> 2), sub & 3, o, fmt);
             else reinterpret_cast<float4 *>(out + (size_t)(row0 + b) * d + head * 64)[sub] = o;
         }
     }
@@ -340,7 +340,7 @@ __global__ __launch_bounds__(256, 4) void attn_decode_beams_kernel(const float *
 template <int R>
 __global__ __launch_bounds__(256) void attn_prefill_rows_kernel(const float *__restrict__ qkv, int total, int heads,
                                                                 int P, int d, int causal, float *__restrict__ out,
-                                                                char *__restrict__ packed_out) {
+                                                                char *__restrict__ packed_out, int fmt) {
     extern __shared__ __attribute__((aligned(16))) float sc_rows[];       // [4 waves][R][P]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int grp = lane >> 4, sub = lane & 15;
@@ -416,7 +416,7 @@ __global__ __launch_bounds__(256) void attn_prefill_rows_kernel(const float *__r
         if (active && grp == 0 && r < nr) {
             const int row = cap * P + i0 + r;
             const float4 o = make_float4(acc[r].x * inv[r], acc[r].y * inv[r], acc[r].z * inv[r], acc[r].w * inv[r]);
-            if (packed_out) x3_store_quad(packed_out, d >> 4, row, head * 4 + (sub >> 2), sub & 3, o);
+            if (packed_out) x3_store_quad(packed_out, d >> 4, row, head * 4 + (sub >> 2), sub & 3, o, fmt);
             else reinterpret_cast<float4 *>(out + (size_t)row * d + head * 64)[sub] = o;
         }
     }
@@ -451,7 +451,7 @@ int launch_kv_scatter_prefill(hipStream_t st, const float *qkv, const KvCache &c
 }
 
 int launch_attn_prefill(hipStream_t st, const float *qkv, const KvCache &c, int layer, int ncap, int P, int beam,
-                        float *out, bool causal, void *packed_out) {
+                        float *out, bool causal, void *packed_out, int fmt) {
     CAPDEC_CHECK(c.hd == 64, "attention: head_dim must be 64");
     CAPDEC_CHECK(P <= ATT_CTX_MAX && P <= c.ctx, "attention: prefix longer than the supported context");
     (void)layer; (void)beam;                      // K / V come straight from qkv (the cache is filled by kv_scatter_prefill)
@@ -460,13 +460,13 @@ int launch_attn_prefill(hipStream_t st, const float *qkv, const KvCache &c, int 
     if (total <= 0) return 0;
     const size_t lds = (size_t)4 * R * P * sizeof(float);
     hipLaunchKernelGGL(attn_prefill_rows_kernel<R>, dim3((total + 3) / 4), dim3(256), lds, st, qkv, total, c.heads, P,
-                       c.heads * c.hd, causal ? 1 : 0, out, (char *)packed_out);
+                       c.heads * c.hd, causal ? 1 : 0, out, (char *)packed_out, fmt);
     CAPDEC_HIP(hipGetLastError());
     return 0;
 }
 
 int launch_attn_decode(hipStream_t st, const float *qkv, const KvCache &c, int layer, int rows, int beam, int L,
-                       const uint8_t *anc, int anc_stride, float *out, void *packed_out, const int *cmap) {
+                       const uint8_t *anc, int anc_stride, float *out, void *packed_out, const int *cmap, int fmt) {
     CAPDEC_CHECK(c.hd == 64, "attention: head_dim must be 64");
     CAPDEC_CHECK(L >= 1 && L <= ATT_CTX_MAX && L <= c.ctx, "attention: context length out of range");
     if (anc != nullptr && beam > 1) {
@@ -477,7 +477,7 @@ int launch_attn_decode(hipStream_t st, const float *qkv, const KvCache &c, int l
         float *kl = c.k + layer * c.layer_stride(), *vl = c.v + layer * c.layer_stride();
 #define LAUNCH_BEAMS(B)                                                                                         \
     hipLaunchKernelGGL(attn_decode_beams_kernel<B>, grid, block, lds, st, qkv, kl, vl, total, c.heads, c.ctx,      \
-                       c.heads * c.hd, L, anc, anc_stride, out, (char *)packed_out, cmap)
+                       c.heads * c.hd, L, anc, anc_stride, out, (char *)packed_out, cmap, fmt)
         switch (beam) {
             case 2: LAUNCH_BEAMS(2); break;
             case 3: LAUNCH_BEAMS(3); break;
@@ -496,7 +496,7 @@ int launch_attn_decode(hipStream_t st, const float *qkv, const KvCache &c, int l
     if (total <= 0) return 0;
     hipLaunchKernelGGL(attn_gpt2_kernel<true>, dim3((total + 3) / 4), dim3(256), 0, st, qkv,
                        c.k + layer * c.layer_stride(), c.v + layer * c.layer_stride(), total, c.heads, c.ctx,
-                       c.heads * c.hd, beam, L, 0, 1, anc, anc_stride, out, (char *)packed_out, cmap);
+                       c.heads * c.hd, beam, L, 0, 1, anc, anc_stride, out, (char *)packed_out, cmap, fmt);
     CAPDEC_HIP(hipGetLastError());
     return 0;
 }

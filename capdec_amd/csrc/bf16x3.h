@@ -39,8 +39,48 @@ __device__ __forceinline__ int x3_group_offset(int r, int quad) {
     return r * X3_ROW_B + (((quad >> 1) ^ ((r >> 3) & 1)) << 4) + ((quad & 1) << 3);
 }
 
+// ---- second packed format, "f16x2" (PK_F16X2): TWO fp16 planes per value,
+//     a = hi + lo * 2^-11,   hi = fp16(a) (RNE; 0 when |a| < 2^-14, fp16's smallest normal),   lo = fp16((a - hi) * 2^11)
+// (11 + 11 significand bits; the low plane is stored scaled by 2^11 so it stays in fp16's normal range wherever it
+// matters -- nothing depends on fp16 subnormals: an element below 2^-14 is carried by the low plane alone with an
+// absolute error <= 2^-26, an element above it has a relative error <= 2^-23).  A product then needs THREE fp16 MFMAs instead of six:
+//     a b = hi_a hi_b + 2^-11 (hi_a lo_b + lo_a hi_b) + 2^-22 lo_a lo_b          (last term dropped: <= 2^-22 |a b|,
+// rms 2^-24.6 |a b|, i.e. below the rounding of an fp32 multiply-add), with the 2^-11 terms summed in their own
+// accumulator.  Same tile-major layout as above with two planes: one (row_tile, k_step) block is 8 KB.
+// |a| is clamped to fp16's largest finite value 65504 (GEMM inputs of this path -- LayerNorm outputs, attention
+// outputs, GELU outputs, weights -- are orders of magnitude below it).
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+enum PackFmt { PK_BF16X3 = 0, PK_F16X2 = 1 };
+constexpr int H2_BLOCK_B = 2 * X3_PLANE_B;            // 8192: one (row_tile, k_step) block of the f16x2 format
+constexpr float H2_LO_SCALE = 2048.0f;                // 2^11
+
+__device__ __forceinline__ void split2h(const float4 v, f16x4 &h, f16x4 &l) {
+    const float a[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const float c = __builtin_fminf(__builtin_fmaxf(a[e], -65504.f), 65504.f);
+        const _Float16 hh = __builtin_fabsf(c) < 0x1p-14f ? (_Float16)0.f : (_Float16)c;
+        const float r = c - (float)hh;                // exact
+        h[e] = hh;
+        l[e] = (_Float16)(r * H2_LO_SCALE);
+    }
+}
+
+__host__ __device__ __forceinline__ int pk_planes(int fmt) { return fmt == PK_F16X2 ? 2 : 3; }
+
 // store the split of 4 consecutive k (one float4) of matrix row `row`, k-step `ks`, quad `quad`
-__device__ __forceinline__ void x3_store_quad(char *packed, int nk, int row, int ks, int quad, const float4 v) {
+// (fmt is uniform across the launch: PK_BF16X3 = three bf16 planes, PK_F16X2 = two fp16 planes)
+__device__ __forceinline__ void x3_store_quad(char *packed, int nk, int row, int ks, int quad, const float4 v,
+                                              int fmt = PK_BF16X3) {
+    if (fmt == PK_F16X2) {
+        f16x4 h, l;
+        split2h(v, h, l);
+        char *p = packed + ((size_t)(row >> 7) * nk + ks) * H2_BLOCK_B + x3_group_offset(row & 127, quad);
+        *reinterpret_cast<f16x4 *>(p) = h;
+        *reinterpret_cast<f16x4 *>(p + X3_PLANE_B) = l;
+        return;
+    }
     bf16x4 h, m, l;
     split3(v, h, m, l);
     char *p = packed + ((size_t)(row >> 7) * nk + ks) * X3_BLOCK_B + x3_group_offset(row & 127, quad);
@@ -49,8 +89,8 @@ __device__ __forceinline__ void x3_store_quad(char *packed, int nk, int row, int
     *reinterpret_cast<bf16x4 *>(p + 2 * X3_PLANE_B) = l;
 }
 
-inline size_t x3_packed_bytes(int rows, int K) {
-    return (size_t)((rows + X3_TILE_ROWS - 1) / X3_TILE_ROWS) * X3_TILE_ROWS * K * 3 * sizeof(uint16_t);
+inline size_t x3_packed_bytes(int rows, int K, int fmt = PK_BF16X3) {
+    return (size_t)((rows + X3_TILE_ROWS - 1) / X3_TILE_ROWS) * X3_TILE_ROWS * K * pk_planes(fmt) * sizeof(uint16_t);
 }
 
 }  // namespace capdec

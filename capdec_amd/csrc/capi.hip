@@ -6,6 +6,7 @@
 #include <memory>
 #include <unordered_map>
 
+#include "bf16x3.h"
 #include "common.h"
 
 namespace capdec {
@@ -76,17 +77,20 @@ struct Tower {
 };
 
 enum Family { F_GEMM = 0, F_LMHEAD, F_ATTN_DEC, F_ATTN_PRE, F_LN, F_EMBED, F_SELECT, F_MAP_ATTN, F_OTHER, F_GEMM_X3,
-              F_LMHEAD_X3, F_GEMM_X3P, F_GEMM_BF16P, F_LMHEAD_BF16, F_COUNT };
+              F_LMHEAD_X3, F_GEMM_X3P, F_GEMM_BF16P, F_LMHEAD_BF16, F_GEMM_H2P, F_LMHEAD_H2, F_PACK, F_COUNT };
 static const char *kFamilyNames[F_COUNT] = {"gemm_f32", "gemm_f32_lmhead_topk", "attn_decode", "attn_prefill",
                                             "layernorm", "embed", "select", "attn_mapper", "other", "gemm_bf16x3",
                                             "gemm_bf16x3_lmhead_topk", "gemm_bf16x3p", "gemm_bf16p",
-                                            "gemm_bf16p_lmhead_topk"};
-enum GemmMode { GEMM_F32 = 0, GEMM_BF16X3 = 1, GEMM_BF16 = 2 };
+                                            "gemm_bf16p_lmhead_topk", "gemm_f16x2p", "gemm_f16x2p_lmhead_topk",
+                                            "pack_activations"};
+constexpr int PROF_SLOTS = 24;   // capdec_profile_get fills at most this many families (engine.py sizes its arrays by it)
+static_assert(F_COUNT <= PROF_SLOTS, "profile arrays too small");
+enum GemmMode { GEMM_F32 = 0, GEMM_BF16X3 = 1, GEMM_BF16 = 2, GEMM_F16X2 = 3 };
 
 struct Prof {
     bool on = false;
     int every = 1;                       // time every `every`-th launch of each family (1 = all)
-    int64_t calls[16] = {0};             // launches seen per family (timed or not)
+    int64_t calls[PROF_SLOTS] = {0};     // launches seen per family (timed or not)
     struct Rec { int fam; hipEvent_t a, b; double flops; };
     std::vector<Rec> recs;
     std::vector<hipEvent_t> pool;
@@ -106,9 +110,10 @@ struct capdec_ctx {
     Mapper map;
     Tower clip_text, clip_vision;
     Prof prof;
-    int gemm_mode = GEMM_BF16X3;
-    std::unordered_map<const void *, std::pair<void *, size_t>> planes;   // fp32 weight -> (three bf16 planes, elements)
-    DBuf x3_tmp, xpk, apk, fpk;          // scratch planes for un-cached matrices; packed split-bf16 LayerNorm output
+    int gemm_mode = GEMM_F16X2;
+    struct Planes { void *p; size_t n; int fmt; };
+    std::unordered_map<const void *, Planes> planes;   // fp32 weight -> (packed planes, elements, PackFmt)
+    DBuf x3_tmp, xpk, apk, fpk, a_tmp;   // scratch planes for un-cached matrices; packed LayerNorm output; packed fp32-A
     int stat_steps = 0, stat_compactions = 0;      // last decode call: steps run, compactions done,
     long long stat_row_steps = 0;                  // activation rows pushed through the GPT-2 body (prefill excluded)
     bool compact = true;       // decode: drop finished captions from the batch at the poll points (CAPDEC_COMPACT=0: off)
@@ -210,30 +215,37 @@ static void free_all(std::vector<void *> &owned) {
 // ---------------------------------------------------------------------------- GEMM wrappers
 // bf16 planes of an [N, K] fp32 weight matrix: made on first use, dropped whenever weights are reloaded
 static void drop_planes(capdec_ctx *c) {
-    for (auto &kv : c->planes) (void)hipFree(kv.second.first);
+    for (auto &kv : c->planes) (void)hipFree(kv.second.p);
     c->planes.clear();
 }
+// packed operand format of the current GEMM mode (bf16x3.h): two fp16 planes (f16x2) or three bf16 planes
+static int pack_fmt(const capdec_ctx *c) { return c->gemm_mode == GEMM_F16X2 ? PK_F16X2 : PK_BF16X3; }
+static int pack_any(capdec_ctx *c, const float *W, int N, int K, int fmt, void *out) {
+    if (fmt == PK_F16X2) return launch_pack_planes_h2(c->stream, W, K, N, K, out);
+    return launch_pack_planes(c->stream, W, N, K, out);
+}
 static int planes_of(capdec_ctx *c, const float *W, int N, int K, bool cache, const void **out) {
-    const size_t n = (size_t)N * K, bytes = packed_planes_bytes(N, K);
+    const int fmt = pack_fmt(c);
+    const size_t n = (size_t)N * K, bytes = x3_packed_bytes(N, K, fmt);
     if (cache) {
         auto it = c->planes.find(W);
         if (it != c->planes.end()) {
-            if (it->second.second == n) {
-                *out = it->second.first;
+            if (it->second.n == n && it->second.fmt == fmt) {
+                *out = it->second.p;
                 return 0;
             }
-            (void)hipFree(it->second.first);      // same address, different matrix
+            (void)hipFree(it->second.p);      // same address, different matrix (or the GEMM mode changed)
             c->planes.erase(it);
         }
         void *p = nullptr;
         CAPDEC_HIP(hipMalloc(&p, bytes));
-        c->planes[W] = std::make_pair(p, n);
-        CAPDEC_TRY(launch_pack_planes(c->stream, W, N, K, p));
+        c->planes[W] = capdec_ctx::Planes{p, n, fmt};
+        CAPDEC_TRY(pack_any(c, W, N, K, fmt, p));
         *out = p;
         return 0;
     }
     CAPDEC_TRY(c->x3_tmp.ensure(bytes));
-    CAPDEC_TRY(launch_pack_planes(c->stream, W, N, K, c->x3_tmp.p));
+    CAPDEC_TRY(pack_any(c, W, N, K, fmt, c->x3_tmp.p));
     *out = c->x3_tmp.p;
     return 0;
 }
@@ -245,6 +257,22 @@ static int gemm(capdec_ctx *c, const float *A, int lda, const float *Bt, int ldb
     e.act = act;
     e.resid = resid;
     e.ldr = ldr;
+    if (c->gemm_mode == GEMM_F16X2 && ldb == K && K % 64 == 0 && lda % 4 == 0 && M > 0) {
+        // fp32 activations in HBM (mapper, patch embedding, CLIP projections): one packing pass (read 4 B, write 4 B
+        // per element), then the packed LDS-DMA kernel
+        const void *pl = nullptr;
+        CAPDEC_TRY(planes_of(c, Bt, N, K, weight, &pl));
+        CAPDEC_TRY(c->a_tmp.ensure(x3_packed_bytes(M, K, PK_F16X2)));
+        { ProfScope ps(c, F_PACK); CAPDEC_TRY(launch_pack_planes_h2(c->stream, A, lda, M, K, c->a_tmp.p)); }
+        const size_t wsb = gemm_splitk_ws_bytes(M, N, K);
+        if (wsb) {
+            CAPDEC_TRY(c->splitk.ensure(wsb));
+            e.splitk_ws = c->splitk.p;
+            e.splitk_ws_bytes = c->splitk.cap;
+        }
+        ProfScope ps(c, F_GEMM_H2P, 2.0 * M * (double)N * K);
+        return launch_gemm_f16x2p(c->stream, c->a_tmp.p, pl, C, ldc, M, N, K, e);
+    }
     // (bf16 mode: GEMMs whose A operand is fp32 in HBM -- mapper, patch embedding -- keep the split kernel)
     if (c->gemm_mode != GEMM_F32 && ldb == K && K % 64 == 0) {   // other K: native fp32 MFMA
         const void *pl = nullptr;
@@ -259,7 +287,8 @@ static int gemm(capdec_ctx *c, const float *A, int lda, const float *Bt, int ldb
 // LayerNorm -> GEMM with the normalised rows handed over in packed split-bf16 form (never fp32 in HBM).
 // Returns 1 in *done when the packed path ran; otherwise the caller runs the fp32-activation path.
 static bool use_packed_a(capdec_ctx *c, int K) {
-    return (c->gemm_mode == GEMM_BF16 || (c->gemm_mode == GEMM_BF16X3 && c->pack_a)) && K % 64 == 0;
+    return (c->gemm_mode == GEMM_BF16 || c->gemm_mode == GEMM_F16X2 || (c->gemm_mode == GEMM_BF16X3 && c->pack_a)) &&
+           K % 64 == 0;
 }
 
 // C = act(Apk . W^T + bias) + resid with A already packed; packed_out != nullptr: the result is written as the
@@ -275,7 +304,7 @@ static int gemm_packed(capdec_ctx *c, const void *Apk, const float *W, float *C,
     e.resid = resid;
     e.ldr = ldr;
     e.packed_out = packed_out;
-    if (c->gemm_mode == GEMM_BF16X3) {
+    if (c->gemm_mode == GEMM_BF16X3 || c->gemm_mode == GEMM_F16X2) {
         const size_t wsb = gemm_splitk_ws_bytes(M, N, K);
         if (wsb) {
             CAPDEC_TRY(c->splitk.ensure(wsb));
@@ -287,6 +316,10 @@ static int gemm_packed(capdec_ctx *c, const void *Apk, const float *W, float *C,
         ProfScope ps(c, F_GEMM_BF16P, 2.0 * M * (double)N * K);
         return launch_gemm_bf16p(c->stream, Apk, pl, C, ldc, M, N, K, e);
     }
+    if (c->gemm_mode == GEMM_F16X2) {   // two fp16 planes, three MFMAs per product (fp32-accurate)
+        ProfScope ps(c, F_GEMM_H2P, 2.0 * M * (double)N * K);
+        return launch_gemm_f16x2p(c->stream, Apk, pl, C, ldc, M, N, K, e);
+    }
     ProfScope ps(c, F_GEMM_X3P, 2.0 * M * (double)N * K);
     if (gemm_bf16x3w_enabled() && M >= 1024)      // experimental wide tile (opt-in, see gemm_bf16x3w.hip)
         return launch_gemm_bf16x3w(c->stream, Apk, pl, C, ldc, M, N, K, e);
@@ -297,7 +330,7 @@ static int ln_gemm_packed(capdec_ctx *c, const float *h, int ldh, const float *l
                           const float *W, float *C, int ldc, int M, int N, int K, const float *bias, int act,
                           void *packed_out = nullptr) {
     CAPDEC_TRY(c->xpk.ensure(x3_packed_bytes_host(M, K)));
-    { ProfScope ps(c, F_LN); CAPDEC_TRY(launch_layernorm_packed(c->stream, h, ldh, lnw, lnb, eps, c->xpk.p, M, K)); }
+    { ProfScope ps(c, F_LN); CAPDEC_TRY(launch_layernorm_packed(c->stream, h, ldh, lnw, lnb, eps, c->xpk.p, M, K, pack_fmt(c))); }
     return gemm_packed(c, c->xpk.p, W, C, ldc, M, N, K, bias, act, nullptr, 0, packed_out);
 }
 
@@ -358,10 +391,10 @@ static int stack_body(capdec_ctx *c, const StackCfg &g, const StepShape &s, cons
             ProfScope ps(c, F_ATTN_PRE);
             if (g.keep_kv)      // the towers never decode: only GPT-2 needs its prefix K/V in the cache
                 CAPDEC_TRY(launch_kv_scatter_prefill(c->stream, qkv, kv, kl, s.ncap, s.P, s.beam));
-            CAPDEC_TRY(launch_attn_prefill(c->stream, qkv, kv, kl, s.ncap, s.P, s.beam, att, g.causal, apk));
+            CAPDEC_TRY(launch_attn_prefill(c->stream, qkv, kv, kl, s.ncap, s.P, s.beam, att, g.causal, apk, pack_fmt(c)));
         } else {
             ProfScope ps(c, F_ATTN_DEC);
-            CAPDEC_TRY(launch_attn_decode(c->stream, qkv, kv, kl, s.rows, s.beam, s.L, s.anc, s.anc_stride, att, apk, s.cmap));
+            CAPDEC_TRY(launch_attn_decode(c->stream, qkv, kv, kl, s.rows, s.beam, s.L, s.anc, s.anc_stride, att, apk, s.cmap, pack_fmt(c)));
         }
         if (chain) CAPDEC_TRY(gemm_packed(c, apk, w.wproj, h, d, M, d, d, w.bproj, CAPDEC_ACT_NONE, h, d));
         else CAPDEC_TRY(gemm(c, att, d, w.wproj, d, h, d, M, d, d, w.bproj, CAPDEC_ACT_NONE, h, d));
@@ -402,10 +435,14 @@ static int lm_head_select(capdec_ctx *c, const float *h0, int ldh, int R, int k,
     CAPDEC_TRY(c->topi.ensure((size_t)R * k * 4));
     if (use_packed_a(c, d)) {
         CAPDEC_TRY(c->xpk.ensure(x3_packed_bytes_host(R, d)));
-        { ProfScope ps(c, F_LN); CAPDEC_TRY(launch_layernorm_packed(c->stream, h0, ldh, g.lnfw, g.lnfb, g.eps, c->xpk.p, R, d)); }
+        { ProfScope ps(c, F_LN); CAPDEC_TRY(launch_layernorm_packed(c->stream, h0, ldh, g.lnfw, g.lnfb, g.eps, c->xpk.p, R, d, pack_fmt(c))); }
         const void *pl = nullptr;
         CAPDEC_TRY(planes_of(c, g.wte, g.vocab, d, true, &pl));
-        if (c->gemm_mode == GEMM_BF16) {
+        if (c->gemm_mode == GEMM_F16X2) {
+            ProfScope ps(c, F_LMHEAD_H2, 2.0 * R * (double)g.vocab * d);
+            CAPDEC_TRY(launch_gemm_f16x2p_topk(c->stream, c->xpk.p, pl, R, g.vocab, d, k, inv_temp, c->tmax.as<float>(),
+                                               c->tsum.as<float>(), c->cval.as<float>(), c->cidx.as<int>()));
+        } else if (c->gemm_mode == GEMM_BF16) {
             ProfScope ps(c, F_LMHEAD_BF16, 2.0 * R * (double)g.vocab * d);
             CAPDEC_TRY(launch_gemm_bf16p_topk(c->stream, c->xpk.p, pl, R, g.vocab, d, k, inv_temp, c->tmax.as<float>(),
                                               c->tsum.as<float>(), c->cval.as<float>(), c->cidx.as<int>()));
@@ -439,6 +476,14 @@ static int lm_head_select(capdec_ctx *c, const float *h0, int ldh, int R, int k,
     return 0;
 }
 
+// geometry only (the CLIP towers attend straight from the qkv activations and never touch a cache)
+static void kv_geometry(KvCache &kv, int rows, int ctx, int heads, int hd) {
+    kv.rows = rows;
+    kv.heads = heads;
+    kv.ctx = ctx;
+    kv.hd = hd;
+    kv.k = kv.v = nullptr;
+}
 static int ensure_kv(capdec_ctx *c, KvCache &kv, int rows, int ctx, int heads = 0, int hd = 0, int layers = 0) {
     const Gpt2 &g = c->gpt;
     kv.rows = rows;
@@ -460,11 +505,19 @@ static int poll_alive(capdec_ctx *c, int *alive) {
     return 0;
 }
 
-// captions per chunk so that the fp32 KV cache fits the budget
+// captions per chunk so that the fp32 KV cache fits the budget: the configured budget (capdec_set_kv_budget, default
+// 192 GiB), clamped to 85 % of what the device can still give (free memory + what the KV buffers already hold), so
+// a GPU that is partly occupied -- torch's caching allocator, the CLIP towers, a smaller part -- gets smaller chunks
+// instead of a failed hipMalloc
 static int chunk_captions(capdec_ctx *c, int n, int beam, int ctx) {
     const Gpt2 &g = c->gpt;
     const size_t per_cap = (size_t)beam * ctx * g.d * 2 * sizeof(float) * g.n_layer;
-    size_t m = c->kv_budget / std::max<size_t>(per_cap, 1);
+    size_t budget = c->kv_budget, free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+        const size_t avail = (size_t)((double)(free_b + c->kc.cap + c->vc.cap) * 0.85);
+        budget = std::min(budget, avail);
+    }
+    size_t m = budget / std::max<size_t>(per_cap, 1);
     m = std::max<size_t>(m, 1);
     return (int)std::min<size_t>(m, (size_t)n);
 }
@@ -676,7 +729,7 @@ static int clip_text_chunk(capdec_ctx *c, const int *tokens, int n, float *out) 
     Tower &t = c->clip_text;
     const int d = t.d, L = t.ctx;
     KvCache kv;
-    CAPDEC_TRY(ensure_kv(c, kv, n, L, t.n_head, d / t.n_head, 1));
+    kv_geometry(kv, n, L, t.n_head, d / t.n_head);
     CAPDEC_TRY(ensure_body_ws(c, n * L, d));
     CAPDEC_TRY(c->t_idx.ensure((size_t)n * 4));
     CAPDEC_TRY(c->xl.ensure((size_t)2 * n * d * 4));
@@ -703,7 +756,7 @@ static int clip_vision_chunk(capdec_ctx *c, const float *pixels, int n, float *o
     Tower &t = c->clip_vision;
     const int d = t.d, L = t.ntok, np = t.ntok - 1, kdim = 3 * t.patch * t.patch;
     KvCache kv;
-    CAPDEC_TRY(ensure_kv(c, kv, n, L, t.n_head, d / t.n_head, 1));
+    kv_geometry(kv, n, L, t.n_head, d / t.n_head);
     CAPDEC_TRY(ensure_body_ws(c, n * L, d));
     CAPDEC_TRY(c->t_patch.ensure((size_t)n * np * kdim * 4));
     CAPDEC_TRY(c->t_pout.ensure((size_t)n * np * d * 4));
@@ -751,8 +804,10 @@ int capdec_create(int device_id, capdec_ctx **out) {
     if (const char *e = getenv("CAPDEC_X3_PACKA")) c->pack_a = atoi(e) != 0;
     if (const char *e = getenv("CAPDEC_X3_CHAIN")) c->pack_chain = atoi(e) != 0;
     if (const char *e = getenv("CAPDEC_COMPACT")) c->compact = atoi(e) != 0;
-    if (const char *e = getenv("CAPDEC_GEMM_MODE"))
-        c->gemm_mode = std::string(e) == "f32" ? GEMM_F32 : std::string(e) == "bf16" ? GEMM_BF16 : GEMM_BF16X3;
+    if (const char *e = getenv("CAPDEC_GEMM_MODE")) {
+        const std::string m(e);
+        c->gemm_mode = m == "f32" ? GEMM_F32 : m == "bf16" ? GEMM_BF16 : m == "bf16x3" ? GEMM_BF16X3 : GEMM_F16X2;
+    }
     CAPDEC_HIP(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
     c->stream = c->own_stream;
     CAPDEC_HIP(hipEventCreate(&c->t0));
@@ -775,7 +830,7 @@ void capdec_destroy(capdec_ctx *c) {
     DBuf *bufs[] = {&c->h, &c->x, &c->qkv, &c->att, &c->ff, &c->xl, &c->tmax, &c->tsum, &c->cval, &c->cidx,
                     &c->lse, &c->topv, &c->topi, &c->kc, &c->vc, &c->tokens, &c->scores, &c->seq, &c->stopped,
                     &c->done, &c->anc, &c->next_tok, &c->alive, &c->gids, &c->glens, &c->m_hid, &c->m_lin, &c->m_seq,
-                    &c->m_x, &c->m_qkv, &c->m_att, &c->m_ff, &c->t_idx, &c->t_patch, &c->t_pout, &c->xpk, &c->apk, &c->fpk, &c->cmap, &c->p_desc, &c->p_inter, &c->splitk};
+                    &c->m_x, &c->m_qkv, &c->m_att, &c->m_ff, &c->t_idx, &c->t_patch, &c->t_pout, &c->xpk, &c->apk, &c->fpk, &c->cmap, &c->p_desc, &c->p_inter, &c->splitk, &c->a_tmp};
     for (DBuf *b : bufs) b->release();
     for (auto &r : c->prof.recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
     for (auto e : c->prof.pool) (void)hipEventDestroy(e);
@@ -802,8 +857,9 @@ int capdec_synchronize(capdec_ctx *c) {
     return 0;
 }
 int capdec_set_gemm_mode(capdec_ctx *c, int mode) {
-    CAPDEC_CHECK(c && (mode == GEMM_F32 || mode == GEMM_BF16X3 || mode == GEMM_BF16),
-                 "set_gemm_mode: mode must be 0 (f32 MFMA), 1 (bf16x3, fp32-accurate) or 2 (bf16 operands)");
+    CAPDEC_CHECK(c && (mode == GEMM_F32 || mode == GEMM_BF16X3 || mode == GEMM_BF16 || mode == GEMM_F16X2),
+                 "set_gemm_mode: mode must be 0 (f32 MFMA), 1 (bf16x3, fp32-accurate), 2 (bf16 operands) or 3 (f16x2, "
+                 "fp32-accurate, default)");
     c->gemm_mode = mode;
     return 0;
 }
@@ -1019,7 +1075,8 @@ int capdec_clip_encode_image(capdec_ctx *c, const float *pixels, int n, float *o
 
 int capdec_normalize_prefix(capdec_ctx *c, const float *x, int n, int dim, int normalize, const float *offset,
                             float *out) {
-    CAPDEC_CHECK(c && x && out && n >= 0 && dim >= 1, "normalize_prefix: bad argument");
+    CAPDEC_CHECK(c && n >= 0 && dim >= 1 && (n == 0 || (x && out)), "normalize_prefix: bad argument");
+    if (n == 0) return 0;
     CAPDEC_HIP(hipSetDevice(c->device));
     ProfScope ps(c, F_OTHER);
     return launch_normalize_prefix(c->stream, x, n, dim, normalize, offset, out);
@@ -1027,8 +1084,9 @@ int capdec_normalize_prefix(capdec_ctx *c, const float *x, int n, int dim, int n
 
 int capdec_noise_inject(capdec_ctx *c, const float *x, int n, int dim, float variance, const float *offset,
                         int uniform, int dont_norm, uint64_t seed, const float *noise, const float *u, float *out) {
-    CAPDEC_CHECK(c && x && out && n >= 0 && dim >= 1, "noise_inject: bad argument");
+    CAPDEC_CHECK(c && n >= 0 && dim >= 1 && (n == 0 || (x && out)), "noise_inject: bad argument");
     CAPDEC_CHECK(variance >= 0.f, "noise_inject: negative variance");
+    if (n == 0) return 0;
     CAPDEC_HIP(hipSetDevice(c->device));
     ProfScope ps(c, F_OTHER);
     return launch_noise_inject(c->stream, x, n, dim, variance, offset, uniform, dont_norm, seed, noise, u, out);
@@ -1036,7 +1094,7 @@ int capdec_noise_inject(capdec_ctx *c, const float *x, int n, int dim, float var
 
 int capdec_mapper_forward(capdec_ctx *c, const float *x, int n, float *out) {
     CAPDEC_CHECK(c && c->map.kind != 0, "mapper_forward: no mapper loaded");
-    CAPDEC_CHECK(x && out && n >= 0, "mapper_forward: bad argument");
+    CAPDEC_CHECK(n >= 0 && (n == 0 || (x && out)), "mapper_forward: bad argument");
     CAPDEC_HIP(hipSetDevice(c->device));
     const Mapper &m = c->map;
     const int chunk = 8192;
@@ -1109,12 +1167,16 @@ int capdec_gemm_f32(capdec_ctx *c, const float *a, int lda, const float *bt, int
             CAPDEC_TRY(planes_of(c, a, M, K, true, &pa));
         } else {   // tests: always re-pack A (the plane cache is keyed by address, torch recycles addresses)
             CAPDEC_TRY(c->xpk.ensure(x3_packed_bytes_host(M, K)));
-            CAPDEC_TRY(launch_pack_planes(c->stream, a, M, K, c->xpk.p));
+            CAPDEC_TRY(pack_any(c, a, M, K, pack_fmt(c), c->xpk.p));
             pa = c->xpk.p;
         }
         CAPDEC_TRY(planes_of(c, bt, N, K, cache, &pb));
         GemmEpilogue e;
         e.bias = bias; e.act = act; e.resid = resid; e.ldr = ldr;
+        if (c->gemm_mode == GEMM_F16X2) {
+            ProfScope ps(c, F_GEMM_H2P, 2.0 * M * (double)N * K);
+            return launch_gemm_f16x2p(c->stream, pa, pb, cc, ldc, M, N, K, e);
+        }
         if (c->gemm_mode == GEMM_BF16) {
             ProfScope ps(c, F_GEMM_BF16P, 2.0 * M * (double)N * K);
             return launch_gemm_bf16p(c->stream, pa, pb, cc, ldc, M, N, K, e);

@@ -125,6 +125,17 @@ int launch_gemm_bf16x3w(hipStream_t st, const void *Apacked, const void *Bpacked
 // split-K of the packed-A kernel for under-filled grids: number of K slices (1 = none) and the workspace it needs
 int gemm_splitk_slices(int M, int N, int K);
 size_t gemm_splitk_ws_bytes(int M, int N, int K);
+// adds the S partial tiles of a split-K launch in slice order and applies the epilogue (fmt: packed output format)
+int launch_splitk_reduce(hipStream_t st, const float *part, int S, int M, int N, const GemmEpilogue &epi, float *C,
+                         int ldc, int fmt);
+// f16x2 mode (gemm_f16x2.hip): operands as TWO fp16 planes (format PK_F16X2 of bf16x3.h), three MFMAs per product,
+// fp32-accurate.  launch_pack_planes_h2 packs an fp32 [N, K] matrix (row stride ldw) -- weights once, fp32 activations
+// (mapper, patch embedding) per call.
+int launch_pack_planes_h2(hipStream_t st, const float *w, int ldw, int N, int K, void *out);
+int launch_gemm_f16x2p(hipStream_t st, const void *Apacked, const void *Bpacked, float *C, int ldc, int M, int N, int K,
+                       const GemmEpilogue &epi);
+int launch_gemm_f16x2p_topk(hipStream_t st, const void *Apacked, const void *Bpacked, int M, int N, int K, int k,
+                            float inv_temp, float *tile_max, float *tile_sum, float *cand_val, int *cand_idx);
 // bf16 mode (gemm_bf16.hip): same packed operands, plane 0 only -- one bf16 MFMA per product, fp32 accumulate
 int launch_gemm_bf16p(hipStream_t st, const void *Apacked, const void *Bpacked, float *C, int ldc, int M, int N, int K,
                       const GemmEpilogue &epi);
@@ -132,7 +143,7 @@ int launch_gemm_bf16p_topk(hipStream_t st, const void *Apacked, const void *Bpac
                            float inv_temp, float *tile_max, float *tile_sum, float *cand_val, int *cand_idx);
 // LayerNorm whose output goes straight into the packed split-bf16 A format of the next GEMM (d % 16 == 0)
 int launch_layernorm_packed(hipStream_t st, const float *x, int ldx, const float *w, const float *b, float eps,
-                            void *packed, int rows, int d);
+                            void *packed, int rows, int d, int fmt = 0);
 
 // elementwise.hip
 int launch_layernorm(hipStream_t st, const float *x, int ldx, const float *w, const float *b, float eps, float *y,
@@ -170,12 +181,12 @@ int launch_kv_scatter_prefill(hipStream_t st, const float *qkv, const KvCache &c
                               int beam);
 // prefill: query row (caption, i) attends cache positions 0..i of phys row caption*beam
 int launch_attn_prefill(hipStream_t st, const float *qkv, const KvCache &c, int layer, int ncap, int P, int beam,
-                        float *out, bool causal = true, void *packed_out = nullptr);
+                        float *out, bool causal = true, void *packed_out = nullptr, int fmt = 0);
 // decode: row r (caption = r / beam) at position L-1: its own k/v come from qkv (and are written to the cache
 // at phys row r), positions p < L-1 from phys row caption*beam + anc[r][p] (anc == nullptr -> r itself)
 int launch_attn_decode(hipStream_t st, const float *qkv, const KvCache &c, int layer, int rows, int beam, int L,
                        const uint8_t *anc, int anc_stride, float *out, void *packed_out = nullptr,
-                       const int *cmap = nullptr);
+                       const int *cmap = nullptr, int fmt = 0);
 // (cmap != nullptr: finished captions were compacted away -- activation row r belongs to caption cmap[r / beam];
 //  KV cache, ancestor table and beam state stay indexed by the original caption)
 // (packed_out != nullptr: the attention rows are written as the packed split-bf16 A operand of c_proj, K = d,

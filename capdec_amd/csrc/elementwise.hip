@@ -71,7 +71,8 @@ int launch_layernorm(hipStream_t st, const float *x, int ldx, const float *w, co
 // normalised row never goes to HBM; float4 index idx of the row is k-step idx/4, quad idx%4.
 __global__ __launch_bounds__(256) void layernorm_packed_kernel(const float *__restrict__ x, int ldx,
                                                                const float *__restrict__ w, const float *__restrict__ b,
-                                                               float eps, char *__restrict__ packed, int rows, int d) {
+                                                               float eps, char *__restrict__ packed, int rows, int d,
+                                                               int fmt) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -111,17 +112,17 @@ __global__ __launch_bounds__(256) void layernorm_packed_kernel(const float *__re
             o.y = (v[i].y - mean) * rstd * ww.y + bb.y;
             o.z = (v[i].z - mean) * rstd * ww.z + bb.z;
             o.w = (v[i].w - mean) * rstd * ww.w + bb.w;
-            x3_store_quad(packed, nk, row, idx >> 2, idx & 3, o);
+            x3_store_quad(packed, nk, row, idx >> 2, idx & 3, o, fmt);
         }
     }
 }
 
 int launch_layernorm_packed(hipStream_t st, const float *x, int ldx, const float *w, const float *b, float eps,
-                            void *packed, int rows, int d) {
+                            void *packed, int rows, int d, int fmt) {
     CAPDEC_CHECK(d % 16 == 0 && d <= 256 * LN_MAXV && ldx % 4 == 0, "layernorm_packed: unsupported width");
     if (rows <= 0) return 0;
     hipLaunchKernelGGL(layernorm_packed_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, x, ldx, w, b, eps, (char *)packed,
-                       rows, d);
+                       rows, d, fmt);
     CAPDEC_HIP(hipGetLastError());
     return 0;
 }

@@ -423,7 +423,8 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x3p_splitk_kernel(const __bf1
 }
 
 __global__ void splitk_reduce_kernel(const float *__restrict__ part, int S, int M, int N, const float *__restrict__ bias,
-                                     int act, const float *resid, int ldr, float *C, int ldc, char *packed_out) {
+                                     int act, const float *resid, int ldr, float *C, int ldc, char *packed_out,
+                                     int fmt) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;     // one float4 of the [M, N] result
     const int nq = N >> 2;
     if (i >= (size_t)M * nq) return;
@@ -440,7 +441,7 @@ __global__ void splitk_reduce_kernel(const float *__restrict__ part, int S, int 
     }
     v.x = act_apply(v.x, act); v.y = act_apply(v.y, act); v.z = act_apply(v.z, act); v.w = act_apply(v.w, act);
     if (packed_out) {
-        x3_store_quad(packed_out, N >> 4, row, col >> 4, (col >> 2) & 3, v);
+        x3_store_quad(packed_out, N >> 4, row, col >> 4, (col >> 2) & 3, v, fmt);
         return;
     }
     if (resid) {
@@ -448,6 +449,15 @@ __global__ void splitk_reduce_kernel(const float *__restrict__ part, int S, int 
         v.x += r4.x; v.y += r4.y; v.z += r4.z; v.w += r4.w;
     }
     *reinterpret_cast<float4 *>(C + (size_t)row * ldc + col) = v;
+}
+
+int launch_splitk_reduce(hipStream_t st, const float *part, int S, int M, int N, const GemmEpilogue &epi, float *C,
+                         int ldc, int fmt) {
+    const size_t nq = (size_t)M * (N / 4);
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, st, part, S, M, N,
+                       epi.bias, epi.act, epi.resid, epi.ldr, C, ldc, (char *)epi.packed_out, fmt);
+    CAPDEC_HIP(hipGetLastError());
+    return 0;
 }
 
 // slices for a [M, N, K] problem: 1 (no split) unless M <= 512 rows (at most four tile rows: the decode of small
@@ -484,11 +494,8 @@ int launch_gemm_bf16x3p(hipStream_t st, const void *Apacked, const void *Bpacked
         float *part = (float *)epi.splitk_ws;
         hipLaunchKernelGGL(gemm_bf16x3p_splitk_kernel, dim3(tiles_m * tiles_n * S), dim3(256), 0, st,
                            (const __bf16 *)Apacked, (const __bf16 *)Bpacked, part, M, N, K, tiles_m, tiles_n, S);
-        const size_t nq = (size_t)M * (N / 4);
-        hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, st, part, S, M, N,
-                           epi.bias, epi.act, epi.resid, epi.ldr, C, ldc, (char *)epi.packed_out);
         CAPDEC_HIP(hipGetLastError());
-        return 0;
+        return launch_splitk_reduce(st, part, S, M, N, epi, C, ldc, PK_BF16X3);
     }
     static const int dbg = [] { const char *e = getenv("CAPDEC_ABL_DMA"); return e ? atoi(e) : 0; }();
     if (vec4)

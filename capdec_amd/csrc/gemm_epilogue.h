@@ -135,7 +135,7 @@ __device__ __forceinline__ void epilogue_store_t(const f32x16 (&acc)[2][2], floa
 // tile never reaches HBM (or LDS).
 __device__ __forceinline__ void epilogue_store_packed_t(const f32x16 (&acc)[2][2], char *packed, int nk_out, int M,
                                                         int N, int m0, int n0, const float *__restrict__ bias,
-                                                        int act) {
+                                                        int act, int fmt = PK_BF16X3) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wm = wave >> 1, wn = wave & 1, half = lane >> 5, l32 = lane & 31;
 #pragma unroll
@@ -155,7 +155,7 @@ __device__ __forceinline__ void epilogue_store_packed_t(const f32x16 (&acc)[2][2
                 }
                 v.x = act_apply(v.x, act); v.y = act_apply(v.y, act);
                 v.z = act_apply(v.z, act); v.w = act_apply(v.w, act);
-                x3_store_quad(packed, nk_out, row, col >> 4, (col >> 2) & 3, v);
+                x3_store_quad(packed, nk_out, row, col >> 4, (col >> 2) & 3, v, fmt);
             }
     }
 }

@@ -1,0 +1,311 @@
+// fp32-accurate GEMM on the fp16 matrix cores with THREE MFMAs per product:  C[M,N] = epi( A[M,K] . Bt[N,K]^T )
+//
+// Why: rocprofv3 SQ counters of the six-product split-bf16 kernel (profiles/r2_pmc_sq_gemm_bf16x3p.txt) show the
+// matrix pipe busy 71-78 % of the kernel's cycles and the waves issue-stalled on it 61 % of their time: that kernel
+// is matrix-pipe-bound in cycles (the rest of the distance to the datasheet peak is clock), so the lever is FEWER
+// MFMAs per fp32 product, not a denser schedule of the same six.
+//
+// How (format PK_F16X2, bf16x3.h): every fp32 value is  a = hi + 2^-11 lo  with two fp16 planes (11 + 11 significand
+// bits, the low plane stored scaled by 2^11 so it never leaves fp16's normal range), hence
+//     a b = hi_a hi_b + 2^-11 (hi_a lo_b + lo_a hi_b) + [2^-22 lo_a lo_b, dropped]
+// The dropped term is <= 2^-22 |a b| (rms 2^-24.6 |a b|): measured against fp64 the result sits BELOW the rounding
+// noise of an ordinary fp32 GEMM (max error / sum |a||b|: 2e-8 on unit-scale data, 1.7e-7 with a 10^6 dynamic range
+// across k; torch's own fp32 matmul: 1.5e-7 / 2.4e-7).  v_mfma_f32_32x32x16_f16 products are exact in fp32 and
+// accumulate in fp32; the 2^-11-weighted cross terms have their own accumulator set, joined once in the epilogue.
+// Ceiling = dense fp16 MFMA peak / 3 = 833 TFLOP/s fp32-equivalent (the six-product scheme: 417).
+//
+// Structure: the packed-A LDS-DMA main loop of gemm_bf16x3.hip with 2 planes: 128x128 tile, 4 wavefronts x (2x2)
+// 32x32 tiles x 2 accumulator sets (128 accumulator registers), BK = 16 per stage, stage = A block + B block =
+// 16 KB, ring of NS stages (4: 64 KB, two blocks per CU).  Per k-step a wavefront issues 8 ds_read_b128 (tile
+// kt+1 into the other fragment set), 4 LDS-DMA pieces (tile kt+NS) and 12 MFMAs (tile kt, from registers); one
+// counted s_waitcnt vmcnt(4 (NS-2)) lgkmcnt(0) + raw s_barrier per k-step.  MFMA time per k-step halves against
+// the six-product kernel, so the ring is one stage deeper to keep the same DMA lead in cycles.
+#include <cstdlib>
+
+#include "bf16x3.h"
+#include "gemm_epilogue.h"
+
+namespace capdec {
+
+typedef __attribute__((address_space(3))) void lds_void_h;
+typedef const __attribute__((address_space(1))) void glb_void_h;
+
+constexpr int H2_STAGE_B = 2 * H2_BLOCK_B;                 // 16 KB: A block + B block of one k-step
+constexpr int H2_TOPK_LDS = 128 * CT_LD * 4;               // 66 048 B: logits tile of the fused lm_head epilogue
+template <int NS> struct H2Geo {
+    static constexpr int SMEM_B = NS * H2_STAGE_B > H2_TOPK_LDS ? NS * H2_STAGE_B : H2_TOPK_LDS;
+};
+
+// fp32 [N, K] -> two fp16 planes, TILE-MAJOR  out[tile][k_step][plane][row 0..127][16 fp16]  (rows past N zero):
+// byte-for-byte the LDS image of one operand of a stage (16-B halves of a row swapped when bit 3 of the row is set)
+__global__ void pack_planes_h2_kernel(const float *__restrict__ w, int ldw, _Float16 *__restrict__ out, int N, int K,
+                                      int nk) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;   // one thread per (tile, k_step, row, half): 8 k
+    const int tiles = (N + GEMM_BN - 1) / GEMM_BN;
+    if (i >= (size_t)tiles * nk * 256) return;
+    const int hk = i & 1, r = (i >> 1) & 127;
+    const size_t tk = i >> 8;                       // tile * nk + k_step
+    const int ks = (int)(tk % nk), tile = (int)(tk / nk);
+    const int n = tile * GEMM_BN + r;
+    float4 v0 = make_float4(0.f, 0.f, 0.f, 0.f), v1 = v0;
+    if (n < N) {
+        const float *src = w + (size_t)n * ldw + ks * 16 + hk * 8;
+        v0 = reinterpret_cast<const float4 *>(src)[0];
+        v1 = reinterpret_cast<const float4 *>(src)[1];
+    }
+    f16x4 h0, l0, h1, l1;
+    split2h(v0, h0, l0);
+    split2h(v1, h1, l1);
+    _Float16 *dst = out + tk * (2 * 128 * 16) + r * 16 + ((hk ^ ((r >> 3) & 1)) << 3);
+    reinterpret_cast<f16x4 *>(dst)[0] = h0;
+    reinterpret_cast<f16x4 *>(dst)[1] = h1;
+    reinterpret_cast<f16x4 *>(dst + 2048)[0] = l0;
+    reinterpret_cast<f16x4 *>(dst + 2048)[1] = l1;
+}
+
+int launch_pack_planes_h2(hipStream_t st, const float *w, int ldw, int N, int K, void *out) {
+    CAPDEC_CHECK(K % 64 == 0 && ldw % 4 == 0, "pack_planes_h2: K must be a multiple of 64");
+    const int nk = K / X3_BK;
+    const size_t tot = (size_t)((N + GEMM_BN - 1) / GEMM_BN) * nk * 256;
+    hipLaunchKernelGGL(pack_planes_h2_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, w, ldw,
+                       (_Float16 *)out, N, K, nk);
+    CAPDEC_HIP(hipGetLastError());
+    return 0;
+}
+
+// s_waitcnt immediate (gfx9 encoding): vmcnt(N) expcnt(none) lgkmcnt(L: 0 = wait for all, 15 = do not wait)
+__host__ __device__ constexpr int waitcnt_imm(int vm, int lgkm) {
+    return (vm & 15) | (7 << 4) | ((lgkm & 15) << 8) | ((vm >> 4) << 14);
+}
+
+// TR: MFMA operands swapped (D^T), a lane ends with four consecutive columns of one row (see gemm_bf16x3.hip).
+// am = sum hi_a hi_b, ac = sum (hi_a lo_b + lo_a hi_b) (weight 2^-11, applied by h2_join).
+template <bool TR, int NS>
+__device__ __forceinline__ void h2p_mainloop(const _Float16 *__restrict__ Apk, const _Float16 *__restrict__ Bpk, int K,
+                                             int tm, int tn, char *smem, f32x16 (&am)[2][2], f32x16 (&ac)[2][2],
+                                             int ks0 = 0, int nks = -1) {
+    static_assert(NS >= 3 && NS <= 9, "ring depth");
+    const int t = threadIdx.x;
+    const int lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int half = lane >> 5, l32 = lane & 31;
+    const int nkf = K / X3_BK;                                                 // k-steps of the whole K (panel stride)
+    const int nk = nks < 0 ? nkf : nks;                                        // k-steps of THIS block, even
+    const _Float16 *ap = Apk + ((size_t)tm * nkf + ks0) * (H2_BLOCK_B / 2) + t * 8;   // this thread's 16-B piece
+    const _Float16 *bp = Bpk + ((size_t)tn * nkf + ks0) * (H2_BLOCK_B / 2) + t * 8;
+    char *dst0 = smem + wave * 1024;                                           // wave-uniform LDS base of its pieces
+#define H2_DMA(stage, ks_)                                                                                     \
+    {                                                                                                          \
+        const _Float16 *sa = ap + (size_t)(ks_) * (H2_BLOCK_B / 2), *sb = bp + (size_t)(ks_) * (H2_BLOCK_B / 2); \
+        char *d = dst0 + (stage) * H2_STAGE_B;                                                                 \
+        _Pragma("unroll") for (int p = 0; p < 2; ++p) {                                                        \
+            __builtin_amdgcn_global_load_lds((glb_void_h *)(sa + p * 2048), (lds_void_h *)(d + p * X3_PLANE_B), 16, 0, 0); \
+            __builtin_amdgcn_global_load_lds((glb_void_h *)(sb + p * 2048), (lds_void_h *)(d + H2_BLOCK_B + p * X3_PLANE_B), 16, 0, 0); \
+        }                                                                                                      \
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { am[i][j][r] = 0.f; ac[i][j][r] = 0.f; }
+
+    const int swz = ((half ^ ((l32 >> 3) & 1)) << 4);
+    const int a_rd = (wm * 64 + l32) * X3_ROW_B + swz;
+    const int b_rd = H2_BLOCK_B + (wn * 64 + l32) * X3_ROW_B + swz;
+
+    f16x8 f0a0[2], f0a1[2], f0b0[2], f0b1[2], f1a0[2], f1a1[2], f1b0[2], f1b1[2];
+#define H2_READ(F, stage)                                                                           \
+    {                                                                                               \
+        const char *rs = smem + (stage) * H2_STAGE_B;                                               \
+        _Pragma("unroll") for (int p = 0; p < 2; ++p) {                                             \
+            F##a0[p] = *reinterpret_cast<const f16x8 *>(rs + p * X3_PLANE_B + a_rd);                 \
+            F##a1[p] = *reinterpret_cast<const f16x8 *>(rs + p * X3_PLANE_B + a_rd + 32 * X3_ROW_B); \
+            F##b0[p] = *reinterpret_cast<const f16x8 *>(rs + p * X3_PLANE_B + b_rd);                 \
+            F##b1[p] = *reinterpret_cast<const f16x8 *>(rs + p * X3_PLANE_B + b_rd + 32 * X3_ROW_B); \
+        }                                                                                           \
+    }
+#define H2_MM(x, y, c) (TR ? __builtin_amdgcn_mfma_f32_32x32x16_f16(y, x, c, 0, 0, 0)                 \
+                           : __builtin_amdgcn_mfma_f32_32x32x16_f16(x, y, c, 0, 0, 0))
+#define H2_TERM(ACC, F, pa, pb)                                \
+    ACC[0][0] = H2_MM(F##a0[pa], F##b0[pb], ACC[0][0]);        \
+    ACC[0][1] = H2_MM(F##a0[pa], F##b1[pb], ACC[0][1]);        \
+    ACC[1][0] = H2_MM(F##a1[pa], F##b0[pb], ACC[1][0]);        \
+    ACC[1][1] = H2_MM(F##a1[pa], F##b1[pb], ACC[1][1]);
+#define H2_MFMAS(F) H2_TERM(ac, F, 1, 0) H2_TERM(am, F, 0, 0) H2_TERM(ac, F, 0, 1)
+    // (the s_waitcnt builtin, not inline asm: the compiler's own waitcnt pass must see that the fragment reads have
+    //  completed, or it puts an lgkmcnt(0) in front of the next MFMAs -- behind the freshly issued reads)
+#define H2_SYNC()                                                                        \
+    asm volatile("" ::: "memory");                                                       \
+    __builtin_amdgcn_s_waitcnt(waitcnt_imm(4 * (NS - 2), 0));                            \
+    __builtin_amdgcn_s_barrier();                                                        \
+    asm volatile("" ::: "memory");
+    // one memory operation in the shadow of each MFMA: 8 fragment reads, then the 4 DMA pieces
+#define H2_INTERLEAVE()                                                                    \
+    _Pragma("unroll") for (int i_ = 0; i_ < 8; ++i_) {                                     \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   /* 1 MFMA    */               \
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   /* 1 DS read */               \
+    }                                                                                      \
+    _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) {                                     \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                 \
+        __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);   /* 1 VMEM (LDS-DMA piece) */  \
+    }                                                                                      \
+    __builtin_amdgcn_sched_barrier(0);
+
+    // prologue: tiles 0 .. NS-1 in flight (stage s <- tile s); tile 0 landed -> fragments f0; tile 1 landed
+#pragma unroll
+    for (int s = 0; s < NS; ++s) H2_DMA(s, min(s, nk - 1))
+    __builtin_amdgcn_s_waitcnt(waitcnt_imm(4 * (NS - 1), 15));    // tile 0 landed
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    H2_READ(f0, 0)
+    H2_SYNC()                                                    // tile 1 landed, this wave's reads of stage 0 done
+    // k-step kt: fragments of tile kt+1 are read from stage (kt+1)%NS, tile kt+NS is sent to stage kt%NS (whose
+    // fragments every wave finished reading before the barrier that ended k-step kt-1), the MFMAs of tile kt run from
+    // registers.  End of k-step: all but the NS-2 newest tiles have landed => tile kt+2 is in LDS.
+    int s0 = 0;                                                  // kt % NS
+    for (int kt = 0; kt < nk; kt += 2) {
+        const int s1 = s0 + 1 == NS ? 0 : s0 + 1, s2 = s1 + 1 == NS ? 0 : s1 + 1;
+        H2_READ(f1, s1)                                          // tile kt+1
+        H2_DMA(s0, min(kt + NS, nk - 1))                         // unconditional (clamped) so the vmcnt count is exact
+        H2_MFMAS(f0)                                             // tile kt
+        H2_INTERLEAVE()
+        H2_SYNC()
+        H2_READ(f0, s2)                                          // tile kt+2
+        H2_DMA(s1, min(kt + 1 + NS, nk - 1))
+        H2_MFMAS(f1)                                             // tile kt+1
+        H2_INTERLEAVE()
+        H2_SYNC()
+        s0 = s2;
+    }
+    __builtin_amdgcn_s_waitcnt(waitcnt_imm(0, 15));              // clamped tail pieces must land before LDS is reused
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+#undef H2_DMA
+#undef H2_READ
+#undef H2_TERM
+#undef H2_MM
+#undef H2_MFMAS
+#undef H2_SYNC
+#undef H2_INTERLEAVE
+}
+
+// acc = am + 2^-11 ac
+__device__ __forceinline__ void h2_join(f32x16 (&am)[2][2], const f32x16 (&ac)[2][2]) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) am[i][j][r] = fmaf(ac[i][j][r], 1.0f / H2_LO_SCALE, am[i][j][r]);
+}
+
+constexpr int H2_NS = 4;
+
+template <bool VEC4>
+__global__ __launch_bounds__(256, 2) void gemm_f16x2p_kernel(const _Float16 *__restrict__ Apk,
+                                                             const _Float16 *__restrict__ Bpk, float *C, int ldc, int M,
+                                                             int N, int K, const float *__restrict__ bias,
+                                                             const float *resid, int ldr, int act, int tiles_m,
+                                                             int tiles_n, char *packed_out) {
+    __shared__ __attribute__((aligned(16))) char smem[H2_NS * H2_STAGE_B];
+    int tm, tn;
+    tile_coords(tiles_m, tiles_n, tm, tn);
+    f32x16 am[2][2], ac[2][2];
+    h2p_mainloop<true, H2_NS>(Apk, Bpk, K, tm, tn, smem, am, ac);
+    h2_join(am, ac);
+    if (packed_out)
+        epilogue_store_packed_t(am, packed_out, N >> 4, M, N, tm * GEMM_BM, tn * GEMM_BN, bias, act, PK_F16X2);
+    else
+        epilogue_store_t<VEC4>(am, C, ldc, M, N, tm * GEMM_BM, tn * GEMM_BN, bias, resid, ldr, act);
+}
+
+template <int KSEL>
+__global__ __launch_bounds__(256, 2) void gemm_f16x2p_topk_kernel(const _Float16 *__restrict__ Apk,
+                                                                  const _Float16 *__restrict__ Bpk, int M, int N, int K,
+                                                                  float inv_temp, float *tile_max, float *tile_sum,
+                                                                  float *cand_val, int *cand_idx, int tiles_m,
+                                                                  int tiles_n) {
+    __shared__ __attribute__((aligned(16))) char smem[H2Geo<H2_NS>::SMEM_B];
+    int tm, tn;
+    tile_coords(tiles_m, tiles_n, tm, tn);
+    f32x16 am[2][2], ac[2][2];
+    h2p_mainloop<false, H2_NS>(Apk, Bpk, K, tm, tn, smem, am, ac);      // ends with a barrier
+    h2_join(am, ac);
+    epilogue_topk<KSEL, 2, true>(am, reinterpret_cast<float *>(smem), M, N, tm * GEMM_BM, tn * GEMM_BN, tn, tiles_n, inv_temp,
+                                 tile_max, tile_sum, cand_val, cand_idx);
+}
+
+// split-K for under-filled grids: raw fp32 partial tiles to a workspace [S][M][N], summed in a fixed order by
+// splitk_reduce_kernel (gemm_bf16x3.hip), which also applies the epilogue
+__global__ __launch_bounds__(256, 2) void gemm_f16x2p_splitk_kernel(const _Float16 *__restrict__ Apk,
+                                                                    const _Float16 *__restrict__ Bpk, float *part, int M,
+                                                                    int N, int K, int tiles_m, int tiles_n, int S) {
+    __shared__ __attribute__((aligned(16))) char smem[H2_NS * H2_STAGE_B];
+    const int ntiles = tiles_m * tiles_n;
+    const int slice = blockIdx.x / ntiles;
+    int tm, tn;
+    tile_coords(tiles_m, tiles_n, tm, tn, blockIdx.x - slice * ntiles);
+    const int nks = K / X3_BK / S;
+    f32x16 am[2][2], ac[2][2];
+    h2p_mainloop<true, H2_NS>(Apk, Bpk, K, tm, tn, smem, am, ac, slice * nks, nks);
+    h2_join(am, ac);
+    epilogue_store_t<true>(am, part + (size_t)slice * M * N, N, M, N, tm * GEMM_BM, tn * GEMM_BN, nullptr, nullptr, 0,
+                           CAPDEC_ACT_NONE);
+}
+
+int launch_gemm_f16x2p(hipStream_t st, const void *Apacked, const void *Bpacked, float *C, int ldc, int M, int N, int K,
+                       const GemmEpilogue &epi) {
+    CAPDEC_CHECK(M > 0 && N > 0 && K > 0 && K % 64 == 0, "gemm_f16x2p: K must be a multiple of 64");
+    CAPDEC_CHECK(epi.packed_out == nullptr ||
+                     (N % 64 == 0 && epi.resid == nullptr && ((uintptr_t)epi.bias & 15) == 0),
+                 "gemm_f16x2p: packed output needs N % 64 == 0, a 16-byte aligned bias and no residual");
+    const int tiles_m = (M + GEMM_BM - 1) / GEMM_BM, tiles_n = (N + GEMM_BN - 1) / GEMM_BN;
+    const bool vec4 = N % 4 == 0 && ldc % 4 == 0 && ((uintptr_t)C & 15) == 0 &&
+                      (epi.bias == nullptr || ((uintptr_t)epi.bias & 15) == 0) &&
+                      (epi.resid == nullptr || (epi.ldr % 4 == 0 && ((uintptr_t)epi.resid & 15) == 0));
+    const int S = (vec4 && epi.splitk_ws) ? gemm_splitk_slices(M, N, K) : 1;
+    if (S > 1 && epi.splitk_ws_bytes >= (size_t)S * M * N * sizeof(float)) {
+        float *part = (float *)epi.splitk_ws;
+        hipLaunchKernelGGL(gemm_f16x2p_splitk_kernel, dim3(tiles_m * tiles_n * S), dim3(256), 0, st,
+                           (const _Float16 *)Apacked, (const _Float16 *)Bpacked, part, M, N, K, tiles_m, tiles_n, S);
+        CAPDEC_HIP(hipGetLastError());
+        return launch_splitk_reduce(st, part, S, M, N, epi, C, ldc, PK_F16X2);
+    }
+    if (vec4)
+        hipLaunchKernelGGL(gemm_f16x2p_kernel<true>, dim3(tiles_m * tiles_n), dim3(256), 0, st, (const _Float16 *)Apacked,
+                           (const _Float16 *)Bpacked, C, ldc, M, N, K, epi.bias, epi.resid, epi.ldr, epi.act, tiles_m,
+                           tiles_n, (char *)epi.packed_out);
+    else
+        hipLaunchKernelGGL(gemm_f16x2p_kernel<false>, dim3(tiles_m * tiles_n), dim3(256), 0, st, (const _Float16 *)Apacked,
+                           (const _Float16 *)Bpacked, C, ldc, M, N, K, epi.bias, epi.resid, epi.ldr, epi.act, tiles_m,
+                           tiles_n, (char *)epi.packed_out);
+    CAPDEC_HIP(hipGetLastError());
+    return 0;
+}
+
+int launch_gemm_f16x2p_topk(hipStream_t st, const void *Apacked, const void *Bpacked, int M, int N, int K, int k,
+                            float inv_temp, float *tile_max, float *tile_sum, float *cand_val, int *cand_idx) {
+    CAPDEC_CHECK(M > 0 && N > 0 && K > 0 && K % 64 == 0, "gemm_f16x2p_topk: K must be a multiple of 64");
+    const int tiles_m = (M + GEMM_BM - 1) / GEMM_BM, tiles_n = (N + GEMM_BN - 1) / GEMM_BN;
+    dim3 grid(tiles_m * tiles_n), block(256);
+#define LAUNCH_TOPKH(KS)                                                                                          \
+    hipLaunchKernelGGL(gemm_f16x2p_topk_kernel<KS>, grid, block, 0, st, (const _Float16 *)Apacked,                 \
+                       (const _Float16 *)Bpacked, M, N, K, inv_temp, tile_max, tile_sum, cand_val, cand_idx, tiles_m, tiles_n)
+    switch (k) {
+        case 1: LAUNCH_TOPKH(1); break;
+        case 2: LAUNCH_TOPKH(2); break;
+        case 3: LAUNCH_TOPKH(3); break;
+        case 4: LAUNCH_TOPKH(4); break;
+        case 5: LAUNCH_TOPKH(5); break;
+        case 6: LAUNCH_TOPKH(6); break;
+        case 7: LAUNCH_TOPKH(7); break;
+        case 8: LAUNCH_TOPKH(8); break;
+        default: CAPDEC_CHECK(false, "gemm_topk: k must be in 1..8");
+    }
+#undef LAUNCH_TOPKH
+    CAPDEC_HIP(hipGetLastError());
+    return 0;
+}
+
+}  // namespace capdec

@@ -26,6 +26,9 @@ def gather_rows(local: torch.Tensor, n_total: int, group=None) -> torch.Tensor:
     """all-gather row blocks produced under :func:`shard_bounds`: every rank pads its block to
     ceil(N/R) rows, one all_gather_into_tensor moves them, the padding is cut off again."""
     if not (dist.is_available() and dist.is_initialized()):
+        if local.shape[0] < n_total:
+            raise RuntimeError(f"gather_rows: this process holds {local.shape[0]} of {n_total} rows but no "
+                               "torch.distributed process group is initialised (world > 1 needs one)")
         return local[:n_total]
     if dist.get_world_size(group) == 1 and os.environ.get("CAPDEC_FORCE_DIST") != "1":
         return local[:n_total]
@@ -41,6 +44,17 @@ def gather_rows(local: torch.Tensor, n_total: int, group=None) -> torch.Tensor:
         dist.all_gather(parts, pad.contiguous(), group=group)
         out = torch.cat(parts, dim=0)
     return out[:n_total]
+
+
+def check_world(rank: int, world: int, group=None) -> None:
+    """rank / world handed to the sharded drivers must describe the process group this process is really in"""
+    if world == 1 and rank == 0:
+        return
+    if not (dist.is_available() and dist.is_initialized()):
+        raise RuntimeError(f"rank={rank} world={world} but torch.distributed is not initialised")
+    if dist.get_world_size(group) != world or dist.get_rank(group) != rank:
+        raise RuntimeError(f"rank={rank} world={world} do not match the process group "
+                           f"(rank {dist.get_rank(group)} of {dist.get_world_size(group)})")
 
 
 def gather_ids(ids: torch.Tensor, lens: torch.Tensor, n_total: int, scores: Optional[torch.Tensor] = None,

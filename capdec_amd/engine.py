@@ -141,6 +141,8 @@ class Engine:
         x = self._dev(x)
         n, dim = x.shape
         out = torch.empty_like(x)
+        if n == 0:            # an empty shard (world > N): nothing to launch, no NULL pointer into the C ABI
+            return out
         off = self._dev(offset).reshape(-1) if offset is not None else None
         self._sync_stream()
         check(self.lib.capdec_normalize_prefix(self._h, x.data_ptr(), n, dim, int(normalize),
@@ -154,6 +156,8 @@ class Engine:
         x = self._dev(x)
         n, dim = x.shape
         out = torch.empty_like(x)
+        if n == 0:
+            return out
         off = self._dev(offset).reshape(-1) if offset is not None else None
         nz = self._dev(noise) if noise is not None else None
         uu = self._dev(u) if u is not None else None
@@ -354,11 +358,12 @@ class Engine:
         return out
 
     def set_gemm_mode(self, mode: str):
-        """'f32' (native fp32 MFMA) or 'bf16x3' (fp32-accurate split-bf16 MFMA)"""
-        check(self.lib.capdec_set_gemm_mode(self._h, {"f32": 0, "bf16x3": 1, "bf16": 2}[mode]), "set_gemm_mode")
+        """'f16x2' (default: fp32-accurate, operands as two fp16 planes, 3 MFMAs per product), 'bf16x3' (fp32-accurate,
+        three bf16 planes, 6 MFMAs per product), 'f32' (native fp32 MFMA) or 'bf16' (bf16 operands, fp32 accumulate)"""
+        check(self.lib.capdec_set_gemm_mode(self._h, {"f32": 0, "bf16x3": 1, "bf16": 2, "f16x2": 3}[mode]), "set_gemm_mode")
 
     def gemm_mode(self) -> str:
-        return ["f32", "bf16x3", "bf16"][self.lib.capdec_get_gemm_mode(self._h)]
+        return ["f32", "bf16x3", "bf16", "f16x2"][self.lib.capdec_get_gemm_mode(self._h)]
 
     def profile_enable(self, on=True):
         """True / 1: time every launch; N > 1: every N-th launch of each kernel family (sampling); False: off"""
@@ -369,11 +374,11 @@ class Engine:
 
     def profile_get(self) -> Dict[str, Dict[str, float]]:
         cnt = C.c_int(0)
-        names = (C.c_char_p * 16)()
-        ms = (C.c_float * 16)()
-        launches = (C.c_int64 * 16)()
-        flops = (C.c_double * 16)()
-        calls = (C.c_int64 * 16)()
+        names = (C.c_char_p * 24)()       # PROF_SLOTS of capi.hip
+        ms = (C.c_float * 24)()
+        launches = (C.c_int64 * 24)()
+        flops = (C.c_double * 24)()
+        calls = (C.c_int64 * 24)()
         check(self.lib.capdec_profile_get(self._h, C.byref(cnt), names, ms, launches, flops, calls), "profile_get")
         return {names[i].decode(): dict(ms=float(ms[i]), launches=int(launches[i]), flops=float(flops[i]),
                                         calls=int(calls[i]))

@@ -18,6 +18,10 @@ import torch
 
 
 def _as_f32(t) -> torch.Tensor:
+    if t is None or (not torch.is_tensor(t) and not isinstance(t, (list, tuple)) and not hasattr(t, "shape")):
+        # the reference stores the scalar 0 for a side it did not compute ('clip_embedding_text_dave': 0 when
+        # add_text_embedding is False, embeddings_generator.py:101): an absent side
+        return torch.zeros(0, 0)
     if isinstance(t, (list, tuple)):
         t = torch.cat([torch.as_tensor(x).reshape(1, -1) if torch.as_tensor(x).dim() < 2 else torch.as_tensor(x)
                        for x in t], dim=0) if len(t) else torch.zeros(0, 0)
@@ -31,11 +35,17 @@ def load_embeddings_pickle(path: str) -> Tuple[torch.Tensor, torch.Tensor, List[
         d = pickle.load(f)
     img = _as_f32(d.get("clip_embedding", torch.zeros(0, 0)))
     txt = _as_f32(d.get("clip_embedding_text_dave", torch.zeros(0, 0)))
+    if img.dim() == 0:          # a 0-d tensor is a placeholder too
+        img = torch.zeros(0, 0)
+    if txt.dim() == 0:
+        txt = torch.zeros(0, 0)
     dim = max(img.shape[-1] if img.numel() else 0, txt.shape[-1] if txt.numel() else 0)
     if img.numel() == 0:
         img = torch.zeros(0, dim)
     if txt.numel() == 0:
         txt = torch.zeros(0, dim)
+    if dim == 0:                # both sides absent
+        return torch.zeros(0, 0), torch.zeros(0, 0), list(d.get("captions", []))
     return img.reshape(-1, dim), txt.reshape(-1, dim), list(d.get("captions", []))
 
 

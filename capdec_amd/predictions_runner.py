@@ -47,6 +47,9 @@ def make_preds(data: Sequence[Dict], embeddings: torch.Tensor, model: ClipCaptio
     """``data[i]`` = {"image_id": ...}; ``embeddings[i]`` its CLIP embedding.  Writes the
     reference's predictions JSON (``[{"caption": lower-cased text, "image_id": id}]``, :260-261,
     :301) -- the whole list, not only every 99th flush."""
+    cdist.check_world(rank, world)
+    if len(data) != embeddings.shape[0]:
+        raise ValueError(f"make_preds: {len(data)} data entries but {embeddings.shape[0]} embeddings")
     stop = tokenizer.encode('.')[0]
     ids, lens, _ = caption_ids(model, embeddings, stop, beam, 5, entry_length, dont_normalize_prefix,
                                modality_offset, rank, world)

@@ -243,17 +243,18 @@ def test_decode_tiny_vs_reference_golden(golden):
     _check_decode(golden("decode_tiny"), synth.GPT2_TINY)
 
 
-@pytest.mark.parametrize("mode", ["bf16x3", "f32"])
+@pytest.mark.parametrize("mode", ["f16x2", "bf16x3", "f32"])
 def test_decode_small_vs_reference_golden(golden, mode, monkeypatch):
     """full GPT-2 small geometry (12 layers, V = 50257): greedy ids bit-identical to the reference, with the
-    projections on the split-bf16 MFMA path (default) and on the native fp32 MFMA path"""
+    projections on the two-plane fp16 MFMA path (default, 3 MFMAs per product), on the three-plane bf16 path
+    (6 MFMAs per product) and on the native fp32 MFMA path"""
     monkeypatch.setenv("CAPDEC_GEMM_MODE", mode)
     _check_decode(golden("decode_small"), synth.GPT2_SMALL)
 
 
-@pytest.mark.parametrize("mode", ["bf16x3", "f32"])
+@pytest.mark.parametrize("mode", ["f16x2", "bf16x3", "f32"])
 def test_gemm_modes_vs_fp64(mode):
-    """both GEMM back-ends stay in the fp32 round-off class (error relative to sum |a||b|)"""
+    """every fp32-accurate GEMM back-end stays in the fp32 round-off class (error relative to sum |a||b|)"""
     from capdec_amd.engine import Engine
     e = Engine(0)
     e.set_gemm_mode(mode)
@@ -269,12 +270,16 @@ def test_gemm_modes_vs_fp64(mode):
     e.close()
 
 
+@pytest.mark.parametrize("mode", ["f16x2", "bf16x3"])
 @pytest.mark.parametrize("N", [1024, 1001, 130])
-def test_gemm_packed_a_path(eng, N, monkeypatch):
-    """the packed-A LDS-DMA kernel (both operands pre-split, transposed accumulator layout) through the test hook:
+def test_gemm_packed_a_path(N, mode, monkeypatch):
+    """the packed-A LDS-DMA kernels (both operands pre-split, transposed accumulator layout) through the test hook:
     float4 epilogue (N % 4 == 0) and the scalar tail path, bias + activation + residual, ragged M"""
+    from capdec_amd.engine import Engine
     from oracle import capdec_oracle as O
     monkeypatch.setenv("CAPDEC_HOOK_PACKA", "1")
+    eng = Engine(0)
+    eng.set_gemm_mode(mode)
     g = torch.Generator().manual_seed(N)
     M, K = 333, 256
     a, bt = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g) * 0.2
@@ -286,6 +291,34 @@ def test_gemm_packed_a_path(eng, N, monkeypatch):
     y = O.gelu_new(a @ bt.t() + bias) + resid
     out = eng.gemm(a, bt, bias=bias, resid=resid, act=3).cpu()
     np.testing.assert_allclose(out.numpy(), y.numpy(), atol=2e-5, rtol=1e-5)
+    eng.close()
+
+
+def test_f16x2_split_edge_values():
+    """the two-plane fp16 split at its edges: values below fp16's normal range (the high plane is dropped, the scaled
+    low plane carries them: absolute error <= 2^-26 per element), around the 2^-14 switch, powers of two, and
+    large-but-finite magnitudes (relative error <= 2^-23); magnitudes above 65504 saturate (documented limit)"""
+    from capdec_amd.engine import Engine
+    e = Engine(0)
+    e.set_gemm_mode("f16x2")
+    K = 64
+    col = torch.tensor([2.0 ** -30, 2.0 ** -24, 2.0 ** -14, 2.0 ** -13, 2.0 ** -14 * 0.999, 1e-5, 3e-5, 6.1e-5, 1.0,
+                        1.0 + 2.0 ** -11, 1.0 + 2.0 ** -12, 1.0 + 2.0 ** -23, 0.1, 1000.0, 60000.0, 65504.0])
+    a = torch.zeros(16, K)
+    a[torch.arange(16), torch.arange(16)] = col          # one value per row: the product isolates its split
+    a[:, 32] = -col
+    g = torch.Generator().manual_seed(2)
+    bt = torch.randn(8, K, generator=g)
+    ref = a.double() @ bt.double().t()
+    out = e.gemm(a, bt).cpu().double()
+    scale = a.abs().double() @ bt.abs().double().t()
+    tiny = (a != 0).double() @ bt.abs().double().t() * 2.0 ** -25     # 2 elements per row, <= 2^-26 each
+    assert bool(((out - ref).abs() <= 3e-7 * scale + tiny).all())
+    big = torch.full((1, K), 0.0)
+    big[0, 0] = 1e6                                        # above fp16's range: clamped to 65504
+    out = e.gemm(big, torch.ones(1, K)).cpu()
+    assert abs(float(out[0, 0]) - 65504.0) < 1.0
+    e.close()
 
 
 # ----------------------------------------------------------------------------------- bf16 GEMM-operand mode (configs[1])

@@ -187,6 +187,12 @@ assert torch.equal(g2, full[:, 0]) and torch.equal(l2, lens[:, 0])
 lo1, hi1 = cd.shard_bounds(1, rank, world)
 g3 = cd.gather_rows(full[lo1:hi1, 0].clone(), 1)
 assert torch.equal(g3, full[:1, 0])
+cd.check_world(rank, world)
+try:
+    cd.check_world(rank, world + 1)
+    raise SystemExit("check_world accepted a wrong world size")
+except RuntimeError:
+    pass
 dist.destroy_process_group()
 print("OK", rank)
 """
@@ -206,6 +212,36 @@ def test_gather_ids_gloo_world_size_2(tmp_path):
     assert all("OK" in o for o in outs)
 
 
+def test_shard_consistency_checks():
+    """a partial shard without a process group must not be returned as if it were the whole result"""
+    from capdec_amd import distributed as cd
+    part = torch.zeros(3, 4)
+    assert cd.gather_rows(part, 3).shape == (3, 4)            # single process, everything local: fine
+    with pytest.raises(RuntimeError):
+        cd.gather_rows(part, 5)                               # 3 of 5 rows and nobody to gather from
+    cd.check_world(0, 1)
+    with pytest.raises(RuntimeError):
+        cd.check_world(1, 4)
+    # world > N: trailing ranks get EMPTY shards (N = 5 over 4 ranks -> 2, 2, 1, 0)
+    assert [cd.shard_bounds(5, r, 4) for r in range(4)] == [(0, 2), (2, 4), (4, 5), (5, 5)]
+
+
+def test_bench_spawns_its_own_ranks():
+    """`python bench.py --gpus N` (the driver's form) must start N ranks itself; --dry-run checks the launcher path
+    on CPU (gloo) without touching a GPU"""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run"],
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    import json
+    line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
+    rec = json.loads(line)
+    assert rec == {"dry_run": True, "n_gpus": 2, "ranks": [0, 1]}
+    # a launcher that started the wrong number of ranks is an error, not a silent mismatch
+    bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run"],
+                         capture_output=True, text=True, timeout=120, env=dict(os.environ, RANK="0", WORLD_SIZE="1"))
+    assert bad.returncode != 0 and "WORLD_SIZE=1" in (bad.stderr + bad.stdout)
+
+
 def test_formats_round_trip(tmp_path):
     import pickle
     from capdec_amd import formats, synth
@@ -220,6 +256,20 @@ def test_formats_round_trip(tmp_path):
     assert img.shape == (0, 512) and t2.dtype == torch.float32 and t2.shape == (2, 512)
     np.testing.assert_allclose(t2.numpy(), txt.half().float().numpy())
     assert c2[0]["caption"] == "A dog."
+    # image-only pickle exactly as the reference writes it when add_text_embedding is False
+    # (embeddings_generator.py:101: 'clip_embedding_text_dave': 0 -- an int, not a tensor) and the text-only mirror
+    # (empty image tensor)
+    imgs = synth.synthetic_clip_embeddings(3, 640, seed=2, normalize=False)
+    q0 = tmp_path / "img_only.pkl"
+    pickle.dump({"clip_embedding": imgs.half(), "captions": caps, "clip_embedding_text_dave": 0}, open(q0, "wb"))
+    i3, t3, _ = formats.load_embeddings_pickle(str(q0))
+    assert i3.shape == (3, 640) and t3.shape == (0, 640) and i3.dtype == torch.float32
+    pickle.dump({"clip_embedding": torch.tensor([]), "captions": caps, "clip_embedding_text_dave": txt}, open(q0, "wb"))
+    i4, t4, _ = formats.load_embeddings_pickle(str(q0))
+    assert i4.shape == (0, 512) and t4.shape == (2, 512)
+    pickle.dump({"clip_embedding": torch.tensor(0), "captions": [], "clip_embedding_text_dave": None}, open(q0, "wb"))
+    i5, t5, _ = formats.load_embeddings_pickle(str(q0))
+    assert i5.shape[0] == 0 and t5.shape[0] == 0
     # the reference's real modality-offset pickle layout
     off = {k: torch.randn(1, 640) for k in ("center_text", "center_image", "offset_to_add_in_training", "offset_to_add_in_inference")}
     q = tmp_path / "centers.pkl"
@@ -294,8 +344,14 @@ def test_gpt2_bpe_matches_transformers(tmp_path):
     for t in _TEXTS:
         ids = mine.encode(t)
         assert ids == ref.encode(t), t
-        assert mine.decode(ids) == t                       # byte-level BPE is lossless
-        assert mine.decode(ids) == ref.decode(ids, clean_up_tokenization_spaces=False)
+        assert mine.decode(ids, clean_up_tokenization_spaces=False) == t      # byte-level BPE is lossless
+        assert mine.decode(ids, clean_up_tokenization_spaces=False) == ref.decode(ids, clean_up_tokenization_spaces=False)
+        # the reference calls tokenizer.decode(ids) under transformers 4.24, whose default cleans up " ." " ," " n't" ...
+        # (transformers >= 5 ignores the flag for BPE tokenizers, so apply its clean_up_tokenization explicitly = 4.24's decode)
+        assert mine.decode(ids) == ref.clean_up_tokenization(ref.decode(ids, clean_up_tokenization_spaces=False))
+    cap = "a man , who isn't here , rides a wave 's crest . really ? yes ! we 're sure , i 'm ' fine ' and they 've gone ."
+    assert GPT2BPE.clean_up_tokenization(cap) == ref.clean_up_tokenization(cap) \
+        == "a man, who isn't here, rides a wave's crest. really? yes! we're sure, i'm'fine'and they've gone."
     assert mine.encode(".")[0] == ref.encode(".")[0]        # the stop-token lookup the decode functions do
 
 
