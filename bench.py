@@ -295,6 +295,26 @@ def main():
     eng.profile_enable(False)
     assert out[0].shape[0] == n_global and int(out[1].min()) >= 1
 
+    # ---- the same gather through the C ABI's own RCCL communicator (capdec_comm_init / capdec_gather_rows: no
+    # torch.distributed in the data path) -- outside the timed region, reported as `capi_collective`
+    capi_collective = None
+    if use_dist:
+        try:
+            cdist.capi_comm_from_torch(eng)
+            lo, hi = cdist.shard_bounds(n_global, rank, world)
+            g_ids = eng.gather_rows(out[0][lo:hi].contiguous(), n_global)
+            g_sc = eng.gather_rows(out[2][lo:hi].contiguous(), n_global) if out[2] is not None else None
+            ok = bool((g_ids == out[0]).all()) and (g_sc is None or bool((g_sc == out[2]).all()))
+            torch.cuda.synchronize()
+            t0c = time.perf_counter()
+            for _ in range(10):
+                eng.gather_rows(out[0][lo:hi].contiguous(), n_global)
+            torch.cuda.synchronize()
+            capi_collective = {"ok": ok, "ranks": world, "ms_per_gather": round((time.perf_counter() - t0c) * 100, 3)}
+            eng.comm_destroy()
+        except Exception as ex:          # never let the optional check take the metric line down
+            capi_collective = {"ok": False, "error": str(ex)[:300]}
+
     # ---- N > 1, strong scaling: the 1-GPU rate of this box (rank 0 alone decodes all captions; the other ranks wait
     # at the barrier) and one weak-scaling step (args.captions per GPU) -- extra fields, outside the timed region
     scaling_check = None
@@ -401,6 +421,7 @@ def main():
                         for k, v in prof.items() if v["launches"]},
             "profile_every": max(1, args.profile_every),
             "scaling_check": scaling_check,
+            "capi_collective": capi_collective,
         }
         if world == 1 and args.cpu_seconds > 0:
             rec["cpu_baseline"] = cpu_baseline(mapper, B, P, T, args.cpu_seconds)

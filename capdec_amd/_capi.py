@@ -102,6 +102,12 @@ SIGNATURES = {
                                   _VP, C.c_int, C.c_int]),
     "capdec_preprocess_images": (C.c_int, [_VP, _VP, C.POINTER(C.c_int64), C.POINTER(C.c_int32), C.POINTER(C.c_int32),
                                            C.c_int, C.c_int, C.c_int, c_float_p, c_float_p, _VP]),
+    "capdec_comm_unique_id": (C.c_int, [C.c_char_p]),
+    "capdec_comm_init": (C.c_int, [_VP, C.c_int, C.c_int, C.c_char_p]),
+    "capdec_comm_destroy": (C.c_int, [_VP]),
+    "capdec_shard_bounds": (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "capdec_gather_rows": (C.c_int, [_VP, _VP, C.c_int, C.c_int, C.c_int, _VP]),
+    "capdec_gather_ids": (C.c_int, [_VP, _VP, _VP, _VP, C.c_int, C.c_int, C.c_int, _VP, _VP, _VP]),
     "capdec_decode_stats": (C.c_int, [_VP, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_longlong)]),
     "capdec_timer_start": (C.c_int, [_VP]),
     "capdec_timer_stop_ms": (C.c_int, [_VP, c_float_p]),

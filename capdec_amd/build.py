@@ -50,7 +50,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
         if p.wait() != 0:
             raise RuntimeError(f"hipcc failed on {src}")
     if force or procs or _stale(LIB_PATH, objs):
-        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", LIB_PATH]
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-ldl", "-o", LIB_PATH]
         if verbose:
             print("[capdec build]", " ".join(cmd), flush=True)
         subprocess.check_call(cmd)

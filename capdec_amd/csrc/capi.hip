@@ -1,5 +1,8 @@
 // C ABI of libcapdec_hip.so (include/capdec.h) and the host-side orchestration of the
 // KV-cached batched decode.  One context per GPU; everything is enqueued on one HIP stream.
+#include <dlfcn.h>
+#include <rccl/rccl.h>      // types only: the library is dlopen'ed (no link-time dependency on RCCL)
+
 #include <algorithm>
 #include <cmath>
 #include <cstring>
@@ -126,6 +129,10 @@ struct capdec_ctx {
     DBuf m_hid, m_lin, m_seq, m_x, m_qkv, m_att, m_ff;
     DBuf t_idx, t_patch, t_pout, p_desc, p_inter, splitk;
     int *alive_host = nullptr;   // pinned
+    // caption-shard communicator (RCCL), see capdec_comm_init
+    ncclComm_t comm = nullptr;
+    int comm_rank = 0, comm_world = 1;
+    DBuf g_pad, g_all;
 };
 
 namespace capdec {
@@ -781,6 +788,48 @@ static int clip_vision_chunk(capdec_ctx *c, const float *pixels, int n, float *o
 
 }  // namespace capdec
 
+// ---- RCCL (dlopen'ed): only the five entry points the path needs
+namespace {
+struct Rccl {
+    void *h = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    const char *(*GetErrorString)(ncclResult_t) = nullptr;
+};
+Rccl *rccl() {
+    static Rccl r;
+    static bool tried = false;
+    if (!tried) {
+        tried = true;
+        const char *names[] = {getenv("CAPDEC_RCCL_LIB"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+        for (const char *n : names) {
+            if (!n || !*n) continue;
+            r.h = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+            if (r.h) break;
+        }
+        if (r.h) {
+            r.GetUniqueId = (decltype(r.GetUniqueId))dlsym(r.h, "ncclGetUniqueId");
+            r.CommInitRank = (decltype(r.CommInitRank))dlsym(r.h, "ncclCommInitRank");
+            r.CommDestroy = (decltype(r.CommDestroy))dlsym(r.h, "ncclCommDestroy");
+            r.AllGather = (decltype(r.AllGather))dlsym(r.h, "ncclAllGather");
+            r.GetErrorString = (decltype(r.GetErrorString))dlsym(r.h, "ncclGetErrorString");
+            if (!r.GetUniqueId || !r.CommInitRank || !r.CommDestroy || !r.AllGather) r.h = nullptr;
+        }
+    }
+    return r.h ? &r : nullptr;
+}
+#define CAPDEC_NCCL(expr)                                                                               \
+    do {                                                                                                \
+        ncclResult_t _r = (expr);                                                                       \
+        if (_r != ncclSuccess) {                                                                        \
+            capdec::set_error(std::string(#expr) + ": " + (rccl()->GetErrorString ? rccl()->GetErrorString(_r) : "RCCL error")); \
+            return 1;                                                                                   \
+        }                                                                                               \
+    } while (0)
+}  // namespace
+
 // =============================================================================== C ABI
 extern "C" {
 
@@ -821,6 +870,9 @@ void capdec_destroy(capdec_ctx *c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
+    if (c->comm && rccl()) { (void)rccl()->CommDestroy(c->comm); c->comm = nullptr; }
+    c->g_pad.release();
+    c->g_all.release();
     free_all(c->gpt.owned);
     free_all(c->map.owned);
     free_all(c->clip_text.owned);
@@ -1231,6 +1283,87 @@ int capdec_preprocess_images(capdec_ctx *c, const uint8_t *d_rgb, const int64_t 
     ProfScope ps(c, F_OTHER);
     return launch_preprocess(c->stream, d_rgb, c->p_desc.as<ImageDesc>(), n, max_h, n_px, c->p_inter.as<uint8_t>(),
                              d_out, mean, stdv);
+}
+
+
+int capdec_comm_unique_id(char *id) {
+    static_assert(CAPDEC_COMM_ID_BYTES == NCCL_UNIQUE_ID_BYTES, "id size");
+    CAPDEC_CHECK(id != nullptr, "comm_unique_id: null id");
+    CAPDEC_CHECK(rccl() != nullptr, "comm: librccl.so.1 could not be loaded (set CAPDEC_RCCL_LIB)");
+    ncclUniqueId u;
+    CAPDEC_NCCL(rccl()->GetUniqueId(&u));
+    memcpy(id, u.internal, NCCL_UNIQUE_ID_BYTES);
+    return 0;
+}
+
+int capdec_comm_init(capdec_ctx *c, int rank, int nranks, const char *id) {
+    CAPDEC_CHECK(c && id && nranks >= 1 && rank >= 0 && rank < nranks, "comm_init: bad argument");
+    CAPDEC_CHECK(c->comm == nullptr, "comm_init: this context already has a communicator");
+    CAPDEC_CHECK(rccl() != nullptr, "comm: librccl.so.1 could not be loaded (set CAPDEC_RCCL_LIB)");
+    CAPDEC_HIP(hipSetDevice(c->device));
+    ncclUniqueId u;
+    memcpy(u.internal, id, NCCL_UNIQUE_ID_BYTES);
+    CAPDEC_NCCL(rccl()->CommInitRank(&c->comm, nranks, u, rank));
+    c->comm_rank = rank;
+    c->comm_world = nranks;
+    return 0;
+}
+
+int capdec_comm_destroy(capdec_ctx *c) {
+    CAPDEC_CHECK(c, "null context");
+    if (c->comm) {
+        (void)hipStreamSynchronize(c->stream);
+        CAPDEC_NCCL(rccl()->CommDestroy(c->comm));
+        c->comm = nullptr;
+    }
+    c->comm_rank = 0;
+    c->comm_world = 1;
+    return 0;
+}
+
+int capdec_shard_bounds(int n_total, int rank, int nranks, int *lo, int *hi) {
+    CAPDEC_CHECK(lo && hi && n_total >= 0 && nranks >= 1 && rank >= 0 && rank < nranks, "shard_bounds: bad argument");
+    const int per = (n_total + nranks - 1) / nranks;
+    *lo = std::min(rank * per, n_total);
+    *hi = std::min(*lo + per, n_total);
+    return 0;
+}
+
+int capdec_gather_rows(capdec_ctx *c, const void *d_local, int n_local, int row_elems, int n_total, void *d_global) {
+    CAPDEC_CHECK(c && n_local >= 0 && row_elems >= 1 && n_total >= 0 && (n_total == 0 || d_global) &&
+                     (n_local == 0 || d_local), "gather_rows: bad argument");
+    CAPDEC_HIP(hipSetDevice(c->device));
+    const size_t row_b = (size_t)row_elems * 4;
+    if (c->comm == nullptr) {
+        CAPDEC_CHECK(n_local == n_total, "gather_rows: this rank holds only part of the rows but the context has no "
+                                         "communicator (capdec_comm_init)");
+        if (n_total && d_local != d_global)
+            CAPDEC_HIP(hipMemcpyAsync(d_global, d_local, (size_t)n_total * row_b, hipMemcpyDeviceToDevice, c->stream));
+        return 0;
+    }
+    int lo = 0, hi = 0;
+    CAPDEC_TRY(capdec_shard_bounds(n_total, c->comm_rank, c->comm_world, &lo, &hi));
+    CAPDEC_CHECK(n_local == hi - lo, "gather_rows: n_local is not this rank's shard of n_total (capdec_shard_bounds)");
+    if (n_total == 0) return 0;
+    const int per = (n_total + c->comm_world - 1) / c->comm_world;
+    CAPDEC_TRY(c->g_pad.ensure((size_t)per * row_b));
+    CAPDEC_TRY(c->g_all.ensure((size_t)per * c->comm_world * row_b));
+    CAPDEC_HIP(hipMemsetAsync(c->g_pad.p, 0, (size_t)per * row_b, c->stream));
+    if (n_local)
+        CAPDEC_HIP(hipMemcpyAsync(c->g_pad.p, d_local, (size_t)n_local * row_b, hipMemcpyDeviceToDevice, c->stream));
+    CAPDEC_NCCL(rccl()->AllGather(c->g_pad.p, c->g_all.p, (size_t)per * row_elems, ncclInt32, c->comm, c->stream));
+    CAPDEC_HIP(hipMemcpyAsync(d_global, c->g_all.p, (size_t)n_total * row_b, hipMemcpyDeviceToDevice, c->stream));
+    return 0;
+}
+
+int capdec_gather_ids(capdec_ctx *c, const int32_t *d_ids, const int32_t *d_lens, const float *d_scores, int n_local,
+                      int T, int n_total, int32_t *d_ids_global, int32_t *d_lens_global, float *d_scores_global) {
+    CAPDEC_CHECK(c && T >= 1, "gather_ids: bad argument");
+    CAPDEC_TRY(capdec_gather_rows(c, d_ids, n_local, T, n_total, d_ids_global));
+    CAPDEC_TRY(capdec_gather_rows(c, d_lens, n_local, 1, n_total, d_lens_global));
+    if (d_scores && d_scores_global) CAPDEC_TRY(capdec_gather_rows(c, d_scores, n_local, 1, n_total, d_scores_global));
+    CAPDEC_HIP(hipStreamSynchronize(c->stream));
+    return 0;
 }
 
 int capdec_decode_stats(capdec_ctx *c, int *steps, int *compactions, long long *row_steps) {

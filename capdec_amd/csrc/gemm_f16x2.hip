@@ -201,18 +201,23 @@ __device__ __forceinline__ void h2_join(f32x16 (&am)[2][2], const f32x16 (&ac)[2
 }
 
 constexpr int H2_NS = 4;
+// ring depth of the plain kernel: CAPDEC_H2_NS = 3 | 4 | 5 (measurement knob; the default is the measured-fastest)
+static int h2_ns() {
+    static const int ns = [] { const char *e = getenv("CAPDEC_H2_NS"); const int v = e ? atoi(e) : H2_NS; return v == 3 || v == 5 ? v : H2_NS; }();
+    return ns;
+}
 
-template <bool VEC4>
+template <bool VEC4, int NS>
 __global__ __launch_bounds__(256, 2) void gemm_f16x2p_kernel(const _Float16 *__restrict__ Apk,
                                                              const _Float16 *__restrict__ Bpk, float *C, int ldc, int M,
                                                              int N, int K, const float *__restrict__ bias,
                                                              const float *resid, int ldr, int act, int tiles_m,
                                                              int tiles_n, char *packed_out) {
-    __shared__ __attribute__((aligned(16))) char smem[H2_NS * H2_STAGE_B];
+    __shared__ __attribute__((aligned(16))) char smem[NS * H2_STAGE_B];
     int tm, tn;
     tile_coords(tiles_m, tiles_n, tm, tn);
     f32x16 am[2][2], ac[2][2];
-    h2p_mainloop<true, H2_NS>(Apk, Bpk, K, tm, tn, smem, am, ac);
+    h2p_mainloop<true, NS>(Apk, Bpk, K, tm, tn, smem, am, ac);
     h2_join(am, ac);
     if (packed_out)
         epilogue_store_packed_t(am, packed_out, N >> 4, M, N, tm * GEMM_BM, tn * GEMM_BN, bias, act, PK_F16X2);
@@ -272,14 +277,17 @@ int launch_gemm_f16x2p(hipStream_t st, const void *Apacked, const void *Bpacked,
         CAPDEC_HIP(hipGetLastError());
         return launch_splitk_reduce(st, part, S, M, N, epi, C, ldc, PK_F16X2);
     }
-    if (vec4)
-        hipLaunchKernelGGL(gemm_f16x2p_kernel<true>, dim3(tiles_m * tiles_n), dim3(256), 0, st, (const _Float16 *)Apacked,
-                           (const _Float16 *)Bpacked, C, ldc, M, N, K, epi.bias, epi.resid, epi.ldr, epi.act, tiles_m,
-                           tiles_n, (char *)epi.packed_out);
-    else
-        hipLaunchKernelGGL(gemm_f16x2p_kernel<false>, dim3(tiles_m * tiles_n), dim3(256), 0, st, (const _Float16 *)Apacked,
-                           (const _Float16 *)Bpacked, C, ldc, M, N, K, epi.bias, epi.resid, epi.ldr, epi.act, tiles_m,
-                           tiles_n, (char *)epi.packed_out);
+#define LAUNCH_H2(V4, NSV)                                                                                            \
+    hipLaunchKernelGGL((gemm_f16x2p_kernel<V4, NSV>), dim3(tiles_m * tiles_n), dim3(256), 0, st, (const _Float16 *)Apacked, \
+                       (const _Float16 *)Bpacked, C, ldc, M, N, K, epi.bias, epi.resid, epi.ldr, epi.act, tiles_m,      \
+                       tiles_n, (char *)epi.packed_out)
+    const int ns = h2_ns();
+    if (vec4) {
+        if (ns == 3) LAUNCH_H2(true, 3); else if (ns == 5) LAUNCH_H2(true, 5); else LAUNCH_H2(true, H2_NS);
+    } else {
+        LAUNCH_H2(false, H2_NS);
+    }
+#undef LAUNCH_H2
     CAPDEC_HIP(hipGetLastError());
     return 0;
 }

@@ -46,6 +46,24 @@ def gather_rows(local: torch.Tensor, n_total: int, group=None) -> torch.Tensor:
     return out[:n_total]
 
 
+def capi_comm_from_torch(engine, group=None) -> None:
+    """Create the engine's C-ABI RCCL communicator (capdec_comm_init) for the ranks of a torch.distributed group: rank 0
+    makes the id, torch broadcasts its 128 bytes.  (A host without torch distributes the id itself -- INTEGRATION.md.)"""
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    backend = dist.get_backend(group)
+    dev = engine.device if backend == "nccl" else torch.device("cpu")
+    buf = torch.zeros(128, dtype=torch.uint8, device=dev)
+    if rank == 0:
+        buf.copy_(torch.frombuffer(bytearray(engine.comm_unique_id()), dtype=torch.uint8))
+    dist.broadcast(buf, src=0, group=group)
+    engine.comm_init(rank, world, bytes(buf.cpu().tolist()))
+
+
+def gather_rows_capi(engine, local: torch.Tensor, n_total: int) -> torch.Tensor:
+    """:func:`gather_rows` through the C ABI's own communicator (RCCL directly, no torch.distributed in the data path)"""
+    return engine.gather_rows(local, n_total)
+
+
 def check_world(rank: int, world: int, group=None) -> None:
     """rank / world handed to the sharded drivers must describe the process group this process is really in"""
     if world == 1 and rank == 0:

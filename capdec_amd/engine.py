@@ -39,6 +39,7 @@ class Engine:
             check(self.lib.capdec_set_kv_budget(self._h, kv_budget_bytes), "set_kv_budget")
         self.gpt_dims: Optional[Dict[str, int]] = None
         self.mapper: Optional[Dict[str, int]] = None
+        self.comm: Optional[Tuple[int, int]] = None          # (rank, world) of the C-ABI RCCL communicator, if any
 
     # ------------------------------------------------------------------ lifetime
     def close(self):
@@ -306,6 +307,35 @@ class Engine:
                                           float(temperature), ids.data_ptr(), lens.data_ptr(), scores.data_ptr(),
                                           order.data_ptr()), "capdec_decode_beam")
         return ids, lens, scores, order
+
+    # ------------------------------------------------------------------ caption-shard communicator (RCCL through the C ABI)
+    def comm_unique_id(self) -> bytes:
+        """rank 0: the 128-byte communicator id every rank passes to :meth:`comm_init`"""
+        buf = C.create_string_buffer(128)
+        check(self.lib.capdec_comm_unique_id(buf), "capdec_comm_unique_id")
+        return buf.raw
+
+    def comm_init(self, rank: int, world: int, comm_id: bytes):
+        if len(comm_id) != 128:
+            raise CapdecError("comm_init: the communicator id is 128 bytes")
+        check(self.lib.capdec_comm_init(self._h, int(rank), int(world), comm_id), "capdec_comm_init")
+        self.comm = (int(rank), int(world))
+
+    def comm_destroy(self):
+        check(self.lib.capdec_comm_destroy(self._h), "capdec_comm_destroy")
+        self.comm = None
+
+    def gather_rows(self, local: torch.Tensor, n_total: int) -> torch.Tensor:
+        """all-gather of this rank's row block (int32 or fp32, [n_local, ...]) in rank order -> [n_total, ...]"""
+        if local.dtype not in (torch.int32, torch.float32):
+            raise CapdecError("gather_rows: int32 or float32 rows")
+        t = local.to(self.device).contiguous()
+        row = int(np.prod(t.shape[1:])) if t.dim() > 1 else 1
+        out = torch.empty((n_total,) + tuple(t.shape[1:]), dtype=t.dtype, device=self.device)
+        self._sync_stream()
+        check(self.lib.capdec_gather_rows(self._h, t.data_ptr() if t.numel() else None, t.shape[0], max(row, 1),
+                                          int(n_total), out.data_ptr() if out.numel() else None), "capdec_gather_rows")
+        return out
 
     # ------------------------------------------------------------------ image preprocessing (SURVEY F3)
     def preprocess_images(self, images, n_px: int = 224, stretch: bool = False,

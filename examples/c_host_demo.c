@@ -2,6 +2,10 @@
  *
  *   gcc -O2 -Iinclude examples/c_host_demo.c -Lcapdec_amd/lib -lcapdec_hip -Wl,-rpath,$PWD/capdec_amd/lib -o /tmp/c_host_demo
  *   /tmp/c_host_demo model.bin [entry_length] [beam]
+ *   /tmp/c_host_demo model.bin T beam RANK NRANKS IDFILE      one process per GPU (device = RANK): the captions are
+ *       sharded with capdec_shard_bounds, rank 0 creates the RCCL id (capdec_comm_unique_id) and publishes it through
+ *       IDFILE, every rank joins with capdec_comm_init and the generated ids are collected with capdec_gather_ids --
+ *       the whole multi-GPU path of SURVEY section 8 row E without Python or torch.distributed.
  *
  * model.bin (little endian, written by tests/test_hip_parity.py::test_c_host_without_torch or any exporter):
  *   int32 magic 0x43415044 ("CAPD"), n_layer, n_head, n_embd, vocab, n_pos; float32 ln_eps;
@@ -12,6 +16,8 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <string.h>
+#include <unistd.h>
 
 #include "capdec.h"
 
@@ -38,6 +44,8 @@ int main(int argc, char **argv) {
         return 2;
     }
     const int T = argc > 2 ? atoi(argv[2]) : 12, beam = argc > 3 ? atoi(argv[3]) : 5;
+    const int rank = argc > 6 ? atoi(argv[4]) : 0, nranks = argc > 6 ? atoi(argv[5]) : 1;
+    const char *idfile = argc > 6 ? argv[6] : NULL;
     FILE *f = fopen(argv[1], "rb");
     if (!f) { perror(argv[1]); return 2; }
     int32_t hdr[6];
@@ -65,14 +73,36 @@ int main(int argc, char **argv) {
     w.ln_f_b = read_floats(f, d);
     int32_t np[2];
     if (fread(np, 4, 2, f) != 2) { fprintf(stderr, "no prefix block\n"); return 2; }
-    const int n = np[0], P = np[1];
-    float *prefix = read_floats(f, (size_t)n * P * d);
+    const int n_total = np[0], P = np[1];
+    float *prefix_all = read_floats(f, (size_t)n_total * P * d);
     fclose(f);
 
     capdec_ctx *ctx = NULL;
-    CHECK(capdec_create(0, &ctx));
+    CHECK(capdec_create(idfile ? rank : 0, &ctx));
     CHECK(capdec_load_gpt2(ctx, &w));
-    void *d_prefix, *d_ids, *d_lens, *d_bids, *d_blens, *d_scores;
+    int lo = 0, hi = n_total;
+    if (idfile) {   /* one RCCL communicator over the ranks; the 128-byte id travels through a file */
+        char id[CAPDEC_COMM_ID_BYTES];
+        if (rank == 0) {
+            char tmp[4096];
+            CHECK(capdec_comm_unique_id(id));
+            snprintf(tmp, sizeof tmp, "%s.tmp", idfile);
+            FILE *g = fopen(tmp, "wb");
+            if (!g || fwrite(id, 1, sizeof id, g) != sizeof id) { perror("idfile"); return 2; }
+            fclose(g);
+            rename(tmp, idfile);
+        } else {
+            FILE *g = NULL;
+            for (int tries = 0; tries < 600 && !(g = fopen(idfile, "rb")); ++tries) usleep(100000);
+            if (!g || fread(id, 1, sizeof id, g) != sizeof id) { fprintf(stderr, "rank %d: no id file\n", rank); return 2; }
+            fclose(g);
+        }
+        CHECK(capdec_comm_init(ctx, rank, nranks, id));
+        CHECK(capdec_shard_bounds(n_total, rank, nranks, &lo, &hi));
+    }
+    const int n = hi - lo;
+    const float *prefix = prefix_all + (size_t)lo * P * d;
+    void *d_prefix, *d_ids, *d_lens, *d_bids, *d_blens, *d_scores, *g_ids = NULL, *g_lens = NULL;
     CHECK(capdec_malloc(ctx, (size_t)n * P * d * 4, &d_prefix));
     CHECK(capdec_malloc(ctx, (size_t)n * T * 4, &d_ids));
     CHECK(capdec_malloc(ctx, (size_t)n * 4, &d_lens));
@@ -85,6 +115,24 @@ int main(int argc, char **argv) {
     /* generate_beam (:50-115) */
     CHECK(capdec_decode_beam(ctx, (const float *)d_prefix, n, P, beam, 13, T, 1.0f, (int32_t *)d_bids, (int32_t *)d_blens,
                              (float *)d_scores, NULL));
+    if (idfile) {   /* the one exchange of the path: greedy ids / lengths of every rank, in caption order */
+        CHECK(capdec_malloc(ctx, (size_t)n_total * T * 4, &g_ids));
+        CHECK(capdec_malloc(ctx, (size_t)n_total * 4, &g_lens));
+        CHECK(capdec_gather_ids(ctx, (const int32_t *)d_ids, (const int32_t *)d_lens, NULL, n, T, n_total,
+                                (int32_t *)g_ids, (int32_t *)g_lens, NULL));
+        if (rank == 0) {
+            int32_t *gi = (int32_t *)malloc((size_t)n_total * T * 4), *gl = (int32_t *)malloc((size_t)n_total * 4);
+            CHECK(capdec_memcpy_d2h(ctx, gi, g_ids, (size_t)n_total * T * 4));
+            CHECK(capdec_memcpy_d2h(ctx, gl, g_lens, (size_t)n_total * 4));
+            for (int r = 0; r < n_total; ++r) {
+                printf("gathered %d :", gl[r]);
+                for (int t = 0; t < gl[r]; ++t) printf(" %d", gi[(size_t)r * T + t]);
+                printf("\n");
+            }
+            free(gi); free(gl);
+        }
+        CHECK(capdec_comm_destroy(ctx));
+    }
     int32_t *ids = (int32_t *)malloc((size_t)n * T * 4), *lens = (int32_t *)malloc((size_t)n * 4);
     int32_t *bids = (int32_t *)malloc((size_t)n * beam * T * 4), *blens = (int32_t *)malloc((size_t)n * beam * 4);
     float *scores = (float *)malloc((size_t)n * beam * 4);
@@ -102,6 +150,7 @@ int main(int argc, char **argv) {
     }
     CHECK(capdec_free(ctx, d_prefix)); CHECK(capdec_free(ctx, d_ids)); CHECK(capdec_free(ctx, d_lens));
     CHECK(capdec_free(ctx, d_bids)); CHECK(capdec_free(ctx, d_blens)); CHECK(capdec_free(ctx, d_scores));
+    CHECK(capdec_free(ctx, g_ids)); CHECK(capdec_free(ctx, g_lens));
     capdec_destroy(ctx);
     return 0;
 }

@@ -221,6 +221,32 @@ int capdec_preprocess_images(capdec_ctx *ctx, const uint8_t *d_rgb, const int64_
  * GPT-2 body after the prefill (n * beam * (steps - 1) without early stopping).  CAPDEC_COMPACT=0 disables compaction. */
 int capdec_decode_stats(capdec_ctx *ctx, int *steps, int *compactions, long long *row_steps);
 
+/* ---- multi-GPU: caption-batch sharding + ONE gather of the generated ids (RCCL over xGMI) ------------------------
+ * The reference has no distributed code: it loops over captions one at a time (predictions_runner.py:194,
+ * embeddings_generator.py:58); every caption is independent.  Rank r of R decodes the contiguous block
+ * [r * ceil(N/R), (r+1) * ceil(N/R)) of the embedding matrix with replicated weights; the only exchange is an
+ * all-gather of int32 token ids / lengths (+ fp32 scores, or fp32 embeddings for the embeddings_generator path),
+ * in rank order, so the gathered matrix equals the single-GPU result.  One communicator per context; RCCL is
+ * dlopen'ed on first use (librccl.so.1), so single-GPU hosts do not need it.  A host without torch distributes the
+ * 128-byte id itself (file, socket, MPI, environment ...); capdec_amd/distributed.py can use torch.distributed or
+ * this communicator. */
+#define CAPDEC_COMM_ID_BYTES 128
+/* rank 0: create the communicator id (ncclGetUniqueId) and hand it to every rank */
+int capdec_comm_unique_id(char *id /* [CAPDEC_COMM_ID_BYTES] */);
+/* every rank, after capdec_create on its own GPU: join (ncclCommInitRank).  nranks == 1 is allowed. */
+int capdec_comm_init(capdec_ctx *ctx, int rank, int nranks, const char *id /* [CAPDEC_COMM_ID_BYTES] */);
+int capdec_comm_destroy(capdec_ctx *ctx);
+/* the shard of rank `rank`: [*lo, *hi) of n_total rows (trailing ranks may get an empty block) */
+int capdec_shard_bounds(int n_total, int rank, int nranks, int *lo, int *hi);
+/* all-gather of row blocks laid out by capdec_shard_bounds: d_local [n_local, row_elems] 4-byte elements (int32 or
+ * fp32) of this rank -> d_global [n_total, row_elems] on every rank (blocks padded to ceil(N/R) rows internally, one
+ * ncclAllGather, padding cut off).  Without a communicator (single GPU) it is a device copy and n_local must equal
+ * n_total. */
+int capdec_gather_rows(capdec_ctx *ctx, const void *d_local, int n_local, int row_elems, int n_total, void *d_global);
+/* ids [n_local, T] + lens [n_local] (+ scores [n_local], may be NULL) of this rank's captions -> global arrays */
+int capdec_gather_ids(capdec_ctx *ctx, const int32_t *d_ids, const int32_t *d_lens, const float *d_scores, int n_local,
+                      int T, int n_total, int32_t *d_ids_global, int32_t *d_lens_global, float *d_scores_global);
+
 /* ---- measurement / test hooks -------------------------------------------------------- */
 /* C[M,N] = act(A[M,K] . Bt[N,K]^T + bias[N]) + resid[M,N]; bias / resid may be NULL.
  * The MFMA GEMM every projection above runs on (nn.Linear weights are already [N,K]). */
@@ -233,7 +259,7 @@ int capdec_timer_stop_ms(capdec_ctx *ctx, float *ms);   /* records, synchronises
 /* per-kernel-family accumulated device time since the last reset (hipEvents around the timed launches).
  * on = 0: off; 1: every launch is timed; N > 1: every N-th launch of each family is timed (sampling: the
  * events of the other launches are skipped, so a timed region is barely perturbed).
- * get: caller arrays of capacity 16, *count entries are filled; ms / launches / flops cover the TIMED launches
+ * get: caller arrays of capacity 24, *count entries are filled; ms / launches / flops cover the TIMED launches
  * (flops: algorithmic FLOPs issued, 0 for non-GEMM families), calls = all launches of the family. */
 int capdec_profile_enable(capdec_ctx *ctx, int on);
 int capdec_profile_get(capdec_ctx *ctx, int *count, const char **names, float *ms, int64_t *launches,

@@ -252,6 +252,82 @@ def test_decode_small_vs_reference_golden(golden, mode, monkeypatch):
     _check_decode(golden("decode_small"), synth.GPT2_SMALL)
 
 
+class PromptTok(FakeTok):
+    def encode(self, s):
+        return [self.stop] if s == "." else [int(v) for v in s.split()]
+
+
+@pytest.mark.parametrize("dims,tag", [(synth.GPT2_TINY, "tiny"), (synth.GPT2_SMALL, "small")], ids=["tiny", "small"])
+def test_prompt_and_tokens_entry_vs_reference_golden(golden, dims, tag):
+    """generate2(tokens=...), generate2(prompt=...), generate_beam(prompt=...) of the facade == strings captured from
+    the reference (gpt2_prefix_eval.py:70-74,86-89,141-151): prompt ids stay in the output, generate_beam slices
+    prompt + generated by the generated length"""
+    from capdec_amd import gpt2_prefix_eval as E
+    g = golden(f"prompt_{tag}")
+    model, sd = _model(dims, "mlp", 512)
+    assert synth.state_dict_checksum(sd) == int(g["sd_crc"]), "RNG drift"
+    prompts = [list(map(int, row[:n])) for row, n in zip(g["prompts"], g["prompt_lens"])]
+    for name, st in (("nostop", dims.vocab + 5), ("stop", int(g["stop_id"]))):
+        for i, p in enumerate(prompts):
+            want2, wantb = str(g[f"generate2_{name}"][i]), [str(t) for t in g[f"generate_beam_{name}"][i]]
+            ptxt = " ".join(str(v) for v in p)
+            assert E.generate2(model, PromptTok(st), tokens=torch.tensor([p]), entry_length=12) == want2
+            assert E.generate2(model, PromptTok(st), prompt=ptxt, entry_length=12) == want2
+            assert E.generate_beam(model, PromptTok(st), prompt=ptxt, entry_length=12) == wantb
+
+
+@pytest.mark.parametrize("dims,tag", [(synth.GPT2_TINY, "tiny"), (synth.GPT2_SMALL, "small")], ids=["tiny", "small"])
+def test_make_preds_driver_vs_reference_golden(golden, dims, tag, tmp_path):
+    """A11: the batched driver (predictions_runner.caption_ids / make_preds = the reference's per-image loop
+    :194-234,300-301) on the golden captions: embeddings -> clip_project -> decode -> ids / JSON must equal what the
+    reference's generate2 / generate_beam(...)[0] produced one caption at a time -- as one batch (rank 0 of 1) and as
+    the concatenation of a manual 2-way shard (the rank / world arithmetic without a process group)."""
+    import json
+    from capdec_amd import predictions_runner as PR, distributed as cdist
+    g = golden(f"decode_{tag}")
+    # ---- beam (config 3 shape): best beam per caption
+    model, _ = _model(dims, "transformer_encoder", 512)
+    x = T(g["beam_x"])
+    nb = x.shape[0]
+    for name, st, el in (("stop", int(g["beam_stop_id"]), 12), ("nostop", dims.vocab + 5, 67)):
+        gt, gl = g[f"beam_{name}_tokens_T{el}"], g[f"beam_{name}_seqlen_T{el}"]
+        go, gs = g[f"beam_{name}_order_T{el}"], g[f"beam_{name}_scores_T{el}"]
+        want_ids = np.stack([gt[r][go[r][0]] for r in range(nb)])
+        want_len = np.array([int(gl[r][go[r][0]]) for r in range(nb)])
+        ids, lens, sc = PR.caption_ids(model, x, st, beam=True, entry_length=el, dont_normalize_prefix=True)
+        np.testing.assert_array_equal(ids.cpu().numpy(), want_ids)
+        np.testing.assert_array_equal(lens.cpu().numpy(), want_len)
+        np.testing.assert_allclose(sc.cpu().numpy(), [gs[r][go[r][0]] for r in range(nb)], atol=1e-4)
+        parts = [PR.caption_ids(model, x[slice(*cdist.shard_bounds(nb, r, 2))], st, beam=True, entry_length=el,
+                                dont_normalize_prefix=True) for r in range(2)]
+        np.testing.assert_array_equal(torch.cat([p[0] for p in parts]).cpu().numpy(), want_ids)
+        np.testing.assert_array_equal(torch.cat([p[1] for p in parts]).cpu().numpy(), want_len)
+    # the synthetic embeddings are unit-norm, so the reference's `prefix / prefix.norm()` (:222) moves them by <= 1 ulp:
+    # the default (normalising) driver must produce the same captions
+    st = int(g["beam_stop_id"])
+    data = [{"image_id": 100 + r} for r in range(nb)]
+    out = tmp_path / "preds.json"
+    preds = PR.make_preds(data, x, model, FakeTok(st), str(out), beam=True, entry_length=12)
+    gt, gl, go = g["beam_stop_tokens_T12"], g["beam_stop_seqlen_T12"], g["beam_stop_order_T12"]
+    want = [{"caption": " ".join(str(int(v)) for v in gt[r][go[r][0]][:int(gl[r][go[r][0]])]), "image_id": 100 + r}
+            for r in range(nb)]
+    assert preds == want and json.load(open(out)) == want
+    # ---- greedy (config 1 shape: 8 x 640-d, MLP mapper)
+    model, _ = _model(dims, "mlp", 640)
+    x = T(g["greedy_x"])
+    st = int(g["greedy_stop_id"])
+    for el in (12, 67):
+        ids, lens, sc = PR.caption_ids(model, x, st, beam=False, entry_length=el, dont_normalize_prefix=True)
+        assert sc is None
+        np.testing.assert_array_equal(ids.cpu().numpy(), g[f"greedy_ids_T{el}"])
+        np.testing.assert_array_equal(lens.cpu().numpy(), g[f"greedy_lens_T{el}"])
+        parts = [PR.caption_ids(model, x, st, beam=False, entry_length=el, dont_normalize_prefix=True, rank=r, world=2)
+                 for r in range(2)]                                  # rank / world arithmetic of the driver itself
+        np.testing.assert_array_equal(torch.cat([p[0] for p in parts]).cpu().numpy(), g[f"greedy_ids_T{el}"])
+    with pytest.raises(RuntimeError):                                # world > 1 without a process group is an error
+        PR.make_preds([{"image_id": r} for r in range(8)], x, model, FakeTok(st), None, beam=False, rank=0, world=2)
+
+
 @pytest.mark.parametrize("mode", ["f16x2", "bf16x3", "f32"])
 def test_gemm_modes_vs_fp64(mode):
     """every fp32-accurate GEMM back-end stays in the fp32 round-off class (error relative to sum |a||b|)"""
@@ -483,6 +559,39 @@ def test_finished_caption_compaction(monkeypatch):
     np.testing.assert_array_equal(outs["1"][2], outs["0"][2])          # scores bit-identical with and without compaction
 
 
+def test_capi_rccl_communicator_single_rank():
+    """SURVEY section 8 B': capdec_comm_unique_id / capdec_comm_init / capdec_gather_rows / capdec_gather_ids over RCCL
+    itself (dlopen'ed librccl, no torch.distributed): a one-rank communicator on the one GPU of this box -- ncclAllGather
+    really runs -- plus the no-communicator copy path and the shard arithmetic"""
+    import ctypes as C
+    from capdec_amd.engine import Engine
+    from capdec_amd._capi import CapdecError
+    e = Engine(0)
+    ids = torch.arange(7 * 12, dtype=torch.int32).view(7, 12).cuda()
+    sc = torch.arange(7, dtype=torch.float32).cuda() * -0.25
+    np.testing.assert_array_equal(e.gather_rows(ids, 7).cpu().numpy(), ids.cpu().numpy())       # no communicator: copy
+    with pytest.raises(CapdecError):
+        e.gather_rows(ids[:3], 7)                                    # partial shard without a communicator
+    e.comm_init(0, 1, e.comm_unique_id())
+    np.testing.assert_array_equal(e.gather_rows(ids, 7).cpu().numpy(), ids.cpu().numpy())       # ncclAllGather, 1 rank
+    np.testing.assert_array_equal(e.gather_rows(sc, 7).cpu().numpy(), sc.cpu().numpy())
+    assert e.gather_rows(ids[:0], 0).shape == (0, 12)
+    with pytest.raises(CapdecError):
+        e.gather_rows(ids[:3], 7)                                    # not this rank's shard of 7
+    with pytest.raises(CapdecError):
+        e.comm_init(0, 1, e.comm_unique_id())                        # one communicator per context
+    e.comm_destroy()
+    lo, hi = C.c_int(), C.c_int()
+    for n, w in ((5, 4), (5000, 8), (0, 2)):
+        spans = []
+        for r in range(w):
+            assert e.lib.capdec_shard_bounds(n, r, w, C.byref(lo), C.byref(hi)) == 0
+            spans.append((lo.value, hi.value))
+        from capdec_amd.distributed import shard_bounds
+        assert spans == [shard_bounds(n, r, w) for r in range(w)]
+    e.close()
+
+
 def test_c_host_without_torch(tmp_path):
     """the C ABI from a plain C program (examples/c_host_demo.c: gcc, no Python, no torch in the process): same ids as
     the Python host on the same weights"""
@@ -532,6 +641,15 @@ def test_c_host_without_torch(tmp_path):
         assert [int(v) for v in toks.split()] == ids[r, :int(lens[r])].tolist()
         head, toks = lines[2 * r + 1].split(":")
         assert int(head.split()[1]) == int(bl[r, 0])
+    # the same program as rank 0 of a one-rank RCCL job (communicator id through a file, capdec_gather_ids)
+    out = subprocess.run([exe, path, str(T), "5", "0", "1", str(tmp_path / "rccl.id")], capture_output=True, text=True,
+                         env=env, timeout=300)
+    assert out.returncode == 0, out.stderr
+    gathered = [ln for ln in out.stdout.splitlines() if ln.startswith("gathered")]
+    assert len(gathered) == n
+    for r in range(n):
+        head, toks = gathered[r].split(":")
+        assert int(head.split()[1]) == int(lens[r]) and [int(v) for v in toks.split()] == ids[r, :int(lens[r])].tolist()
         assert abs(float(head.split()[2]) - float(bs[r, 0])) < 1e-5
         assert [int(v) for v in toks.split()] == bi[r, 0, :int(bl[r, 0])].tolist()
     e.close()

@@ -150,6 +150,42 @@ def test_decode_small(golden):
     _check_decode(golden("decode_small"), synth.GPT2_SMALL, 1, 1)
 
 
+# ------------------------------------------------------------------ prompt / tokens entry of generate2 / generate_beam
+def _prompt_expectations(g, name):
+    """the fixture's strings -> id lists (reference tokenizer stand-in: decode = ' '.join(ids))"""
+    g2 = [[int(v) for v in str(t).split()] for t in g[f"generate2_{name}"]]
+    gb = [[[int(v) for v in str(t).split()] for t in row] for row in g[f"generate_beam_{name}"]]
+    return g2, gb
+
+
+def _check_prompt(g, dims, n_beam_rows):
+    """reference gpt2_prefix_eval.py:70-74,86-89,141-151: the prefix is wte(prompt ids); generate2 returns prompt +
+    generated ids; generate_beam returns the first seq_length (GENERATED count, :111) ids of prompt + generated"""
+    sd = synth.hot_state_dict(42, "mlp", 512, 10, dims=dims)
+    assert synth.state_dict_checksum(sd) == int(g["sd_crc"]), "RNG drift"
+    prompts = [list(map(int, row[:n])) for row, n in zip(g["prompts"], g["prompt_lens"])]
+    for name, st in (("nostop", dims.vocab + 5), ("stop", int(g["stop_id"]))):
+        g2, gb = _prompt_expectations(g, name)
+        for i, p in enumerate(prompts):
+            pe = O.wte(torch.tensor([p]), sd)
+            ids, lens = O.greedy_cached(sd, pe, stop_id=st, entry_length=12, n_head=dims.n_head)
+            assert p + ids[0, :int(lens[0])].tolist() == g2[i]
+            if i < n_beam_rows:
+                tok, seq, sc = O.beam_cached(sd, pe, 5, st, 12, n_head=dims.n_head)
+                order = O.beam_output_order(sc)[0]
+                got = [(p + tok[0, b].tolist())[:int(seq[0, b])] for b in order]
+                assert got == gb[i]
+
+
+def test_prompt_tiny(golden):
+    _check_prompt(golden("prompt_tiny"), synth.GPT2_TINY, 4)
+
+
+@pytest.mark.slow
+def test_prompt_small(golden):
+    _check_prompt(golden("prompt_small"), synth.GPT2_SMALL, 1)
+
+
 # ------------------------------------------------------------------ CLIP ViT-B/32 (HF stand-in pin)
 def _check_clip(g, dims):
     sd = synth.hot_clip_state_dict(43, dims)

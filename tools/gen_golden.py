@@ -283,6 +283,54 @@ def gen_decode_p40(refs, dims, tag):
     print(f"decode_p40_{tag}.npz written")
 
 
+class PromptTok(FakeTok):
+    """tokenizer stand-in for the prompt / tokens entry of generate2 / generate_beam: a prompt is a string of ids."""
+
+    def encode(self, s):
+        return [self.stop] if s == "." else [int(v) for v in s.split()]
+
+
+def gen_prompt(refs, dims, tag):
+    """generate2(tokens=...), generate2(prompt=...), generate_beam(prompt=...) (reference gpt2_prefix_eval.py:70-74,
+    86-89,141-151): the prefix is wte(prompt ids) instead of a mapped CLIP embedding, and the prompt ids stay in the
+    output (generate_beam even slices the concatenated row by the GENERATED length only, :111)."""
+    gpt2_prefix, gpt2_prefix_eval = refs[0], refs[1]
+    model, sd = build_ref_model(gpt2_prefix, dims, "mlp", 512, 10)
+    out = {"sd_crc": np.uint32(synth.state_dict_checksum(sd))}
+    g = torch.Generator().manual_seed(31)
+    prompts = [torch.randint(1, dims.vocab - 1, (L,), generator=g).tolist() for L in (1, 3, 7, 5)]
+    out["prompt_lens"] = np.array([len(p) for p in prompts], np.int64)
+    pp = np.zeros((len(prompts), 8), np.int64)
+    for i, p in enumerate(prompts):
+        pp[i, :len(p)] = p
+    out["prompts"] = pp
+    T = 12
+    free = []
+    with torch.no_grad():
+        for p in prompts:          # pass 1: never stop
+            txt = gpt2_prefix_eval.generate2(model, PromptTok(stop=dims.vocab + 5), tokens=torch.tensor([p]), entry_length=T)
+            free.append([int(v) for v in txt.split()])
+    gen_part = np.concatenate([np.array(f[len(p) + 2:]) for f, p in zip(free, prompts)])
+    vals, counts = np.unique(gen_part, return_counts=True)
+    stop = int(vals[np.argmax(counts)])
+    out["stop_id"] = np.int64(stop)
+    for name, st in (("nostop", dims.vocab + 5), ("stop", stop)):
+        texts_tok, texts_prompt, beams = [], [], []
+        with torch.no_grad():
+            for p in prompts:
+                a = gpt2_prefix_eval.generate2(model, PromptTok(stop=st), tokens=torch.tensor([p]), entry_length=T)
+                b = gpt2_prefix_eval.generate2(model, PromptTok(stop=st), prompt=" ".join(str(v) for v in p), entry_length=T)
+                assert a == b
+                texts_tok.append(a)
+                texts_prompt.append(b)
+                beams.append(gpt2_prefix_eval.generate_beam(model, PromptTok(stop=st), prompt=" ".join(str(v) for v in p),
+                                                            entry_length=T))
+        out[f"generate2_{name}"] = np.array(texts_tok)
+        out[f"generate_beam_{name}"] = np.array(beams)          # [n_prompts, 5] strings, best first
+    np.savez_compressed(os.path.join(OUT, f"prompt_{tag}.npz"), **out)
+    print(f"prompt_{tag}.npz written; stop {stop}", out["generate2_stop"], out["generate_beam_stop"][1])
+
+
 def openai_to_hf_clip(sd, dims):
     """Map an OpenAI-CLIP-named state dict onto transformers.CLIPModel names (the independent
     stand-in used to pin the CLIP kernels: the reference's own `clip` package is not installed)."""
@@ -386,6 +434,8 @@ def main():
         "decode_tiny": lambda: gen_decode(refs, synth.GPT2_TINY, "tiny", 8, 6, (12, 67)),
         "decode_small": lambda: gen_decode(refs, synth.GPT2_SMALL, "small", 8, 4, (12, 67)),
         "decode_p40_tiny": lambda: gen_decode_p40(refs, synth.GPT2_TINY, "tiny"),
+        "prompt_tiny": lambda: gen_prompt(refs, synth.GPT2_TINY, "tiny"),
+        "prompt_small": lambda: gen_prompt(refs, synth.GPT2_SMALL, "small"),
         "clip_tiny": lambda: gen_clip(synth.CLIP_TINY, "tiny", 6, 3),
         "clip_b32": lambda: gen_clip(synth.CLIP_VIT_B32, "b32", 6, 3),
         "preprocess": gen_preprocess,
