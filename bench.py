@@ -112,7 +112,7 @@ def cpu_baseline(mapper, beam, P, T, budget_s=20.0, D=512):
                       f"thread count chosen by a 1.5 s probe, warm-up discarded"}
 
 
-def side_workload(args, world, rank, dev):
+def side_workload(args, world, rank, dev, emit=print):
     """configs[3] / configs[4] of BASELINE.json: parity-test cases, measured here for DESIGN.md (not the metric line)."""
     from capdec_amd import clip as cclip, distributed as cdist, embeddings_generator as eg
     from capdec_amd.gpt2_prefix import ClipCaptionModel, MappingType
@@ -151,13 +151,13 @@ def side_workload(args, world, rank, dev):
     dt = time.perf_counter() - t0
     prof = cm._engine.profile_get()
     if rank == 0:
-        print(json.dumps({"metric": f"{'captions' if text else 'images'}/sec, side workload {args.workload}",
+        emit(json.dumps({"metric": f"{'captions' if text else 'images'}/sec, side workload {args.workload}",
                           "clip_tower_kernels": {k: {"ms_est": round(v["ms"] * v["calls"] / v["launches"], 2),
                                                      "launches": v["calls"], "avg_ms": round(v["ms"] / v["launches"], 4)}
                                                  for k, v in prof.items() if v["launches"]},
                           "value": round(n_global * args.steps / dt, 2), "unit": "items/s", "n_gpus": world,
                           "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 2),
-                          "config": {"workload": args.workload, "items_per_step": n_global}}), flush=True)
+                          "config": {"workload": args.workload, "items_per_step": n_global}}))
 
 
 def respawn_under_torchrun(n):
@@ -210,6 +210,15 @@ def main():
 
     if args.gpus > 1 and "RANK" not in os.environ:
         sys.exit(respawn_under_torchrun(args.gpus))
+    # stdout carries exactly ONE line (the JSON record): RCCL prints a version banner to stdout when a communicator is
+    # created, so everything else written to fd 1 during the run is sent to stderr
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
+    def emit(line):
+        sys.stdout.flush()
+        os.write(json_fd, (line + "\n").encode())
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -228,7 +237,7 @@ def main():
             seen = [int(p) for p in parts]
             dist.destroy_process_group()
         if rank == 0:
-            print(json.dumps({"dry_run": True, "n_gpus": world, "ranks": seen}), flush=True)
+            emit(json.dumps({"dry_run": True, "n_gpus": world, "ranks": seen}))
         return
     if use_dist:
         import torch.distributed as dist
@@ -245,7 +254,7 @@ def main():
     from capdec_amd.predictions_runner import caption_ids
 
     if args.workload in ("text_embed", "image_beam"):
-        return side_workload(args, world, rank, dev)
+        return side_workload(args, world, rank, dev, emit)
     beam = args.workload == "beam_transformer"
     mapper = "transformer_encoder" if beam else "mlp"
     P, T, B = args.prefix_length, args.entry_length, (5 if beam else 1)
@@ -427,7 +436,7 @@ def main():
             rec["cpu_baseline"] = cpu_baseline(mapper, B, P, T, args.cpu_seconds)
         else:
             rec["cpu_baseline"] = None
-        print(json.dumps(rec), flush=True)
+        emit(json.dumps(rec))
     if use_dist:
         import torch.distributed as dist
         dist.barrier()

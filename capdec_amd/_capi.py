@@ -69,6 +69,7 @@ class ClipVisionWeights(C.Structure):
 _VP = C.c_void_p
 SIGNATURES = {
     "capdec_abi_version": (C.c_int, []),
+    "capdec_build_id": (C.c_char_p, []),
     "capdec_last_error": (C.c_char_p, []),
     "capdec_create": (C.c_int, [C.c_int, C.POINTER(_VP)]),
     "capdec_destroy": (None, [_VP]),
@@ -142,6 +143,17 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
         fn.argtypes = args
     if lib.capdec_abi_version() != 1:
         raise CapdecError("libcapdec_hip.so ABI version mismatch")
+    if path is None and os.environ.get("CAPDEC_SKIP_BUILD_ID_CHECK") != "1":
+        # stale-library guard: the id compiled into the .so must match the sources lying next to it
+        try:
+            from .build import source_hash
+            want = source_hash()
+        except OSError:
+            want = None                     # sources not shipped with the package: nothing to compare against
+        got = lib.capdec_build_id().decode()
+        if want is not None and got != want:
+            raise CapdecError(f"stale HIP extension: {p} was built from other sources (build id {got}, tree {want}). "
+                              "Run `python -m capdec_amd.build`.")
     if path is None:
         _lib = lib
     return lib

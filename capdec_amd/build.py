@@ -22,6 +22,19 @@ def _hipcc() -> str:
     return exe
 
 
+def source_hash() -> str:
+    """sha256 over every translation unit and header the library is built from: compiled into the library
+    (capdec_build_id) and re-computed by capdec_amd._capi.load_library, so a stale .so is refused instead of silently
+    running old kernels"""
+    import hashlib
+    h = hashlib.sha256()
+    for path in sorted([os.path.join(CSRC, s) for s in SOURCES] + HEADERS):
+        h.update(os.path.basename(path).encode())
+        with open(path, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
 def _stale(target: str, deps) -> bool:
     if not os.path.exists(target):
         return True
@@ -37,12 +50,17 @@ def build(force: bool = False, verbose: bool = True) -> str:
     os.makedirs(obj_dir, exist_ok=True)
     hipcc = _hipcc()
     objs, procs = [], []
+    build_id = source_hash()
+    id_file = os.path.join(obj_dir, "build_id.txt")
+    id_changed = not os.path.exists(id_file) or open(id_file).read().strip() != build_id
     for src in SOURCES:
         sp = os.path.join(CSRC, src)
         op = os.path.join(obj_dir, src.replace(".hip", ".o"))
         objs.append(op)
-        if force or _stale(op, [sp] + HEADERS):
+        if force or _stale(op, [sp] + HEADERS) or (src == "capi.hip" and id_changed):
             cmd = [hipcc, *FLAGS, "-c", sp, "-o", op]
+            if src == "capi.hip":
+                cmd.insert(-4, f'-DCAPDEC_BUILD_ID="{build_id}"')
             if verbose:
                 print("[capdec build]", " ".join(cmd), flush=True)
             procs.append((src, subprocess.Popen(cmd)))
@@ -54,6 +72,8 @@ def build(force: bool = False, verbose: bool = True) -> str:
         if verbose:
             print("[capdec build]", " ".join(cmd), flush=True)
         subprocess.check_call(cmd)
+    with open(id_file, "w") as f:
+        f.write(build_id + "\n")
     return LIB_PATH
 
 

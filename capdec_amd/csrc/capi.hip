@@ -834,6 +834,10 @@ Rccl *rccl() {
 extern "C" {
 
 int capdec_abi_version(void) { return CAPDEC_ABI_VERSION; }
+#ifndef CAPDEC_BUILD_ID
+#define CAPDEC_BUILD_ID "unknown"
+#endif
+const char *capdec_build_id(void) { return CAPDEC_BUILD_ID; }
 const char *capdec_last_error(void) { return g_err.c_str(); }
 
 int capdec_create(int device_id, capdec_ctx **out) {

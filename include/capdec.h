@@ -41,6 +41,9 @@ enum { CAPDEC_ACT_NONE = 0, CAPDEC_ACT_TANH = 1, CAPDEC_ACT_RELU = 2, CAPDEC_ACT
 
 /* ---- context ------------------------------------------------------------------------ */
 int capdec_abi_version(void);
+/* hash of the sources this library was compiled from (capdec_amd/build.py:source_hash); the Python host refuses a
+ * library whose id differs from the source tree next to it (a stale .so would silently run old kernels) */
+const char *capdec_build_id(void);
 const char *capdec_last_error(void);
 /* replaces `device = CUDA(0); model = model.to(device)` (reference predictions_runner.py:154-155) */
 int capdec_create(int device_id, capdec_ctx **out);
@@ -198,6 +201,12 @@ int capdec_wte_lookup(capdec_ctx *ctx, const int32_t *d_ids, int n, float *d_out
  * :187; pass -1 to disable). */
 int capdec_decode_greedy(capdec_ctx *ctx, const float *d_prefix, int n, int P, int stop_id,
                          int alt_stop_id, int entry_length, int32_t *d_ids, int32_t *d_lens);
+
+/* Limits of the decode entry points (the reference has none, gpt2_prefix_eval.py:50-51,118-129; each is checked and
+ * reported through capdec_last_error): beam size 1..8; head_dim = 64 (GPT-2 / CLIP ViT-B/32); context prefix_length +
+ * entry_length - 1 <= 256 and <= n_positions; entry_length <= 128; n_embd a multiple of 32, <= 1024.  In the default
+ * f16x2 GEMM mode GEMM inputs are clamped to +-65504 (fp16's range; LayerNorm / attention / GELU outputs and weights
+ * are orders of magnitude below it). */
 
 /* generate_beam, batched (reference gpt2_prefix_eval.py:50-115).  d_prefix [n, P, d] ->
  * d_ids [n, beam, entry_length], d_lens [n, beam] (= int(seq_lengths)), d_scores [n, beam]

@@ -641,6 +641,8 @@ def test_c_host_without_torch(tmp_path):
         assert [int(v) for v in toks.split()] == ids[r, :int(lens[r])].tolist()
         head, toks = lines[2 * r + 1].split(":")
         assert int(head.split()[1]) == int(bl[r, 0])
+        assert abs(float(head.split()[2]) - float(bs[r, 0])) < 1e-5
+        assert [int(v) for v in toks.split()] == bi[r, 0, :int(bl[r, 0])].tolist()
     # the same program as rank 0 of a one-rank RCCL job (communicator id through a file, capdec_gather_ids)
     out = subprocess.run([exe, path, str(T), "5", "0", "1", str(tmp_path / "rccl.id")], capture_output=True, text=True,
                          env=env, timeout=300)
@@ -650,8 +652,6 @@ def test_c_host_without_torch(tmp_path):
     for r in range(n):
         head, toks = gathered[r].split(":")
         assert int(head.split()[1]) == int(lens[r]) and [int(v) for v in toks.split()] == ids[r, :int(lens[r])].tolist()
-        assert abs(float(head.split()[2]) - float(bs[r, 0])) < 1e-5
-        assert [int(v) for v in toks.split()] == bi[r, 0, :int(bl[r, 0])].tolist()
     e.close()
 
 
