@@ -97,6 +97,7 @@ SIGNATURES = {
     "capdec_gpt2_logits": (C.c_int, [_VP, _VP, C.c_int, C.c_int, C.c_int, _VP]),
     "capdec_wte_lookup": (C.c_int, [_VP, _VP, C.c_int, _VP]),
     "capdec_decode_greedy": (C.c_int, [_VP, _VP, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _VP, _VP]),
+    "capdec_decode_greedy_forced": (C.c_int, [_VP, _VP, C.c_int, C.c_int, C.c_int, _VP, _VP, _VP]),
     "capdec_decode_beam": (C.c_int, [_VP, _VP, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, _VP, _VP,
                                      _VP, _VP]),
     "capdec_gemm_f32": (C.c_int, [_VP, _VP, C.c_int, _VP, C.c_int, _VP, C.c_int, C.c_int, C.c_int, C.c_int, _VP,

@@ -6,8 +6,11 @@ Differences that follow from the offline environment (no checkpoint / BPE vocabu
 ``load`` takes an OpenAI-CLIP state dict (or a ``.pt`` path holding one) instead of a model name
 to download; ``tokenize`` needs a vocabulary file and otherwise raises.  Only ViT towers
 (ViT-B/32: head_dim 64) are supported; the reference's default RN50x4 image tower is out of
-scope (its pre-extracted 640-d embeddings are supported downstream).  Compute is fp32 (the
-reference's GPU path is fp16, cast `.float()` by its callers)."""
+scope (its pre-extracted 640-d embeddings are supported downstream).  Compute is fp32-accurate by
+default; ``load(..., precision="fp16")`` runs the towers' block GEMMs with fp16 operands (fp32
+accumulate, fp32 residual stream / LayerNorm / softmax) -- the precision class of the reference
+on a GPU, where ``clip.load`` converts the model to fp16 and the callers cast the result back
+with ``.float()`` (predictions_runner.py:218,220)."""
 from __future__ import annotations
 
 from typing import Dict, Optional, Union
@@ -19,9 +22,14 @@ from .engine import Engine
 
 
 class ClipModel:
-    def __init__(self, state_dict: Dict[str, torch.Tensor], device=0):
+    def __init__(self, state_dict: Dict[str, torch.Tensor], device=0, precision: str = "fp32"):
         idx = device if isinstance(device, int) else (torch.device(device).index or 0)
         self._engine = Engine(idx)
+        if precision not in ("fp32", "fp16", "bf16"):
+            raise CapdecError("clip.load: precision must be 'fp32', 'fp16' or 'bf16'")
+        self.precision = precision
+        if precision != "fp32":
+            self._engine.set_gemm_mode({"fp16": "f16", "bf16": "bf16"}[precision])
         sd = {k: v for k, v in state_dict.items()}
         self.has_vision = "visual.conv1.weight" in sd
         self._engine.load_clip(sd, text=True, vision=self.has_vision)
@@ -42,7 +50,8 @@ class ClipModel:
         return self._engine.clip_encode_image(image)
 
 
-def load(name_or_state_dict: Union[str, Dict[str, torch.Tensor]], device=0, jit: bool = False):
+def load(name_or_state_dict: Union[str, Dict[str, torch.Tensor]], device=0, jit: bool = False,
+         precision: str = "fp32"):
     """``clip.load("ViT-B/32", device=device, jit=False)`` -> (model, preprocess).  Pass the state dict
     (or the path of a ``torch.save``d one / an OpenAI ``.pt`` archive readable by torch.load)."""
     if isinstance(name_or_state_dict, str):
@@ -50,7 +59,7 @@ def load(name_or_state_dict: Union[str, Dict[str, torch.Tensor]], device=0, jit:
         sd = obj.state_dict() if hasattr(obj, "state_dict") else obj
     else:
         sd = name_or_state_dict
-    model = ClipModel(sd, device)
+    model = ClipModel(sd, device, precision)
     return model, Preprocess(model._engine, model.input_resolution)
 
 

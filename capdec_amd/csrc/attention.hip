@@ -7,6 +7,8 @@
 // The KV cache is [layer][phys_row][head][ctx][64]: consecutive positions of a head are
 // contiguous.  Beam search never copies K/V: row r reads position p from physical row
 // caption*beam + anc[r][p] (ancestor table maintained by the beam-step kernel).
+#include <cstdlib>
+
 #include "bf16x3.h"
 #include "common.h"
 
@@ -25,13 +27,36 @@ __device__ __forceinline__ float groups4_sum(float v) {
     return v;
 }
 
+// ---- KV cache element type: fp32 (parity modes) or bf16 (CAPDEC_GEMM_MODE=bf16, BASELINE configs[1]: K / V are rounded
+// to bf16 (RNE) when they are produced -- the value that is cached is also the value the producing step attends to)
+template <typename KV> struct KvIo;
+template <> struct KvIo<float> {
+    static __device__ __forceinline__ float4 ld4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
+    static __device__ __forceinline__ void st4(float *p, const float4 v) { *reinterpret_cast<float4 *>(p) = v; }
+    static __device__ __forceinline__ float4 round4(const float4 v) { return v; }
+};
+template <> struct KvIo<__bf16> {
+    static __device__ __forceinline__ float4 ld4(const __bf16 *p) {
+        const bf16x4 t = *reinterpret_cast<const bf16x4 *>(p);
+        return make_float4((float)t[0], (float)t[1], (float)t[2], (float)t[3]);
+    }
+    static __device__ __forceinline__ void st4(__bf16 *p, const float4 v) {
+        bf16x4 t;
+        t[0] = (__bf16)v.x; t[1] = (__bf16)v.y; t[2] = (__bf16)v.z; t[3] = (__bf16)v.w;
+        *reinterpret_cast<bf16x4 *>(p) = t;
+    }
+    static __device__ __forceinline__ float4 round4(const float4 v) {
+        return make_float4((float)(__bf16)v.x, (float)(__bf16)v.y, (float)(__bf16)v.z, (float)(__bf16)v.w);
+    }
+};
+
 // DECODE = true : rows = captions*beam, every row at context length L; own k/v (position L-1)
 //                 taken from qkv and appended to the cache at phys row r.
 // DECODE = false: prefill rows (caption, i), L = i + 1, everything read from the cache at phys
 //                 row caption*beam (written by kv_scatter_prefill beforehand).
-template <bool DECODE>
-__global__ __launch_bounds__(256) void attn_gpt2_kernel(const float *__restrict__ qkv, float *__restrict__ kc,
-                                                        float *__restrict__ vc, int total, int heads, int ctx,
+template <bool DECODE, typename KV>
+__global__ __launch_bounds__(256) void attn_gpt2_kernel(const float *__restrict__ qkv, KV *__restrict__ kc,
+                                                        KV *__restrict__ vc, int total, int heads, int ctx,
                                                         int d, int beam, int Lparam, int P, int causal,
                                                         const uint8_t *__restrict__ anc, int anc_stride,
                                                         float *__restrict__ out, char *__restrict__ packed_out,
@@ -63,12 +88,12 @@ __global__ __launch_bounds__(256) void attn_gpt2_kernel(const float *__restrict_
     float4 kcur, vcur;
     const int Lpast = DECODE ? L - 1 : L;
     if (DECODE) {
-        kcur = reinterpret_cast<const float4 *>(qrow + d + head * 64)[sub];
-        vcur = reinterpret_cast<const float4 *>(qrow + 2 * d + head * 64)[sub];
+        kcur = KvIo<KV>::round4(reinterpret_cast<const float4 *>(qrow + d + head * 64)[sub]);
+        vcur = KvIo<KV>::round4(reinterpret_cast<const float4 *>(qrow + 2 * d + head * 64)[sub]);
         if (active && grp == 0) {
             const size_t o = ((size_t)phys_self * heads + head) * hstride + (size_t)(L - 1) * 64;
-            reinterpret_cast<float4 *>(kc + o)[sub] = kcur;
-            reinterpret_cast<float4 *>(vc + o)[sub] = vcur;
+            KvIo<KV>::st4(kc + o + sub * 4, kcur);
+            KvIo<KV>::st4(vc + o + sub * 4, vcur);
         }
     }
     // ---- scores
@@ -77,7 +102,7 @@ __global__ __launch_bounds__(256) void attn_gpt2_kernel(const float *__restrict_
         if (p < Lpast) {
             int phys = phys_self;
             if (DECODE && anc) phys = cap_base + anc[(size_t)srow * anc_stride + p];
-            const float4 k = reinterpret_cast<const float4 *>(kc + ((size_t)phys * heads + head) * hstride + (size_t)p * 64)[sub];
+            const float4 k = KvIo<KV>::ld4(kc + ((size_t)phys * heads + head) * hstride + (size_t)p * 64 + sub * 4);
             const float s = group16_sum(dot4(q, k));
             if (sub == 0) sc[wave][p] = s;
         }
@@ -106,7 +131,7 @@ __global__ __launch_bounds__(256) void attn_gpt2_kernel(const float *__restrict_
         if (p < Lpast) {
             int phys = phys_self;
             if (DECODE && anc) phys = cap_base + anc[(size_t)srow * anc_stride + p];
-            const float4 v = reinterpret_cast<const float4 *>(vc + ((size_t)phys * heads + head) * hstride + (size_t)p * 64)[sub];
+            const float4 v = KvIo<KV>::ld4(vc + ((size_t)phys * heads + head) * hstride + (size_t)p * 64 + sub * 4);
             const float w = sc[wave][p];
             acc.x += w * v.x; acc.y += w * v.y; acc.z += w * v.z; acc.w += w * v.w;
         }
@@ -127,25 +152,30 @@ __global__ __launch_bounds__(256) void attn_gpt2_kernel(const float *__restrict_
 // Beam-shared decode attention: one wavefront per (caption, head) serves all BEAM rows of the caption.
 // The beams of a caption mostly share their ancestors (the whole prefix, and usually all but the last
 // few generated positions), so K/V of position p are loaded once per DISTINCT physical slot among
-// consecutive beams instead of once per row: the 5 q vectors / 5 accumulators live in registers, a
-// loaded key or value is reused while anc[b][p] does not change from beam b-1 to beam b.
-template <int BEAM>
-__global__ __launch_bounds__(256, 4) void attn_decode_beams_kernel(const float *__restrict__ qkv, float *__restrict__ kc,
-                                                                float *__restrict__ vc, int total, int heads,
+// consecutive beams instead of once per row: the BEAM q vectors / accumulators live in registers.
+//
+// Single pass, online softmax (round 2): the wavefront is four 16-lane groups; group g owns the positions
+// p = g (mod 4) and keeps its OWN running (max, sum, weighted-V accumulator) per beam, so the K and the V of a
+// chunk of positions are loaded TOGETHER (twice the bytes in flight per wavefront, half the dependent memory round
+// trips of the former scores -> LDS -> softmax -> P.V structure), no score ever goes through LDS and there is no
+// block barrier in the loop; the four partial softmaxes are merged once at the end (max / rescale / sum across the
+// groups).  LDS only holds the caption's ancestor-slot table.
+template <int BEAM, typename KV, int OCC>
+__global__ __launch_bounds__(256, OCC) void attn_decode_beams_kernel(const float *__restrict__ qkv, KV *__restrict__ kc,
+                                                                KV *__restrict__ vc, int total, int heads,
                                                                 int ctx, int d, int L,
                                                                 const uint8_t *__restrict__ anc, int anc_stride,
                                                                 float *__restrict__ out,
                                                                 char *__restrict__ packed_out,
                                                                 const int *__restrict__ cmap, int fmt) {
-    extern __shared__ __attribute__((aligned(16))) float sc_all[];      // [4 waves][BEAM][L] scores + [4][BEAM][L] slots
+    extern __shared__ __attribute__((aligned(16))) int sl_all[];      // [4 waves][BEAM][L] ancestor slots
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int grp = lane >> 4, sub = lane & 15;
     const int gw = blockIdx.x * 4 + wave;
     const bool active = gw < total;
     const int cap = active ? gw / heads : 0;
     const int head = active ? gw - cap * heads : 0;
-    float *sc = sc_all + (size_t)wave * BEAM * L;
-    int *sl = reinterpret_cast<int *>(sc_all + (size_t)4 * BEAM * L) + (size_t)wave * BEAM * L;
+    int *sl = sl_all + (size_t)wave * BEAM * L;
     const size_t hstride = (size_t)ctx * 64;
     const int row0 = cap * BEAM;                                   // activation rows (compact)
     const int srow0 = (cmap ? cmap[cap] : cap) * BEAM;             // state rows: KV cache / ancestor table (original)
@@ -157,32 +187,34 @@ __global__ __launch_bounds__(256, 4) void attn_decode_beams_kernel(const float *
         sl[b * L + p] = anc[(size_t)(srow0 + b) * anc_stride + p];
     }
 
-    float4 q[BEAM];
+    float4 q[BEAM], acc[BEAM];
+    float mrun[BEAM], lrun[BEAM];
 #pragma unroll
     for (int b = 0; b < BEAM; ++b) {
         const float *qrow = qkv + (size_t)(row0 + b) * 3 * d;
         q[b] = reinterpret_cast<const float4 *>(qrow + head * 64)[sub];
         q[b].x *= 0.125f; q[b].y *= 0.125f; q[b].z *= 0.125f; q[b].w *= 0.125f;
-        // the row's own key / value: score from registers, appended to the cache at its own slot
-        const float4 kcur = reinterpret_cast<const float4 *>(qrow + d + head * 64)[sub];
-        const float4 vcur = reinterpret_cast<const float4 *>(qrow + 2 * d + head * 64)[sub];
+        // the row's own key / value: appended to the cache at its own slot; group 0 starts its running softmax with it
+        const float4 kcur = KvIo<KV>::round4(reinterpret_cast<const float4 *>(qrow + d + head * 64)[sub]);
+        const float4 vcur = KvIo<KV>::round4(reinterpret_cast<const float4 *>(qrow + 2 * d + head * 64)[sub]);
         if (active && grp == 0) {
-            const size_t o = ((size_t)(srow0 + b) * heads + head) * hstride + (size_t)Lpast * 64;
-            reinterpret_cast<float4 *>(kc + o)[sub] = kcur;
-            reinterpret_cast<float4 *>(vc + o)[sub] = vcur;
+            const size_t o = ((size_t)(srow0 + b) * heads + head) * hstride + (size_t)Lpast * 64 + sub * 4;
+            KvIo<KV>::st4(kc + o, kcur);
+            KvIo<KV>::st4(vc + o, vcur);
         }
         const float s = group16_sum(dot4(q[b], kcur));
-        if (lane == 0) sc[b * L + Lpast] = s;
+        mrun[b] = grp == 0 ? s : -INFINITY;
+        lrun[b] = grp == 0 ? 1.f : 0.f;
+        acc[b] = grp == 0 ? vcur : make_float4(0.f, 0.f, 0.f, 0.f);
     }
-    __syncthreads();
-    const float *kbase = kc + ((size_t)srow0 * heads + head) * hstride + sub * 4;
-    const float *vbase = vc + ((size_t)srow0 * heads + head) * hstride + sub * 4;
+    __syncthreads();                                               // slot table visible
+    const KV *kbase = kc + ((size_t)srow0 * heads + head) * hstride + sub * 4;
+    const KV *vbase = vc + ((size_t)srow0 * heads + head) * hstride + sub * 4;
     const size_t slot_stride = (size_t)heads * hstride;
     // The beams of a caption are paths of one tree: if they all sit on the same node at position p they share every
     // earlier position too, so "all beams read the same slot" holds exactly on a PREFIX [0, nconv) of the history
     // (the CLIP prefix and the converged part of the generated text).  Phase A streams that prefix without any
-    // per-beam slot logic, four positions per 16-lane group per iteration (4 KB per wavefront in flight); phase B
-    // handles the diverged tail.
+    // per-beam slot logic; phase B handles the diverged tail.
     int nconv = Lpast;
     for (int base = 0; base < Lpast; base += 64) {
         const int p = base + lane;
@@ -194,137 +226,88 @@ __global__ __launch_bounds__(256, 4) void attn_decode_beams_kernel(const float *
         const unsigned long long m = __ballot(differs);
         if (m) { nconv = base + __ffsll((long long)m) - 1; break; }
     }
-    const float *dummy = qkv + (size_t)row0 * 3 * d + head * 64 + sub * 4;   // an L1-hot line for masked-off loads
-    // ---- scores, phase A
-    for (int p0 = 0; p0 < nconv; p0 += 16) {
-        int pp[4];
-        float4 kk[4];
+    const KV *dummy = kbase;                                       // a valid address for masked-off loads (value unused)
+    // online-softmax update of beam b with NP (score, value) pairs of this group; sv[j] = -inf marks "no position"
+#define ATT_UPDATE(b, NP, sv, xv)                                                                        \
+    {                                                                                                    \
+        float mx_ = mrun[b];                                                                             \
+        _Pragma("unroll") for (int j_ = 0; j_ < NP; ++j_) mx_ = fmaxf(mx_, sv[j_]);                      \
+        if (mx_ > -INFINITY) {                                                                           \
+            const float sc_ = expf(mrun[b] - mx_);      /* 0 while this group has seen nothing */        \
+            float ls_ = lrun[b] * sc_;                                                                   \
+            float4 a_ = make_float4(acc[b].x * sc_, acc[b].y * sc_, acc[b].z * sc_, acc[b].w * sc_);     \
+            _Pragma("unroll") for (int j_ = 0; j_ < NP; ++j_) {                                          \
+                const float w_ = expf(sv[j_] - mx_);    /* exp(-inf) = 0 for masked positions */         \
+                ls_ += w_;                                                                               \
+                a_.x += w_ * xv[j_].x; a_.y += w_ * xv[j_].y; a_.z += w_ * xv[j_].z; a_.w += w_ * xv[j_].w; \
+            }                                                                                            \
+            mrun[b] = mx_; lrun[b] = ls_; acc[b] = a_;                                                   \
+        }                                                                                                \
+    }
+    // ---- phase A: converged prefix, two positions per group per iteration: 2 K + 2 V loads in flight per lane
+    for (int p0 = 0; p0 < nconv; p0 += 8) {
+        int pp[2];
+        float4 kk[2], vv[2];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < 2; ++j) {
             pp[j] = p0 + 4 * j + grp;
             const bool v = pp[j] < nconv;
-            const int s0 = v ? sl[pp[j]] : 0;
-            kk[j] = *reinterpret_cast<const float4 *>(v ? kbase + s0 * slot_stride + (size_t)pp[j] * 64 : dummy);
+            const size_t o = v ? (size_t)sl[pp[j]] * slot_stride + (size_t)pp[j] * 64 : 0;
+            kk[j] = KvIo<KV>::ld4(v ? kbase + o : dummy);
+            vv[j] = KvIo<KV>::ld4(v ? vbase + o : dummy);
         }
 #pragma unroll
         for (int b = 0; b < BEAM; ++b) {
+            float sv[2];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const float sv = group16_sum(dot4(q[b], kk[j]));
-                if (sub == 0 && pp[j] < nconv) sc[b * L + pp[j]] = sv;
+            for (int j = 0; j < 2; ++j) {
+                const float t = group16_sum(dot4(q[b], kk[j]));
+                sv[j] = pp[j] < nconv ? t : -INFINITY;
             }
+            ATT_UPDATE(b, 2, sv, vv)
         }
     }
-    // ---- scores, phase B: two positions per group per iteration.  All 2 x BEAM loads are issued back to back (no
-    // branch, no wait between them): a beam whose slot equals the previous beam's re-reads the L1-hot dummy line and
-    // takes the previous beam's registers, so HBM traffic stays one load per DISTINCT consecutive slot while the
-    // wavefront keeps 2 x BEAM requests in flight.
-    for (int p0 = nconv; p0 < Lpast; p0 += 8) {
-        const int pa = p0 + grp, pb = p0 + 4 + grp;
-        const bool va = pa < Lpast, vb = pb < Lpast;
-        int sa[BEAM], sb[BEAM];
-        float4 ka[BEAM], kb[BEAM];
+    // ---- phase B: diverged tail, one position per group per iteration.  All 2 x BEAM loads are issued back to back
+    // (no branch, no wait between them): a beam whose slot equals the previous beam's re-reads the hot dummy line and
+    // takes the previous beam's registers, so HBM traffic stays one load per DISTINCT consecutive slot.
+    for (int p0 = nconv; p0 < Lpast; p0 += 4) {
+        const int pa = p0 + grp;
+        const bool va = pa < Lpast;
+        int sa[BEAM];
+        float4 ka[BEAM], xa[BEAM];
+#pragma unroll
+        for (int b = 0; b < BEAM; ++b) sa[b] = va ? sl[b * L + pa] : 0;
 #pragma unroll
         for (int b = 0; b < BEAM; ++b) {
-            sa[b] = va ? sl[b * L + pa] : 0;
-            sb[b] = vb ? sl[b * L + pb] : 0;
+            const bool na = va && (b == 0 || sa[b] != sa[b - 1]);
+            const size_t o = (size_t)sa[b] * slot_stride + (size_t)pa * 64;
+            ka[b] = KvIo<KV>::ld4(na ? kbase + o : dummy);
+            xa[b] = KvIo<KV>::ld4(na ? vbase + o : dummy);
         }
 #pragma unroll
         for (int b = 0; b < BEAM; ++b) {
-            const bool na = va && (b == 0 || sa[b] != sa[b - 1]), nb = vb && (b == 0 || sb[b] != sb[b - 1]);
-            ka[b] = *reinterpret_cast<const float4 *>(na ? kbase + sa[b] * slot_stride + (size_t)pa * 64 : dummy);
-            kb[b] = *reinterpret_cast<const float4 *>(nb ? kbase + sb[b] * slot_stride + (size_t)pb * 64 : dummy);
-        }
-#pragma unroll
-        for (int b = 0; b < BEAM; ++b) {
-            if (b > 0 && sa[b] == sa[b - 1]) ka[b] = ka[b - 1];
-            if (b > 0 && sb[b] == sb[b - 1]) kb[b] = kb[b - 1];
-            const float s0 = group16_sum(dot4(q[b], ka[b]));
-            const float s1 = group16_sum(dot4(q[b], kb[b]));
-            if (sub == 0) {
-                if (va) sc[b * L + pa] = s0;
-                if (vb) sc[b * L + pb] = s1;
-            }
+            if (b > 0 && sa[b] == sa[b - 1]) { ka[b] = ka[b - 1]; xa[b] = xa[b - 1]; }
+            float sv[1];
+            const float t = group16_sum(dot4(q[b], ka[b]));
+            sv[0] = va ? t : -INFINITY;
+            const float4 *xv = &xa[b];
+            ATT_UPDATE(b, 1, sv, xv)
         }
     }
-    __syncthreads();
-    // ---- softmax statistics per beam
-    float inv[BEAM];
+#undef ATT_UPDATE
+    // ---- merge the four groups' partial softmaxes and write the rows
 #pragma unroll
     for (int b = 0; b < BEAM; ++b) {
-        float mx = -INFINITY;
-        for (int p = lane; p < L; p += 64) mx = fmaxf(mx, sc[b * L + p]);
-        mx = wave_max(mx);
-        float sum = 0.f;
-        for (int p = lane; p < L; p += 64) {
-            const float e = expf(sc[b * L + p] - mx);
-            sc[b * L + p] = e;
-            sum += e;
-        }
-        inv[b] = 1.0f / wave_sum(sum);
-    }
-    __syncthreads();
-    // ---- P.V
-    float4 acc[BEAM];
-#pragma unroll
-    for (int b = 0; b < BEAM; ++b) acc[b] = make_float4(0.f, 0.f, 0.f, 0.f);
-    // phase A: converged prefix, four positions per group per iteration
-    for (int p0 = 0; p0 < nconv; p0 += 16) {
-        int pp[4];
-        float4 xx[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            pp[j] = p0 + 4 * j + grp;
-            const bool v = pp[j] < nconv;
-            const int s0 = v ? sl[pp[j]] : 0;
-            xx[j] = *reinterpret_cast<const float4 *>(v ? vbase + s0 * slot_stride + (size_t)pp[j] * 64 : dummy);
-        }
-#pragma unroll
-        for (int b = 0; b < BEAM; ++b) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const float w = pp[j] < nconv ? sc[b * L + pp[j]] : 0.f;
-                acc[b].x += w * xx[j].x; acc[b].y += w * xx[j].y; acc[b].z += w * xx[j].z; acc[b].w += w * xx[j].w;
-            }
-        }
-    }
-    // phase B: diverged tail
-    for (int p0 = nconv; p0 < Lpast; p0 += 8) {
-        const int pa = p0 + grp, pb = p0 + 4 + grp;
-        const bool va = pa < Lpast, vb = pb < Lpast;
-        int sa[BEAM], sb[BEAM];
-        float4 xa[BEAM], xb[BEAM];
-#pragma unroll
-        for (int b = 0; b < BEAM; ++b) {
-            sa[b] = va ? sl[b * L + pa] : 0;
-            sb[b] = vb ? sl[b * L + pb] : 0;
-        }
-#pragma unroll
-        for (int b = 0; b < BEAM; ++b) {
-            const bool na = va && (b == 0 || sa[b] != sa[b - 1]), nb = vb && (b == 0 || sb[b] != sb[b - 1]);
-            xa[b] = *reinterpret_cast<const float4 *>(na ? vbase + sa[b] * slot_stride + (size_t)pa * 64 : dummy);
-            xb[b] = *reinterpret_cast<const float4 *>(nb ? vbase + sb[b] * slot_stride + (size_t)pb * 64 : dummy);
-        }
-#pragma unroll
-        for (int b = 0; b < BEAM; ++b) {
-            if (b > 0 && sa[b] == sa[b - 1]) xa[b] = xa[b - 1];
-            if (b > 0 && sb[b] == sb[b - 1]) xb[b] = xb[b - 1];
-            const float wa = va ? sc[b * L + pa] : 0.f, wb = vb ? sc[b * L + pb] : 0.f;
-            acc[b].x += wa * xa[b].x + wb * xb[b].x; acc[b].y += wa * xa[b].y + wb * xb[b].y;
-            acc[b].z += wa * xa[b].z + wb * xb[b].z; acc[b].w += wa * xa[b].w + wb * xb[b].w;
-        }
-    }
-#pragma unroll
-    for (int b = 0; b < BEAM; ++b) {
-        if (grp == 0) {   // own token
-            const float4 vcur = reinterpret_cast<const float4 *>(qkv + (size_t)(row0 + b) * 3 * d + 2 * d + head * 64)[sub];
-            const float w = sc[b * L + Lpast];
-            acc[b].x += w * vcur.x; acc[b].y += w * vcur.y; acc[b].z += w * vcur.z; acc[b].w += w * vcur.w;
-        }
-        acc[b].x = groups4_sum(acc[b].x); acc[b].y = groups4_sum(acc[b].y);
-        acc[b].z = groups4_sum(acc[b].z); acc[b].w = groups4_sum(acc[b].w);
+        float M = mrun[b];
+        M = fmaxf(M, __shfl_xor(M, 16, 64));
+        M = fmaxf(M, __shfl_xor(M, 32, 64));                       // finite: group 0 holds the row's own token
+        const float sc = expf(mrun[b] - M);
+        const float lt = groups4_sum(lrun[b] * sc);
+        float4 a = make_float4(acc[b].x * sc, acc[b].y * sc, acc[b].z * sc, acc[b].w * sc);
+        a.x = groups4_sum(a.x); a.y = groups4_sum(a.y); a.z = groups4_sum(a.z); a.w = groups4_sum(a.w);
         if (active && grp == 0) {
-            const float4 o = make_float4(acc[b].x * inv[b], acc[b].y * inv[b], acc[b].z * inv[b], acc[b].w * inv[b]);
+            const float inv = 1.0f / lt;
+            const float4 o = make_float4(a.x * inv, a.y * inv, a.z * inv, a.w * inv);
             if (packed_out) x3_store_quad(packed_out, d >> 4, row0 + b, head * 4 + (sub >> 2), sub & 3, o, fmt);
             else reinterpret_cast<float4 *>(out + (size_t)(row0 + b) * d + head * 64)[sub] = o;
         }
@@ -337,7 +320,7 @@ __global__ __launch_bounds__(256, 4) void attn_decode_beams_kernel(const float *
 // per R queries instead of once per query: the per-row kernel above moved 61 GB per launch through L2 on the 77-token
 // text tower (20 TB/s).  Same lane mapping and summation order as the per-row kernel: 16-lane group g owns the
 // positions p = g (mod 4), four positions per group per iteration; scores through LDS; causal rows mask p > i.
-template <int R>
+template <int R, typename KV>
 __global__ __launch_bounds__(256) void attn_prefill_rows_kernel(const float *__restrict__ qkv, int total, int heads,
                                                                 int P, int d, int causal, float *__restrict__ out,
                                                                 char *__restrict__ packed_out, int fmt) {
@@ -364,7 +347,7 @@ __global__ __launch_bounds__(256) void attn_prefill_rows_kernel(const float *__r
         float4 kk[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j)
-            kk[j] = *reinterpret_cast<const float4 *>(base + (size_t)min(p0 + 4 * j + grp, P - 1) * 3 * d + d);
+            kk[j] = KvIo<KV>::round4(*reinterpret_cast<const float4 *>(base + (size_t)min(p0 + 4 * j + grp, P - 1) * 3 * d + d));
 #pragma unroll
         for (int r = 0; r < R; ++r) {
 #pragma unroll
@@ -398,7 +381,7 @@ __global__ __launch_bounds__(256) void attn_prefill_rows_kernel(const float *__r
         float4 xx[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j)
-            xx[j] = *reinterpret_cast<const float4 *>(base + (size_t)min(p0 + 4 * j + grp, P - 1) * 3 * d + 2 * d);
+            xx[j] = KvIo<KV>::round4(*reinterpret_cast<const float4 *>(base + (size_t)min(p0 + 4 * j + grp, P - 1) * 3 * d + 2 * d));
 #pragma unroll
         for (int r = 0; r < R; ++r) {
 #pragma unroll
@@ -423,8 +406,9 @@ __global__ __launch_bounds__(256) void attn_prefill_rows_kernel(const float *__r
 }
 
 // K/V of prefill row (cap, i) -> cache[phys = cap*beam][head][i][:]
-__global__ void kv_scatter_prefill_kernel(const float *__restrict__ qkv, float *__restrict__ kc,
-                                          float *__restrict__ vc, int ncap, int P, int beam, int heads, int ctx,
+template <typename KV>
+__global__ void kv_scatter_prefill_kernel(const float *__restrict__ qkv, KV *__restrict__ kc,
+                                          KV *__restrict__ vc, int ncap, int P, int beam, int heads, int ctx,
                                           int d) {
     const int nv = d / 4;                       // float4 per row per tensor
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -434,8 +418,8 @@ __global__ void kv_scatter_prefill_kernel(const float *__restrict__ qkv, float *
     const int head = (c4 * 4) / 64, within = (c4 * 4) % 64;
     const size_t o = (((size_t)cap * beam * heads + head) * ctx + pos) * 64 + within;
     const float *r = qkv + (size_t)row * 3 * d;
-    *reinterpret_cast<float4 *>(kc + o) = reinterpret_cast<const float4 *>(r + d)[c4];
-    *reinterpret_cast<float4 *>(vc + o) = reinterpret_cast<const float4 *>(r + 2 * d)[c4];
+    KvIo<KV>::st4(kc + o, reinterpret_cast<const float4 *>(r + d)[c4]);
+    KvIo<KV>::st4(vc + o, reinterpret_cast<const float4 *>(r + 2 * d)[c4]);
 }
 
 int launch_kv_scatter_prefill(hipStream_t st, const float *qkv, const KvCache &c, int layer, int ncap, int P,
@@ -443,9 +427,12 @@ int launch_kv_scatter_prefill(hipStream_t st, const float *qkv, const KvCache &c
     const int d = c.heads * c.hd;
     const int tot = ncap * P * (d / 4);
     if (tot <= 0) return 0;
-    hipLaunchKernelGGL(kv_scatter_prefill_kernel, dim3((tot + 255) / 256), dim3(256), 0, st, qkv,
-                       c.k + layer * c.layer_stride(), c.v + layer * c.layer_stride(), ncap, P, beam, c.heads, c.ctx,
-                       d);
+    if (c.bf16)
+        hipLaunchKernelGGL(kv_scatter_prefill_kernel<__bf16>, dim3((tot + 255) / 256), dim3(256), 0, st, qkv,
+                           c.kp<__bf16>(layer), c.vp<__bf16>(layer), ncap, P, beam, c.heads, c.ctx, d);
+    else
+        hipLaunchKernelGGL(kv_scatter_prefill_kernel<float>, dim3((tot + 255) / 256), dim3(256), 0, st, qkv,
+                           c.kp<float>(layer), c.vp<float>(layer), ncap, P, beam, c.heads, c.ctx, d);
     CAPDEC_HIP(hipGetLastError());
     return 0;
 }
@@ -459,33 +446,40 @@ int launch_attn_prefill(hipStream_t st, const float *qkv, const KvCache &c, int 
     const int total = ncap * c.heads * ((P + R - 1) / R);
     if (total <= 0) return 0;
     const size_t lds = (size_t)4 * R * P * sizeof(float);
-    hipLaunchKernelGGL(attn_prefill_rows_kernel<R>, dim3((total + 3) / 4), dim3(256), lds, st, qkv, total, c.heads, P,
-                       c.heads * c.hd, causal ? 1 : 0, out, (char *)packed_out, fmt);
+    if (c.bf16)     // the keys / values this pass attends to are the bf16-rounded ones the cache will hold
+        hipLaunchKernelGGL((attn_prefill_rows_kernel<R, __bf16>), dim3((total + 3) / 4), dim3(256), lds, st, qkv, total,
+                           c.heads, P, c.heads * c.hd, causal ? 1 : 0, out, (char *)packed_out, fmt);
+    else
+        hipLaunchKernelGGL((attn_prefill_rows_kernel<R, float>), dim3((total + 3) / 4), dim3(256), lds, st, qkv, total,
+                           c.heads, P, c.heads * c.hd, causal ? 1 : 0, out, (char *)packed_out, fmt);
     CAPDEC_HIP(hipGetLastError());
     return 0;
 }
 
-int launch_attn_decode(hipStream_t st, const float *qkv, const KvCache &c, int layer, int rows, int beam, int L,
-                       const uint8_t *anc, int anc_stride, float *out, void *packed_out, const int *cmap, int fmt) {
-    CAPDEC_CHECK(c.hd == 64, "attention: head_dim must be 64");
-    CAPDEC_CHECK(L >= 1 && L <= ATT_CTX_MAX && L <= c.ctx, "attention: context length out of range");
+template <typename KV>
+static int attn_decode_typed(hipStream_t st, const float *qkv, const KvCache &c, int layer, int rows, int beam, int L,
+                             const uint8_t *anc, int anc_stride, float *out, void *packed_out, const int *cmap,
+                             int fmt) {
+    KV *kl = c.kp<KV>(layer), *vl = c.vp<KV>(layer);
     if (anc != nullptr && beam > 1) {
         const int ncap = rows / beam, total = ncap * c.heads;
         if (total <= 0) return 0;
-        const size_t lds = (size_t)2 * 4 * beam * L * sizeof(float);   // scores + ancestor slots
+        const size_t lds = (size_t)4 * beam * L * sizeof(int);   // ancestor slots
         dim3 grid((total + 3) / 4), block(256);
-        float *kl = c.k + layer * c.layer_stride(), *vl = c.v + layer * c.layer_stride();
-#define LAUNCH_BEAMS(B)                                                                                         \
-    hipLaunchKernelGGL(attn_decode_beams_kernel<B>, grid, block, lds, st, qkv, kl, vl, total, c.heads, c.ctx,      \
+        // waves per SIMD the register allocation is sized for: beam <= 4 fits 4 without spilling; beam 5 needs 132
+        // registers (4 waves: 128 + 4 spilled dwords; 3 waves: no spill) -- CAPDEC_ATT_OCC picks, default = measured best
+        static const int occ5 = [] { const char *e = getenv("CAPDEC_ATT_OCC"); return e && atoi(e) == 3 ? 3 : 4; }();
+#define LAUNCH_BEAMS(B, OCC)                                                                                    \
+    hipLaunchKernelGGL((attn_decode_beams_kernel<B, KV, OCC>), grid, block, lds, st, qkv, kl, vl, total, c.heads, c.ctx, \
                        c.heads * c.hd, L, anc, anc_stride, out, (char *)packed_out, cmap, fmt)
         switch (beam) {
-            case 2: LAUNCH_BEAMS(2); break;
-            case 3: LAUNCH_BEAMS(3); break;
-            case 4: LAUNCH_BEAMS(4); break;
-            case 5: LAUNCH_BEAMS(5); break;
-            case 6: LAUNCH_BEAMS(6); break;
-            case 7: LAUNCH_BEAMS(7); break;
-            case 8: LAUNCH_BEAMS(8); break;
+            case 2: LAUNCH_BEAMS(2, 4); break;
+            case 3: LAUNCH_BEAMS(3, 4); break;
+            case 4: LAUNCH_BEAMS(4, 4); break;
+            case 5: if (occ5 == 3) LAUNCH_BEAMS(5, 3); else LAUNCH_BEAMS(5, 4); break;
+            case 6: LAUNCH_BEAMS(6, 2); break;
+            case 7: LAUNCH_BEAMS(7, 2); break;
+            case 8: LAUNCH_BEAMS(8, 2); break;
             default: CAPDEC_CHECK(false, "attention: beam must be in 1..8");
         }
 #undef LAUNCH_BEAMS
@@ -494,11 +488,18 @@ int launch_attn_decode(hipStream_t st, const float *qkv, const KvCache &c, int l
     }
     const int total = rows * c.heads;
     if (total <= 0) return 0;
-    hipLaunchKernelGGL(attn_gpt2_kernel<true>, dim3((total + 3) / 4), dim3(256), 0, st, qkv,
-                       c.k + layer * c.layer_stride(), c.v + layer * c.layer_stride(), total, c.heads, c.ctx,
-                       c.heads * c.hd, beam, L, 0, 1, anc, anc_stride, out, (char *)packed_out, cmap, fmt);
+    hipLaunchKernelGGL((attn_gpt2_kernel<true, KV>), dim3((total + 3) / 4), dim3(256), 0, st, qkv, kl, vl, total, c.heads,
+                       c.ctx, c.heads * c.hd, beam, L, 0, 1, anc, anc_stride, out, (char *)packed_out, cmap, fmt);
     CAPDEC_HIP(hipGetLastError());
     return 0;
+}
+
+int launch_attn_decode(hipStream_t st, const float *qkv, const KvCache &c, int layer, int rows, int beam, int L,
+                       const uint8_t *anc, int anc_stride, float *out, void *packed_out, const int *cmap, int fmt) {
+    CAPDEC_CHECK(c.hd == 64, "attention: head_dim must be 64");
+    CAPDEC_CHECK(L >= 1 && L <= ATT_CTX_MAX && L <= c.ctx, "attention: context length out of range");
+    return c.bf16 ? attn_decode_typed<__bf16>(st, qkv, c, layer, rows, beam, L, anc, anc_stride, out, packed_out, cmap, fmt)
+                  : attn_decode_typed<float>(st, qkv, c, layer, rows, beam, L, anc, anc_stride, out, packed_out, cmap, fmt);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -51,7 +51,10 @@ __device__ __forceinline__ int x3_group_offset(int r, int quad) {
 // outputs, GELU outputs, weights -- are orders of magnitude below it).
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
-enum PackFmt { PK_BF16X3 = 0, PK_F16X2 = 1 };
+// PK_BF16X1 / PK_F16X1: ONE plane -- the operand rounded to bf16 / fp16 (RNE; fp16 clamped to +-65504): the reduced-
+// precision modes (bf16: BASELINE configs[1]; fp16: the arithmetic of the reference's CLIP towers on a GPU), one MFMA per
+// product, 4 KB per (row_tile, k_step) block.
+enum PackFmt { PK_BF16X3 = 0, PK_F16X2 = 1, PK_BF16X1 = 2, PK_F16X1 = 3 };
 constexpr int H2_BLOCK_B = 2 * X3_PLANE_B;            // 8192: one (row_tile, k_step) block of the f16x2 format
 constexpr float H2_LO_SCALE = 2048.0f;                // 2^11
 
@@ -67,12 +70,30 @@ __device__ __forceinline__ void split2h(const float4 v, f16x4 &h, f16x4 &l) {
     }
 }
 
-__host__ __device__ __forceinline__ int pk_planes(int fmt) { return fmt == PK_F16X2 ? 2 : 3; }
+__host__ __device__ __forceinline__ int pk_planes(int fmt) {
+    return fmt == PK_F16X2 ? 2 : (fmt == PK_BF16X1 || fmt == PK_F16X1) ? 1 : 3;
+}
 
 // store the split of 4 consecutive k (one float4) of matrix row `row`, k-step `ks`, quad `quad`
 // (fmt is uniform across the launch: PK_BF16X3 = three bf16 planes, PK_F16X2 = two fp16 planes)
 __device__ __forceinline__ void x3_store_quad(char *packed, int nk, int row, int ks, int quad, const float4 v,
                                               int fmt = PK_BF16X3) {
+    if (fmt == PK_BF16X1 || fmt == PK_F16X1) {
+        char *p = packed + ((size_t)(row >> 7) * nk + ks) * X3_PLANE_B + x3_group_offset(row & 127, quad);
+        if (fmt == PK_BF16X1) {
+            bf16x4 h;
+            h[0] = (__bf16)v.x; h[1] = (__bf16)v.y; h[2] = (__bf16)v.z; h[3] = (__bf16)v.w;
+            *reinterpret_cast<bf16x4 *>(p) = h;
+        } else {
+            f16x4 h;
+            h[0] = (_Float16)__builtin_fminf(__builtin_fmaxf(v.x, -65504.f), 65504.f);
+            h[1] = (_Float16)__builtin_fminf(__builtin_fmaxf(v.y, -65504.f), 65504.f);
+            h[2] = (_Float16)__builtin_fminf(__builtin_fmaxf(v.z, -65504.f), 65504.f);
+            h[3] = (_Float16)__builtin_fminf(__builtin_fmaxf(v.w, -65504.f), 65504.f);
+            *reinterpret_cast<f16x4 *>(p) = h;
+        }
+        return;
+    }
     if (fmt == PK_F16X2) {
         f16x4 h, l;
         split2h(v, h, l);

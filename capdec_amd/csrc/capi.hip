@@ -88,7 +88,7 @@ static const char *kFamilyNames[F_COUNT] = {"gemm_f32", "gemm_f32_lmhead_topk", 
                                             "pack_activations"};
 constexpr int PROF_SLOTS = 24;   // capdec_profile_get fills at most this many families (engine.py sizes its arrays by it)
 static_assert(F_COUNT <= PROF_SLOTS, "profile arrays too small");
-enum GemmMode { GEMM_F32 = 0, GEMM_BF16X3 = 1, GEMM_BF16 = 2, GEMM_F16X2 = 3 };
+enum GemmMode { GEMM_F32 = 0, GEMM_BF16X3 = 1, GEMM_BF16 = 2, GEMM_F16X2 = 3, GEMM_F16 = 4 };
 
 struct Prof {
     bool on = false;
@@ -225,14 +225,24 @@ static void drop_planes(capdec_ctx *c) {
     for (auto &kv : c->planes) (void)hipFree(kv.second.p);
     c->planes.clear();
 }
-// packed operand format of the current GEMM mode (bf16x3.h): two fp16 planes (f16x2) or three bf16 planes
-static int pack_fmt(const capdec_ctx *c) { return c->gemm_mode == GEMM_F16X2 ? PK_F16X2 : PK_BF16X3; }
+// packed operand format of the block-stack / lm_head GEMMs in the current mode (bf16x3.h): two fp16 planes (f16x2),
+// three bf16 planes (bf16x3), or ONE bf16 / fp16 plane (the reduced-precision modes)
+static int pack_fmt(const capdec_ctx *c) {
+    switch (c->gemm_mode) {
+        case GEMM_F16X2: return PK_F16X2;
+        case GEMM_BF16: return PK_BF16X1;
+        case GEMM_F16: return PK_F16X1;
+        default: return PK_BF16X3;
+    }
+}
+static bool mode_single(const capdec_ctx *c) { return c->gemm_mode == GEMM_BF16 || c->gemm_mode == GEMM_F16; }
 static int pack_any(capdec_ctx *c, const float *W, int N, int K, int fmt, void *out) {
     if (fmt == PK_F16X2) return launch_pack_planes_h2(c->stream, W, K, N, K, out);
-    return launch_pack_planes(c->stream, W, N, K, out);
+    if (fmt == PK_BF16X3) return launch_pack_planes(c->stream, W, N, K, out);
+    return launch_pack_planes_fmt(c->stream, W, K, N, K, out, fmt);
 }
-static int planes_of(capdec_ctx *c, const float *W, int N, int K, bool cache, const void **out) {
-    const int fmt = pack_fmt(c);
+static int planes_of(capdec_ctx *c, const float *W, int N, int K, bool cache, const void **out, int fmt_override = -1) {
+    const int fmt = fmt_override >= 0 ? fmt_override : pack_fmt(c);
     const size_t n = (size_t)N * K, bytes = x3_packed_bytes(N, K, fmt);
     if (cache) {
         auto it = c->planes.find(W);
@@ -264,11 +274,12 @@ static int gemm(capdec_ctx *c, const float *A, int lda, const float *Bt, int ldb
     e.act = act;
     e.resid = resid;
     e.ldr = ldr;
-    if (c->gemm_mode == GEMM_F16X2 && ldb == K && K % 64 == 0 && lda % 4 == 0 && M > 0) {
+    if ((c->gemm_mode == GEMM_F16X2 || mode_single(c)) && ldb == K && K % 64 == 0 && lda % 4 == 0 && M > 0) {
         // fp32 activations in HBM (mapper, patch embedding, CLIP projections): one packing pass (read 4 B, write 4 B
-        // per element), then the packed LDS-DMA kernel
+        // per element), then the packed LDS-DMA kernel -- fp32-accurate (f16x2) also in the reduced-precision modes,
+        // whose 16-bit operands are confined to the GPT-2 / CLIP block stacks and the lm_head
         const void *pl = nullptr;
-        CAPDEC_TRY(planes_of(c, Bt, N, K, weight, &pl));
+        CAPDEC_TRY(planes_of(c, Bt, N, K, weight, &pl, PK_F16X2));
         CAPDEC_TRY(c->a_tmp.ensure(x3_packed_bytes(M, K, PK_F16X2)));
         { ProfScope ps(c, F_PACK); CAPDEC_TRY(launch_pack_planes_h2(c->stream, A, lda, M, K, c->a_tmp.p)); }
         const size_t wsb = gemm_splitk_ws_bytes(M, N, K);
@@ -294,8 +305,7 @@ static int gemm(capdec_ctx *c, const float *A, int lda, const float *Bt, int ldb
 // LayerNorm -> GEMM with the normalised rows handed over in packed split-bf16 form (never fp32 in HBM).
 // Returns 1 in *done when the packed path ran; otherwise the caller runs the fp32-activation path.
 static bool use_packed_a(capdec_ctx *c, int K) {
-    return (c->gemm_mode == GEMM_BF16 || c->gemm_mode == GEMM_F16X2 || (c->gemm_mode == GEMM_BF16X3 && c->pack_a)) &&
-           K % 64 == 0;
+    return (mode_single(c) || c->gemm_mode == GEMM_F16X2 || (c->gemm_mode == GEMM_BF16X3 && c->pack_a)) && K % 64 == 0;
 }
 
 // C = act(Apk . W^T + bias) + resid with A already packed; packed_out != nullptr: the result is written as the
@@ -319,9 +329,9 @@ static int gemm_packed(capdec_ctx *c, const void *Apk, const float *W, float *C,
             e.splitk_ws_bytes = c->splitk.cap;
         }
     }
-    if (c->gemm_mode == GEMM_BF16) {   // plane 0 only: bf16 operands, one MFMA per product
+    if (mode_single(c)) {   // one 16-bit plane per operand (bf16 / fp16), one MFMA per product
         ProfScope ps(c, F_GEMM_BF16P, 2.0 * M * (double)N * K);
-        return launch_gemm_bf16p(c->stream, Apk, pl, C, ldc, M, N, K, e);
+        return launch_gemm_bf16p(c->stream, Apk, pl, C, ldc, M, N, K, e, pack_fmt(c));
     }
     if (c->gemm_mode == GEMM_F16X2) {   // two fp16 planes, three MFMAs per product (fp32-accurate)
         ProfScope ps(c, F_GEMM_H2P, 2.0 * M * (double)N * K);
@@ -449,10 +459,10 @@ static int lm_head_select(capdec_ctx *c, const float *h0, int ldh, int R, int k,
             ProfScope ps(c, F_LMHEAD_H2, 2.0 * R * (double)g.vocab * d);
             CAPDEC_TRY(launch_gemm_f16x2p_topk(c->stream, c->xpk.p, pl, R, g.vocab, d, k, inv_temp, c->tmax.as<float>(),
                                                c->tsum.as<float>(), c->cval.as<float>(), c->cidx.as<int>()));
-        } else if (c->gemm_mode == GEMM_BF16) {
+        } else if (mode_single(c)) {
             ProfScope ps(c, F_LMHEAD_BF16, 2.0 * R * (double)g.vocab * d);
             CAPDEC_TRY(launch_gemm_bf16p_topk(c->stream, c->xpk.p, pl, R, g.vocab, d, k, inv_temp, c->tmax.as<float>(),
-                                              c->tsum.as<float>(), c->cval.as<float>(), c->cidx.as<int>()));
+                                              c->tsum.as<float>(), c->cval.as<float>(), c->cidx.as<int>(), pack_fmt(c)));
         } else {
             ProfScope ps(c, F_LMHEAD_X3, 2.0 * R * (double)g.vocab * d);
             CAPDEC_TRY(launch_gemm_bf16x3p_topk(c->stream, c->xpk.p, pl, R, g.vocab, d, k, inv_temp,
@@ -497,11 +507,12 @@ static int ensure_kv(capdec_ctx *c, KvCache &kv, int rows, int ctx, int heads = 
     kv.heads = heads ? heads : g.n_head;
     kv.ctx = ctx;
     kv.hd = hd ? hd : g.d / g.n_head;
-    const size_t bytes = kv.layer_stride() * (layers ? layers : g.n_layer) * sizeof(float);
+    kv.bf16 = c->gemm_mode == GEMM_BF16;      // BASELINE configs[1]: bf16 weights / GEMM operands / KV cache
+    const size_t bytes = kv.layer_stride() * (layers ? layers : g.n_layer) * kv.elem_bytes();
     CAPDEC_TRY(c->kc.ensure(bytes));
     CAPDEC_TRY(c->vc.ensure(bytes));
-    kv.k = c->kc.as<float>();
-    kv.v = c->vc.as<float>();
+    kv.k = c->kc.p;
+    kv.v = c->vc.p;
     return 0;
 }
 
@@ -518,7 +529,7 @@ static int poll_alive(capdec_ctx *c, int *alive) {
 // instead of a failed hipMalloc
 static int chunk_captions(capdec_ctx *c, int n, int beam, int ctx) {
     const Gpt2 &g = c->gpt;
-    const size_t per_cap = (size_t)beam * ctx * g.d * 2 * sizeof(float) * g.n_layer;
+    const size_t per_cap = (size_t)beam * ctx * g.d * 2 * (c->gemm_mode == GEMM_BF16 ? 2 : 4) * g.n_layer;
     size_t budget = c->kv_budget, free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
         const size_t avail = (size_t)((double)(free_b + c->kc.cap + c->vc.cap) * 0.85);
@@ -531,12 +542,13 @@ static int chunk_captions(capdec_ctx *c, int n, int beam, int ctx) {
 
 // ---------------------------------------------------------------------------- decode drivers
 static int decode_chunk(capdec_ctx *c, const float *prefix, int nc, int P, int beam, bool greedy, int stop_id,
-                        int alt_stop_id, int T, float temperature, int *ids, int *lens, float *scores, int *order) {
+                        int alt_stop_id, int T, float temperature, int *ids, int *lens, float *scores, int *order,
+                        const int *forced = nullptr, float *stats = nullptr) {
     const Gpt2 &g = c->gpt;
     const int d = g.d;
     const int ctx = P + T - 1;
     const int rows = nc * beam;
-    const int k = beam;   // candidates kept per row
+    const int k = (greedy && stats) ? 2 : beam;   // candidates kept per row (teacher-forced statistics: top-2)
     const float inv_temp = 1.0f / (temperature > 0.f ? temperature : 1.0f);
     KvCache kv;
     CAPDEC_TRY(ensure_kv(c, kv, rows, ctx));
@@ -580,7 +592,8 @@ static int decode_chunk(capdec_ctx *c, const float *prefix, int nc, int P, int b
     if (greedy) {
         ProfScope ps(c, F_SELECT);
         CAPDEC_TRY(launch_greedy_step(c->stream, c->topi.as<int>(), nc, 0, T, stop_id, alt_stop_id, ids, lens,
-                                      c->done.as<uint8_t>(), c->next_tok.as<int>(), c->alive.as<int>()));
+                                      c->done.as<uint8_t>(), c->next_tok.as<int>(), c->alive.as<int>(), nullptr, k, forced,
+                                      c->topv.as<float>(), c->lse.as<float>(), stats));
     } else {
         ProfScope ps(c, F_SELECT);
         CAPDEC_TRY(launch_beam_init(c->stream, bs, c->lse.as<float>(), c->topv.as<float>(), c->topi.as<int>(), nc,
@@ -630,7 +643,8 @@ static int decode_chunk(capdec_ctx *c, const float *prefix, int nc, int P, int b
         ProfScope ps(c, F_SELECT);
         if (greedy) {
             CAPDEC_TRY(launch_greedy_step(c->stream, c->topi.as<int>(), arows, i, T, stop_id, alt_stop_id, ids, lens,
-                                          c->done.as<uint8_t>(), c->next_tok.as<int>(), c->alive.as<int>(), cmap));
+                                          c->done.as<uint8_t>(), c->next_tok.as<int>(), c->alive.as<int>(), cmap, k, forced,
+                                          c->topv.as<float>(), c->lse.as<float>(), stats));
         } else {
             CAPDEC_TRY(launch_beam_step(c->stream, bs, c->lse.as<float>(), c->topv.as<float>(), c->topi.as<int>(), na,
                                         beam, k, T, ctx, i, pos, g.vocab, stop_id, cmap));
@@ -645,7 +659,7 @@ static int decode_chunk(capdec_ctx *c, const float *prefix, int nc, int P, int b
 
 static int decode_common(capdec_ctx *c, const float *prefix, int n, int P, int beam, bool greedy, int stop_id,
                          int alt_stop_id, int T, float temperature, int *ids, int *lens, float *scores,
-                         int *order) {
+                         int *order, const int *forced = nullptr, float *stats = nullptr) {
     CAPDEC_CHECK(c && c->gpt.loaded, "decode: GPT-2 weights not loaded");
     CAPDEC_CHECK(n >= 0 && P >= 1 && T >= 1, "decode: bad sizes");
     CAPDEC_CHECK(P + T - 1 <= c->gpt.n_pos, "decode: prefix + entry_length exceeds n_positions");
@@ -664,7 +678,8 @@ static int decode_common(capdec_ctx *c, const float *prefix, int n, int P, int b
         CAPDEC_TRY(decode_chunk(c, prefix + (size_t)c0 * P * c->gpt.d, nc, P, beam, greedy, stop_id, alt_stop_id, T,
                                 temperature, ids + (size_t)c0 * beam * T, lens + (size_t)c0 * beam,
                                 scores ? scores + (size_t)c0 * beam : nullptr,
-                                order ? order + (size_t)c0 * beam : nullptr));
+                                order ? order + (size_t)c0 * beam : nullptr,
+                                forced ? forced + (size_t)c0 * T : nullptr, stats ? stats + (size_t)c0 * T * 3 : nullptr));
     }
     CAPDEC_HIP(hipStreamSynchronize(c->stream));
     return 0;
@@ -859,7 +874,7 @@ int capdec_create(int device_id, capdec_ctx **out) {
     if (const char *e = getenv("CAPDEC_COMPACT")) c->compact = atoi(e) != 0;
     if (const char *e = getenv("CAPDEC_GEMM_MODE")) {
         const std::string m(e);
-        c->gemm_mode = m == "f32" ? GEMM_F32 : m == "bf16" ? GEMM_BF16 : m == "bf16x3" ? GEMM_BF16X3 : GEMM_F16X2;
+        c->gemm_mode = m == "f32" ? GEMM_F32 : m == "bf16" ? GEMM_BF16 : m == "bf16x3" ? GEMM_BF16X3 : m == "f16" ? GEMM_F16 : GEMM_F16X2;
     }
     CAPDEC_HIP(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
     c->stream = c->own_stream;
@@ -913,9 +928,9 @@ int capdec_synchronize(capdec_ctx *c) {
     return 0;
 }
 int capdec_set_gemm_mode(capdec_ctx *c, int mode) {
-    CAPDEC_CHECK(c && (mode == GEMM_F32 || mode == GEMM_BF16X3 || mode == GEMM_BF16 || mode == GEMM_F16X2),
-                 "set_gemm_mode: mode must be 0 (f32 MFMA), 1 (bf16x3, fp32-accurate), 2 (bf16 operands) or 3 (f16x2, "
-                 "fp32-accurate, default)");
+    CAPDEC_CHECK(c && mode >= GEMM_F32 && mode <= GEMM_F16,
+                 "set_gemm_mode: mode must be 0 (f32 MFMA), 1 (bf16x3, fp32-accurate), 2 (bf16 operands), 3 (f16x2, "
+                 "fp32-accurate, default) or 4 (fp16 operands)");
     c->gemm_mode = mode;
     return 0;
 }
@@ -1203,6 +1218,20 @@ int capdec_decode_greedy(capdec_ctx *c, const float *prefix, int n, int P, int s
                          nullptr);
 }
 
+int capdec_decode_greedy_forced(capdec_ctx *c, const float *prefix, int n, int P, int entry_length,
+                                const int32_t *forced, int32_t *ids, float *stats) {
+    CAPDEC_CHECK(c && (n == 0 || (prefix && forced && ids)), "decode_greedy_forced: null argument");
+    DBuf lens;
+    CAPDEC_TRY(lens.ensure((size_t)std::max(n, 1) * 4));
+    const bool compact = c->compact;
+    c->compact = false;                       // every caption runs every step
+    const int rc = decode_common(c, prefix, n, P, 1, true, -1, -1, entry_length, 1.0f, ids, lens.as<int>(), nullptr, nullptr,
+                                 forced, stats);
+    c->compact = compact;
+    lens.release();
+    return rc;
+}
+
 int capdec_decode_beam(capdec_ctx *c, const float *prefix, int n, int P, int beam, int stop_id, int entry_length,
                        float temperature, int32_t *ids, int32_t *lens, float *scores, int32_t *order) {
     CAPDEC_CHECK(c && (n == 0 || (prefix && ids && lens && scores)), "decode_beam: null argument");
@@ -1217,7 +1246,7 @@ int capdec_gemm_f32(capdec_ctx *c, const float *a, int lda, const float *bt, int
     CAPDEC_HIP(hipSetDevice(c->device));
     const bool cache = getenv("CAPDEC_HOOK_CACHE") != nullptr;   // benchmarking: treat Bt as a resident weight
     const bool packa = getenv("CAPDEC_HOOK_PACKA") != nullptr;   // tests / benchmarking: pre-packed A (the LayerNorm -> GEMM path)
-    if ((packa || c->gemm_mode == GEMM_BF16) && c->gemm_mode != GEMM_F32 && lda == K && ldb == K && K % 64 == 0) {
+    if ((packa || mode_single(c)) && c->gemm_mode != GEMM_F32 && lda == K && ldb == K && K % 64 == 0) {
         const void *pa = nullptr, *pb = nullptr;
         if (cache) {
             CAPDEC_TRY(planes_of(c, a, M, K, true, &pa));
@@ -1233,9 +1262,9 @@ int capdec_gemm_f32(capdec_ctx *c, const float *a, int lda, const float *bt, int
             ProfScope ps(c, F_GEMM_H2P, 2.0 * M * (double)N * K);
             return launch_gemm_f16x2p(c->stream, pa, pb, cc, ldc, M, N, K, e);
         }
-        if (c->gemm_mode == GEMM_BF16) {
+        if (mode_single(c)) {
             ProfScope ps(c, F_GEMM_BF16P, 2.0 * M * (double)N * K);
-            return launch_gemm_bf16p(c->stream, pa, pb, cc, ldc, M, N, K, e);
+            return launch_gemm_bf16p(c->stream, pa, pb, cc, ldc, M, N, K, e, pack_fmt(c));
         }
         ProfScope ps(c, F_GEMM_X3P, 2.0 * M * (double)N * K);
         if (gemm_bf16x3w_enabled()) return launch_gemm_bf16x3w(c->stream, pa, pb, cc, ldc, M, N, K, e);

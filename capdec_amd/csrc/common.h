@@ -137,10 +137,12 @@ int launch_gemm_f16x2p(hipStream_t st, const void *Apacked, const void *Bpacked,
 int launch_gemm_f16x2p_topk(hipStream_t st, const void *Apacked, const void *Bpacked, int M, int N, int K, int k,
                             float inv_temp, float *tile_max, float *tile_sum, float *cand_val, int *cand_idx);
 // bf16 mode (gemm_bf16.hip): same packed operands, plane 0 only -- one bf16 MFMA per product, fp32 accumulate
+// (fmt: PackFmt of both operands -- PK_BF16X1 / PK_F16X1; the packed output uses the same format)
 int launch_gemm_bf16p(hipStream_t st, const void *Apacked, const void *Bpacked, float *C, int ldc, int M, int N, int K,
-                      const GemmEpilogue &epi);
+                      const GemmEpilogue &epi, int fmt);
 int launch_gemm_bf16p_topk(hipStream_t st, const void *Apacked, const void *Bpacked, int M, int N, int K, int k,
-                           float inv_temp, float *tile_max, float *tile_sum, float *cand_val, int *cand_idx);
+                           float inv_temp, float *tile_max, float *tile_sum, float *cand_val, int *cand_idx, int fmt);
+int launch_pack_planes_fmt(hipStream_t st, const float *w, int ldw, int N, int K, void *out, int fmt);
 // LayerNorm whose output goes straight into the packed split-bf16 A format of the next GEMM (d % 16 == 0)
 int launch_layernorm_packed(hipStream_t st, const float *x, int ldx, const float *w, const float *b, float eps,
                             void *packed, int rows, int d, int fmt = 0);
@@ -171,10 +173,14 @@ int launch_vision_assemble(hipStream_t st, const float *patch_out, const float *
 
 // attention.hip
 struct KvCache {
-    float *k = nullptr;  // [layer][phys_row][head][ctx][hd]
-    float *v = nullptr;
+    void *k = nullptr;   // [layer][phys_row][head][ctx][hd], fp32 -- or bf16 when `bf16` is set (bf16 GEMM mode)
+    void *v = nullptr;
     int rows = 0, heads = 0, ctx = 0, hd = 0;
-    size_t layer_stride() const { return (size_t)rows * heads * ctx * hd; }
+    bool bf16 = false;
+    size_t layer_stride() const { return (size_t)rows * heads * ctx * hd; }      // elements
+    size_t elem_bytes() const { return bf16 ? 2 : 4; }
+    template <typename T> T *kp(int layer) const { return reinterpret_cast<T *>(k) + (size_t)layer * layer_stride(); }
+    template <typename T> T *vp(int layer) const { return reinterpret_cast<T *>(v) + (size_t)layer * layer_stride(); }
 };
 // write K/V of `rows` prefill rows (row = caption * P + i) into phys row caption*beam, position i
 int launch_kv_scatter_prefill(hipStream_t st, const float *qkv, const KvCache &c, int layer, int ncap, int P,
@@ -217,7 +223,8 @@ int launch_beam_finalize(hipStream_t st, const BeamState &s, int ncap, int beam,
                          float *scores, int *order);
 int launch_greedy_step(hipStream_t st, const int *top_idx, int rows, int step, int T, int stop_id, int alt_stop_id,
                        int *ids, int *lens, uint8_t *done, int *next_tok, int *alive_count,
-                       const int *cmap = nullptr);
+                       const int *cmap = nullptr, int k = 1, const int *forced = nullptr, const float *top_val = nullptr,
+                       const float *lse = nullptr, float *stats = nullptr);
 // cmap[0..count) = indices of the captions with done[c] == 0, ascending; *count = how many (one block)
 int launch_compact_alive(hipStream_t st, const uint8_t *done, int ncap, int *cmap, int *count);
 

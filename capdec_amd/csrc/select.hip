@@ -92,14 +92,31 @@ int launch_topk_merge(hipStream_t st, const float *tile_max, const float *tile_s
 }
 
 // ---- greedy: reference gpt2_prefix_eval.py:177-188 (argmax; stop on '.' or id 764)
+// (k candidates per row: k = 1 normally; teacher forcing -- forced != nullptr -- feeds forced[row, step] as the next
+//  token instead of the arg-max and, with k = 2, records (top-1 logit, top-2 logit, logsumexp) of every step)
 __global__ void greedy_step_kernel(const int *__restrict__ top_idx, int rows, int step, int T, int stop_id,
                                    int alt_stop_id, int *__restrict__ ids, int *__restrict__ lens,
                                    uint8_t *__restrict__ done, int *__restrict__ next_tok,
-                                   int *__restrict__ alive_count, const int *__restrict__ cmap) {
+                                   int *__restrict__ alive_count, const int *__restrict__ cmap, int k,
+                                   const int *__restrict__ forced, const float *__restrict__ top_val,
+                                   const float *__restrict__ lse, float *__restrict__ stats) {
     const int r = blockIdx.x * blockDim.x + threadIdx.x;       // activation row (compact)
     if (r >= rows) return;
     const int row = cmap ? cmap[r] : r;                        // caption
-    const int tok = top_idx[r];
+    const int tok = top_idx[(size_t)r * k];
+    if (stats) {
+        float *o = stats + ((size_t)row * T + step) * 3;
+        o[0] = top_val[(size_t)r * k];
+        o[1] = k > 1 ? top_val[(size_t)r * k + 1] : -INFINITY;
+        o[2] = lse[r];
+    }
+    if (forced) {                                              // teacher forcing: nothing stops, every step is recorded
+        next_tok[row] = forced[(size_t)row * T + step];
+        ids[(size_t)row * T + step] = tok;
+        lens[row] = step + 1;
+        atomicAdd(alive_count, 1);
+        return;
+    }
     next_tok[row] = tok;
     if (done[row]) return;
     ids[(size_t)row * T + step] = tok;
@@ -109,10 +126,11 @@ __global__ void greedy_step_kernel(const int *__restrict__ top_idx, int rows, in
 }
 
 int launch_greedy_step(hipStream_t st, const int *top_idx, int rows, int step, int T, int stop_id, int alt_stop_id,
-                       int *ids, int *lens, uint8_t *done, int *next_tok, int *alive_count, const int *cmap) {
+                       int *ids, int *lens, uint8_t *done, int *next_tok, int *alive_count, const int *cmap, int k,
+                       const int *forced, const float *top_val, const float *lse, float *stats) {
     if (rows <= 0) return 0;
     hipLaunchKernelGGL(greedy_step_kernel, dim3((rows + 255) / 256), dim3(256), 0, st, top_idx, rows, step, T,
-                       stop_id, alt_stop_id, ids, lens, done, next_tok, alive_count, cmap);
+                       stop_id, alt_stop_id, ids, lens, done, next_tok, alive_count, cmap, k, forced, top_val, lse, stats);
     CAPDEC_HIP(hipGetLastError());
     return 0;
 }

@@ -291,6 +291,20 @@ class Engine:
                                             int(entry_length), ids.data_ptr(), lens.data_ptr()), "capdec_decode_greedy")
         return ids, lens
 
+    def decode_greedy_forced(self, prefix_embed: torch.Tensor, forced_ids: torch.Tensor):
+        """teacher-forced greedy decode: feeds ``forced_ids`` [n, T] and returns (arg-max ids [n, T], stats [n, T, 3] =
+        (top-1 logit, top-2 logit, logsumexp) of every step)"""
+        p = self._dev(prefix_embed)
+        f = self._dev(forced_ids, torch.int32)
+        n, P, _ = p.shape
+        T = f.shape[1]
+        ids = torch.empty(n, T, device=self.device, dtype=torch.int32)
+        stats = torch.empty(n, T, 3, device=self.device, dtype=torch.float32)
+        self._sync_stream()
+        check(self.lib.capdec_decode_greedy_forced(self._h, p.data_ptr(), n, P, T, f.data_ptr(), ids.data_ptr(),
+                                                   stats.data_ptr()), "capdec_decode_greedy_forced")
+        return ids, stats
+
     def decode_beam(self, prefix_embed: torch.Tensor, stop_id: int, beam_size: int = 5, entry_length: int = 67,
                     temperature: float = 1.0):
         """-> ids [n, beam, T], lens [n, beam], mean-log-prob scores [n, beam] (sorted by score
@@ -389,11 +403,12 @@ class Engine:
 
     def set_gemm_mode(self, mode: str):
         """'f16x2' (default: fp32-accurate, operands as two fp16 planes, 3 MFMAs per product), 'bf16x3' (fp32-accurate,
-        three bf16 planes, 6 MFMAs per product), 'f32' (native fp32 MFMA) or 'bf16' (bf16 operands, fp32 accumulate)"""
-        check(self.lib.capdec_set_gemm_mode(self._h, {"f32": 0, "bf16x3": 1, "bf16": 2, "f16x2": 3}[mode]), "set_gemm_mode")
+        three bf16 planes, 6 MFMAs per product), 'f32' (native fp32 MFMA), 'bf16' (bf16 GEMM operands and KV cache, fp32
+        accumulate: BASELINE configs[1]) or 'f16' (fp16 GEMM operands: the reference's CLIP-tower arithmetic on a GPU)"""
+        check(self.lib.capdec_set_gemm_mode(self._h, {"f32": 0, "bf16x3": 1, "bf16": 2, "f16x2": 3, "f16": 4}[mode]), "set_gemm_mode")
 
     def gemm_mode(self) -> str:
-        return ["f32", "bf16x3", "bf16", "f16x2"][self.lib.capdec_get_gemm_mode(self._h)]
+        return ["f32", "bf16x3", "bf16", "f16x2", "f16"][self.lib.capdec_get_gemm_mode(self._h)]
 
     def profile_enable(self, on=True):
         """True / 1: time every launch; N > 1: every N-th launch of each kernel family (sampling); False: off"""

@@ -202,6 +202,14 @@ int capdec_wte_lookup(capdec_ctx *ctx, const int32_t *d_ids, int n, float *d_out
 int capdec_decode_greedy(capdec_ctx *ctx, const float *d_prefix, int n, int P, int stop_id,
                          int alt_stop_id, int entry_length, int32_t *d_ids, int32_t *d_lens);
 
+/* Teacher-forced greedy decode (evaluation / test hook of the reduced-precision modes, where free-running sequences
+ * of two bf16 pipelines diverge by construction): the token fed at step i is d_forced[r, i] (int32 [n, entry_length],
+ * e.g. the ids an fp32 run produced) instead of the arg-max; d_ids [n, entry_length] receives the arg-max of every
+ * step, d_stats (may be NULL) fp32 [n, entry_length, 3] = (top-1 logit, top-2 logit, logsumexp over the vocabulary) of
+ * every step.  Same kernels and KV cache as capdec_decode_greedy; nothing stops early. */
+int capdec_decode_greedy_forced(capdec_ctx *ctx, const float *d_prefix, int n, int P, int entry_length,
+                                const int32_t *d_forced, int32_t *d_ids, float *d_stats);
+
 /* Limits of the decode entry points (the reference has none, gpt2_prefix_eval.py:50-51,118-129; each is checked and
  * reported through capdec_last_error): beam size 1..8; head_dim = 64 (GPT-2 / CLIP ViT-B/32); context prefix_length +
  * entry_length - 1 <= 256 and <= n_positions; entry_length <= 128; n_embd a multiple of 32, <= 1024.  In the default

@@ -137,29 +137,33 @@ def gelu_new(x: Tensor) -> Tensor:
     return 0.5 * x * (1.0 + torch.tanh(math.sqrt(2.0 / math.pi) * (x + 0.044715 * torch.pow(x, 3.0))))
 
 
-# bf16 GEMM-operand mode (BASELINE configs[1]; include/capdec.h CAPDEC_GEMM_BF16): inside ``bf16_gemm_operands()`` both
-# operands of every GPT-2 projection and of the lm_head are rounded to bf16 (round-to-nearest-even) before an fp32
-# matmul -- the arithmetic of the HIP bf16 mode (one bf16 MFMA per product, fp32 accumulate; residual stream,
-# LayerNorm, softmax, KV cache fp32).  Default: no rounding, the reference's fp32 path.
+# bf16 mode (BASELINE configs[1]; include/capdec.h gemm mode 2): inside ``bf16_gemm_operands()`` both operands of every
+# GPT-2 projection and of the lm_head are rounded to bf16 (round-to-nearest-even) before an fp32 matmul, and K / V are
+# rounded to bf16 when they are produced (the bf16 KV cache: the rounded value is what the producing step and every
+# later step attend to) -- the arithmetic of the HIP bf16 mode (one bf16 MFMA per product, fp32 accumulate; residual
+# stream, LayerNorm, softmax fp32).  ``bf16_gemm_operands(dtype=torch.float16)`` is the fp16-operand variant (CLIP
+# towers; no KV cache there).  Default: no rounding, the reference's fp32 path.
 _GEMM_BF16 = False
+_GEMM_DT = torch.bfloat16
 _RW_CACHE: dict = {}       # id(weight) -> (weight, rounded weight): a GPT-2-small step would otherwise re-round 124 M values
 
 
 @contextlib.contextmanager
-def bf16_gemm_operands():
-    global _GEMM_BF16
-    old, _GEMM_BF16 = _GEMM_BF16, True
+def bf16_gemm_operands(dtype=torch.bfloat16):
+    global _GEMM_BF16, _GEMM_DT
+    old, old_dt = _GEMM_BF16, _GEMM_DT
+    _GEMM_BF16, _GEMM_DT = True, dtype
+    _RW_CACHE.clear()
     try:
         yield
     finally:
-        _GEMM_BF16 = old
-        if not old:
-            _RW_CACHE.clear()
+        _GEMM_BF16, _GEMM_DT = old, old_dt
+        _RW_CACHE.clear()
 
 
 def _r(x: Tensor) -> Tensor:
-    """GEMM-input activation: rounded to bf16 inside ``bf16_gemm_operands()``, untouched otherwise"""
-    return x.to(torch.bfloat16).to(torch.float32) if _GEMM_BF16 else x
+    """GEMM-input activation (and K / V at cache-write time): rounded to 16 bits inside ``bf16_gemm_operands()``"""
+    return x.to(_GEMM_DT).to(torch.float32) if _GEMM_BF16 else x
 
 
 def _rw(w: Tensor) -> Tensor:
@@ -169,7 +173,7 @@ def _rw(w: Tensor) -> Tensor:
         return w
     hit = _RW_CACHE.get(id(w))
     if hit is None or hit[0] is not w:
-        hit = (w, w.to(torch.bfloat16).to(torch.float32))
+        hit = (w, w.to(_GEMM_DT).to(torch.float32))
         _RW_CACHE[id(w)] = hit
     return hit[1]
 
@@ -198,8 +202,8 @@ def gpt2_hidden(embeds: Tensor, sd: SD, n_head: int = 12, g: str = "gpt.", pos0:
         qkv = torch.addmm(sd[b + "attn.c_attn.bias"], _r(a.reshape(-1, d)), _rw(sd[b + "attn.c_attn.weight"])).view(N, L, 3 * d)
         q, k, v = qkv.split(d, dim=2)
         q = q.view(N, L, n_head, hd).transpose(1, 2)
-        k = k.view(N, L, n_head, hd).transpose(1, 2)
-        v = v.view(N, L, n_head, hd).transpose(1, 2)
+        k = _r(k.view(N, L, n_head, hd).transpose(1, 2))          # bf16 mode: K / V live in bf16 from the moment they exist
+        v = _r(v.view(N, L, n_head, hd).transpose(1, 2))
         if cache is not None:
             if cache[i] is not None:
                 k = torch.cat((cache[i][0], k), dim=2)
@@ -339,6 +343,30 @@ def greedy_cached(sd: SD, prefix: Tensor, stop_id: int = 13, entry_length: int =
     return ids, lens
 
 
+def greedy_forced(sd: SD, prefix: Tensor, forced: Tensor, n_head: int = 12) -> Tuple[Tensor, Tensor]:
+    """Teacher-forced KV-cached greedy decode (capdec_decode_greedy_forced): step i feeds ``forced[:, i]`` whatever the
+    arg-max was.  -> (arg-max ids int32 [N, T], stats fp32 [N, T, 3] = top-1 logit, top-2 logit, logsumexp)."""
+    N, P, d = prefix.shape
+    T = forced.shape[1]
+    g = "gpt."
+    cache: list = [None] * _n_layer(sd, g)
+    W = sd[g + "transformer.wte.weight"]
+    Wr = _rw(W)
+    ids = torch.zeros(N, T, dtype=torch.int32)
+    stats = torch.zeros(N, T, 3)
+    h = gpt2_hidden(prefix, sd, n_head, g, 0, cache)[:, -1]
+    for i in range(T):
+        logits = _r(h) @ Wr.t()
+        top = logits.topk(2, -1)
+        ids[:, i] = top.indices[:, 0].to(torch.int32)
+        stats[:, i, 0], stats[:, i, 1] = top.values[:, 0], top.values[:, 1]
+        stats[:, i, 2] = torch.logsumexp(logits, -1)
+        if i == T - 1:
+            break
+        h = gpt2_hidden(W[forced[:, i].long()].unsqueeze(1), sd, n_head, g, P + i, cache)[:, -1]
+    return ids, stats
+
+
 def beam_cached(sd: SD, prefix: Tensor, beam_size: int = 5, stop_id: int = 13, entry_length: int = 67,
                 temperature: float = 1.0, n_head: int = 12, margins: Optional[list] = None) -> Tuple[Tensor, Tensor, Tensor]:
     """Batched beam search with a KV cache, per caption identical in arithmetic to
@@ -432,7 +460,8 @@ def _clip_resblocks(x: Tensor, sd: SD, prefix: str, n_head: int, causal: bool) -
     while f"{prefix}transformer.resblocks.{i}.ln_1.weight" in sd:
         b = f"{prefix}transformer.resblocks.{i}."
         a = F.layer_norm(x, (d,), sd[b + "ln_1.weight"], sd[b + "ln_1.bias"], 1e-5)
-        qkv = F.linear(a, sd[b + "attn.in_proj_weight"], sd[b + "attn.in_proj_bias"])
+        # (_r / _rw: 16-bit GEMM operands inside ``bf16_gemm_operands(dtype)`` -- the HIP f16 / bf16 tower modes)
+        qkv = F.linear(_r(a), _rw(sd[b + "attn.in_proj_weight"]), sd[b + "attn.in_proj_bias"])
         q, k, v = qkv.split(d, dim=2)
         q = q.view(N, L, n_head, hd).transpose(1, 2) * (hd ** -0.5)     # nn.MultiheadAttention scales q
         k = k.view(N, L, n_head, hd).transpose(1, 2)
@@ -441,11 +470,11 @@ def _clip_resblocks(x: Tensor, sd: SD, prefix: str, n_head: int, causal: bool) -
         if causal:                                                        # build_attention_mask: -inf above the diagonal
             w = w + torch.full((L, L), float("-inf")).triu_(1)
         o = torch.matmul(w.softmax(dim=-1), v).transpose(1, 2).reshape(N, L, d)
-        x = x + F.linear(o, sd[b + "attn.out_proj.weight"], sd[b + "attn.out_proj.bias"])
+        x = x + F.linear(_r(o), _rw(sd[b + "attn.out_proj.weight"]), sd[b + "attn.out_proj.bias"])
         m = F.layer_norm(x, (d,), sd[b + "ln_2.weight"], sd[b + "ln_2.bias"], 1e-5)
-        m = F.linear(m, sd[b + "mlp.c_fc.weight"], sd[b + "mlp.c_fc.bias"])
+        m = F.linear(_r(m), _rw(sd[b + "mlp.c_fc.weight"]), sd[b + "mlp.c_fc.bias"])
         m = m * torch.sigmoid(1.702 * m)                                  # QuickGELU
-        x = x + F.linear(m, sd[b + "mlp.c_proj.weight"], sd[b + "mlp.c_proj.bias"])
+        x = x + F.linear(_r(m), _rw(sd[b + "mlp.c_proj.weight"]), sd[b + "mlp.c_proj.bias"])
         i += 1
     return x
 

@@ -385,6 +385,17 @@ def gen_clip(dims, tag, n_text, n_img):
     vf = getattr(vf, "pooler_output", vf)
     out = {"crc": np.uint32(synth.state_dict_checksum(sd)), "tokens": toks.numpy(), "text_features": tf.numpy(),
            "image_seed": np.int64(4), "image_features": vf.numpy()}
+    # the same stand-in in half precision = the arithmetic class of the reference on a GPU (`clip.load(..., device=cuda)`
+    # converts the model to fp16, predictions_runner.py:218,220 cast the result back with .float())
+    try:
+        mh = model.half()
+        with torch.no_grad():
+            tfh = mh.get_text_features(input_ids=toks)
+            vfh = mh.get_image_features(pixel_values=imgs.half())
+        out["text_features_fp16"] = getattr(tfh, "pooler_output", tfh).float().numpy()
+        out["image_features_fp16"] = getattr(vfh, "pooler_output", vfh).float().numpy()
+    except Exception as ex:                      # CPU half kernels missing: keep the fp32 pin only
+        print("fp16 stand-in not available:", ex)
     np.savez_compressed(os.path.join(OUT, f"clip_{tag}.npz"), **out)
     print(f"clip_{tag}.npz", tf.shape, vf.shape, float(tf.norm(dim=1).mean()), float(vf.norm(dim=1).mean()))
 
