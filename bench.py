@@ -320,7 +320,7 @@ def main():
         eng.set_gemm_mode(low_mode)
         tf_low, st = eng.decode_greedy_forced(pe, ids_ref)
         eq = (ids_low == ids_ref)
-        first_div = torch.where(eq.all(1), torch.full((eq.shape[0],), T), (~eq).float().argmax(1))
+        first_div = torch.where(eq.all(1), torch.full((eq.shape[0],), T, device=eq.device), (~eq).float().argmax(1))
         margin = st[:, :, 0] - st[:, :, 1]
         match = {"captions": int(sub.shape[0]), "free_running_token_match": round(float(eq.float().mean()), 4),
                  "identical_captions": round(float(eq.all(1).float().mean()), 4),

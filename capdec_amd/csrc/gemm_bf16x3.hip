@@ -460,16 +460,30 @@ int launch_splitk_reduce(hipStream_t st, const float *part, int S, int M, int N,
     return 0;
 }
 
-// slices for a [M, N, K] problem: 1 (no split) unless M <= 512 rows (at most four tile rows: the decode of small
-// batches).  S depends on K ONLY -- the largest divisor of the k-step count that leaves >= 8 (an even number of)
-// k-steps per slice -- so a row's result is bit-identical for every batch size in this regime (and for every batch
-// size in the unsplit regime above it); across the boundary the fp32 summation order differs.
+// slices for a [M, N, K] problem (1 = no split).  Two under-filled regimes (the chip runs 512 blocks at a time):
+//  (a) M <= 512 rows (at most four tile rows: the decode of small batches): S depends on K ONLY -- the largest divisor of
+//      the k-step count that leaves >= 8 (an even number of) k-steps per slice -- so a row's result is bit-identical for
+//      every batch size in this regime;
+//  (b) larger M whose grid is still at most HALF of the chip (<= 256 tiles: the N = 768 projections at a few thousand
+//      rows, e.g. 625 captions x beam 5 = 3125 rows -> 150 tiles): the largest S with tiles x S <= 512 and >= 16 (even)
+//      k-steps per slice.  mlp.c_proj (K = 3072, 150 tiles walking 192 k-steps each): 58 -> ~35 us.
+// Across a regime / S boundary the fp32 summation order of a row changes (round-off level; the unsplit regime above is
+// again batch-size independent).  CAPDEC_SPLITK=0 disables both, CAPDEC_SPLITK_MID=0 only (b).
 int gemm_splitk_slices(int M, int N, int K) {
     static const int off = [] { const char *e = getenv("CAPDEC_SPLITK"); return e && atoi(e) == 0 ? 1 : 0; }();
+    static const int mid_off = [] { const char *e = getenv("CAPDEC_SPLITK_MID"); return e && atoi(e) == 0 ? 1 : 0; }();
     const int nk = K / X3_BK;
-    if (off || M > 4 * GEMM_BM || N % 4 != 0) return 1;
+    if (off || N % 4 != 0) return 1;
     int best = 1;
-    for (int s = 2; s <= nk / 8; ++s)
+    if (M <= 4 * GEMM_BM) {
+        for (int s = 2; s <= nk / 8; ++s)
+            if (nk % s == 0 && (nk / s) % 2 == 0) best = s;
+        return best;
+    }
+    if (mid_off) return 1;
+    const int tiles = ((M + GEMM_BM - 1) / GEMM_BM) * ((N + GEMM_BN - 1) / GEMM_BN);
+    if (tiles > 256) return 1;
+    for (int s = 2; s <= nk / 16 && tiles * s <= 512; ++s)
         if (nk % s == 0 && (nk / s) % 2 == 0) best = s;
     return best;
 }
