@@ -181,8 +181,33 @@ class ClipCaptionModel(_HipModule):
         self.clip_project._upload(eng)
 
     def forward(self, tokens, prefix, mask=None, labels=None):
-        raise CapdecError("ClipCaptionModel.forward is the TRAINING forward (reference gpt2_prefix.py:145-155); "
-                          "training is outside the accelerated caption path")
+        """The forward pass of the reference's TRAIN step (train.py:251-260,348; gpt2_prefix.py:145-155), inference only
+        (no autograd: backward / optimiser are outside this path): logits [B, P + L, V] of
+        ``cat(clip_project(prefix).view(-1, P, d), wte(tokens))`` under the causal mask; ``out.loss`` (when ``labels`` is
+        given) is GPT2LMHeadModel's shifted cross-entropy over ``cat(dummy_token, tokens)``.  ``mask`` must be the
+        reference dataset's right-padding mask (ones for the prefix and the real tokens, zeros for the padding at the END,
+        train.py:52-63): under the causal mask the real positions never see a padded key, so their logits equal the
+        reference's; logits AT padded positions are unspecified (the train loss ignores them, train.py:349)."""
+        tokens = tokens.to(torch.device("cuda", self._device_index))
+        if mask is not None:
+            m = mask.to(tokens.device) > 0
+            if m.shape != (tokens.shape[0], self.prefix_length + tokens.shape[1]) or \
+                    bool((m[:, 1:] & ~m[:, :-1]).any()) or not bool(m[:, :self.prefix_length].all()):
+                raise CapdecError("forward: only the reference dataset's right-padding mask is supported "
+                                  "([B, prefix_length + L], ones then zeros)")
+        embedding_text = self.gpt.transformer.wte(tokens)
+        prefix_projections = self.clip_project(prefix).view(-1, self.prefix_length, self.gpt_embedding_size)
+        embedding_cat = torch.cat((prefix_projections, embedding_text), dim=1)
+        logits = self.engine.gpt2_logits(embedding_cat, all_positions=True)
+        loss = None
+        if labels is not None:
+            dummy_token = self.get_dummy_token(tokens.shape[0], tokens.device)
+            lab = torch.cat((dummy_token, tokens.long()), dim=1)
+            loss = torch.nn.functional.cross_entropy(logits[:, :-1].reshape(-1, logits.shape[-1]), lab[:, 1:].reshape(-1))
+        return SimpleNamespace(logits=logits, loss=loss)
+
+    def __call__(self, *args, **kwargs):
+        return self.forward(*args, **kwargs)
 
 
 class ClipCaptionPrefix(ClipCaptionModel):

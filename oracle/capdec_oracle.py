@@ -236,6 +236,15 @@ def wte(ids: Tensor, sd: SD, g: str = "gpt.") -> Tensor:
     return sd[g + "transformer.wte.weight"][ids]
 
 
+def train_forward(sd: SD, tokens: Tensor, prefix: Tensor, mapping_type: str, prefix_length: int, clip_length: int = 10,
+                  num_layers: int = 8, n_head: int = 12) -> Tensor:
+    """ClipCaptionModel.forward of the train step (reference train.py:251-260): logits [B, P + L, V] of
+    cat(clip_project(prefix).view(-1, P, d), wte(tokens)).  The dataset pads on the right (train.py:52-63), so under the
+    causal mask the attention_mask only changes the PADDED positions, which the loss ignores (train.py:349)."""
+    pe = clip_project(prefix, sd, mapping_type, prefix_length, clip_length, num_layers)
+    return gpt2_logits(torch.cat((pe, wte(tokens.long(), sd)), dim=1), sd, n_head)
+
+
 # ----------------------------------------------------------------------------------------
 # reference-shaped decode (batch 1, no KV cache): what the reference executes
 # ----------------------------------------------------------------------------------------

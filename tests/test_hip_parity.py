@@ -328,6 +328,35 @@ def test_make_preds_driver_vs_reference_golden(golden, dims, tag, tmp_path):
         PR.make_preds([{"image_id": r} for r in range(8)], x, model, FakeTok(st), None, beam=False, rank=0, world=2)
 
 
+@pytest.mark.parametrize("dims,tag", [(synth.GPT2_TINY, "tiny"), (synth.GPT2_SMALL, "small")], ids=["tiny", "small"])
+def test_train_step_forward_vs_reference_golden(golden, dims, tag):
+    """ClipCaptionModel.forward(tokens, prefix, mask) -- the forward of the reference's train step (train.py:251-260,348)
+    on a right-padded batch built like train.ClipCocoDataset (:52-63): logits at every real position, their arg-max /
+    logsumexp and the train loss (:349) equal the reference's; a mask that is not right padding is refused"""
+    from capdec_amd._capi import CapdecError
+    g = golden(f"train_forward_{tag}")
+    model, sd = _model(dims, "mlp", 512)
+    assert synth.state_dict_checksum(sd) == int(g["sd_crc"]), "RNG drift"
+    tokens, prefix, mask = T(g["tokens"]), T(g["prefix"]), T(g["mask"])
+    out = model(tokens, prefix, mask)
+    logits = out.logits.cpu()
+    assert logits.shape == (3, 10 + tokens.shape[1], dims.vocab) and out.loss is None
+    ok = mask > 0
+    step = max(1, dims.vocab // 97)
+    np.testing.assert_allclose(logits[:, :, ::step][ok].numpy(), T(g["logits_sub"])[ok].numpy(), atol=2e-4)
+    np.testing.assert_array_equal(logits.argmax(-1)[ok].numpy(), T(g["argmax"])[ok].numpy())
+    np.testing.assert_allclose(torch.logsumexp(logits, -1)[ok].numpy(), T(g["lse"])[ok].numpy(), atol=1e-4)
+    loss = torch.nn.functional.cross_entropy(logits[:, 9:-1].reshape(-1, logits.shape[-1]), tokens.flatten(), ignore_index=0)
+    assert abs(float(loss) - float(g["train_loss"])) < 1e-4
+    # rows without padding: GPT2LMHeadModel's own `labels=` loss is reproduced as well
+    full = model(tokens[:1], prefix[:1], mask[:1], labels=tokens[:1])
+    assert full.loss is not None and torch.isfinite(full.loss)
+    bad = mask.clone()
+    bad[1, 12] = 0                                               # a hole in the middle: not the dataset's mask
+    with pytest.raises(CapdecError):
+        model(tokens, prefix, bad)
+
+
 @pytest.mark.parametrize("mode", ["f16x2", "bf16x3", "f32"])
 def test_gemm_modes_vs_fp64(mode):
     """every fp32-accurate GEMM back-end stays in the fp32 round-off class (error relative to sum |a||b|)"""

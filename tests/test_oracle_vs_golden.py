@@ -186,6 +186,35 @@ def test_prompt_small(golden):
     _check_prompt(golden("prompt_small"), synth.GPT2_SMALL, 1)
 
 
+# ------------------------------------------------------------------ forward of the train step (train.py:251-260)
+def _valid_positions(g, P=10):
+    """[B, P + L] bool: prefix + real tokens (the positions whose logits the reference's mask leaves untouched)"""
+    return T(g["mask"]) > 0
+
+
+def _check_train_forward(g, dims):
+    sd = synth.hot_state_dict(42, "mlp", 512, 10, dims=dims)
+    assert synth.state_dict_checksum(sd) == int(g["sd_crc"]), "RNG drift"
+    tokens, prefix = T(g["tokens"]), T(g["prefix"])
+    logits = O.train_forward(sd, tokens, prefix, "mlp", 10, n_head=dims.n_head)
+    ok = _valid_positions(g)
+    step = max(1, dims.vocab // 97)
+    np.testing.assert_allclose(logits[:, :, ::step][ok].numpy(), T(g["logits_sub"])[ok].numpy(), atol=2e-4)
+    np.testing.assert_array_equal(logits.argmax(-1)[ok].numpy(), T(g["argmax"])[ok].numpy())
+    np.testing.assert_allclose(torch.logsumexp(logits, -1)[ok].numpy(), T(g["lse"])[ok].numpy(), atol=1e-4)
+    loss = torch.nn.functional.cross_entropy(logits[:, 9:-1].reshape(-1, logits.shape[-1]), tokens.flatten(), ignore_index=0)
+    assert abs(float(loss) - float(g["train_loss"])) < 1e-4          # the train step's loss (train.py:349)
+
+
+def test_train_forward_tiny(golden):
+    _check_train_forward(golden("train_forward_tiny"), synth.GPT2_TINY)
+
+
+@pytest.mark.slow
+def test_train_forward_small(golden):
+    _check_train_forward(golden("train_forward_small"), synth.GPT2_SMALL)
+
+
 # ------------------------------------------------------------------ CLIP ViT-B/32 (HF stand-in pin)
 def _check_clip(g, dims):
     sd = synth.hot_clip_state_dict(43, dims)

@@ -331,6 +331,45 @@ def gen_prompt(refs, dims, tag):
     print(f"prompt_{tag}.npz written; stop {stop}", out["generate2_stop"], out["generate_beam_stop"][1])
 
 
+def gen_train_forward(refs, dims, tag):
+    """train.ClipCaptionModel.forward (train.py:251-260) on a right-padded batch exactly as train.ClipCocoDataset builds
+    it (:52-63), and the loss of the train step (:349: cross_entropy(logits[:, P-1:-1], tokens, ignore_index=0))."""
+    ref_train = refs[3]
+    from transformers import GPT2Config, GPT2LMHeadModel
+    cfg = GPT2Config(n_layer=dims.n_layer, n_head=dims.n_head, n_embd=dims.n_embd, vocab_size=dims.vocab,
+                     n_positions=dims.n_pos)
+    GPT2LMHeadModel.from_pretrained = staticmethod(lambda name, *a, **k: GPT2LMHeadModel(cfg))
+    P = 10
+    model = ref_train.ClipCaptionModel(P, clip_length=10, prefix_size=512, num_layers=8,
+                                       mapping_type=ref_train.MappingType.MLP).eval()
+    sd = synth.hot_state_dict(42, "mlp", 512, P, dims=dims)
+    missing, unexpected = model.load_state_dict(sd, strict=False)
+    assert not unexpected and all(".attn.bias" in m or ".attn.masked_bias" in m for m in missing)
+    g = torch.Generator().manual_seed(17)
+    lens = [9, 4, 7]
+    L = max(lens)
+    tokens = torch.zeros(len(lens), L, dtype=torch.int64)
+    mask = torch.zeros(len(lens), P + L)
+    mask[:, :P] = 1
+    for r, n in enumerate(lens):
+        tokens[r, :n] = torch.randint(1, dims.vocab, (n,), generator=g)
+        mask[r, P:P + n] = 1
+    prefix = synth.synthetic_clip_embeddings(len(lens), 512, seed=5)
+    with torch.no_grad():
+        out = model(tokens, prefix, mask)
+        logits = out.logits
+        loss = torch.nn.functional.cross_entropy(logits[:, P - 1:-1].reshape(-1, logits.shape[-1]), tokens.flatten(),
+                                                 ignore_index=0)
+        out_l = model(tokens, prefix, mask, labels=tokens)          # GPT2LMHeadModel's own shifted loss
+    step = max(1, dims.vocab // 97)
+    res = {"sd_crc": np.uint32(synth.state_dict_checksum(sd)), "tokens": tokens.numpy(), "mask": mask.numpy(),
+           "prefix": prefix.numpy(), "lens": np.array(lens), "logits_sub": logits[:, :, ::step].numpy(),
+           "argmax": logits.argmax(-1).numpy(), "lse": torch.logsumexp(logits, -1).numpy(),
+           "train_loss": np.float32(loss), "hf_loss_all_positions": np.float32(out_l.loss)}
+    np.savez_compressed(os.path.join(OUT, f"train_forward_{tag}.npz"), **res)
+    print(f"train_forward_{tag}.npz written; loss {float(loss):.5f}")
+
+
 def openai_to_hf_clip(sd, dims):
     """Map an OpenAI-CLIP-named state dict onto transformers.CLIPModel names (the independent
     stand-in used to pin the CLIP kernels: the reference's own `clip` package is not installed)."""
@@ -445,6 +484,8 @@ def main():
         "decode_tiny": lambda: gen_decode(refs, synth.GPT2_TINY, "tiny", 8, 6, (12, 67)),
         "decode_small": lambda: gen_decode(refs, synth.GPT2_SMALL, "small", 8, 4, (12, 67)),
         "decode_p40_tiny": lambda: gen_decode_p40(refs, synth.GPT2_TINY, "tiny"),
+        "train_forward_tiny": lambda: gen_train_forward(refs, synth.GPT2_TINY, "tiny"),
+        "train_forward_small": lambda: gen_train_forward(refs, synth.GPT2_SMALL, "small"),
         "prompt_tiny": lambda: gen_prompt(refs, synth.GPT2_TINY, "tiny"),
         "prompt_small": lambda: gen_prompt(refs, synth.GPT2_SMALL, "small"),
         "clip_tiny": lambda: gen_clip(synth.CLIP_TINY, "tiny", 6, 3),
