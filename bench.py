@@ -39,7 +39,7 @@ from capdec_amd import synth  # noqa: E402
 PEAK_F32_MFMA_TFLOPS = 157.3    # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 PEAK_BF16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA (not the 2:1-sparse marketing figure)
 STOP_ID, D_EMB = 13, 768
-PMC_TRAFFIC_FILE = "r1_pmc_traffic.json"   # rocprofv3 --pmc summary the `roofline.traffic` field is read from
+PMC_TRAFFIC_FILE = "r2_pmc_traffic.json"   # rocprofv3 --pmc summary the `roofline.traffic` field is read from
 
 
 def algorithmic_flops_per_caption(P, T, beam, mapper, dims=synth.GPT2_SMALL, D=512, clip_len=10):
@@ -62,13 +62,14 @@ def algorithmic_flops_per_caption(P, T, beam, mapper, dims=synth.GPT2_SMALL, D=5
     return f
 
 
-def cpu_baseline(mapper, beam, P, T, budget_s=20.0, D=512):
+def cpu_baseline(mapper, beam, P, T, budget_s=20.0, D=512, captions=0):
     """The oracle's reference-shaped path (batch 1, NO KV cache, lm_head on every position, fp32
     torch CPU ops: the algorithm of reference gpt2_prefix_eval.py:50-198 driven like
     predictions_runner.py:221-232) timed on this box's host cores on a BOUNDED sample: decode
     steps of the same workload are run for ~budget_s seconds; the reference's cost per step is
     proportional to the token-rows it pushes through GPT-2 (rows x context, no cache), so
-    captions/s = (token-rows done / token-rows per caption) / elapsed."""
+    captions/s = (token-rows done / token-rows per caption) / elapsed.  ``captions`` > 0 (--cpu-captions, e.g. the 32 of
+    SURVEY D.5) times that many WHOLE captions instead of a time budget (minutes of CPU work: not the default)."""
     from oracle import capdec_oracle as O
     ncpu = os.cpu_count() or 1
     sd = synth.hot_state_dict(42, mapper, D, P)
@@ -100,9 +101,9 @@ def cpu_baseline(mapper, beam, P, T, budget_s=20.0, D=512):
                 best = (th, r / dt)
         torch.set_num_threads(best[0])
         rows, dt, r = 0, 0.0, 2
-        while dt < budget_s:                          # whole captions until the budget is used up
+        while (dt < budget_s) if captions <= 0 else (r - 2 < captions):   # whole captions until the budget is used up
             e = O.clip_project(O.normalize_prefix(synth.synthetic_clip_embeddings(r + 1, D, seed=0)[r:r + 1]), sd, mapper, P)
-            rr, dd = run(e, budget_s - dt, T)
+            rr, dd = run(e, (budget_s - dt) if captions <= 0 else 1e9, T)
             rows, dt, r = rows + rr, dt + dd, r + 1
     frac = rows / rows_per_caption
     return {"value": frac / dt, "unit": "captions/s", "cores": best[0], "kind": "port",
@@ -203,6 +204,8 @@ def main():
                     help="hipEvent-time every N-th launch of each kernel family inside the timed region (1 = all; "
                          "7 is coprime to the 4-GEMM / 12-layer launch cycles, so every shape is sampled evenly)")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="wall-clock budget of the CPU baseline (0 = skip)")
+    ap.add_argument("--cpu-captions", type=int, default=0,
+                    help="CPU baseline on this many WHOLE captions instead of the time budget (SURVEY D.5: 32; several minutes)")
     ap.add_argument("--dry-run", action="store_true",
                     help="launcher check without a GPU (CPU tests): join a gloo group, all-gather the ranks, print "
                          "{n_gpus, ranks} and exit")
@@ -459,7 +462,7 @@ def main():
             "match_vs_fp32": match,
         }
         if world == 1 and args.cpu_seconds > 0:
-            rec["cpu_baseline"] = cpu_baseline(mapper, B, P, T, args.cpu_seconds)
+            rec["cpu_baseline"] = cpu_baseline(mapper, B, P, T, args.cpu_seconds, captions=args.cpu_captions)
         else:
             rec["cpu_baseline"] = None
         emit(json.dumps(rec))

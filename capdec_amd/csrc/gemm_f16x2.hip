@@ -80,7 +80,9 @@ __host__ __device__ constexpr int waitcnt_imm(int vm, int lgkm) {
 
 // TR: MFMA operands swapped (D^T), a lane ends with four consecutive columns of one row (see gemm_bf16x3.hip).
 // am = sum hi_a hi_b, ac = sum (hi_a lo_b + lo_a hi_b) (weight 2^-11, applied by h2_join).
-template <bool TR, int NS>
+// ABL (measurement only, CAPDEC_H2_ABL; results are WRONG for ABL != 0): 1 = no s_barrier in the loop, 2 = no LDS-DMA in
+// the loop, 3 = no fragment reads in the loop, 4 = neither barrier nor DMA
+template <bool TR, int NS, int ABL = 0>
 __device__ __forceinline__ void h2p_mainloop(const _Float16 *__restrict__ Apk, const _Float16 *__restrict__ Bpk, int K,
                                              int tm, int tn, char *smem, f32x16 (&am)[2][2], f32x16 (&ac)[2][2],
                                              int ks0 = 0, int nks = -1) {
@@ -137,8 +139,9 @@ __device__ __forceinline__ void h2p_mainloop(const _Float16 *__restrict__ Apk, c
     //  completed, or it puts an lgkmcnt(0) in front of the next MFMAs -- behind the freshly issued reads)
 #define H2_SYNC()                                                                        \
     asm volatile("" ::: "memory");                                                       \
-    __builtin_amdgcn_s_waitcnt(waitcnt_imm(4 * (NS - 2), 0));                            \
-    __builtin_amdgcn_s_barrier();                                                        \
+    if constexpr (ABL == 2 || ABL == 4) __builtin_amdgcn_s_waitcnt(waitcnt_imm(0, 0));   \
+    else __builtin_amdgcn_s_waitcnt(waitcnt_imm(4 * (NS - 2), 0));                       \
+    if constexpr (ABL != 1 && ABL != 4) __builtin_amdgcn_s_barrier();                    \
     asm volatile("" ::: "memory");
     // one memory operation in the shadow of each MFMA: 8 fragment reads, then the 4 DMA pieces
 #define H2_INTERLEAVE()                                                                    \
@@ -166,15 +169,15 @@ __device__ __forceinline__ void h2p_mainloop(const _Float16 *__restrict__ Apk, c
     int s0 = 0;                                                  // kt % NS
     for (int kt = 0; kt < nk; kt += 2) {
         const int s1 = s0 + 1 == NS ? 0 : s0 + 1, s2 = s1 + 1 == NS ? 0 : s1 + 1;
-        H2_READ(f1, s1)                                          // tile kt+1
-        H2_DMA(s0, min(kt + NS, nk - 1))                         // unconditional (clamped) so the vmcnt count is exact
+        if constexpr (ABL != 3) H2_READ(f1, s1)                  // tile kt+1
+        if constexpr (ABL != 2 && ABL != 4) H2_DMA(s0, min(kt + NS, nk - 1))   // unconditional (clamped): exact vmcnt count
         H2_MFMAS(f0)                                             // tile kt
-        H2_INTERLEAVE()
+        if constexpr (ABL == 0) { H2_INTERLEAVE() }
         H2_SYNC()
-        H2_READ(f0, s2)                                          // tile kt+2
-        H2_DMA(s1, min(kt + 1 + NS, nk - 1))
+        if constexpr (ABL != 3) H2_READ(f0, s2)                  // tile kt+2
+        if constexpr (ABL != 2 && ABL != 4) H2_DMA(s1, min(kt + 1 + NS, nk - 1))
         H2_MFMAS(f1)                                             // tile kt+1
-        H2_INTERLEAVE()
+        if constexpr (ABL == 0) { H2_INTERLEAVE() }
         H2_SYNC()
         s0 = s2;
     }
@@ -207,7 +210,7 @@ static int h2_ns() {
     return ns;
 }
 
-template <bool VEC4, int NS>
+template <bool VEC4, int NS, int ABL = 0>
 __global__ __launch_bounds__(256, 2) void gemm_f16x2p_kernel(const _Float16 *__restrict__ Apk,
                                                              const _Float16 *__restrict__ Bpk, float *C, int ldc, int M,
                                                              int N, int K, const float *__restrict__ bias,
@@ -217,7 +220,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f16x2p_kernel(const _Float16 *__r
     int tm, tn;
     tile_coords(tiles_m, tiles_n, tm, tn);
     f32x16 am[2][2], ac[2][2];
-    h2p_mainloop<true, NS>(Apk, Bpk, K, tm, tn, smem, am, ac);
+    h2p_mainloop<true, NS, ABL>(Apk, Bpk, K, tm, tn, smem, am, ac);
     h2_join(am, ac);
     if (packed_out)
         epilogue_store_packed_t(am, packed_out, N >> 4, M, N, tm * GEMM_BM, tn * GEMM_BN, bias, act, PK_F16X2);
@@ -282,6 +285,17 @@ int launch_gemm_f16x2p(hipStream_t st, const void *Apacked, const void *Bpacked,
                        (const _Float16 *)Bpacked, C, ldc, M, N, K, epi.bias, epi.resid, epi.ldr, epi.act, tiles_m,      \
                        tiles_n, (char *)epi.packed_out)
     const int ns = h2_ns();
+    static const int abl = [] { const char *e = getenv("CAPDEC_H2_ABL"); return e ? atoi(e) : 0; }();
+    if (vec4 && abl >= 1 && abl <= 4) {     // measurement only
+#define LAUNCH_H2A(A)                                                                                               \
+    hipLaunchKernelGGL((gemm_f16x2p_kernel<true, H2_NS, A>), dim3(tiles_m * tiles_n), dim3(256), 0, st,               \
+                       (const _Float16 *)Apacked, (const _Float16 *)Bpacked, C, ldc, M, N, K, epi.bias, epi.resid,   \
+                       epi.ldr, epi.act, tiles_m, tiles_n, (char *)epi.packed_out)
+        if (abl == 1) LAUNCH_H2A(1); else if (abl == 2) LAUNCH_H2A(2); else if (abl == 3) LAUNCH_H2A(3); else LAUNCH_H2A(4);
+#undef LAUNCH_H2A
+        CAPDEC_HIP(hipGetLastError());
+        return 0;
+    }
     if (vec4) {
         if (ns == 3) LAUNCH_H2(true, 3); else if (ns == 5) LAUNCH_H2(true, 5); else LAUNCH_H2(true, H2_NS);
     } else {

@@ -2,6 +2,7 @@
 """Summarise rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE, one pass each) into profiles/<name>.json.
 
 usage: pmc_summary.py <dir with *counter_collection.csv (searched recursively)> <out.json> "<command that was profiled>"
+                      [gemm_mode [captions_per_gpu]]     (recorded so that bench.py only quotes matching traffic)
 
 Per kernel: launches, average FETCH_SIZE / WRITE_SIZE (KB, as rocprofv3 reports them) and
 traffic_bytes_per_launch = (2 x FETCH_SIZE + WRITE_SIZE) x 1024: gfx950's FETCH_SIZE counts a 128-byte request as
@@ -37,6 +38,8 @@ def main():
         kernels[k] = {"launches": max(f[0], w[0]), "fetch_KB_raw": round(fk, 1), "write_KB": round(wk, 1),
                       "traffic_bytes_per_launch": int((2 * fk + wk) * 1024)}
     rec = {"source": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes): " + cmd,
+           "gemm_mode": sys.argv[4] if len(sys.argv) > 4 else "bf16x3",
+           "captions_per_gpu": int(sys.argv[5]) if len(sys.argv) > 5 else 5000,
            "correction": "traffic = (2 x FETCH_SIZE + WRITE_SIZE) KB: gfx950 FETCH_SIZE counts 128-B requests as 64 B; "
                          "counters sit at the L2<->fabric boundary (Infinity-Cache hits included)",
            "kernels": kernels}
