@@ -338,8 +338,6 @@ static int gemm_packed(capdec_ctx *c, const void *Apk, const float *W, float *C,
         return launch_gemm_f16x2p(c->stream, Apk, pl, C, ldc, M, N, K, e);
     }
     ProfScope ps(c, F_GEMM_X3P, 2.0 * M * (double)N * K);
-    if (gemm_bf16x3w_enabled() && M >= 1024)      // experimental wide tile (opt-in, see gemm_bf16x3w.hip)
-        return launch_gemm_bf16x3w(c->stream, Apk, pl, C, ldc, M, N, K, e);
     return launch_gemm_bf16x3p(c->stream, Apk, pl, C, ldc, M, N, K, e);
 }
 
@@ -1267,7 +1265,6 @@ int capdec_gemm_f32(capdec_ctx *c, const float *a, int lda, const float *bt, int
             return launch_gemm_bf16p(c->stream, pa, pb, cc, ldc, M, N, K, e, pack_fmt(c));
         }
         ProfScope ps(c, F_GEMM_X3P, 2.0 * M * (double)N * K);
-        if (gemm_bf16x3w_enabled()) return launch_gemm_bf16x3w(c->stream, pa, pb, cc, ldc, M, N, K, e);
         return launch_gemm_bf16x3p(c->stream, pa, pb, cc, ldc, M, N, K, e);
     }
     return gemm(c, a, lda, bt, ldb, cc, ldc, M, N, K, bias, act, resid, ldr, /*weight=*/cache);

@@ -118,10 +118,6 @@ int launch_gemm_bf16x3p(hipStream_t st, const void *Apacked, const void *Bpacked
                         const GemmEpilogue &epi);
 int launch_gemm_bf16x3p_topk(hipStream_t st, const void *Apacked, const void *Bpacked, int M, int N, int K, int k,
                              float inv_temp, float *tile_max, float *tile_sum, float *cand_val, int *cand_idx);
-// EXPERIMENTAL 256x256-tile variant (gemm_bf16x3w.hip), opt-in with CAPDEC_X3_TILE=256, not yet validated on hardware
-bool gemm_bf16x3w_enabled();
-int launch_gemm_bf16x3w(hipStream_t st, const void *Apacked, const void *Bpacked, float *C, int ldc, int M, int N, int K,
-                        const GemmEpilogue &epi);
 // split-K of the packed-A kernel for under-filled grids: number of K slices (1 = none) and the workspace it needs
 int gemm_splitk_slices(int M, int N, int K);
 size_t gemm_splitk_ws_bytes(int M, int N, int K);
