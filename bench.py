@@ -119,11 +119,14 @@ def side_workload(args, world, rank, dev, emit=print):
     from capdec_amd.gpt2_prefix import ClipCaptionModel, MappingType
     from capdec_amd.predictions_runner import caption_ids
     P, T = args.prefix_length, args.entry_length
-    cm, _ = cclip.load(synth.hot_clip_state_dict(43), device=dev.index or 0)
+    prec = {"f16": "fp16", "bf16": "bf16"}.get(args.gemm_mode or "", "fp32")      # towers: fp32-accurate unless asked
+    cm, _ = cclip.load(synth.hot_clip_state_dict(43), device=dev.index or 0, precision=prec)
     text = args.workload == "text_embed"
     mt = MappingType.MLP if text else MappingType.TransformerEncoder
     model = ClipCaptionModel(P, clip_length=10, prefix_dim=512, num_layers=8, mapping_type=mt).to(dev).eval()
     model.load_state_dict(synth.hot_state_dict(42, "mlp" if text else "transformer_encoder", 512, P))
+    if args.gemm_mode:
+        model.engine.set_gemm_mode(args.gemm_mode)
     n_global = args.captions * world
     if text:
         inp = synth.synthetic_clip_tokens(n_global, seed=2).to(dev)
@@ -158,7 +161,8 @@ def side_workload(args, world, rank, dev, emit=print):
                                                  for k, v in prof.items() if v["launches"]},
                           "value": round(n_global * args.steps / dt, 2), "unit": "items/s", "n_gpus": world,
                           "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 2),
-                          "config": {"workload": args.workload, "items_per_step": n_global}}))
+                          "config": {"workload": args.workload, "items_per_step": n_global, "clip_precision": prec,
+                                     "gemm_mode": model.engine.gemm_mode()}}))
 
 
 def respawn_under_torchrun(n):
@@ -385,7 +389,7 @@ def main():
         mode = eng.gemm_mode()
         est = lambda f: f["ms"] * f["calls"] / f["launches"] if f and f["launches"] else 0.0
         if mode in ("bf16", "f16"):
-            fam, kname, peak = prof["gemm_bf16p"], "gemm_bf16p_kernel", PEAK_BF16_MFMA_TFLOPS
+            fam, kname, peak = prof["gemm_x1"], "gemm_x1_kernel", PEAK_BF16_MFMA_TFLOPS
             peak_note = "dense bf16 / fp16 MFMA peak (16-bit operands, one MFMA per product)"
             products = 1
         elif mode == "bf16x3":

@@ -83,8 +83,8 @@ enum Family { F_GEMM = 0, F_LMHEAD, F_ATTN_DEC, F_ATTN_PRE, F_LN, F_EMBED, F_SEL
               F_LMHEAD_X3, F_GEMM_X3P, F_GEMM_BF16P, F_LMHEAD_BF16, F_GEMM_H2P, F_LMHEAD_H2, F_PACK, F_COUNT };
 static const char *kFamilyNames[F_COUNT] = {"gemm_f32", "gemm_f32_lmhead_topk", "attn_decode", "attn_prefill",
                                             "layernorm", "embed", "select", "attn_mapper", "other", "gemm_bf16x3",
-                                            "gemm_bf16x3_lmhead_topk", "gemm_bf16x3p", "gemm_bf16p",
-                                            "gemm_bf16p_lmhead_topk", "gemm_f16x2p", "gemm_f16x2p_lmhead_topk",
+                                            "gemm_bf16x3_lmhead_topk", "gemm_bf16x3p", "gemm_x1",
+                                            "gemm_x1_lmhead_topk", "gemm_f16x2p", "gemm_f16x2p_lmhead_topk",
                                             "pack_activations"};
 constexpr int PROF_SLOTS = 24;   // capdec_profile_get fills at most this many families (engine.py sizes its arrays by it)
 static_assert(F_COUNT <= PROF_SLOTS, "profile arrays too small");
@@ -236,6 +236,10 @@ static int pack_fmt(const capdec_ctx *c) {
     }
 }
 static bool mode_single(const capdec_ctx *c) { return c->gemm_mode == GEMM_BF16 || c->gemm_mode == GEMM_F16; }
+static int gemm_single(capdec_ctx *c, const void *A, const void *B, float *C, int ldc, int M, int N, int K,
+                       const GemmEpilogue &e) {
+    return launch_gemm_x1(c->stream, A, B, C, ldc, M, N, K, e, pack_fmt(c));
+}
 static int pack_any(capdec_ctx *c, const float *W, int N, int K, int fmt, void *out) {
     if (fmt == PK_F16X2) return launch_pack_planes_h2(c->stream, W, K, N, K, out);
     if (fmt == PK_BF16X3) return launch_pack_planes(c->stream, W, N, K, out);
@@ -331,7 +335,7 @@ static int gemm_packed(capdec_ctx *c, const void *Apk, const float *W, float *C,
     }
     if (mode_single(c)) {   // one 16-bit plane per operand (bf16 / fp16), one MFMA per product
         ProfScope ps(c, F_GEMM_BF16P, 2.0 * M * (double)N * K);
-        return launch_gemm_bf16p(c->stream, Apk, pl, C, ldc, M, N, K, e, pack_fmt(c));
+        return gemm_single(c, Apk, pl, C, ldc, M, N, K, e);
     }
     if (c->gemm_mode == GEMM_F16X2) {   // two fp16 planes, three MFMAs per product (fp32-accurate)
         ProfScope ps(c, F_GEMM_H2P, 2.0 * M * (double)N * K);
@@ -459,8 +463,8 @@ static int lm_head_select(capdec_ctx *c, const float *h0, int ldh, int R, int k,
                                                c->tsum.as<float>(), c->cval.as<float>(), c->cidx.as<int>()));
         } else if (mode_single(c)) {
             ProfScope ps(c, F_LMHEAD_BF16, 2.0 * R * (double)g.vocab * d);
-            CAPDEC_TRY(launch_gemm_bf16p_topk(c->stream, c->xpk.p, pl, R, g.vocab, d, k, inv_temp, c->tmax.as<float>(),
-                                              c->tsum.as<float>(), c->cval.as<float>(), c->cidx.as<int>(), pack_fmt(c)));
+            CAPDEC_TRY(launch_gemm_x1_topk(c->stream, c->xpk.p, pl, R, g.vocab, d, k, inv_temp, c->tmax.as<float>(),
+                                           c->tsum.as<float>(), c->cval.as<float>(), c->cidx.as<int>(), pack_fmt(c)));
         } else {
             ProfScope ps(c, F_LMHEAD_X3, 2.0 * R * (double)g.vocab * d);
             CAPDEC_TRY(launch_gemm_bf16x3p_topk(c->stream, c->xpk.p, pl, R, g.vocab, d, k, inv_temp,
@@ -1262,7 +1266,7 @@ int capdec_gemm_f32(capdec_ctx *c, const float *a, int lda, const float *bt, int
         }
         if (mode_single(c)) {
             ProfScope ps(c, F_GEMM_BF16P, 2.0 * M * (double)N * K);
-            return launch_gemm_bf16p(c->stream, pa, pb, cc, ldc, M, N, K, e, pack_fmt(c));
+            return gemm_single(c, pa, pb, cc, ldc, M, N, K, e);
         }
         ProfScope ps(c, F_GEMM_X3P, 2.0 * M * (double)N * K);
         return launch_gemm_bf16x3p(c->stream, pa, pb, cc, ldc, M, N, K, e);

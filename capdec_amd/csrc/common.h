@@ -132,13 +132,13 @@ int launch_gemm_f16x2p(hipStream_t st, const void *Apacked, const void *Bpacked,
                        const GemmEpilogue &epi);
 int launch_gemm_f16x2p_topk(hipStream_t st, const void *Apacked, const void *Bpacked, int M, int N, int K, int k,
                             float inv_temp, float *tile_max, float *tile_sum, float *cand_val, int *cand_idx);
-// bf16 mode (gemm_bf16.hip): same packed operands, plane 0 only -- one bf16 MFMA per product, fp32 accumulate
-// (fmt: PackFmt of both operands -- PK_BF16X1 / PK_F16X1; the packed output uses the same format)
-int launch_gemm_bf16p(hipStream_t st, const void *Apacked, const void *Bpacked, float *C, int ldc, int M, int N, int K,
-                      const GemmEpilogue &epi, int fmt);
-int launch_gemm_bf16p_topk(hipStream_t st, const void *Apacked, const void *Bpacked, int M, int N, int K, int k,
-                           float inv_temp, float *tile_max, float *tile_sum, float *cand_val, int *cand_idx, int fmt);
+// generic packer for any PackFmt (gemm_f16x2.hip); the one-plane formats use it
 int launch_pack_planes_fmt(hipStream_t st, const float *w, int ldw, int N, int K, void *out, int fmt);
+// round-2 one-plane kernels on the f16x2 main loop (gemm_f16x2.hip): 128x128 tile, two blocks per CU, 32-deep stages
+int launch_gemm_x1(hipStream_t st, const void *Apacked, const void *Bpacked, float *C, int ldc, int M, int N, int K,
+                   const GemmEpilogue &epi, int fmt);
+int launch_gemm_x1_topk(hipStream_t st, const void *Apacked, const void *Bpacked, int M, int N, int K, int k,
+                        float inv_temp, float *tile_max, float *tile_sum, float *cand_val, int *cand_idx, int fmt);
 // LayerNorm whose output goes straight into the packed split-bf16 A format of the next GEMM (d % 16 == 0)
 int launch_layernorm_packed(hipStream_t st, const float *x, int ldx, const float *w, const float *b, float eps,
                             void *packed, int rows, int d, int fmt = 0);

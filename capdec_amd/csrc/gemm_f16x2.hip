@@ -82,7 +82,11 @@ __host__ __device__ constexpr int waitcnt_imm(int vm, int lgkm) {
 // am = sum hi_a hi_b, ac = sum (hi_a lo_b + lo_a hi_b) (weight 2^-11, applied by h2_join).
 // ABL (measurement only, CAPDEC_H2_ABL; results are WRONG for ABL != 0): 1 = no s_barrier in the loop, 2 = no LDS-DMA in
 // the loop, 3 = no fragment reads in the loop, 4 = neither barrier nor DMA
-template <bool TR, int NS, int ABL = 0>
+// KIND: 0 = f16x2 (the fp32-accurate scheme above).  1 / 2 = ONE-plane fp16 / bf16 operands (formats PK_F16X1 /
+// PK_BF16X1: the reduced-precision modes, one MFMA per product): the same ring, DMA pieces and fragment reads, but a
+// stage holds TWO consecutive k-steps of the single plane where f16x2 holds the two planes of one k-step (both are
+// 2 x 4 KB contiguous per operand), so a stage is 32 deep and carries 8 MFMAs per wavefront instead of 12.
+template <bool TR, int NS, int ABL = 0, int KIND = 0>
 __device__ __forceinline__ void h2p_mainloop(const _Float16 *__restrict__ Apk, const _Float16 *__restrict__ Bpk, int K,
                                              int tm, int tn, char *smem, f32x16 (&am)[2][2], f32x16 (&ac)[2][2],
                                              int ks0 = 0, int nks = -1) {
@@ -91,8 +95,8 @@ __device__ __forceinline__ void h2p_mainloop(const _Float16 *__restrict__ Apk, c
     const int lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int wm = wave >> 1, wn = wave & 1;
     const int half = lane >> 5, l32 = lane & 31;
-    const int nkf = K / X3_BK;                                                 // k-steps of the whole K (panel stride)
-    const int nk = nks < 0 ? nkf : nks;                                        // k-steps of THIS block, even
+    const int nkf = K / (KIND == 0 ? X3_BK : 2 * X3_BK);                       // stages of the whole K (panel stride)
+    const int nk = nks < 0 ? nkf : nks;                                        // stages of THIS block, even
     const _Float16 *ap = Apk + ((size_t)tm * nkf + ks0) * (H2_BLOCK_B / 2) + t * 8;   // this thread's 16-B piece
     const _Float16 *bp = Bpk + ((size_t)tn * nkf + ks0) * (H2_BLOCK_B / 2) + t * 8;
     char *dst0 = smem + wave * 1024;                                           // wave-uniform LDS base of its pieces
@@ -127,14 +131,17 @@ __device__ __forceinline__ void h2p_mainloop(const _Float16 *__restrict__ Apk, c
             F##b1[p] = *reinterpret_cast<const f16x8 *>(rs + p * X3_PLANE_B + b_rd + 32 * X3_ROW_B); \
         }                                                                                           \
     }
-#define H2_MM(x, y, c) (TR ? __builtin_amdgcn_mfma_f32_32x32x16_f16(y, x, c, 0, 0, 0)                 \
-                           : __builtin_amdgcn_mfma_f32_32x32x16_f16(x, y, c, 0, 0, 0))
+#define H2_MM1(x, y, c) (KIND == 2 ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, x), __builtin_bit_cast(bf16x8, y), c, 0, 0, 0) \
+                                   : __builtin_amdgcn_mfma_f32_32x32x16_f16(x, y, c, 0, 0, 0))
+#define H2_MM(x, y, c) (TR ? H2_MM1(y, x, c) : H2_MM1(x, y, c))
 #define H2_TERM(ACC, F, pa, pb)                                \
     ACC[0][0] = H2_MM(F##a0[pa], F##b0[pb], ACC[0][0]);        \
     ACC[0][1] = H2_MM(F##a0[pa], F##b1[pb], ACC[0][1]);        \
     ACC[1][0] = H2_MM(F##a1[pa], F##b0[pb], ACC[1][0]);        \
     ACC[1][1] = H2_MM(F##a1[pa], F##b1[pb], ACC[1][1]);
-#define H2_MFMAS(F) H2_TERM(ac, F, 1, 0) H2_TERM(am, F, 0, 0) H2_TERM(ac, F, 0, 1)
+#define H2_MFMAS(F)                                                                      \
+    if constexpr (KIND == 0) { H2_TERM(ac, F, 1, 0) H2_TERM(am, F, 0, 0) H2_TERM(ac, F, 0, 1) } \
+    else { H2_TERM(am, F, 0, 0) H2_TERM(am, F, 1, 1) }
     // (the s_waitcnt builtin, not inline asm: the compiler's own waitcnt pass must see that the fragment reads have
     //  completed, or it puts an lgkmcnt(0) in front of the next MFMAs -- behind the freshly issued reads)
 #define H2_SYNC()                                                                        \
@@ -145,13 +152,24 @@ __device__ __forceinline__ void h2p_mainloop(const _Float16 *__restrict__ Apk, c
     asm volatile("" ::: "memory");
     // one memory operation in the shadow of each MFMA: 8 fragment reads, then the 4 DMA pieces
 #define H2_INTERLEAVE()                                                                    \
-    _Pragma("unroll") for (int i_ = 0; i_ < 8; ++i_) {                                     \
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   /* 1 MFMA    */               \
-        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   /* 1 DS read */               \
-    }                                                                                      \
-    _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) {                                     \
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                 \
-        __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);   /* 1 VMEM (LDS-DMA piece) */  \
+    if constexpr (KIND == 0) {                                                             \
+        _Pragma("unroll") for (int i_ = 0; i_ < 8; ++i_) {                                 \
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   /* 1 MFMA    */           \
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   /* 1 DS read */           \
+        }                                                                                  \
+        _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) {                                 \
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                             \
+            __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);   /* 1 VMEM (LDS-DMA piece) */ \
+        }                                                                                  \
+    } else {   /* 8 MFMAs: 4 x (MFMA, 2 reads), 4 x (MFMA, 1 DMA piece) */                 \
+        _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) {                                 \
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                             \
+            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);                             \
+        }                                                                                  \
+        _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) {                                 \
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                             \
+            __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);                             \
+        }                                                                                  \
     }                                                                                      \
     __builtin_amdgcn_sched_barrier(0);
 
@@ -188,6 +206,7 @@ __device__ __forceinline__ void h2p_mainloop(const _Float16 *__restrict__ Apk, c
 #undef H2_READ
 #undef H2_TERM
 #undef H2_MM
+#undef H2_MM1
 #undef H2_MFMAS
 #undef H2_SYNC
 #undef H2_INTERLEAVE
@@ -326,6 +345,118 @@ int launch_gemm_f16x2p_topk(hipStream_t st, const void *Apacked, const void *Bpa
         default: CAPDEC_CHECK(false, "gemm_topk: k must be in 1..8");
     }
 #undef LAUNCH_TOPKH
+    CAPDEC_HIP(hipGetLastError());
+    return 0;
+}
+
+// ---- one-plane (reduced-precision) kernels on the same main loop: KIND 1 = fp16 operands, 2 = bf16 operands
+// (NS = 4: 64 KB, two blocks per CU; NS = 3: 48 KB and <= 168 registers, THREE blocks per CU -- CAPDEC_X1_NS picks)
+template <bool VEC4, int KIND, int NS>
+__global__ __launch_bounds__(256, (NS == 3 ? 3 : 2)) void gemm_x1_kernel(const _Float16 *__restrict__ Apk, const _Float16 *__restrict__ Bpk,
+                                                         float *C, int ldc, int M, int N, int K,
+                                                         const float *__restrict__ bias, const float *resid, int ldr,
+                                                         int act, int tiles_m, int tiles_n, char *packed_out, int out_fmt) {
+    __shared__ __attribute__((aligned(16))) char smem[NS * H2_STAGE_B];
+    int tm, tn;
+    tile_coords(tiles_m, tiles_n, tm, tn);
+    f32x16 am[2][2], ac[2][2];
+    h2p_mainloop<true, NS, 0, KIND>(Apk, Bpk, K, tm, tn, smem, am, ac);
+    if (packed_out)
+        epilogue_store_packed_t(am, packed_out, N >> 4, M, N, tm * GEMM_BM, tn * GEMM_BN, bias, act, out_fmt);
+    else
+        epilogue_store_t<VEC4>(am, C, ldc, M, N, tm * GEMM_BM, tn * GEMM_BN, bias, resid, ldr, act);
+}
+
+template <int KSEL, int KIND>
+__global__ __launch_bounds__(256, 2) void gemm_x1_topk_kernel(const _Float16 *__restrict__ Apk,
+                                                              const _Float16 *__restrict__ Bpk, int M, int N, int K,
+                                                              float inv_temp, float *tile_max, float *tile_sum,
+                                                              float *cand_val, int *cand_idx, int tiles_m, int tiles_n) {
+    __shared__ __attribute__((aligned(16))) char smem[H2Geo<H2_NS>::SMEM_B];
+    int tm, tn;
+    tile_coords(tiles_m, tiles_n, tm, tn);
+    f32x16 am[2][2], ac[2][2];
+    h2p_mainloop<false, H2_NS, 0, KIND>(Apk, Bpk, K, tm, tn, smem, am, ac);      // ends with a barrier
+    epilogue_topk<KSEL, 2, true>(am, reinterpret_cast<float *>(smem), M, N, tm * GEMM_BM, tn * GEMM_BN, tn, tiles_n, inv_temp,
+                                 tile_max, tile_sum, cand_val, cand_idx);
+}
+
+// fmt = PK_F16X1 or PK_BF16X1 (both operands; a packed output is written in the same format)
+int launch_gemm_x1(hipStream_t st, const void *Apacked, const void *Bpacked, float *C, int ldc, int M, int N, int K,
+                   const GemmEpilogue &epi, int fmt) {
+    CAPDEC_CHECK(M > 0 && N > 0 && K > 0 && K % 64 == 0, "gemm_x1: K must be a multiple of 64");
+    CAPDEC_CHECK(fmt == PK_F16X1 || fmt == PK_BF16X1, "gemm_x1: one-plane operand formats only");
+    CAPDEC_CHECK(epi.packed_out == nullptr ||
+                     (N % 64 == 0 && epi.resid == nullptr && ((uintptr_t)epi.bias & 15) == 0),
+                 "gemm_x1: packed output needs N % 64 == 0, a 16-byte aligned bias and no residual");
+    const int tiles_m = (M + GEMM_BM - 1) / GEMM_BM, tiles_n = (N + GEMM_BN - 1) / GEMM_BN;
+    const bool vec4 = N % 4 == 0 && ldc % 4 == 0 && ((uintptr_t)C & 15) == 0 &&
+                      (epi.bias == nullptr || ((uintptr_t)epi.bias & 15) == 0) &&
+                      (epi.resid == nullptr || (epi.ldr % 4 == 0 && ((uintptr_t)epi.resid & 15) == 0));
+    // three blocks per CU measured +3 % at 25 000 rows, +1.3 % on the greedy bf16 workload; CAPDEC_X1_NS=4: two blocks
+    static const int ns3 = [] { const char *e = getenv("CAPDEC_X1_NS"); return e && atoi(e) == 4 ? 0 : 1; }();
+#define LAUNCH_X1V(V4, KD, NSV)                                                                                         \
+    hipLaunchKernelGGL((gemm_x1_kernel<V4, KD, NSV>), dim3(tiles_m * tiles_n), dim3(256), 0, st, (const _Float16 *)Apacked, \
+                       (const _Float16 *)Bpacked, C, ldc, M, N, K, epi.bias, epi.resid, epi.ldr, epi.act, tiles_m,      \
+                       tiles_n, (char *)epi.packed_out, fmt)
+#define LAUNCH_X1K(KD)                                                                        \
+    if (vec4) { if (ns3) LAUNCH_X1V(true, KD, 3); else LAUNCH_X1V(true, KD, 4); }             \
+    else LAUNCH_X1V(false, KD, 4)
+    if (fmt == PK_F16X1) { LAUNCH_X1K(1); } else { LAUNCH_X1K(2); }
+#undef LAUNCH_X1K
+#undef LAUNCH_X1V
+    CAPDEC_HIP(hipGetLastError());
+    return 0;
+}
+
+int launch_gemm_x1_topk(hipStream_t st, const void *Apacked, const void *Bpacked, int M, int N, int K, int k,
+                        float inv_temp, float *tile_max, float *tile_sum, float *cand_val, int *cand_idx, int fmt) {
+    CAPDEC_CHECK(M > 0 && N > 0 && K > 0 && K % 64 == 0, "gemm_x1_topk: K must be a multiple of 64");
+    CAPDEC_CHECK(fmt == PK_F16X1 || fmt == PK_BF16X1, "gemm_x1_topk: one-plane operand formats only");
+    const int tiles_m = (M + GEMM_BM - 1) / GEMM_BM, tiles_n = (N + GEMM_BN - 1) / GEMM_BN;
+    dim3 grid(tiles_m * tiles_n), block(256);
+#define LAUNCH_TOPKX(KS)                                                                                              \
+    if (fmt == PK_F16X1)                                                                                              \
+        hipLaunchKernelGGL((gemm_x1_topk_kernel<KS, 1>), grid, block, 0, st, (const _Float16 *)Apacked,                \
+                           (const _Float16 *)Bpacked, M, N, K, inv_temp, tile_max, tile_sum, cand_val, cand_idx, tiles_m, tiles_n); \
+    else                                                                                                              \
+        hipLaunchKernelGGL((gemm_x1_topk_kernel<KS, 2>), grid, block, 0, st, (const _Float16 *)Apacked,                \
+                           (const _Float16 *)Bpacked, M, N, K, inv_temp, tile_max, tile_sum, cand_val, cand_idx, tiles_m, tiles_n)
+    switch (k) {
+        case 1: LAUNCH_TOPKX(1); break;
+        case 2: LAUNCH_TOPKX(2); break;
+        case 3: LAUNCH_TOPKX(3); break;
+        case 4: LAUNCH_TOPKX(4); break;
+        case 5: LAUNCH_TOPKX(5); break;
+        case 6: LAUNCH_TOPKX(6); break;
+        case 7: LAUNCH_TOPKX(7); break;
+        case 8: LAUNCH_TOPKX(8); break;
+        default: CAPDEC_CHECK(false, "gemm_topk: k must be in 1..8");
+    }
+#undef LAUNCH_TOPKX
+    CAPDEC_HIP(hipGetLastError());
+    return 0;
+}
+
+// generic packer (any PackFmt): fp32 [N, K] (row stride ldw) -> tile-major planes, rows past N zero.  One thread per
+// (padded row, quad of 4 k); used for the one-plane formats (the split formats have their own 16-byte-store packers)
+__global__ void pack_planes_fmt_kernel(const float *__restrict__ w, int ldw, char *__restrict__ out, int N, int K,
+                                       int rows_pad, int fmt) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int nq = K >> 2;
+    if (i >= (size_t)rows_pad * nq) return;
+    const int row = (int)(i / nq), qd = (int)(i - (size_t)row * nq);
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (row < N) v = *reinterpret_cast<const float4 *>(w + (size_t)row * ldw + qd * 4);
+    x3_store_quad(out, K >> 4, row, qd >> 2, qd & 3, v, fmt);
+}
+
+int launch_pack_planes_fmt(hipStream_t st, const float *w, int ldw, int N, int K, void *out, int fmt) {
+    CAPDEC_CHECK(K % 64 == 0 && ldw % 4 == 0, "pack_planes: K must be a multiple of 64");
+    const int rows_pad = (N + 127) / 128 * 128;
+    const size_t tot = (size_t)rows_pad * (K >> 2);
+    hipLaunchKernelGGL(pack_planes_fmt_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, w, ldw, (char *)out,
+                       N, K, rows_pad, fmt);
     CAPDEC_HIP(hipGetLastError());
     return 0;
 }
