@@ -13,6 +13,10 @@ from collections import defaultdict
 
 
 def short(name: str) -> str:
+    m = re.match(r"_ZN6capdec(\d+)", name)       # rocprofv3 leaves some template kernels mangled: _ZN6capdec<len><name>I...
+    if m:
+        n = int(m.group(1))
+        return name[m.end():m.end() + n]
     name = re.sub(r"^void ", "", name)
     name = re.sub(r"\(.*$", "", name)          # drop the argument list
     return name.replace("capdec::", "")
