@@ -149,6 +149,10 @@ __global__ __launch_bounds__(256) void attn_gpt2_kernel(const float *__restrict_
     }
 }
 
+constexpr float ATT_QSCALE = 0.125f * 1.4426950408889634f;          // 1/sqrt(head_dim) * log2(e)
+constexpr float ATT_NEG = -1.0e30f;                                 // "no score yet": finite, so max - max never is inf - inf
+__device__ __forceinline__ float att_exp2(float x) { return __builtin_amdgcn_exp2f(x); }   // v_exp_f32; 2^-inf = 0
+
 // Beam-shared decode attention: one wavefront per (caption, head) serves all BEAM rows of the caption.
 // The beams of a caption mostly share their ancestors (the whole prefix, and usually all but the last
 // few generated positions), so K/V of position p are loaded once per DISTINCT physical slot among
@@ -160,7 +164,7 @@ __global__ __launch_bounds__(256) void attn_gpt2_kernel(const float *__restrict_
 // trips of the former scores -> LDS -> softmax -> P.V structure), no score ever goes through LDS and there is no
 // block barrier in the loop; the four partial softmaxes are merged once at the end (max / rescale / sum across the
 // groups).  LDS only holds the caption's ancestor-slot table.
-template <int BEAM, typename KV, int OCC>
+template <int BEAM, typename KV, int OCC, int NA = 2>
 __global__ __launch_bounds__(256, OCC) void attn_decode_beams_kernel(const float *__restrict__ qkv, KV *__restrict__ kc,
                                                                 KV *__restrict__ vc, int total, int heads,
                                                                 int ctx, int d, int L,
@@ -193,7 +197,10 @@ __global__ __launch_bounds__(256, OCC) void attn_decode_beams_kernel(const float
     for (int b = 0; b < BEAM; ++b) {
         const float *qrow = qkv + (size_t)(row0 + b) * 3 * d;
         q[b] = reinterpret_cast<const float4 *>(qrow + head * 64)[sub];
-        q[b].x *= 0.125f; q[b].y *= 0.125f; q[b].z *= 0.125f; q[b].w *= 0.125f;
+        // scores are kept in the log2 domain (q pre-scaled by 1/sqrt(64) * log2 e): the softmax weights are then ONE
+        // v_exp_f32 each (2^x, ~1 ulp) instead of an expf call -- every lane of a 16-lane group evaluates its group's
+        // weights, so the exponential is the dominant VALU cost of this kernel
+        q[b].x *= ATT_QSCALE; q[b].y *= ATT_QSCALE; q[b].z *= ATT_QSCALE; q[b].w *= ATT_QSCALE;
         // the row's own key / value: appended to the cache at its own slot; group 0 starts its running softmax with it
         const float4 kcur = KvIo<KV>::round4(reinterpret_cast<const float4 *>(qrow + d + head * 64)[sub]);
         const float4 vcur = KvIo<KV>::round4(reinterpret_cast<const float4 *>(qrow + 2 * d + head * 64)[sub]);
@@ -203,14 +210,14 @@ __global__ __launch_bounds__(256, OCC) void attn_decode_beams_kernel(const float
             KvIo<KV>::st4(vc + o, vcur);
         }
         const float s = group16_sum(dot4(q[b], kcur));
-        mrun[b] = grp == 0 ? s : -INFINITY;
+        mrun[b] = grp == 0 ? s : ATT_NEG;
         lrun[b] = grp == 0 ? 1.f : 0.f;
         acc[b] = grp == 0 ? vcur : make_float4(0.f, 0.f, 0.f, 0.f);
     }
     __syncthreads();                                               // slot table visible
     const KV *kbase = kc + ((size_t)srow0 * heads + head) * hstride + sub * 4;
     const KV *vbase = vc + ((size_t)srow0 * heads + head) * hstride + sub * 4;
-    const size_t slot_stride = (size_t)heads * hstride;
+    const int slot_stride = heads * ctx * 64;      // offsets inside one caption's K / V region fit 32 bits (<= 8 x 16 x 256 x 64)
     // The beams of a caption are paths of one tree: if they all sit on the same node at position p they share every
     // earlier position too, so "all beams read the same slot" holds exactly on a PREFIX [0, nconv) of the history
     // (the CLIP prefix and the converged part of the generated text).  Phase A streams that prefix without any
@@ -230,41 +237,39 @@ __global__ __launch_bounds__(256, OCC) void attn_decode_beams_kernel(const float
     // online-softmax update of beam b with NP (score, value) pairs of this group; sv[j] = -inf marks "no position"
 #define ATT_UPDATE(b, NP, sv, xv)                                                                        \
     {                                                                                                    \
-        float mx_ = mrun[b];                                                                             \
-        _Pragma("unroll") for (int j_ = 0; j_ < NP; ++j_) mx_ = fmaxf(mx_, sv[j_]);                      \
-        if (mx_ > -INFINITY) {                                                                           \
-            const float sc_ = expf(mrun[b] - mx_);      /* 0 while this group has seen nothing */        \
-            float ls_ = lrun[b] * sc_;                                                                   \
-            float4 a_ = make_float4(acc[b].x * sc_, acc[b].y * sc_, acc[b].z * sc_, acc[b].w * sc_);     \
-            _Pragma("unroll") for (int j_ = 0; j_ < NP; ++j_) {                                          \
-                const float w_ = expf(sv[j_] - mx_);    /* exp(-inf) = 0 for masked positions */         \
-                ls_ += w_;                                                                               \
-                a_.x += w_ * xv[j_].x; a_.y += w_ * xv[j_].y; a_.z += w_ * xv[j_].z; a_.w += w_ * xv[j_].w; \
-            }                                                                                            \
-            mrun[b] = mx_; lrun[b] = ls_; acc[b] = a_;                                                   \
+        float mx_ = fmaxf(mrun[b], ATT_NEG);          /* branch-free: a group that has seen nothing keeps */ \
+        _Pragma("unroll") for (int j_ = 0; j_ < NP; ++j_) mx_ = fmaxf(mx_, sv[j_]);   /* max = ATT_NEG, weights 2^-inf = 0 */ \
+        const float sc_ = att_exp2(mrun[b] - mx_);                                                       \
+        float ls_ = lrun[b] * sc_;                                                                       \
+        float4 a_ = make_float4(acc[b].x * sc_, acc[b].y * sc_, acc[b].z * sc_, acc[b].w * sc_);         \
+        _Pragma("unroll") for (int j_ = 0; j_ < NP; ++j_) {                                              \
+            const float w_ = att_exp2(sv[j_] - mx_);      /* 2^-inf = 0 for masked positions */          \
+            ls_ += w_;                                                                                   \
+            a_.x += w_ * xv[j_].x; a_.y += w_ * xv[j_].y; a_.z += w_ * xv[j_].z; a_.w += w_ * xv[j_].w;  \
         }                                                                                                \
+        mrun[b] = mx_; lrun[b] = ls_; acc[b] = a_;                                                       \
     }
-    // ---- phase A: converged prefix, two positions per group per iteration: 2 K + 2 V loads in flight per lane
-    for (int p0 = 0; p0 < nconv; p0 += 8) {
-        int pp[2];
-        float4 kk[2], vv[2];
+    // ---- phase A: converged prefix, NA positions per group per iteration: NA K + NA V loads in flight per lane
+    for (int p0 = 0; p0 < nconv; p0 += 4 * NA) {
+        int pp[NA];
+        float4 kk[NA], vv[NA];
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
+        for (int j = 0; j < NA; ++j) {
             pp[j] = p0 + 4 * j + grp;
             const bool v = pp[j] < nconv;
-            const size_t o = v ? (size_t)sl[pp[j]] * slot_stride + (size_t)pp[j] * 64 : 0;
+            const int o = v ? sl[pp[j]] * slot_stride + pp[j] * 64 : 0;
             kk[j] = KvIo<KV>::ld4(v ? kbase + o : dummy);
             vv[j] = KvIo<KV>::ld4(v ? vbase + o : dummy);
         }
 #pragma unroll
         for (int b = 0; b < BEAM; ++b) {
-            float sv[2];
+            float sv[NA];
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
+            for (int j = 0; j < NA; ++j) {
                 const float t = group16_sum(dot4(q[b], kk[j]));
                 sv[j] = pp[j] < nconv ? t : -INFINITY;
             }
-            ATT_UPDATE(b, 2, sv, vv)
+            ATT_UPDATE(b, NA, sv, vv)
         }
     }
     // ---- phase B: diverged tail, one position per group per iteration.  All 2 x BEAM loads are issued back to back
@@ -280,7 +285,7 @@ __global__ __launch_bounds__(256, OCC) void attn_decode_beams_kernel(const float
 #pragma unroll
         for (int b = 0; b < BEAM; ++b) {
             const bool na = va && (b == 0 || sa[b] != sa[b - 1]);
-            const size_t o = (size_t)sa[b] * slot_stride + (size_t)pa * 64;
+            const int o = sa[b] * slot_stride + pa * 64;
             ka[b] = KvIo<KV>::ld4(na ? kbase + o : dummy);
             xa[b] = KvIo<KV>::ld4(na ? vbase + o : dummy);
         }
@@ -301,7 +306,7 @@ __global__ __launch_bounds__(256, OCC) void attn_decode_beams_kernel(const float
         float M = mrun[b];
         M = fmaxf(M, __shfl_xor(M, 16, 64));
         M = fmaxf(M, __shfl_xor(M, 32, 64));                       // finite: group 0 holds the row's own token
-        const float sc = expf(mrun[b] - M);
+        const float sc = att_exp2(mrun[b] - M);
         const float lt = groups4_sum(lrun[b] * sc);
         float4 a = make_float4(acc[b].x * sc, acc[b].y * sc, acc[b].z * sc, acc[b].w * sc);
         a.x = groups4_sum(a.x); a.y = groups4_sum(a.y); a.z = groups4_sum(a.z); a.w = groups4_sum(a.w);
@@ -469,9 +474,14 @@ static int attn_decode_typed(hipStream_t st, const float *qkv, const KvCache &c,
         // waves per SIMD the register allocation is sized for: beam <= 4 fits 4 without spilling; beam 5 needs 132
         // registers (4 waves: 128 + 4 spilled dwords; 3 waves: no spill) -- CAPDEC_ATT_OCC picks, default = measured best
         static const int occ5 = [] { const char *e = getenv("CAPDEC_ATT_OCC"); return e && atoi(e) == 3 ? 3 : 4; }();
+        static const int na4 = [] { const char *e = getenv("CAPDEC_ATT_NA"); return e && atoi(e) == 4 ? 1 : 0; }();
 #define LAUNCH_BEAMS(B, OCC)                                                                                    \
-    hipLaunchKernelGGL((attn_decode_beams_kernel<B, KV, OCC>), grid, block, lds, st, qkv, kl, vl, total, c.heads, c.ctx, \
-                       c.heads * c.hd, L, anc, anc_stride, out, (char *)packed_out, cmap, fmt)
+    if (na4 && B <= 5)                                                                                          \
+        hipLaunchKernelGGL((attn_decode_beams_kernel<B, KV, OCC, 4>), grid, block, lds, st, qkv, kl, vl, total, c.heads, \
+                           c.ctx, c.heads * c.hd, L, anc, anc_stride, out, (char *)packed_out, cmap, fmt);       \
+    else                                                                                                        \
+        hipLaunchKernelGGL((attn_decode_beams_kernel<B, KV, OCC>), grid, block, lds, st, qkv, kl, vl, total, c.heads, \
+                           c.ctx, c.heads * c.hd, L, anc, anc_stride, out, (char *)packed_out, cmap, fmt)
         switch (beam) {
             case 2: LAUNCH_BEAMS(2, 4); break;
             case 3: LAUNCH_BEAMS(3, 4); break;
