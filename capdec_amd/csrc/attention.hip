@@ -50,105 +50,6 @@ template <> struct KvIo<__bf16> {
     }
 };
 
-// DECODE = true : rows = captions*beam, every row at context length L; own k/v (position L-1)
-//                 taken from qkv and appended to the cache at phys row r.
-// DECODE = false: prefill rows (caption, i), L = i + 1, everything read from the cache at phys
-//                 row caption*beam (written by kv_scatter_prefill beforehand).
-template <bool DECODE, typename KV>
-__global__ __launch_bounds__(256) void attn_gpt2_kernel(const float *__restrict__ qkv, KV *__restrict__ kc,
-                                                        KV *__restrict__ vc, int total, int heads, int ctx,
-                                                        int d, int beam, int Lparam, int P, int causal,
-                                                        const uint8_t *__restrict__ anc, int anc_stride,
-                                                        float *__restrict__ out, char *__restrict__ packed_out,
-                                                        const int *__restrict__ cmap, int fmt) {
-    __shared__ float sc[4][ATT_CTX_MAX];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int grp = lane >> 4, sub = lane & 15;
-    const int gw = blockIdx.x * 4 + wave;
-    const bool active = gw < total;
-    const int row = active ? gw / heads : 0;
-    const int head = active ? gw - row * heads : 0;
-    // state row: after finished captions were compacted away, activation row r belongs to caption cmap[r / beam]
-    // (KV cache, ancestor table and beam state keep the ORIGINAL caption indexing)
-    const int srow = (DECODE && cmap) ? cmap[row / beam] * beam + row % beam : row;
-    int L, phys_self;
-    if (DECODE) {
-        L = Lparam;
-        phys_self = srow;
-    } else {
-        const int cap = row / P, i = row - cap * P;
-        L = causal ? i + 1 : P;                  // CLIP's vision tower attends to the whole sequence
-        phys_self = cap * beam;
-    }
-    const int cap_base = DECODE ? (srow / beam) * beam : phys_self;
-    const size_t hstride = (size_t)ctx * 64;
-    const float *qrow = qkv + (size_t)row * 3 * d;
-    float4 q = reinterpret_cast<const float4 *>(qrow + head * 64)[sub];
-    q.x *= 0.125f; q.y *= 0.125f; q.z *= 0.125f; q.w *= 0.125f;     // 1/sqrt(64), exact
-    float4 kcur, vcur;
-    const int Lpast = DECODE ? L - 1 : L;
-    if (DECODE) {
-        kcur = KvIo<KV>::round4(reinterpret_cast<const float4 *>(qrow + d + head * 64)[sub]);
-        vcur = KvIo<KV>::round4(reinterpret_cast<const float4 *>(qrow + 2 * d + head * 64)[sub]);
-        if (active && grp == 0) {
-            const size_t o = ((size_t)phys_self * heads + head) * hstride + (size_t)(L - 1) * 64;
-            KvIo<KV>::st4(kc + o + sub * 4, kcur);
-            KvIo<KV>::st4(vc + o + sub * 4, vcur);
-        }
-    }
-    // ---- scores
-    for (int p0 = 0; p0 < Lpast; p0 += 4) {
-        const int p = p0 + grp;
-        if (p < Lpast) {
-            int phys = phys_self;
-            if (DECODE && anc) phys = cap_base + anc[(size_t)srow * anc_stride + p];
-            const float4 k = KvIo<KV>::ld4(kc + ((size_t)phys * heads + head) * hstride + (size_t)p * 64 + sub * 4);
-            const float s = group16_sum(dot4(q, k));
-            if (sub == 0) sc[wave][p] = s;
-        }
-    }
-    if (DECODE) {
-        const float s = group16_sum(dot4(q, kcur));
-        if (lane == 0) sc[wave][L - 1] = s;
-    }
-    __syncthreads();
-    // ---- softmax statistics over L positions
-    float mx = -INFINITY;
-    for (int p = lane; p < L; p += 64) mx = fmaxf(mx, sc[wave][p]);
-    mx = wave_max(mx);
-    float sum = 0.f;
-    for (int p = lane; p < L; p += 64) {
-        const float e = expf(sc[wave][p] - mx);
-        sc[wave][p] = e;
-        sum += e;
-    }
-    sum = wave_sum(sum);
-    __syncthreads();
-    // ---- P.V
-    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int p0 = 0; p0 < Lpast; p0 += 4) {
-        const int p = p0 + grp;
-        if (p < Lpast) {
-            int phys = phys_self;
-            if (DECODE && anc) phys = cap_base + anc[(size_t)srow * anc_stride + p];
-            const float4 v = KvIo<KV>::ld4(vc + ((size_t)phys * heads + head) * hstride + (size_t)p * 64 + sub * 4);
-            const float w = sc[wave][p];
-            acc.x += w * v.x; acc.y += w * v.y; acc.z += w * v.z; acc.w += w * v.w;
-        }
-    }
-    if (DECODE && grp == 0) {
-        const float w = sc[wave][L - 1];
-        acc.x += w * vcur.x; acc.y += w * vcur.y; acc.z += w * vcur.z; acc.w += w * vcur.w;
-    }
-    acc.x = groups4_sum(acc.x); acc.y = groups4_sum(acc.y); acc.z = groups4_sum(acc.z); acc.w = groups4_sum(acc.w);
-    if (active && grp == 0) {
-        const float inv = 1.0f / sum;
-        const float4 o = make_float4(acc.x * inv, acc.y * inv, acc.z * inv, acc.w * inv);
-        if (packed_out) x3_store_quad(packed_out, d >> 4, row, head * 4 + (sub >> 2), sub & 3, o, fmt);   // A operand of c_proj
-        else reinterpret_cast<float4 *>(out + (size_t)row * d + head * 64)[sub] = o;
-    }
-}
-
 constexpr float ATT_QSCALE = 0.125f * 1.4426950408889634f;          // 1/sqrt(head_dim) * log2(e)
 constexpr float ATT_NEG = -1.0e30f;                                 // "no score yet": finite, so max - max never is inf - inf
 __device__ __forceinline__ float att_exp2(float x) { return __builtin_amdgcn_exp2f(x); }   // v_exp_f32; 2^-inf = 0
@@ -186,9 +87,10 @@ __global__ __launch_bounds__(256, OCC) void attn_decode_beams_kernel(const float
     const int Lpast = L - 1;
 
     // ancestor slots of this caption -> LDS (removes the dependent byte load in front of every K/V load)
+    // (anc == nullptr: greedy decode -- one row per caption, everything in its own slot 0)
     for (int i = lane; i < BEAM * Lpast; i += 64) {
         const int b = i / Lpast, p = i - b * Lpast;
-        sl[b * L + p] = anc[(size_t)(srow0 + b) * anc_stride + p];
+        sl[b * L + p] = anc ? anc[(size_t)(srow0 + b) * anc_stride + p] : 0;
     }
 
     float4 q[BEAM], acc[BEAM];
@@ -466,13 +368,13 @@ static int attn_decode_typed(hipStream_t st, const float *qkv, const KvCache &c,
                              const uint8_t *anc, int anc_stride, float *out, void *packed_out, const int *cmap,
                              int fmt) {
     KV *kl = c.kp<KV>(layer), *vl = c.vp<KV>(layer);
-    if (anc != nullptr && beam > 1) {
+    {
         const int ncap = rows / beam, total = ncap * c.heads;
         if (total <= 0) return 0;
-        const size_t lds = (size_t)4 * beam * L * sizeof(int);   // ancestor slots
+        size_t lds = (size_t)4 * beam * L * sizeof(int);   // ancestor slots
         dim3 grid((total + 3) / 4), block(256);
-        // waves per SIMD the register allocation is sized for: beam <= 4 fits 4 without spilling; beam 5 needs 132
-        // registers (4 waves: 128 + 4 spilled dwords; 3 waves: no spill) -- CAPDEC_ATT_OCC picks, default = measured best
+        // waves per SIMD the register allocation is sized for: beam <= 4 fits 4 without spilling; beam 5 needs 124
+        // registers at 4 waves; CAPDEC_ATT_OCC=3 / CAPDEC_ATT_NA=4 are measurement knobs (default = measured best)
         static const int occ5 = [] { const char *e = getenv("CAPDEC_ATT_OCC"); return e && atoi(e) == 3 ? 3 : 4; }();
         static const int na4 = [] { const char *e = getenv("CAPDEC_ATT_NA"); return e && atoi(e) == 4 ? 1 : 0; }();
 #define LAUNCH_BEAMS(B, OCC)                                                                                    \
@@ -483,6 +385,7 @@ static int attn_decode_typed(hipStream_t st, const float *qkv, const KvCache &c,
         hipLaunchKernelGGL((attn_decode_beams_kernel<B, KV, OCC>), grid, block, lds, st, qkv, kl, vl, total, c.heads, \
                            c.ctx, c.heads * c.hd, L, anc, anc_stride, out, (char *)packed_out, cmap, fmt)
         switch (beam) {
+            case 1: LAUNCH_BEAMS(1, 4); break;      // greedy: the same single-pass kernel with one row per caption
             case 2: LAUNCH_BEAMS(2, 4); break;
             case 3: LAUNCH_BEAMS(3, 4); break;
             case 4: LAUNCH_BEAMS(4, 4); break;
@@ -496,12 +399,6 @@ static int attn_decode_typed(hipStream_t st, const float *qkv, const KvCache &c,
         CAPDEC_HIP(hipGetLastError());
         return 0;
     }
-    const int total = rows * c.heads;
-    if (total <= 0) return 0;
-    hipLaunchKernelGGL((attn_gpt2_kernel<true, KV>), dim3((total + 3) / 4), dim3(256), 0, st, qkv, kl, vl, total, c.heads,
-                       c.ctx, c.heads * c.hd, beam, L, 0, 1, anc, anc_stride, out, (char *)packed_out, cmap, fmt);
-    CAPDEC_HIP(hipGetLastError());
-    return 0;
 }
 
 int launch_attn_decode(hipStream_t st, const float *qkv, const KvCache &c, int layer, int rows, int beam, int L,
