@@ -1,4 +1,6 @@
 #!/bin/bash
+# (historical: the CAPDEC_ATT_SPLIT_MAX variant this probe compared was measured slower at every size and removed; the
+#  script still prints the batch-size curve 625 / 1250 / 2500 captions quoted in profiles/r2_gemm_ablations.txt)
 set -u
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$R/gpurun_out
