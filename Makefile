@@ -8,7 +8,7 @@ test-gpu: build
 	python -m pytest tests -q -m gpu
 bench: build
 	python bench.py
-profiles:            # on an MI355X box; then copy gpurun_out/r1_* into profiles/
-	bash tools/collect_profiles.sh r1
+profiles:            # on an MI355X box; then copy gpurun_out/r2_* into profiles/
+	bash tools/collect_profiles.sh r2
 golden:              # needs /root/reference and PIL (build container only)
 	python tools/gen_golden.py

@@ -54,15 +54,20 @@ void capdec_destroy(capdec_ctx *ctx);
 int capdec_set_stream(capdec_ctx *ctx, void *hip_stream);
 int capdec_use_own_stream(capdec_ctx *ctx);
 int capdec_synchronize(capdec_ctx *ctx);
-/* how the dense projections run: 0 = native fp32 MFMA (v_mfma_f32_32x32x2_f32, exact fma chain);
- * 1 = fp32-accurate split-bf16 ("bf16x3": operands split into three bf16 planes, six
- * v_mfma_f32_32x32x16_bf16 per product, fp32 accumulate; 2.7x the MFMA throughput, same fp32
- * round-off class: every parity test passes in both modes);
- * 2 = bf16 operands (BASELINE configs[1]): weights and GEMM-input activations of the GPT-2 / CLIP block stacks and
- * the lm_head rounded to bf16 (RNE), ONE MFMA per product, fp32 accumulate; residual stream, LayerNorm, softmax, KV
- * cache and the mapper GEMMs stay fp32-accurate.  Not bit-comparable with the fp32 reference (tolerance tests).
- * Default 1; the environment variable CAPDEC_GEMM_MODE=f32|bf16x3|bf16 overrides it at capdec_create. */
-enum { CAPDEC_GEMM_F32 = 0, CAPDEC_GEMM_BF16X3 = 1, CAPDEC_GEMM_BF16 = 2 };
+/* how the dense projections (GPT-2 / CLIP block stacks, lm_head) run:
+ * 3 = "f16x2" (DEFAULT): fp32-accurate -- every fp32 operand is two fp16 planes (a = hi + 2^-11 lo), THREE
+ *     v_mfma_f32_32x32x16_f16 per product, fp32 accumulate; error below the rounding noise of an fp32 GEMM, every
+ *     parity test (token ids bit-identical to the fp32 reference) passes; GEMM inputs are clamped to +-65504;
+ * 1 = "bf16x3": fp32-accurate, three bf16 planes, six v_mfma_f32_32x32x16_bf16 per product (round-1 scheme, A/B);
+ * 0 = native fp32 MFMA (v_mfma_f32_32x32x2_f32, exact fma chain);
+ * 2 = "bf16" (BASELINE configs[1]): weights and GEMM-input activations rounded to bf16 (RNE) and a bf16 KV cache, ONE
+ *     MFMA per product, fp32 accumulate; residual stream, LayerNorm and softmax stay fp32.  Not bit-comparable with
+ *     the fp32 reference (teacher-forced tolerance tests, capdec_decode_greedy_forced);
+ * 4 = "f16": fp16 GEMM operands, fp32 everything else (KV cache included): the precision class of the reference's
+ *     CLIP towers on a GPU (clip.load converts to fp16).
+ * The mapper, patch-embedding and projection GEMMs are fp32-accurate in every mode.
+ * The environment variable CAPDEC_GEMM_MODE=f16x2|bf16x3|f32|bf16|f16 overrides the default at capdec_create. */
+enum { CAPDEC_GEMM_F32 = 0, CAPDEC_GEMM_BF16X3 = 1, CAPDEC_GEMM_BF16 = 2, CAPDEC_GEMM_F16X2 = 3, CAPDEC_GEMM_F16 = 4 };
 int capdec_set_gemm_mode(capdec_ctx *ctx, int mode);
 int capdec_get_gemm_mode(capdec_ctx *ctx);
 /* cap on bytes the decode KV cache may take (captions are processed in chunks that fit);
