@@ -242,10 +242,17 @@ def test_decode_p40_tiny(golden):
     g = golden("decode_p40_tiny")
     dims = synth.GPT2_TINY
     for mapping in ("mlp", "transformer_encoder"):
-        sd = synth.hot_state_dict(11, mapping, 640, 40, 40, 2, dims)
-        assert synth.state_dict_checksum(sd) == int(g[f"{mapping}_crc"]), "RNG drift"
-        pe = O.clip_project(T(g[f"{mapping}_x"]), sd, mapping, 40, 40, 2)
-        np.testing.assert_allclose(pe.numpy(), g[f"{mapping}_prefix_embed"], atol=3e-4)
+        if mapping == "mlp":
+            # the P = 40 MLP mapper is 472 M parameters (640 -> 15360 -> 30720): regenerating and hashing it costs more
+            # than the rest of the CPU suite together, so here only the GPT-2 half is rebuilt (independent generator
+            # stream, synth.hot_state_dict) and the decode starts from the fixture's prefix; the mapper itself is pinned
+            # at this geometry on the GPU (test_decode_p40_notebook_geometry) and at P = 10 above
+            sd = synth.hot_gpt2_state_dict(11, dims)
+        else:
+            sd = synth.hot_state_dict(11, mapping, 640, 40, 40, 2, dims)
+            assert synth.state_dict_checksum(sd) == int(g[f"{mapping}_crc"]), "RNG drift"
+            pe = O.clip_project(T(g[f"{mapping}_x"]), sd, mapping, 40, 40, 2)
+            np.testing.assert_allclose(pe.numpy(), g[f"{mapping}_prefix_embed"], atol=3e-4)
         pe = T(g[f"{mapping}_prefix_embed"])
         ids, lens = O.greedy_cached(sd, pe, stop_id=dims.vocab + 5, entry_length=67, alt_stop_id=764)
         np.testing.assert_array_equal(ids.numpy(), g[f"{mapping}_greedy_ids"])
