@@ -454,6 +454,8 @@ def main():
                          "mfma_tflops_executed": round(achieved * products, 1) if products else None,
                          "mfma_frac_of_dense_peak": round(achieved * products / PEAK_BF16_MFMA_TFLOPS, 4) if products else None,
                          "vs_native_f32_mfma_peak": round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
+                         # the same achieved rate against round 1's ceiling (six bf16 MFMAs per fp32 product: 2500 / 6)
+                         "vs_six_product_ceiling_416_7": round(achieved / (PEAK_BF16_MFMA_TFLOPS / 6.0), 4),
                          "whole_path_tflops": round(alg / dt / 1e12, 2)},
             # per family: ms_est = hipEvent time of the timed launches scaled to all launches of the timed region
             "kernels": {k: {"ms_est": round(v["ms"] * v["calls"] / v["launches"], 2), "launches": v["calls"],
