@@ -314,9 +314,12 @@ static bool use_packed_a(capdec_ctx *c, int K) {
 
 // C = act(Apk . W^T + bias) + resid with A already packed; packed_out != nullptr: the result is written as the
 // packed A operand of the next GEMM instead of fp32 C
+// (next_ln: the LayerNorm that follows this GEMM in the block stack; when the launch splits K it is fused into the
+//  reduce pass, its packed output lands in c->xpk and *ln_done is set -- see GemmEpilogue)
+struct NextLn { const float *w, *b; float eps; int *done; };
 static int gemm_packed(capdec_ctx *c, const void *Apk, const float *W, float *C, int ldc, int M, int N, int K,
                        const float *bias, int act, const float *resid = nullptr, int ldr = 0,
-                       void *packed_out = nullptr) {
+                       void *packed_out = nullptr, const NextLn *next_ln = nullptr) {
     const void *pl = nullptr;
     CAPDEC_TRY(planes_of(c, W, N, K, true, &pl));
     GemmEpilogue e;
@@ -325,6 +328,10 @@ static int gemm_packed(capdec_ctx *c, const void *Apk, const float *W, float *C,
     e.resid = resid;
     e.ldr = ldr;
     e.packed_out = packed_out;
+    if (next_ln && next_ln->w && ldc == N && (const void *)Apk != c->xpk.p) {
+        CAPDEC_TRY(c->xpk.ensure(x3_packed_bytes_host(M, N)));
+        e.ln_w = next_ln->w; e.ln_b = next_ln->b; e.ln_eps = next_ln->eps; e.ln_out = c->xpk.p; e.ln_done = next_ln->done;
+    }
     if (c->gemm_mode == GEMM_BF16X3 || c->gemm_mode == GEMM_F16X2) {
         const size_t wsb = gemm_splitk_ws_bytes(M, N, K);
         if (wsb) {
@@ -345,11 +352,15 @@ static int gemm_packed(capdec_ctx *c, const void *Apk, const float *W, float *C,
     return launch_gemm_bf16x3p(c->stream, Apk, pl, C, ldc, M, N, K, e);
 }
 
+// (ln_ready: c->xpk already holds LayerNorm(h) -- written by the fused split-K reduce of the previous GEMM)
 static int ln_gemm_packed(capdec_ctx *c, const float *h, int ldh, const float *lnw, const float *lnb, float eps,
                           const float *W, float *C, int ldc, int M, int N, int K, const float *bias, int act,
-                          void *packed_out = nullptr) {
+                          void *packed_out = nullptr, bool ln_ready = false) {
     CAPDEC_TRY(c->xpk.ensure(x3_packed_bytes_host(M, K)));
-    { ProfScope ps(c, F_LN); CAPDEC_TRY(launch_layernorm_packed(c->stream, h, ldh, lnw, lnb, eps, c->xpk.p, M, K, pack_fmt(c))); }
+    if (!ln_ready) {
+        ProfScope ps(c, F_LN);
+        CAPDEC_TRY(launch_layernorm_packed(c->stream, h, ldh, lnw, lnb, eps, c->xpk.p, M, K, pack_fmt(c)));
+    }
     return gemm_packed(c, c->xpk.p, W, C, ldc, M, N, K, bias, act, nullptr, 0, packed_out);
 }
 
@@ -397,11 +408,14 @@ static int stack_body(capdec_ctx *c, const StackCfg &g, const StepShape &s, cons
         apk = c->apk.p;
         fpk = c->fpk.p;
     }
+    int ln1_ready = 0;      // xpk already holds this layer's LN1(h): fused into the previous layer's mlp c_proj reduce
     for (int l = 0; l < g.n_layer; ++l) {
         const Gpt2Layer &w = (*g.layers)[l];
         const int kl = g.keep_kv ? l : 0;
         if (use_packed_a(c, d)) {
-            CAPDEC_TRY(ln_gemm_packed(c, h, d, w.ln1w, w.ln1b, g.eps, w.wqkv, qkv, 3 * d, M, 3 * d, d, w.bqkv, CAPDEC_ACT_NONE));
+            CAPDEC_TRY(ln_gemm_packed(c, h, d, w.ln1w, w.ln1b, g.eps, w.wqkv, qkv, 3 * d, M, 3 * d, d, w.bqkv, CAPDEC_ACT_NONE,
+                                      nullptr, ln1_ready != 0));
+            ln1_ready = 0;
         } else {
             { ProfScope ps(c, F_LN); CAPDEC_TRY(launch_layernorm(c->stream, h, d, w.ln1w, w.ln1b, g.eps, x, d, M, d)); }
             CAPDEC_TRY(gemm(c, x, d, w.wqkv, d, qkv, 3 * d, M, 3 * d, d, w.bqkv, CAPDEC_ACT_NONE));
@@ -415,11 +429,22 @@ static int stack_body(capdec_ctx *c, const StackCfg &g, const StepShape &s, cons
             ProfScope ps(c, F_ATTN_DEC);
             CAPDEC_TRY(launch_attn_decode(c->stream, qkv, kv, kl, s.rows, s.beam, s.L, s.anc, s.anc_stride, att, apk, s.cmap, pack_fmt(c)));
         }
-        if (chain) CAPDEC_TRY(gemm_packed(c, apk, w.wproj, h, d, M, d, d, w.bproj, CAPDEC_ACT_NONE, h, d));
-        else CAPDEC_TRY(gemm(c, att, d, w.wproj, d, h, d, M, d, d, w.bproj, CAPDEC_ACT_NONE, h, d));
+        int ln2_ready = 0;
         if (chain) {
-            CAPDEC_TRY(ln_gemm_packed(c, h, d, w.ln2w, w.ln2b, g.eps, w.wfc, ff, 4 * d, M, 4 * d, d, w.bfc, g.act, fpk));
-            CAPDEC_TRY(gemm_packed(c, fpk, w.wproj2, h, d, M, d, 4 * d, w.bproj2, CAPDEC_ACT_NONE, h, d));
+            const NextLn n2{w.ln2w, w.ln2b, g.eps, &ln2_ready};
+            CAPDEC_TRY(gemm_packed(c, apk, w.wproj, h, d, M, d, d, w.bproj, CAPDEC_ACT_NONE, h, d, nullptr, &n2));
+        } else {
+            CAPDEC_TRY(gemm(c, att, d, w.wproj, d, h, d, M, d, d, w.bproj, CAPDEC_ACT_NONE, h, d));
+        }
+        if (chain) {
+            CAPDEC_TRY(ln_gemm_packed(c, h, d, w.ln2w, w.ln2b, g.eps, w.wfc, ff, 4 * d, M, 4 * d, d, w.bfc, g.act, fpk,
+                                      ln2_ready != 0));
+            // the LayerNorm after mlp c_proj is the NEXT layer's ln_1 (the final ln_f runs on its own: it may see strided rows)
+            const bool has_next = l + 1 < g.n_layer;
+            const NextLn n1{has_next ? (*g.layers)[l + 1].ln1w : nullptr, has_next ? (*g.layers)[l + 1].ln1b : nullptr, g.eps,
+                            &ln1_ready};
+            CAPDEC_TRY(gemm_packed(c, fpk, w.wproj2, h, d, M, d, 4 * d, w.bproj2, CAPDEC_ACT_NONE, h, d, nullptr,
+                                   has_next ? &n1 : nullptr));
             continue;
         }
         if (use_packed_a(c, d)) {

@@ -94,6 +94,13 @@ struct GemmEpilogue {
     size_t splitk_ws_bytes = 0;    // under-filled grids run unsplit
     void *packed_out = nullptr;    // bf16x3p only: write act(acc + bias) as the packed split-bf16 A operand (K = N)
                                    // of the next GEMM instead of fp32 C
+    // Optional LayerNorm of the RESULT rows, fused into the split-K reduce pass (only when the launch splits K, C has
+    // N = ldc columns and N <= 1024): ln_out receives LayerNorm(C row) as a packed operand (format of the launch);
+    // *ln_done is set to 1 when the fusion happened, left untouched otherwise (the caller then runs its own LayerNorm)
+    const float *ln_w = nullptr, *ln_b = nullptr;
+    float ln_eps = 1e-5f;
+    void *ln_out = nullptr;
+    int *ln_done = nullptr;
 };
 int launch_gemm_f32(hipStream_t st, const float *A, int lda, const float *Bt, int ldb, float *C, int ldc,
                     int M, int N, int K, const GemmEpilogue &epi);

@@ -451,8 +451,98 @@ __global__ void splitk_reduce_kernel(const float *__restrict__ part, int S, int 
     *reinterpret_cast<float4 *>(C + (size_t)row * ldc + col) = v;
 }
 
+// split-K reduce + bias + residual (no activation) of a full-width result (N = row length <= 1024) with the LayerNorm
+// that FOLLOWS it in the block stack fused in: one wavefront per row adds the S partial rows in slice order, writes the
+// new residual-stream row C (fp32, may alias resid), then normalises it in registers and writes the packed operand of
+// the next GEMM -- one launch instead of reduce + LayerNorm, and the row is read once instead of twice.
+__global__ __launch_bounds__(256) void splitk_reduce_ln_kernel(const float *__restrict__ part, int S, int M, int N,
+                                                               const float *__restrict__ bias, const float *resid, int ldr,
+                                                               float *C, int ldc, const float *__restrict__ lnw,
+                                                               const float *__restrict__ lnb, float eps,
+                                                               char *__restrict__ ln_packed, int fmt) {
+    constexpr int MAXV = 4;                                   // float4s per lane: N <= 1024
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const int nv = N >> 2, nk = N / X3_BK;
+    const size_t sl = (size_t)M * N;
+    float4 v[MAXV];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int idx = lane + 64 * i;
+        v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (idx < nv) {
+            float4 a = reinterpret_cast<const float4 *>(part + (size_t)row * N)[idx];
+            int k = 1;
+            for (; k + 3 < S; k += 4) {          // four slices in flight, added in slice order
+                const float4 p0 = reinterpret_cast<const float4 *>(part + (k + 0) * sl + (size_t)row * N)[idx];
+                const float4 p1 = reinterpret_cast<const float4 *>(part + (k + 1) * sl + (size_t)row * N)[idx];
+                const float4 p2 = reinterpret_cast<const float4 *>(part + (k + 2) * sl + (size_t)row * N)[idx];
+                const float4 p3 = reinterpret_cast<const float4 *>(part + (k + 3) * sl + (size_t)row * N)[idx];
+                a.x += p0.x; a.y += p0.y; a.z += p0.z; a.w += p0.w;
+                a.x += p1.x; a.y += p1.y; a.z += p1.z; a.w += p1.w;
+                a.x += p2.x; a.y += p2.y; a.z += p2.z; a.w += p2.w;
+                a.x += p3.x; a.y += p3.y; a.z += p3.z; a.w += p3.w;
+            }
+            for (; k < S; ++k) {
+                const float4 p = reinterpret_cast<const float4 *>(part + k * sl + (size_t)row * N)[idx];
+                a.x += p.x; a.y += p.y; a.z += p.z; a.w += p.w;
+            }
+            if (bias) {
+                const float4 b = reinterpret_cast<const float4 *>(bias)[idx];
+                a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+            }
+            if (resid) {
+                const float4 r4 = reinterpret_cast<const float4 *>(resid + (size_t)row * ldr)[idx];
+                a.x += r4.x; a.y += r4.y; a.z += r4.z; a.w += r4.w;
+            }
+            reinterpret_cast<float4 *>(C + (size_t)row * ldc)[idx] = a;
+            v[i] = a;
+            s += (a.x + a.y) + (a.z + a.w);
+        }
+    }
+    // LayerNorm exactly as layernorm_packed_kernel (elementwise.hip): two-pass in registers, biased variance
+    const float mean = wave_sum(s) / (float)N;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int idx = lane + 64 * i;
+        if (idx < nv) {
+            const float a = v[i].x - mean, b2 = v[i].y - mean, c = v[i].z - mean, e = v[i].w - mean;
+            q += (a * a + b2 * b2) + (c * c + e * e);
+        }
+    }
+    const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)N + eps);
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int idx = lane + 64 * i;
+        if (idx < nv) {
+            const float4 ww = reinterpret_cast<const float4 *>(lnw)[idx];
+            const float4 bb = reinterpret_cast<const float4 *>(lnb)[idx];
+            float4 o;
+            o.x = (v[i].x - mean) * rstd * ww.x + bb.x;
+            o.y = (v[i].y - mean) * rstd * ww.y + bb.y;
+            o.z = (v[i].z - mean) * rstd * ww.z + bb.z;
+            o.w = (v[i].w - mean) * rstd * ww.w + bb.w;
+            x3_store_quad(ln_packed, nk, row, idx >> 2, idx & 3, o, fmt);
+        }
+    }
+}
+
 int launch_splitk_reduce(hipStream_t st, const float *part, int S, int M, int N, const GemmEpilogue &epi, float *C,
                          int ldc, int fmt) {
+    static const int fuse_off = [] { const char *e = getenv("CAPDEC_FUSE_LN"); return e && atoi(e) == 0 ? 1 : 0; }();
+    // (below ~1000 rows the element-parallel reduce + a separate LayerNorm keep more loads in flight than one wavefront
+    //  per row: 8 captions x beam 5 measured 74 vs 81 ms per pass)
+    if (!fuse_off && M >= 1024 && epi.ln_out && epi.ln_w && epi.ln_b && epi.packed_out == nullptr && epi.act == CAPDEC_ACT_NONE &&
+        N % 16 == 0 && N <= 1024 && ldc % 4 == 0 && ((uintptr_t)epi.ln_w & 15) == 0 && ((uintptr_t)epi.ln_b & 15) == 0) {
+        hipLaunchKernelGGL(splitk_reduce_ln_kernel, dim3((M + 3) / 4), dim3(256), 0, st, part, S, M, N, epi.bias, epi.resid,
+                           epi.ldr, C, ldc, epi.ln_w, epi.ln_b, epi.ln_eps, (char *)epi.ln_out, fmt);
+        CAPDEC_HIP(hipGetLastError());
+        if (epi.ln_done) *epi.ln_done = 1;
+        return 0;
+    }
     const size_t nq = (size_t)M * (N / 4);
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, st, part, S, M, N,
                        epi.bias, epi.act, epi.resid, epi.ldr, C, ldc, (char *)epi.packed_out, fmt);
