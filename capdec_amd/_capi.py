@@ -65,6 +65,18 @@ class ClipVisionWeights(C.Structure):
                 ("proj", c_float_p)]
 
 
+class ConvBn(C.Structure):
+    _fields_ = [("w", c_float_p), ("bn_w", c_float_p), ("bn_b", c_float_p), ("bn_mean", c_float_p),
+                ("bn_var", c_float_p), ("cin", C.c_int), ("cout", C.c_int), ("k", C.c_int)]
+
+
+class ClipResNetWeights(C.Structure):
+    _fields_ = [("image_size", C.c_int), ("width", C.c_int), ("embed_dim", C.c_int), ("layers", C.c_int * 4),
+                ("stem", C.POINTER(ConvBn)), ("blocks", C.POINTER(ConvBn)), ("positional_embedding", c_float_p),
+                ("q_w", c_float_p), ("q_b", c_float_p), ("k_w", c_float_p), ("k_b", c_float_p),
+                ("v_w", c_float_p), ("v_b", c_float_p), ("c_w", c_float_p), ("c_b", c_float_p)]
+
+
 #: every symbol include/capdec.h declares: name -> (restype, argtypes)
 _VP = C.c_void_p
 SIGNATURES = {
@@ -88,6 +100,7 @@ SIGNATURES = {
     "capdec_load_mapper_transformer": (C.c_int, [_VP, C.POINTER(TMapperWeights)]),
     "capdec_load_clip_text": (C.c_int, [_VP, C.POINTER(ClipTextWeights)]),
     "capdec_load_clip_vision": (C.c_int, [_VP, C.POINTER(ClipVisionWeights)]),
+    "capdec_load_clip_resnet": (C.c_int, [_VP, C.POINTER(ClipResNetWeights)]),
     "capdec_clip_encode_text": (C.c_int, [_VP, _VP, C.c_int, _VP]),
     "capdec_clip_encode_image": (C.c_int, [_VP, _VP, C.c_int, _VP]),
     "capdec_normalize_prefix": (C.c_int, [_VP, _VP, C.c_int, C.c_int, C.c_int, _VP, _VP]),

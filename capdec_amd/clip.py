@@ -4,9 +4,9 @@
 
 Differences that follow from the offline environment (no checkpoint / BPE vocabulary files):
 ``load`` takes an OpenAI-CLIP state dict (or a ``.pt`` path holding one) instead of a model name
-to download; ``tokenize`` needs a vocabulary file and otherwise raises.  Only ViT towers
-(ViT-B/32: head_dim 64) are supported; the reference's default RN50x4 image tower is out of
-scope (its pre-extracted 640-d embeddings are supported downstream).  Compute is fp32-accurate by
+to download; ``tokenize`` needs a vocabulary file and otherwise raises.  The visual tower is a ViT
+(ViT-B/32: head_dim 64) or a ModifiedResNet (RN50x4, the reference's default backbone: folded
+BatchNorm, im2col + GEMM convolutions, attention pool).  Compute is fp32-accurate by
 default; ``load(..., precision="fp16")`` runs the towers' block GEMMs with fp16 operands (fp32
 accumulate, fp32 residual stream / LayerNorm / softmax) -- the precision class of the reference
 on a GPU, where ``clip.load`` converts the model to fp16 and the callers cast the result back
@@ -31,9 +31,12 @@ class ClipModel:
         if precision != "fp32":
             self._engine.set_gemm_mode({"fp16": "f16", "bf16": "bf16"}[precision])
         sd = {k: v for k, v in state_dict.items()}
-        self.has_vision = "visual.conv1.weight" in sd
-        self._engine.load_clip(sd, text=True, vision=self.has_vision)
-        self.context_length = self._engine.clip_text["context_length"]
+        self.has_vision = "visual.conv1.weight" in sd           # ViT patch embedding or the ResNet stem
+        self.has_text = "token_embedding.weight" in sd
+        if not (self.has_vision or self.has_text):
+            raise CapdecError("clip.load: the state dict holds neither a text nor a visual tower")
+        self._engine.load_clip(sd, text=self.has_text, vision=self.has_vision)
+        self.context_length = self._engine.clip_text["context_length"] if self.has_text else 77
         self.input_resolution = self._engine.clip_vision["image_size"] if self.has_vision else 224
         self.device = self._engine.device
 
@@ -42,11 +45,13 @@ class ClipModel:
 
     def encode_text(self, text: torch.Tensor) -> torch.Tensor:
         """int tokens [N, 77] -> [N, 512] (not normalised, reference embeddings_generator.py:86-87)"""
+        if not self.has_text:
+            raise CapdecError("this CLIP state dict has no text tower")
         return self._engine.clip_encode_text(text)
 
     def encode_image(self, image: torch.Tensor) -> torch.Tensor:
         if not self.has_vision:
-            raise CapdecError("this CLIP state dict has no ViT visual tower")
+            raise CapdecError("this CLIP state dict has no visual tower")
         return self._engine.clip_encode_image(image)
 
 

@@ -79,6 +79,23 @@ struct Tower {
     float *conv_w = nullptr, *cls = nullptr, *ln_pre_w = nullptr, *ln_pre_b = nullptr;
 };
 
+// CLIP ModifiedResNet: a convolution with its BatchNorm folded in, as a GEMM operand
+struct ConvW {
+    float *w = nullptr;      // [cout_p, K]: K = k*k*cin_p in (ky, kx, c) order (first stem conv: 27 real columns, padded to 64)
+    float *b = nullptr;      // [cout_p]
+    int cin = 0, cout = 0, k = 0, cin_p = 0, cout_p = 0, K = 0;
+};
+struct ResNet {
+    bool loaded = false;
+    int image = 0, width = 0, embed = 0, feat = 0, heads = 0, sp = 0;
+    int layers[4] = {0, 0, 0, 0};
+    ConvW stem[3];
+    std::vector<ConvW> blocks;          // 4 per bottleneck (conv1, conv2, conv3, downsample; downsample.w may be null)
+    float *pos = nullptr, *wq = nullptr, *bq = nullptr, *wk = nullptr, *bk = nullptr, *wv = nullptr, *bv = nullptr,
+          *wc = nullptr, *bc = nullptr;
+    std::vector<void *> owned;
+};
+
 enum Family { F_GEMM = 0, F_LMHEAD, F_ATTN_DEC, F_ATTN_PRE, F_LN, F_EMBED, F_SELECT, F_MAP_ATTN, F_OTHER, F_GEMM_X3,
               F_LMHEAD_X3, F_GEMM_X3P, F_GEMM_BF16P, F_LMHEAD_BF16, F_GEMM_H2P, F_LMHEAD_H2, F_PACK, F_COUNT };
 static const char *kFamilyNames[F_COUNT] = {"gemm_f32", "gemm_f32_lmhead_topk", "attn_decode", "attn_prefill",
@@ -112,6 +129,8 @@ struct capdec_ctx {
     Gpt2 gpt;
     Mapper map;
     Tower clip_text, clip_vision;
+    ResNet clip_resnet;
+    DBuf r_a, r_b, r_c, r_d, r_e, r_f, r_col;      // ResNet activation buffers (NHWC) + im2col
     Prof prof;
     int gemm_mode = GEMM_F16X2;
     struct Planes { void *p; size_t n; int fmt; };
@@ -830,6 +849,116 @@ static int clip_vision_chunk(capdec_ctx *c, const float *pixels, int n, float *o
 
 }  // namespace capdec
 
+// ---------------------------------------------------------------------------- CLIP ModifiedResNet tower
+static int pad64(int c) { return (c + 63) / 64 * 64; }
+
+// fold BatchNorm (inference) into the convolution, reorder to [cout_p][(ky, kx, c_p)], pad, upload
+static int upload_conv_bn(ResNet &r, const capdec_conv_bn &s, bool first, ConvW *out) {
+    CAPDEC_CHECK(s.w && s.bn_w && s.bn_b && s.bn_mean && s.bn_var, "load_clip_resnet: null convolution tensor");
+    CAPDEC_CHECK((s.k == 1 || s.k == 3) && s.cin >= 1 && s.cout >= 1, "load_clip_resnet: 1x1 or 3x3 convolutions only");
+    ConvW c;
+    c.cin = s.cin; c.cout = s.cout; c.k = s.k;
+    c.cin_p = first ? s.cin : pad64(s.cin);
+    c.cout_p = pad64(s.cout);
+    c.K = first ? 64 : s.k * s.k * c.cin_p;
+    CAPDEC_CHECK(!first || (s.cin == 3 && s.k == 3), "load_clip_resnet: the first convolution is 3x3 on 3 channels");
+    std::vector<float> w((size_t)c.cout_p * c.K, 0.f), b((size_t)c.cout_p, 0.f);
+    for (int o = 0; o < s.cout; ++o) {
+        const float scale = s.bn_w[o] / std::sqrt(s.bn_var[o] + 1e-5f);
+        b[o] = s.bn_b[o] - s.bn_mean[o] * scale;
+        for (int ci = 0; ci < s.cin; ++ci)
+            for (int t = 0; t < s.k * s.k; ++t)
+                w[(size_t)o * c.K + (size_t)t * c.cin_p + ci] = s.w[((size_t)o * s.cin + ci) * s.k * s.k + t] * scale;
+    }
+    CAPDEC_TRY(upload(r.owned, w.data(), w.size(), &c.w));
+    CAPDEC_TRY(upload(r.owned, b.data(), b.size(), &c.b));
+    *out = c;
+    return 0;
+}
+
+// out[N, Ho, Wo, cout_p] = act(conv(in) folded-BN (+ resid)); k = 3: im2col + GEMM; returns the output spatial size
+static int conv_bn_forward(capdec_ctx *c, const ConvW &w, const float *in, int N, int H, int W, int stride, bool nchw3,
+                           float *out, int act, const float *resid, int *Ho_, int *Wo_) {
+    int Ho = H, Wo = W;
+    const float *A = in;
+    if (w.k == 3) {
+        Ho = (H + 2 - 3) / stride + 1;
+        Wo = (W + 2 - 3) / stride + 1;
+        CAPDEC_TRY(c->r_col.ensure((size_t)N * Ho * Wo * w.K * 4));
+        { ProfScope ps(c, F_OTHER); CAPDEC_TRY(launch_im2col3x3(c->stream, in, c->r_col.as<float>(), N, H, W, w.cin_p, stride, nchw3, w.K)); }
+        A = c->r_col.as<float>();
+    }
+    CAPDEC_TRY(gemm(c, A, w.K, w.w, w.K, out, w.cout_p, N * Ho * Wo, w.cout_p, w.K, w.b, act, resid, w.cout_p));
+    if (Ho_) *Ho_ = Ho;
+    if (Wo_) *Wo_ = Wo;
+    return 0;
+}
+
+// one chunk of images: pixels [n, 3, S, S] (NCHW) -> out [n, embed]
+static int clip_resnet_chunk(capdec_ctx *c, const float *pixels, int n, float *out) {
+    ResNet &r = c->clip_resnet;
+    const int S = r.image;
+    // worst-case activation sizes (floats per image): stem conv outputs at S/2, stage outputs at S/4 ... S/32
+    const size_t half = (size_t)(S / 2) * (S / 2), quarter = (size_t)(S / 4) * (S / 4);
+    size_t act = half * pad64(r.width);                                        // stem
+    int planes = r.width, sp = S / 4;
+    for (int li = 0; li < 4; ++li, planes *= 2) {
+        const int spin = sp;                                                   // spatial size entering the stage
+        if (li > 0) sp /= 2;
+        act = std::max(act, (size_t)spin * spin * pad64(planes * 4));          // identity / stage output
+        act = std::max(act, (size_t)spin * spin * pad64(planes));              // conv1 / conv2 outputs before the pool
+        act = std::max(act, (size_t)spin * spin * pad64(li ? planes * 2 : planes));   // stage input
+    }
+    act = std::max(act, quarter * pad64(r.width));
+    act = std::max(act, ((size_t)r.sp * r.sp + 1) * r.feat);                   // attention-pool tokens / keys / values
+    for (DBuf *b : {&c->r_a, &c->r_b, &c->r_c, &c->r_d, &c->r_e, &c->r_f}) CAPDEC_TRY(b->ensure((size_t)n * act * 4));
+    float *x = c->r_a.as<float>(), *y = c->r_b.as<float>(), *t1 = c->r_c.as<float>(), *t2 = c->r_d.as<float>(),
+          *xi = c->r_e.as<float>(), *idb = c->r_f.as<float>();
+    int H = S, W = S;
+    // stem: conv3x3 stride 2 (from NCHW pixels), two conv3x3, AvgPool2d(2)
+    CAPDEC_TRY(conv_bn_forward(c, r.stem[0], pixels, n, H, W, 2, true, t1, CAPDEC_ACT_RELU, nullptr, &H, &W));
+    CAPDEC_TRY(conv_bn_forward(c, r.stem[1], t1, n, H, W, 1, false, t2, CAPDEC_ACT_RELU, nullptr, &H, &W));
+    CAPDEC_TRY(conv_bn_forward(c, r.stem[2], t2, n, H, W, 1, false, t1, CAPDEC_ACT_RELU, nullptr, &H, &W));
+    { ProfScope ps(c, F_OTHER); CAPDEC_TRY(launch_avgpool2(c->stream, t1, x, n, H, W, r.stem[2].cout_p)); }
+    H /= 2; W /= 2;
+    size_t bi = 0;
+    for (int li = 0; li < 4; ++li) {
+        for (int b = 0; b < r.layers[li]; ++b, bi += 4) {
+            const ConvW &c1 = r.blocks[bi], &c2 = r.blocks[bi + 1], &c3 = r.blocks[bi + 2], &ds = r.blocks[bi + 3];
+            const int stride = (b == 0 && li > 0) ? 2 : 1;
+            CAPDEC_TRY(conv_bn_forward(c, c1, x, n, H, W, 1, false, t1, CAPDEC_ACT_RELU, nullptr, nullptr, nullptr));
+            CAPDEC_TRY(conv_bn_forward(c, c2, t1, n, H, W, 1, false, t2, CAPDEC_ACT_RELU, nullptr, nullptr, nullptr));
+            int Ho = H, Wo = W;
+            const float *branch = t2, *idt = x;
+            if (stride > 1) {      // anti-aliased stride: an average pool on the branch and in front of the downsample conv
+                ProfScope ps(c, F_OTHER);
+                CAPDEC_TRY(launch_avgpool2(c->stream, t2, t1, n, H, W, c2.cout_p));
+                CAPDEC_TRY(launch_avgpool2(c->stream, x, xi, n, H, W, c1.cin_p));
+                branch = t1;
+                Ho = H / 2; Wo = W / 2;
+            }
+            if (ds.w) {
+                CAPDEC_TRY(conv_bn_forward(c, ds, stride > 1 ? xi : x, n, Ho, Wo, 1, false, idb, CAPDEC_ACT_NONE, nullptr,
+                                           nullptr, nullptr));
+                idt = idb;
+            }
+            CAPDEC_TRY(conv_bn_forward(c, c3, branch, n, Ho, Wo, 1, false, y, CAPDEC_ACT_RESID_RELU, idt, nullptr, nullptr));
+            std::swap(x, y);
+            H = Ho; W = Wo;
+        }
+    }
+    // attention pool: tokens = [mean; features] + pos; one query (the mean token) over all tokens
+    const int C = r.feat, HW = H * W, T = HW + 1;
+    CAPDEC_CHECK(H == r.sp && W == r.sp, "clip_resnet: unexpected spatial size in front of the attention pool");
+    float *tok = y, *kk = t1, *vv = t2, *qq = xi, *oo = idb;
+    { ProfScope ps(c, F_OTHER); CAPDEC_TRY(launch_attnpool_tokens(c->stream, x, r.pos, tok, n, HW, C)); }
+    CAPDEC_TRY(gemm(c, tok, C, r.wk, C, kk, C, n * T, C, C, r.bk, CAPDEC_ACT_NONE));
+    CAPDEC_TRY(gemm(c, tok, C, r.wv, C, vv, C, n * T, C, C, r.bv, CAPDEC_ACT_NONE));
+    CAPDEC_TRY(gemm(c, tok, T * C, r.wq, C, qq, C, n, C, C, r.bq, CAPDEC_ACT_NONE));          // token 0 of every image
+    { ProfScope ps(c, F_MAP_ATTN); CAPDEC_TRY(launch_attnpool_attend(c->stream, qq, kk, vv, oo, n, r.heads, T, C)); }
+    return gemm(c, oo, C, r.wc, C, out, r.embed, n, r.embed, C, r.bc, CAPDEC_ACT_NONE);
+}
+
 // ---- RCCL (dlopen'ed): only the five entry points the path needs
 namespace {
 struct Rccl {
@@ -923,12 +1052,14 @@ void capdec_destroy(capdec_ctx *c) {
     free_all(c->map.owned);
     free_all(c->clip_text.owned);
     free_all(c->clip_vision.owned);
+    free_all(c->clip_resnet.owned);
     drop_planes(c);
     c->x3_tmp.release();
     DBuf *bufs[] = {&c->h, &c->x, &c->qkv, &c->att, &c->ff, &c->xl, &c->tmax, &c->tsum, &c->cval, &c->cidx,
                     &c->lse, &c->topv, &c->topi, &c->kc, &c->vc, &c->tokens, &c->scores, &c->seq, &c->stopped,
                     &c->done, &c->anc, &c->next_tok, &c->alive, &c->gids, &c->glens, &c->m_hid, &c->m_lin, &c->m_seq,
-                    &c->m_x, &c->m_qkv, &c->m_att, &c->m_ff, &c->t_idx, &c->t_patch, &c->t_pout, &c->xpk, &c->apk, &c->fpk, &c->cmap, &c->p_desc, &c->p_inter, &c->splitk, &c->a_tmp};
+                    &c->m_x, &c->m_qkv, &c->m_att, &c->m_ff, &c->t_idx, &c->t_patch, &c->t_pout, &c->xpk, &c->apk, &c->fpk, &c->cmap, &c->p_desc, &c->p_inter, &c->splitk, &c->a_tmp,
+                    &c->r_a, &c->r_b, &c->r_c, &c->r_d, &c->r_e, &c->r_f, &c->r_col};
     for (DBuf *b : bufs) b->release();
     for (auto &r : c->prof.recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
     for (auto e : c->prof.pool) (void)hipEventDestroy(e);
@@ -1125,6 +1256,8 @@ int capdec_load_clip_vision(capdec_ctx *c, const capdec_clip_vision_weights *w) 
     CAPDEC_HIP(hipSetDevice(c->device));
     Tower &t = c->clip_vision;
     free_all(t.owned);
+    free_all(c->clip_resnet.owned);                 // one image tower at a time
+    c->clip_resnet = ResNet();
     drop_planes(c);
     t = Tower();
     t.n_layer = w->layers; t.n_head = w->heads; t.d = w->width; t.embed = w->embed_dim; t.image = w->image_size;
@@ -1145,6 +1278,44 @@ int capdec_load_clip_vision(capdec_ctx *c, const capdec_clip_vision_weights *w) 
     return 0;
 }
 
+int capdec_load_clip_resnet(capdec_ctx *c, const capdec_clip_resnet_weights *w) {
+    CAPDEC_CHECK(c && w && w->stem && w->blocks, "load_clip_resnet: null argument");
+    CAPDEC_CHECK(w->width >= 2 && w->width % 2 == 0 && (w->width * 32) % 64 == 0 && w->embed_dim >= 1 &&
+                     w->image_size >= 64 && w->image_size % 32 == 0,
+                 "load_clip_resnet: bad geometry (width even, 32 * width a multiple of 64, image_size a multiple of 32)");
+    CAPDEC_CHECK((w->image_size / 32) * (w->image_size / 32) + 1 <= 256, "load_clip_resnet: more than 256 attention-pool tokens");
+    CAPDEC_HIP(hipSetDevice(c->device));
+    ResNet &r = c->clip_resnet;
+    free_all(r.owned);
+    drop_planes(c);
+    r = ResNet();
+    free_all(c->clip_vision.owned);                 // one image tower at a time
+    c->clip_vision = Tower();
+    r.image = w->image_size; r.width = w->width; r.embed = w->embed_dim; r.feat = w->width * 32; r.heads = r.feat / 64;
+    r.sp = w->image_size / 32;
+    int nblocks = 0;
+    for (int i = 0; i < 4; ++i) {
+        CAPDEC_CHECK(w->layers[i] >= 1, "load_clip_resnet: every stage needs at least one block");
+        r.layers[i] = w->layers[i];
+        nblocks += w->layers[i];
+    }
+    for (int i = 0; i < 3; ++i) CAPDEC_TRY(upload_conv_bn(r, w->stem[i], i == 0, &r.stem[i]));
+    r.blocks.resize((size_t)4 * nblocks);
+    for (int i = 0; i < 4 * nblocks; ++i) {
+        if (i % 4 == 3 && w->blocks[i].w == nullptr) continue;          // no downsample in this block
+        CAPDEC_TRY(upload_conv_bn(r, w->blocks[i], false, &r.blocks[(size_t)i]));
+    }
+    const size_t C = (size_t)r.feat, T = (size_t)r.sp * r.sp + 1;
+    CAPDEC_CHECK(r.feat % 64 == 0 && r.embed % 32 == 0, "load_clip_resnet: feature / embedding widths must be multiples of 64 / 32");
+    CAPDEC_TRY(upload(r.owned, w->positional_embedding, T * C, &r.pos));
+    CAPDEC_TRY(upload(r.owned, w->q_w, C * C, &r.wq)); CAPDEC_TRY(upload(r.owned, w->q_b, C, &r.bq));
+    CAPDEC_TRY(upload(r.owned, w->k_w, C * C, &r.wk)); CAPDEC_TRY(upload(r.owned, w->k_b, C, &r.bk));
+    CAPDEC_TRY(upload(r.owned, w->v_w, C * C, &r.wv)); CAPDEC_TRY(upload(r.owned, w->v_b, C, &r.bv));
+    CAPDEC_TRY(upload(r.owned, w->c_w, (size_t)r.embed * C, &r.wc)); CAPDEC_TRY(upload(r.owned, w->c_b, (size_t)r.embed, &r.bc));
+    r.loaded = true;
+    return 0;
+}
+
 int capdec_clip_encode_text(capdec_ctx *c, const int32_t *tokens, int n, float *out) {
     CAPDEC_CHECK(c && c->clip_text.loaded, "clip_encode_text: text tower not loaded");
     CAPDEC_CHECK(n >= 0 && (n == 0 || (tokens && out)), "clip_encode_text: bad argument");
@@ -1159,9 +1330,20 @@ int capdec_clip_encode_text(capdec_ctx *c, const int32_t *tokens, int n, float *
 }
 
 int capdec_clip_encode_image(capdec_ctx *c, const float *pixels, int n, float *out) {
-    CAPDEC_CHECK(c && c->clip_vision.loaded, "clip_encode_image: vision tower not loaded");
+    CAPDEC_CHECK(c && (c->clip_vision.loaded || c->clip_resnet.loaded), "clip_encode_image: vision tower not loaded");
     CAPDEC_CHECK(n >= 0 && (n == 0 || (pixels && out)), "clip_encode_image: bad argument");
     CAPDEC_HIP(hipSetDevice(c->device));
+    if (c->clip_resnet.loaded) {
+        const ResNet &r = c->clip_resnet;
+        // images per chunk: the im2col buffer of the stem (S/2 x S/2 pixels x 9 x 64 floats) stays under ~1.5 GB
+        const size_t per_img = (size_t)(r.image / 2) * (r.image / 2) * 9 * pad64(r.width / 2) * 4;
+        const int chunk = (int)std::max<size_t>(1, ((size_t)3 << 29) / std::max<size_t>(per_img, 1));
+        for (int c0 = 0; c0 < n; c0 += chunk) {
+            const int nc = std::min(chunk, n - c0);
+            CAPDEC_TRY(clip_resnet_chunk(c, pixels + (size_t)c0 * 3 * r.image * r.image, nc, out + (size_t)c0 * r.embed));
+        }
+        return 0;
+    }
     const Tower &t = c->clip_vision;
     const int chunk = 2048;
     for (int c0 = 0; c0 < n; c0 += chunk) {

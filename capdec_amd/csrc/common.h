@@ -174,6 +174,14 @@ int launch_im2col_patches(hipStream_t st, const float *pixels, float *patches, i
 int launch_vision_assemble(hipStream_t st, const float *patch_out, const float *cls, const float *pos, float *seq,
                            int n, int ntok, int d);
 
+// resnet.hip: glue of CLIP's ModifiedResNet tower (NHWC fp32, channels padded to multiples of 64)
+int launch_im2col3x3(hipStream_t st, const float *in, float *out, int N, int H, int W, int C, int stride, bool nchw3,
+                     int Kp);
+int launch_avgpool2(hipStream_t st, const float *in, float *out, int N, int H, int W, int C);
+int launch_attnpool_tokens(hipStream_t st, const float *feat, const float *pos, float *t, int N, int HW, int C);
+int launch_attnpool_attend(hipStream_t st, const float *q, const float *k, const float *v, float *out, int N, int heads,
+                           int T, int C);
+
 // attention.hip
 struct KvCache {
     void *k = nullptr;   // [layer][phys_row][head][ctx][hd], fp32 -- or bf16 when `bf16` is set (bf16 GEMM mode)

@@ -446,7 +446,8 @@ __global__ void splitk_reduce_kernel(const float *__restrict__ part, int S, int 
     }
     if (resid) {
         const float4 r4 = *reinterpret_cast<const float4 *>(resid + (size_t)row * ldr + col);
-        v.x += r4.x; v.y += r4.y; v.z += r4.z; v.w += r4.w;
+        v.x = post_resid(v.x + r4.x, act); v.y = post_resid(v.y + r4.y, act);
+        v.z = post_resid(v.z + r4.z, act); v.w = post_resid(v.w + r4.w, act);
     }
     *reinterpret_cast<float4 *>(C + (size_t)row * ldc + col) = v;
 }

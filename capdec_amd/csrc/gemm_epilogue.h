@@ -24,6 +24,9 @@ __device__ __forceinline__ float act_apply(float v, int act) {
     }
 }
 
+// CAPDEC_ACT_RESID_RELU: the activation comes AFTER the residual add (act_apply leaves the value alone for this code)
+__device__ __forceinline__ float post_resid(float v, int act) { return act == CAPDEC_ACT_RESID_RELU ? fmaxf(v, 0.f) : v; }
+
 // XCD-aware, L2-friendly tile order: consecutive ids of one XCD walk 8 M-tiles per N-tile.
 __device__ __forceinline__ void tile_coords(int tiles_m, int tiles_n, int &tm, int &tn, int block_id = -1) {
     constexpr int GM = 8;   // (2..32 measured within noise: neither panel set fits the 4 MB L2 of an XCD)
@@ -71,7 +74,7 @@ __device__ __forceinline__ void epilogue_store(const f32x16 (&acc)[2][WaveGrid<W
                 const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
                 if (row < M) {
                     float v = act_apply(acc[i][j][r] + bv, act);
-                    if (resid) v += resid[(size_t)row * ldr + col];
+                    if (resid) v = post_resid(v + resid[(size_t)row * ldr + col], act);
                     C[(size_t)row * ldc + col] = v;
                 }
             }
@@ -113,7 +116,8 @@ __device__ __forceinline__ void epilogue_store_t(const f32x16 (&acc)[2][2], floa
                     v.z = act_apply(v.z, act); v.w = act_apply(v.w, act);
                     if (resid) {
                         const float4 r4 = *reinterpret_cast<const float4 *>(resid + (size_t)row * ldr + col);
-                        v.x += r4.x; v.y += r4.y; v.z += r4.z; v.w += r4.w;
+                        v.x = post_resid(v.x + r4.x, act); v.y = post_resid(v.y + r4.y, act);
+                        v.z = post_resid(v.z + r4.z, act); v.w = post_resid(v.w + r4.w, act);
                     }
                     *reinterpret_cast<float4 *>(C + (size_t)row * ldc + col) = v;
                 } else {
@@ -122,7 +126,7 @@ __device__ __forceinline__ void epilogue_store_t(const f32x16 (&acc)[2][2], floa
                     for (int q = 0; q < 4; ++q)
                         if (col + q < N) {
                             float x = act_apply(e[q] + (bias ? bias[col + q] : 0.f), act);
-                            if (resid) x += resid[(size_t)row * ldr + col + q];
+                            if (resid) x = post_resid(x + resid[(size_t)row * ldr + col + q], act);
                             C[(size_t)row * ldc + col + q] = x;
                         }
                 }

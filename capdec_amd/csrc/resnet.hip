@@ -1,0 +1,189 @@
+// Glue kernels of CLIP's ModifiedResNet image tower (RN50x4: the reference's default backbone, call sites
+// predictions_runner.py:158,220; embeddings_generator.py:89,113).  All arithmetic-heavy work is the MFMA GEMM: a 1x1
+// convolution is a GEMM on NHWC activations, a 3x3 convolution is im2col + GEMM, BatchNorm (inference statistics) is
+// folded into the convolution's weights and bias at load time, ReLU / residual-add-ReLU live in the GEMM epilogue.
+// What remains here is memory-bound data movement: im2col, 2x2 average pooling (the tower's anti-aliased stride), and
+// the attention pool's token assembly and single-query attention.
+//
+// Layout: activations are NHWC fp32 with the channel count padded to a multiple of 64 (zero channels: the folded
+// weights have zero rows / columns there), so every GEMM has K % 64 == 0 and runs on the packed-operand kernels.
+#include "common.h"
+
+namespace capdec {
+
+// ---- im2col for a 3x3 convolution with padding 1: out[(n, oy, ox)][(ky, kx, c)] = in[n][oy*s+ky-1][ox*s+kx-1][c]
+// (NHWC input, C % 4 == 0); one thread per (output pixel, tap, 4 channels)
+__global__ void im2col3x3_nhwc_kernel(const float *__restrict__ in, float *__restrict__ out, int N, int H, int W, int C,
+                                      int stride, int Ho, int Wo) {
+    const int c4 = C >> 2;
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t total = (size_t)N * Ho * Wo * 9 * c4;
+    if (i >= total) return;
+    const int cq = (int)(i % c4);
+    size_t r = i / c4;
+    const int tap = (int)(r % 9);
+    r /= 9;                                              // output pixel index
+    const int ox = (int)(r % Wo), oy = (int)((r / Wo) % Ho), n = (int)(r / ((size_t)Wo * Ho));
+    const int iy = oy * stride + tap / 3 - 1, ix = ox * stride + tap % 3 - 1;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (iy >= 0 && iy < H && ix >= 0 && ix < W)
+        v = reinterpret_cast<const float4 *>(in + (((size_t)n * H + iy) * W + ix) * C)[cq];
+    reinterpret_cast<float4 *>(out + r * (size_t)(9 * C) + (size_t)tap * C)[cq] = v;
+}
+
+// first convolution: NCHW fp32 pixels with 3 channels -> rows of Kp (>= 27, zero padded) in (ky, kx, c) order
+__global__ void im2col3x3_nchw3_kernel(const float *__restrict__ in, float *__restrict__ out, int N, int H, int W,
+                                       int stride, int Ho, int Wo, int Kp) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;          // one thread per (output pixel, k)
+    const size_t total = (size_t)N * Ho * Wo * Kp;
+    if (i >= total) return;
+    const int k = (int)(i % Kp);
+    const size_t r = i / Kp;
+    float v = 0.f;
+    if (k < 27) {
+        const int tap = k / 3, c = k - tap * 3;
+        const int ox = (int)(r % Wo), oy = (int)((r / Wo) % Ho), n = (int)(r / ((size_t)Wo * Ho));
+        const int iy = oy * stride + tap / 3 - 1, ix = ox * stride + tap % 3 - 1;
+        if (iy >= 0 && iy < H && ix >= 0 && ix < W) v = in[(((size_t)n * 3 + c) * H + iy) * W + ix];
+    }
+    out[i] = v;
+}
+
+int launch_im2col3x3(hipStream_t st, const float *in, float *out, int N, int H, int W, int C, int stride, bool nchw3,
+                     int Kp) {
+    const int Ho = (H + 2 - 3) / stride + 1, Wo = (W + 2 - 3) / stride + 1;
+    if (N <= 0) return 0;
+    if (nchw3) {
+        const size_t tot = (size_t)N * Ho * Wo * Kp;
+        hipLaunchKernelGGL(im2col3x3_nchw3_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, in, out, N, H, W,
+                           stride, Ho, Wo, Kp);
+    } else {
+        CAPDEC_CHECK(C % 4 == 0 && Kp == 9 * C, "im2col: channel count must be a multiple of 4");
+        const size_t tot = (size_t)N * Ho * Wo * 9 * (C >> 2);
+        hipLaunchKernelGGL(im2col3x3_nhwc_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, in, out, N, H, W, C,
+                           stride, Ho, Wo);
+    }
+    CAPDEC_HIP(hipGetLastError());
+    return 0;
+}
+
+// ---- AvgPool2d(2) on NHWC (H, W even): the tower's stride
+__global__ void avgpool2_nhwc_kernel(const float *__restrict__ in, float *__restrict__ out, int N, int H, int W, int C) {
+    const int c4 = C >> 2, Ho = H >> 1, Wo = W >> 1;
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)N * Ho * Wo * c4) return;
+    const int cq = (int)(i % c4);
+    const size_t r = i / c4;
+    const int ox = (int)(r % Wo), oy = (int)((r / Wo) % Ho), n = (int)(r / ((size_t)Wo * Ho));
+    const float *p = in + (((size_t)n * H + 2 * oy) * W + 2 * ox) * C;
+    const float4 a = reinterpret_cast<const float4 *>(p)[cq], b = reinterpret_cast<const float4 *>(p + C)[cq];
+    const float4 c = reinterpret_cast<const float4 *>(p + (size_t)W * C)[cq],
+                 d = reinterpret_cast<const float4 *>(p + (size_t)W * C + C)[cq];
+    float4 o;      // torch avg_pool2d: sum of the window, then one division
+    o.x = ((a.x + b.x) + (c.x + d.x)) * 0.25f; o.y = ((a.y + b.y) + (c.y + d.y)) * 0.25f;
+    o.z = ((a.z + b.z) + (c.z + d.z)) * 0.25f; o.w = ((a.w + b.w) + (c.w + d.w)) * 0.25f;
+    reinterpret_cast<float4 *>(out + r * (size_t)C)[cq] = o;
+}
+
+int launch_avgpool2(hipStream_t st, const float *in, float *out, int N, int H, int W, int C) {
+    CAPDEC_CHECK(H % 2 == 0 && W % 2 == 0 && C % 4 == 0, "avgpool2: even spatial size, C % 4 == 0");
+    const size_t tot = (size_t)N * (H >> 1) * (W >> 1) * (C >> 2);
+    if (tot == 0) return 0;
+    hipLaunchKernelGGL(avgpool2_nhwc_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, in, out, N, H, W, C);
+    CAPDEC_HIP(hipGetLastError());
+    return 0;
+}
+
+// ---- attention pool, token assembly: t[n][0] = mean over the HW feature rows, t[n][1 + i] = feature row i, + pos
+__global__ void attnpool_tokens_kernel(const float *__restrict__ feat, const float *__restrict__ pos, float *__restrict__ t,
+                                       int N, int HW, int C) {
+    const int c4 = C >> 2;
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;     // one thread per (image, 4 channels)
+    if (i >= (size_t)N * c4) return;
+    const int cq = (int)(i % c4), n = (int)(i / c4);
+    const float *f = feat + (size_t)n * HW * C;
+    float *o = t + (size_t)n * (HW + 1) * C;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int j = 0; j < HW; ++j) {
+        const float4 v = reinterpret_cast<const float4 *>(f + (size_t)j * C)[cq];
+        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        const float4 p = reinterpret_cast<const float4 *>(pos + (size_t)(j + 1) * C)[cq];
+        reinterpret_cast<float4 *>(o + (size_t)(j + 1) * C)[cq] = make_float4(v.x + p.x, v.y + p.y, v.z + p.z, v.w + p.w);
+    }
+    const float inv = 1.0f / (float)HW;
+    const float4 p0 = reinterpret_cast<const float4 *>(pos)[cq];
+    reinterpret_cast<float4 *>(o)[cq] = make_float4(s.x * inv + p0.x, s.y * inv + p0.y, s.z * inv + p0.z, s.w * inv + p0.w);
+}
+
+int launch_attnpool_tokens(hipStream_t st, const float *feat, const float *pos, float *t, int N, int HW, int C) {
+    const size_t tot = (size_t)N * (C >> 2);
+    if (tot == 0) return 0;
+    hipLaunchKernelGGL(attnpool_tokens_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, feat, pos, t, N, HW, C);
+    CAPDEC_HIP(hipGetLastError());
+    return 0;
+}
+
+// ---- attention pool, the single query: one wavefront per (image, head); head_dim 64 as four 16-lane groups (a group
+// owns one key per iteration, a lane a float4 of the head); q is scaled by head_dim^-0.5 (nn.MultiheadAttention)
+__global__ __launch_bounds__(256) void attnpool_attend_kernel(const float *__restrict__ q, const float *__restrict__ k,
+                                                              const float *__restrict__ v, float *__restrict__ out,
+                                                              int total, int heads, int T, int C) {
+    __shared__ float sc[4][256];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int grp = lane >> 4, sub = lane & 15;
+    const int gw = blockIdx.x * 4 + wave;
+    const bool active = gw < total;
+    const int n = active ? gw / heads : 0, h = active ? gw - n * heads : 0;
+    float4 qv = reinterpret_cast<const float4 *>(q + (size_t)n * C + h * 64)[sub];
+    qv.x *= 0.125f; qv.y *= 0.125f; qv.z *= 0.125f; qv.w *= 0.125f;
+    const float *kb = k + (size_t)n * T * C + h * 64, *vb = v + (size_t)n * T * C + h * 64;
+    for (int t0 = 0; t0 < T; t0 += 4) {
+        const int t = t0 + grp;
+        if (t < T) {
+            const float4 kk = reinterpret_cast<const float4 *>(kb + (size_t)t * C)[sub];
+            const float s = row16_sum((qv.x * kk.x + qv.y * kk.y) + (qv.z * kk.z + qv.w * kk.w));
+            if (sub == 0) sc[wave][t] = s;
+        }
+    }
+    __syncthreads();
+    float mx = -INFINITY;
+    for (int t = lane; t < T; t += 64) mx = fmaxf(mx, sc[wave][t]);
+    mx = wave_max(mx);
+    float sum = 0.f;
+    for (int t = lane; t < T; t += 64) {
+        const float e = expf(sc[wave][t] - mx);
+        sc[wave][t] = e;
+        sum += e;
+    }
+    sum = wave_sum(sum);
+    __syncthreads();
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int t0 = 0; t0 < T; t0 += 4) {
+        const int t = t0 + grp;
+        if (t < T) {
+            const float4 vv = reinterpret_cast<const float4 *>(vb + (size_t)t * C)[sub];
+            const float w = sc[wave][t];
+            acc.x += w * vv.x; acc.y += w * vv.y; acc.z += w * vv.z; acc.w += w * vv.w;
+        }
+    }
+    acc.x += __shfl_xor(acc.x, 16, 64); acc.y += __shfl_xor(acc.y, 16, 64);
+    acc.z += __shfl_xor(acc.z, 16, 64); acc.w += __shfl_xor(acc.w, 16, 64);
+    acc.x += __shfl_xor(acc.x, 32, 64); acc.y += __shfl_xor(acc.y, 32, 64);
+    acc.z += __shfl_xor(acc.z, 32, 64); acc.w += __shfl_xor(acc.w, 32, 64);
+    if (active && grp == 0) {
+        const float inv = 1.0f / sum;
+        reinterpret_cast<float4 *>(out + (size_t)n * C + h * 64)[sub] = make_float4(acc.x * inv, acc.y * inv, acc.z * inv, acc.w * inv);
+    }
+}
+
+int launch_attnpool_attend(hipStream_t st, const float *q, const float *k, const float *v, float *out, int N, int heads,
+                           int T, int C) {
+    CAPDEC_CHECK(C == heads * 64 && T <= 256, "attention pool: head_dim must be 64, at most 256 tokens");
+    const int total = N * heads;
+    if (total <= 0) return 0;
+    hipLaunchKernelGGL(attnpool_attend_kernel, dim3((total + 3) / 4), dim3(256), 0, st, q, k, v, out, total, heads, T, C);
+    CAPDEC_HIP(hipGetLastError());
+    return 0;
+}
+
+}  // namespace capdec

@@ -206,8 +206,9 @@ class Engine:
         return n
 
     def load_clip(self, sd: Dict[str, torch.Tensor], text: bool = True, vision: bool = True):
-        """OpenAI CLIP ViT state dict (what `clip.load(...)[0].state_dict()` holds; fp16 weights are
-        upcast).  ModifiedResNet visual towers (RN50x4) are not supported."""
+        """OpenAI CLIP state dict (what `clip.load(...)[0].state_dict()` holds; fp16 weights are upcast).  The visual
+        tower is a ViT (`visual.class_embedding` present) or a ModifiedResNet (`visual.layer1...`: RN50x4, the
+        reference's default backbone)."""
         keep: list = []
         if text:
             te, pe = _f32(sd["token_embedding.weight"]), _f32(sd["positional_embedding"])
@@ -220,9 +221,11 @@ class Engine:
                                       _fp(pe), self._clip_blocks(sd, "", layers, keep), _fp(lw), _fp(lb), _fp(proj))
             check(self.lib.capdec_load_clip_text(self._h, C.byref(w)), "capdec_load_clip_text")
             self.clip_text = dict(context_length=pe.shape[0], embed_dim=proj.shape[1], vocab=te.shape[0])
-        if vision:
+        if vision and "visual.layer1.0.conv1.weight" in sd:
+            self._load_clip_resnet(sd)
+        elif vision:
             if "visual.conv1.weight" not in sd or "visual.class_embedding" not in sd:
-                raise CapdecError("only ViT visual towers are supported (no visual.conv1/class_embedding in the state dict)")
+                raise CapdecError("no visual tower in the state dict (neither visual.class_embedding nor visual.layer1)")
             cw = _f32(sd["visual.conv1.weight"])
             ce, pe = _f32(sd["visual.class_embedding"]), _f32(sd["visual.positional_embedding"])
             l1w, l1b = _f32(sd["visual.ln_pre.weight"]), _f32(sd["visual.ln_pre.bias"])
@@ -237,6 +240,43 @@ class Engine:
                                         _fp(l2b), _fp(proj))
             check(self.lib.capdec_load_clip_vision(self._h, C.byref(w)), "capdec_load_clip_vision")
             self.clip_vision = dict(image_size=image, embed_dim=proj.shape[1])
+
+    def _load_clip_resnet(self, sd: Dict[str, torch.Tensor]):
+        """ModifiedResNet tower (`visual.conv1..3`, `visual.layer1..4`, `visual.attnpool`): every convolution goes
+        over with its BatchNorm statistics; the library folds them at load time."""
+        keep: list = []
+
+        def conv_bn(conv: str, bn: str) -> _capi.ConvBn:
+            if conv + ".weight" not in sd:
+                return _capi.ConvBn()
+            w = _f32(sd[conv + ".weight"])
+            t = [w] + [_f32(sd[f"{bn}.{k}"]) for k in ("weight", "bias", "running_mean", "running_var")]
+            keep.extend(t)
+            if w.shape[2] != w.shape[3]:
+                raise CapdecError(f"{conv}: square kernels only")
+            return _capi.ConvBn(*[_fp(x) for x in t], w.shape[1], w.shape[0], w.shape[2])
+
+        stem = (_capi.ConvBn * 3)(*[conv_bn(f"visual.conv{i}", f"visual.bn{i}") for i in (1, 2, 3)])
+        layers = [len({k.split(".")[2] for k in sd if k.startswith(f"visual.layer{li}.")}) for li in (1, 2, 3, 4)]
+        blocks = []
+        for li, nb in enumerate(layers, start=1):
+            for b in range(nb):
+                p = f"visual.layer{li}.{b}."
+                blocks += [conv_bn(p + f"conv{i}", p + f"bn{i}") for i in (1, 2, 3)]
+                blocks.append(conv_bn(p + "downsample.0", p + "downsample.1"))
+        barr = (_capi.ConvBn * len(blocks))(*blocks)
+        a = "visual.attnpool."
+        pos = _f32(sd[a + "positional_embedding"])
+        names = ["q_proj", "k_proj", "v_proj", "c_proj"]
+        proj = [(_f32(sd[a + n + ".weight"]), _f32(sd[a + n + ".bias"])) for n in names]
+        keep += [pos] + [t for pr in proj for t in pr]
+        width = sd["visual.layer1.0.conv1.weight"].shape[0]
+        image = int(round((pos.shape[0] - 1) ** 0.5)) * 32
+        embed = proj[3][0].shape[0]
+        w = _capi.ClipResNetWeights(image, width, embed, (C.c_int * 4)(*layers), stem, barr, _fp(pos),
+                                    *[_fp(t) for pr in proj for t in pr])
+        check(self.lib.capdec_load_clip_resnet(self._h, C.byref(w)), "capdec_load_clip_resnet")
+        self.clip_vision = dict(image_size=image, embed_dim=embed, kind="resnet")
 
     def clip_encode_text(self, tokens: torch.Tensor) -> torch.Tensor:
         t = self._dev(tokens, torch.int32)

@@ -221,6 +221,74 @@ def hot_clip_state_dict(seed: int = 43, dims: ClipDims = CLIP_VIT_B32) -> "Order
     return sd
 
 
+# ----------------------------------------------------------------------------------------------
+# CLIP ModifiedResNet image tower (RN50x4: the reference's DEFAULT backbone, predictions_runner.py:158,
+# embeddings_generator.py:113, train.py:445; `clip.load("RN50x4")`).  OpenAI state-dict names under "visual.".
+@dataclass(frozen=True)
+class ResNetDims:
+    layers: tuple = (4, 6, 10, 6)
+    width: int = 80
+    image_size: int = 288
+    embed_dim: int = 640          # output_dim of the attention pool; heads = width * 32 // 64
+
+    @property
+    def feat_dim(self) -> int:    # channels entering the attention pool
+        return self.width * 32
+
+    @property
+    def heads(self) -> int:
+        return self.width * 32 // 64
+
+
+CLIP_RN50X4 = ResNetDims()
+#: small geometry for tests: same block structure (stem, 4 stages with strides 1/2/2/2, attention pool, head_dim 64)
+CLIP_RN_TINY = ResNetDims(layers=(1, 2, 1, 1), width=16, image_size=64, embed_dim=128)
+
+
+def _hot_bn(g, sd, p: str, c: int, gain: float = 1.0):
+    sd[p + "weight"] = _randn(g, c, std=0.1 * gain, mean=gain)
+    sd[p + "bias"] = _randn(g, c, std=0.1)
+    sd[p + "running_mean"] = _randn(g, c, std=0.1)
+    sd[p + "running_var"] = (torch.rand(c, generator=g, dtype=torch.float32) * 0.5 + 0.75)
+    sd[p + "num_batches_tracked"] = torch.tensor(1000)
+
+
+def hot_clip_resnet_state_dict(seed: int = 44, dims: ResNetDims = CLIP_RN50X4) -> "OrderedDict[str, torch.Tensor]":
+    """Seeded weights of CLIP's ModifiedResNet visual tower under OpenAI state-dict names (He-style conv scales so
+    activations keep O(1) magnitude through the 4 stages)."""
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    sd: "OrderedDict[str, torch.Tensor]" = OrderedDict()
+    w = dims.width
+
+    def conv(name, cout, cin, k):
+        sd[name] = _randn(g, cout, cin, k, k, std=(2.0 / (cin * k * k)) ** 0.5)
+
+    conv("visual.conv1.weight", w // 2, 3, 3); _hot_bn(g, sd, "visual.bn1.", w // 2)
+    conv("visual.conv2.weight", w // 2, w // 2, 3); _hot_bn(g, sd, "visual.bn2.", w // 2)
+    conv("visual.conv3.weight", w, w // 2, 3); _hot_bn(g, sd, "visual.bn3.", w)
+    inplanes = w
+    for li, (planes, blocks) in enumerate(zip((w, 2 * w, 4 * w, 8 * w), dims.layers), start=1):
+        for b in range(blocks):
+            p = f"visual.layer{li}.{b}."
+            stride = 2 if (b == 0 and li > 1) else 1
+            conv(p + "conv1.weight", planes, inplanes, 1); _hot_bn(g, sd, p + "bn1.", planes)
+            conv(p + "conv2.weight", planes, planes, 3); _hot_bn(g, sd, p + "bn2.", planes)
+            # (the branch's last BatchNorm is damped so that the residual stream stays O(1) through 26 blocks)
+            conv(p + "conv3.weight", planes * 4, planes, 1); _hot_bn(g, sd, p + "bn3.", planes * 4, gain=0.2)
+            if stride > 1 or inplanes != planes * 4:
+                conv(p + "downsample.0.weight", planes * 4, inplanes, 1); _hot_bn(g, sd, p + "downsample.1.", planes * 4)
+            inplanes = planes * 4
+    e = dims.feat_dim
+    sp = dims.image_size // 32
+    sd["visual.attnpool.positional_embedding"] = _randn(g, sp * sp + 1, e, std=e ** -0.5)
+    for n in ("q_proj", "k_proj", "v_proj"):
+        sd[f"visual.attnpool.{n}.weight"] = _randn(g, e, e, std=e ** -0.5)
+        sd[f"visual.attnpool.{n}.bias"] = _randn(g, e, std=0.02)
+    sd["visual.attnpool.c_proj.weight"] = _randn(g, dims.embed_dim, e, std=e ** -0.5)
+    sd["visual.attnpool.c_proj.bias"] = _randn(g, dims.embed_dim, std=0.02)
+    return sd
+
+
 def synthetic_clip_tokens(n: int, seed: int = 2, context_length: int = 77, vocab: int = 49408,
                           min_len: int = 8, max_len: int = 20) -> torch.Tensor:
     """int64 [n, 77] rows shaped like clip.tokenize output (reference embeddings_generator.py:80-85):

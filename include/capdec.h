@@ -37,7 +37,8 @@ typedef struct capdec_ctx capdec_ctx;
 
 /* activation codes for capdec_gemm_f32 (test hook) */
 enum { CAPDEC_ACT_NONE = 0, CAPDEC_ACT_TANH = 1, CAPDEC_ACT_RELU = 2, CAPDEC_ACT_GELU_NEW = 3,
-       CAPDEC_ACT_QUICK_GELU = 4 };
+       CAPDEC_ACT_QUICK_GELU = 4,
+       CAPDEC_ACT_RESID_RELU = 5 /* relu(acc + bias + resid): the tail of a ResNet bottleneck */ };
 
 /* ---- context ------------------------------------------------------------------------ */
 int capdec_abi_version(void);
@@ -183,6 +184,31 @@ typedef struct capdec_clip_vision_weights {
 
 int capdec_load_clip_text(capdec_ctx *ctx, const capdec_clip_text_weights *h_w);
 int capdec_load_clip_vision(capdec_ctx *ctx, const capdec_clip_vision_weights *h_w);
+
+/* CLIP ModifiedResNet visual tower (`clip.load("RN50x4")`: the reference's DEFAULT image backbone,
+ * predictions_runner.py:158,220; embeddings_generator.py:89,113; train.py:445).  One entry per convolution with the
+ * BatchNorm that follows it (inference statistics; folded into the convolution at load time).  Host fp32 pointers in
+ * the OpenAI state-dict layouts: w [cout, cin, k, k] (k = 1, or 3 with padding 1), bn_* [cout]. */
+typedef struct {
+    const float *w, *bn_w, *bn_b, *bn_mean, *bn_var;   /* w == NULL: this convolution does not exist (no downsample) */
+    int cin, cout, k;
+} capdec_conv_bn;
+typedef struct {
+    int image_size;        /* 288 for RN50x4 */
+    int width;             /* 80 for RN50x4: stage planes width * {1,2,4,8}, attention-pool input 32 * width channels */
+    int embed_dim;         /* 640 */
+    int layers[4];         /* bottleneck blocks per stage: {4, 6, 10, 6} */
+    const capdec_conv_bn *stem;     /* [3]: visual.conv1/bn1 (stride 2), conv2/bn2, conv3/bn3; then AvgPool2d(2) */
+    const capdec_conv_bn *blocks;   /* [4 * sum(layers)]: per bottleneck conv1/bn1, conv2/bn2, conv3/bn3, downsample.0/.1;
+                                       the first block of stages 2..4 has stride 2 (AvgPool2d(2) after conv2 and in front
+                                       of the downsample convolution) */
+    const float *positional_embedding;                 /* visual.attnpool.positional_embedding [(S/32)^2 + 1, 32 width] */
+    const float *q_w, *q_b, *k_w, *k_b, *v_w, *v_b;    /* attnpool.{q,k,v}_proj: [32w, 32w], [32w] */
+    const float *c_w, *c_b;                            /* attnpool.c_proj: [embed_dim, 32w], [embed_dim] */
+} capdec_clip_resnet_weights;
+/* after this call capdec_clip_encode_image takes [n, 3, image_size, image_size] pixels through the ResNet tower
+ * (a ViT tower loaded earlier is replaced, and vice versa) */
+int capdec_load_clip_resnet(capdec_ctx *ctx, const capdec_clip_resnet_weights *h_weights);
 /* `clip_model.encode_text(clip.tokenize(caption))`: d_tokens int32 [n, context_length] (SOT ... EOT,
  * zero padded; the EOT row is found as argmax of the ids) -> d_out [n, embed_dim], NOT normalised */
 int capdec_clip_encode_text(capdec_ctx *ctx, const int32_t *d_tokens, int n, float *d_out);

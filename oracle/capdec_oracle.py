@@ -514,6 +514,71 @@ def clip_encode_image(image: Tensor, sd: SD, n_head: int = 12) -> Tensor:
 
 
 # ----------------------------------------------------------------------------------------
+# CLIP ModifiedResNet image tower (`clip.load("RN50x4")`: the reference's default backbone, predictions_runner.py:158,
+# 220; embeddings_generator.py:89,113).  The `clip` package is not installed and NO stand-in for this architecture
+# exists in the container (transformers has no ModifiedResNet): the functions below restate the published openai/CLIP
+# model (clip/model.py: Bottleneck, AttentionPool2d, ModifiedResNet) -- PARITY UNPINNED, see DESIGN.md section 2.
+#   stem: 3 x (conv3x3 -> BatchNorm -> ReLU) with the first conv at stride 2, then AvgPool2d(2);
+#   4 stages of Bottleneck blocks (1x1 -> 3x3 -> [AvgPool2d(stride)] -> 1x1 (x4 planes), BatchNorm after every conv,
+#   anti-aliased striding: the stride is an average pool, never a strided conv; downsample = AvgPool2d(stride) ->
+#   conv1x1 -> BatchNorm whenever stride > 1 or the channel count changes; out = ReLU(out + identity));
+#   attention pool: tokens = [mean token; HW tokens] + positional embedding, ONE query (the mean token) attends over
+#   all tokens with nn.MultiheadAttention semantics (separate q/k/v projections with bias, q scaled by head_dim^-0.5),
+#   c_proj -> output_dim.
+# ----------------------------------------------------------------------------------------
+def _bn2d(x: Tensor, sd: SD, p: str) -> Tensor:
+    return F.batch_norm(x, sd[p + "running_mean"], sd[p + "running_var"], sd[p + "weight"], sd[p + "bias"], False, 0.0, 1e-5)
+
+
+def _rn_bottleneck(x: Tensor, sd: SD, p: str, stride: int) -> Tensor:
+    out = F.relu(_bn2d(F.conv2d(x, sd[p + "conv1.weight"]), sd, p + "bn1."))
+    out = F.relu(_bn2d(F.conv2d(out, sd[p + "conv2.weight"], padding=1), sd, p + "bn2."))
+    if stride > 1:
+        out = F.avg_pool2d(out, stride)
+    out = _bn2d(F.conv2d(out, sd[p + "conv3.weight"]), sd, p + "bn3.")
+    if p + "downsample.0.weight" in sd:
+        idt = F.avg_pool2d(x, stride) if stride > 1 else x
+        idt = _bn2d(F.conv2d(idt, sd[p + "downsample.0.weight"]), sd, p + "downsample.1.")
+    else:
+        idt = x
+    return F.relu(out + idt)
+
+
+def clip_resnet_features(image: Tensor, sd: SD) -> Tensor:
+    """ModifiedResNet up to (not including) the attention pool: [N, 3, S, S] -> [N, 32 * width, S/32, S/32]."""
+    v = "visual."
+    x = F.relu(_bn2d(F.conv2d(image, sd[v + "conv1.weight"], stride=2, padding=1), sd, v + "bn1."))
+    x = F.relu(_bn2d(F.conv2d(x, sd[v + "conv2.weight"], padding=1), sd, v + "bn2."))
+    x = F.relu(_bn2d(F.conv2d(x, sd[v + "conv3.weight"], padding=1), sd, v + "bn3."))
+    x = F.avg_pool2d(x, 2)
+    for li in range(1, 5):
+        b = 0
+        while f"{v}layer{li}.{b}.conv1.weight" in sd:
+            x = _rn_bottleneck(x, sd, f"{v}layer{li}.{b}.", 2 if (b == 0 and li > 1) else 1)
+            b += 1
+    return x
+
+
+def clip_attention_pool(x: Tensor, sd: SD, p: str = "visual.attnpool.") -> Tensor:
+    """AttentionPool2d: [N, C, H, W] -> [N, output_dim]; heads = C // 64."""
+    N, C = x.shape[0], x.shape[1]
+    heads, hd = C // 64, 64
+    t = x.flatten(2).permute(0, 2, 1)                                   # [N, HW, C]
+    t = torch.cat([t.mean(dim=1, keepdim=True), t], dim=1) + sd[p + "positional_embedding"][None]
+    q = (F.linear(t[:, :1], sd[p + "q_proj.weight"], sd[p + "q_proj.bias"]) * hd ** -0.5).view(N, 1, heads, hd).transpose(1, 2)
+    k = F.linear(t, sd[p + "k_proj.weight"], sd[p + "k_proj.bias"]).view(N, -1, heads, hd).transpose(1, 2)
+    v = F.linear(t, sd[p + "v_proj.weight"], sd[p + "v_proj.bias"]).view(N, -1, heads, hd).transpose(1, 2)
+    w = torch.matmul(q, k.transpose(-1, -2)).softmax(dim=-1)
+    o = torch.matmul(w, v).transpose(1, 2).reshape(N, C)
+    return F.linear(o, sd[p + "c_proj.weight"], sd[p + "c_proj.bias"])
+
+
+def clip_encode_image_resnet(image: Tensor, sd: SD) -> Tensor:
+    """CLIP.encode_image for a ModifiedResNet visual tower (RN50x4: [N, 3, 288, 288] -> [N, 640])."""
+    return clip_attention_pool(clip_resnet_features(image, sd), sd)
+
+
+# ----------------------------------------------------------------------------------------
 # Image preprocessing in front of encode_image (SURVEY §8 F3): the `preprocess` callable that
 # `clip.load` returns and the reference applies to every PIL image (predictions_runner.py:212,
 # embeddings_generator.py:72) = torchvision Compose[Resize(n_px, BICUBIC), CenterCrop(n_px),

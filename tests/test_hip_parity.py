@@ -794,6 +794,61 @@ def test_clip_b32_towers(golden):
     _check_clip(golden("clip_b32"), synth.CLIP_VIT_B32)
 
 
+def _rn_check(model, sd, imgs, atol_rel):
+    from oracle import capdec_oracle as O
+    want = O.clip_encode_image_resnet(imgs, sd)
+    got = model.encode_image(imgs).cpu()
+    assert got.shape == want.shape
+    scale = float(want.abs().max())
+    err = float((got - want).abs().max())
+    assert err < atol_rel * scale, (err, scale)
+    return got, want
+
+
+def test_clip_resnet_tiny_tower():
+    """ModifiedResNet image tower (the structure of RN50x4, the reference's default backbone: predictions_runner.py:158,
+    220) at a small geometry vs the oracle restatement: stem with stride-2 convolution + average pool, bottlenecks with
+    anti-aliased stride and downsample branches, attention pool.  Parity vs openai/CLIP itself is UNPINNED (package
+    absent from the image; the oracle's attention pool is pinned against torch's multi_head_attention_forward in
+    tests/test_oracle_vs_golden.py)."""
+    from capdec_amd import clip as cclip
+    from capdec_amd._capi import CapdecError
+    sd = synth.hot_clip_resnet_state_dict(44, synth.CLIP_RN_TINY)
+    model, pre = cclip.load(sd, device=0)
+    assert model.input_resolution == 64 and pre.n_px == 64 and not model.has_text
+    imgs = synth.synthetic_images(5, seed=12, size=64)                   # ragged: not a multiple of anything
+    got, want = _rn_check(model, sd, imgs, 2e-5)
+    # every image its own answer, order preserved, batch-size independent
+    assert float((want[0] - want[1]).abs().max()) > 1e-2 * float(want.abs().max())
+    one = model.encode_image(imgs[3:4]).cpu()
+    assert float((one - got[3:4]).abs().max()) < 1e-5 * float(want.abs().max())
+    assert model.encode_image(imgs[:0]).shape == (0, 128)
+    with pytest.raises(CapdecError):
+        model.encode_text(torch.zeros(1, 77, dtype=torch.int64))
+    with pytest.raises(CapdecError):
+        model.encode_image(torch.zeros(1, 3, 32, 32))
+    # a ViT tower loaded afterwards replaces the ResNet one in the same context (and vice versa)
+    eng = model._engine
+    vit = synth.hot_clip_state_dict(43, synth.CLIP_TINY)
+    eng.load_clip(vit, text=False, vision=True)
+    from oracle import capdec_oracle as O
+    im2 = synth.synthetic_images(2, seed=3)
+    np.testing.assert_allclose(eng.clip_encode_image(im2).cpu().numpy(), O.clip_encode_image(im2, vit).numpy(), atol=5e-4)
+    eng.load_clip(sd, text=False, vision=True)
+    assert float((eng.clip_encode_image(imgs).cpu() - got).abs().max()) == 0.0
+
+
+def test_clip_resnet_rn50x4_tower():
+    """the full RN50x4 geometry (layers 4/6/10/6, width 80, 288 x 288 pixels, 2560-channel attention pool with 40 heads
+    over 82 tokens, 640-d output): channel counts that need padding (40, 80, 160) included"""
+    from capdec_amd import clip as cclip
+    sd = synth.hot_clip_resnet_state_dict(44, synth.CLIP_RN50X4)
+    model, _ = cclip.load(sd, device=0)
+    assert model.input_resolution == 288
+    imgs = synth.synthetic_images(2, seed=13, size=288)
+    _rn_check(model, sd, imgs, 5e-5)
+
+
 @pytest.mark.parametrize("dims,tag", [(synth.CLIP_TINY, "tiny"), (synth.CLIP_VIT_B32, "b32")], ids=["tiny", "b32"])
 def test_clip_fp16_tower_mode(golden, dims, tag):
     """`clip.load(..., precision="fp16")`: block GEMMs with fp16 operands (the reference's GPU precision class,

@@ -291,3 +291,56 @@ def test_clip_preprocess_vs_live_pil():
         ref = np.asarray(Image.fromarray(img).resize((rw, rh), Image.BICUBIC))
         np.testing.assert_array_equal(O.pil_bicubic_resize(img, rw, rh), ref)
         assert ref[top:top + 224, left:left + 224].shape == (224, 224, 3)
+
+
+def test_oracle_resnet_tower_building_blocks():
+    """RN50x4 tower (openai/CLIP is absent from the image, so parity vs the package is UNPINNED):
+    the oracle's attention pool equals torch's own multi_head_attention_forward called the way CLIP's AttentionPool2d
+    calls it, and its bottleneck equals torch.nn modules (Conv2d / BatchNorm2d.eval() / AvgPool2d) wired as the
+    published architecture describes."""
+    import torch.nn as nn
+    import torch.nn.functional as F
+    dims = synth.CLIP_RN_TINY
+    sd = synth.hot_clip_resnet_state_dict(44, dims)
+    feats = O.clip_resnet_features(synth.synthetic_images(2, seed=12, size=dims.image_size), sd)
+    assert tuple(feats.shape) == (2, dims.feat_dim, 2, 2) and bool((feats >= 0).all()) and float(feats.std()) > 0.05
+    # --- attention pool
+    p = "visual.attnpool."
+    x = feats.flatten(2).permute(2, 0, 1)
+    x = torch.cat([x.mean(dim=0, keepdim=True), x], dim=0) + sd[p + "positional_embedding"][:, None, :]
+    want, _ = F.multi_head_attention_forward(
+        query=x[:1], key=x, value=x, embed_dim_to_check=x.shape[-1], num_heads=dims.heads,
+        q_proj_weight=sd[p + "q_proj.weight"], k_proj_weight=sd[p + "k_proj.weight"], v_proj_weight=sd[p + "v_proj.weight"],
+        in_proj_weight=None, in_proj_bias=torch.cat([sd[p + "q_proj.bias"], sd[p + "k_proj.bias"], sd[p + "v_proj.bias"]]),
+        bias_k=None, bias_v=None, add_zero_attn=False, dropout_p=0.0, out_proj_weight=sd[p + "c_proj.weight"],
+        out_proj_bias=sd[p + "c_proj.bias"], use_separate_proj_weight=True, training=False, need_weights=False)
+    got = O.clip_attention_pool(feats, sd)
+    assert float((got - want.squeeze(0)).abs().max()) < 1e-5 * float(want.abs().max())
+    # --- a strided bottleneck with a downsample branch (layer2.0) out of nn modules
+    pre = "visual.layer2.0."
+    inpl, planes = dims.width * 4, dims.width * 2
+
+    def bn(prefix, c):
+        m = nn.BatchNorm2d(c).eval()
+        m.load_state_dict({k: sd[prefix + k] for k in ("weight", "bias", "running_mean", "running_var", "num_batches_tracked")})
+        return m
+
+    def conv(name, cin, cout, k):
+        m = nn.Conv2d(cin, cout, k, padding=k // 2, bias=False)
+        m.weight.data.copy_(sd[name])
+        return m
+
+    g = torch.Generator().manual_seed(3)
+    xin = torch.randn(2, inpl, 8, 8, generator=g).relu()
+    with torch.no_grad():
+        out = F.relu(bn(pre + "bn1.", planes)(conv(pre + "conv1.weight", inpl, planes, 1)(xin)))
+        out = F.relu(bn(pre + "bn2.", planes)(conv(pre + "conv2.weight", planes, planes, 3)(out)))
+        out = nn.AvgPool2d(2)(out)
+        out = bn(pre + "bn3.", planes * 4)(conv(pre + "conv3.weight", planes, planes * 4, 1)(out))
+        idt = bn(pre + "downsample.1.", planes * 4)(conv(pre + "downsample.0.weight", inpl, planes * 4, 1)(nn.AvgPool2d(2)(xin)))
+        want_b = F.relu(out + idt)
+    got_b = O._rn_bottleneck(xin, sd, pre, 2)
+    assert float((got_b - want_b).abs().max()) < 1e-5
+    # the tower's output depends on the image and has the embedding width
+    e = O.clip_encode_image_resnet(synth.synthetic_images(2, seed=12, size=dims.image_size), sd)
+    assert tuple(e.shape) == (2, dims.embed_dim) and float((e[0] - e[1]).abs().max()) > 1e-3
