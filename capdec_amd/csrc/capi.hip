@@ -1467,6 +1467,14 @@ int capdec_gemm_f32(capdec_ctx *c, const float *a, int lda, const float *bt, int
         CAPDEC_TRY(planes_of(c, bt, N, K, cache, &pb));
         GemmEpilogue e;
         e.bias = bias; e.act = act; e.resid = resid; e.ldr = ldr;
+        if (c->gemm_mode == GEMM_F16X2 || c->gemm_mode == GEMM_BF16X3) {
+            const size_t wsb = gemm_splitk_ws_bytes(M, N, K);
+            if (wsb) {
+                CAPDEC_TRY(c->splitk.ensure(wsb));
+                e.splitk_ws = c->splitk.p;
+                e.splitk_ws_bytes = c->splitk.cap;
+                }
+        }
         if (c->gemm_mode == GEMM_F16X2) {
             ProfScope ps(c, F_GEMM_H2P, 2.0 * M * (double)N * K);
             return launch_gemm_f16x2p(c->stream, pa, pb, cc, ldc, M, N, K, e);

@@ -578,6 +578,10 @@ int gemm_splitk_slices(int M, int N, int K) {
         if (nk % s == 0 && (nk / s) % 2 == 0) best = s;
     return best;
 }
+// (Tried and removed: cutting only the tiles of the last, partly filled round of a > 512-tile grid into K-slices inside
+//  the same launch, summed by the last piece to arrive at a per-tile counter.  Device-scope fences cost an L2 write-back +
+//  invalidate per piece; with sc1 write-through dumps instead, the dump + arrival + re-read still cost more than the
+//  round they save: 3125 x 3072 x 768: 55 -> 68 us, 25000 x 768 x 3072: 393 -> 440 us.  DESIGN.md section 5.)
 size_t gemm_splitk_ws_bytes(int M, int N, int K) {
     const int s = gemm_splitk_slices(M, N, K);
     return s > 1 ? (size_t)s * M * N * sizeof(float) : 0;
