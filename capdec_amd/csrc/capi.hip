@@ -880,15 +880,32 @@ static int upload_conv_bn(ResNet &r, const capdec_conv_bn &s, bool first, ConvW 
 static int conv_bn_forward(capdec_ctx *c, const ConvW &w, const float *in, int N, int H, int W, int stride, bool nchw3,
                            float *out, int act, const float *resid, int *Ho_, int *Wo_) {
     int Ho = H, Wo = W;
-    const float *A = in;
     if (w.k == 3) {
         Ho = (H + 2 - 3) / stride + 1;
         Wo = (W + 2 - 3) / stride + 1;
-        CAPDEC_TRY(c->r_col.ensure((size_t)N * Ho * Wo * w.K * 4));
-        { ProfScope ps(c, F_OTHER); CAPDEC_TRY(launch_im2col3x3(c->stream, in, c->r_col.as<float>(), N, H, W, w.cin_p, stride, nchw3, w.K)); }
-        A = c->r_col.as<float>();
     }
-    CAPDEC_TRY(gemm(c, A, w.K, w.w, w.K, out, w.cout_p, N * Ho * Wo, w.cout_p, w.K, w.b, act, resid, w.cout_p));
+    const int M = N * Ho * Wo;
+    static const bool fused = [] { const char *e = getenv("CAPDEC_RN_PACKED"); return !(e && atoi(e) == 0); }();
+    if (fused && c->gemm_mode != GEMM_F32) {
+        // the A operand goes straight into the packed planes of the mode (two fp16 planes by default, one 16-bit plane
+        // under clip.load(..., precision="fp16" | "bf16")): im2col for 3x3, a plain packing pass for 1x1
+        const int fmt = pack_fmt(c);
+        CAPDEC_TRY(c->r_col.ensure(x3_packed_bytes(M, w.K, fmt)));
+        {
+            ProfScope ps(c, F_PACK);
+            if (w.k == 3) CAPDEC_TRY(launch_im2col3x3_packed(c->stream, in, c->r_col.p, N, H, W, w.cin_p, stride, nchw3, w.K, fmt));
+            else CAPDEC_TRY(pack_any(c, in, M, w.K, fmt, c->r_col.p));
+        }
+        CAPDEC_TRY(gemm_packed(c, c->r_col.p, w.w, out, w.cout_p, M, w.cout_p, w.K, w.b, act, resid, w.cout_p));
+    } else {
+        const float *A = in;
+        if (w.k == 3) {
+            CAPDEC_TRY(c->r_col.ensure((size_t)M * w.K * 4));
+            { ProfScope ps(c, F_OTHER); CAPDEC_TRY(launch_im2col3x3(c->stream, in, c->r_col.as<float>(), N, H, W, w.cin_p, stride, nchw3, w.K)); }
+            A = c->r_col.as<float>();
+        }
+        CAPDEC_TRY(gemm(c, A, w.K, w.w, w.K, out, w.cout_p, M, w.cout_p, w.K, w.b, act, resid, w.cout_p));
+    }
     if (Ho_) *Ho_ = Ho;
     if (Wo_) *Wo_ = Wo;
     return 0;
@@ -1335,9 +1352,15 @@ int capdec_clip_encode_image(capdec_ctx *c, const float *pixels, int n, float *o
     CAPDEC_HIP(hipSetDevice(c->device));
     if (c->clip_resnet.loaded) {
         const ResNet &r = c->clip_resnet;
-        // images per chunk: the im2col buffer of the stem (S/2 x S/2 pixels x 9 x 64 floats) stays under ~1.5 GB
+        // images per chunk: the late stages have few pixels per image (9 x 9 at the end), so their GEMMs only fill the
+        // chip with ~100 images in flight; the largest temporary is the im2col operand of the stem (S/2 x S/2 pixels x
+        // 9 x 64 values x 4 B): up to 8 GB of it (a 288 GB part), less when the device is short of free memory
         const size_t per_img = (size_t)(r.image / 2) * (r.image / 2) * 9 * pad64(r.width / 2) * 4;
-        const int chunk = (int)std::max<size_t>(1, ((size_t)3 << 29) / std::max<size_t>(per_img, 1));
+        size_t free_b = 0, total_b = 0;
+        CAPDEC_HIP(hipMemGetInfo(&free_b, &total_b));
+        const size_t have = c->r_col.cap + c->a_tmp.cap + c->r_a.cap * 6;         // what this path already holds
+        const size_t budget = std::min<size_t>((size_t)8 << 30, (free_b + have) / 4);
+        const int chunk = (int)std::max<size_t>(1, budget / std::max<size_t>(per_img, 1));
         for (int c0 = 0; c0 < n; c0 += chunk) {
             const int nc = std::min(chunk, n - c0);
             CAPDEC_TRY(clip_resnet_chunk(c, pixels + (size_t)c0 * 3 * r.image * r.image, nc, out + (size_t)c0 * r.embed));

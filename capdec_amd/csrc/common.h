@@ -177,6 +177,9 @@ int launch_vision_assemble(hipStream_t st, const float *patch_out, const float *
 // resnet.hip: glue of CLIP's ModifiedResNet tower (NHWC fp32, channels padded to multiples of 64)
 int launch_im2col3x3(hipStream_t st, const float *in, float *out, int N, int H, int W, int C, int stride, bool nchw3,
                      int Kp);
+// the same straight into the packed GEMM operand of format fmt (PK_*: bf16x3.h): no fp32 im2col matrix in HBM
+int launch_im2col3x3_packed(hipStream_t st, const float *in, void *out, int N, int H, int W, int C, int stride, bool nchw3,
+                            int Kp, int fmt);
 int launch_avgpool2(hipStream_t st, const float *in, float *out, int N, int H, int W, int C);
 int launch_attnpool_tokens(hipStream_t st, const float *feat, const float *pos, float *t, int N, int HW, int C);
 int launch_attnpool_attend(hipStream_t st, const float *q, const float *k, const float *v, float *out, int N, int heads,

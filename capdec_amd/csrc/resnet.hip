@@ -7,9 +7,85 @@
 //
 // Layout: activations are NHWC fp32 with the channel count padded to a multiple of 64 (zero channels: the folded
 // weights have zero rows / columns there), so every GEMM has K % 64 == 0 and runs on the packed-operand kernels.
+#include "bf16x3.h"
 #include "common.h"
 
 namespace capdec {
+
+// ---- im2col straight into the packed GEMM operand (format fmt, tile-major planes: bf16x3.h): one thread per (matrix
+// row = output pixel, k-step = 16 consecutive (tap, channel) columns).  The 128 threads of one (row tile, k-step) block
+// are consecutive, so a block of the operand is written whole; rows beyond M are written as zeros.
+__global__ void im2col3x3_packed_kernel(const float *__restrict__ in, char *__restrict__ out, int M, int H, int W, int C,
+                                        int stride, int Ho, int Wo, int nk, int fmt, size_t total) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const size_t blk = i >> 7;
+    const int ks = (int)(blk % nk);
+    const int row = (int)(blk / nk) * 128 + (int)(i & 127);
+    const int k0 = ks << 4, tap = k0 / C, c0 = k0 - tap * C;                  // C % 16 == 0: a k-step stays within one tap
+    float4 v[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) v[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (row < M) {
+        const int ox = row % Wo, oy = (row / Wo) % Ho, n = row / (Wo * Ho);
+        const int iy = oy * stride + tap / 3 - 1, ix = ox * stride + tap % 3 - 1;
+        if (iy >= 0 && iy < H && ix >= 0 && ix < W) {
+            const float4 *p = reinterpret_cast<const float4 *>(in + (((size_t)n * H + iy) * W + ix) * C + c0);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v[q] = p[q];
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) x3_store_quad(out, nk, row, ks, q, v[q], fmt);
+}
+
+// first convolution: NCHW fp32 pixels, 3 channels, K = 27 padded to 64 (four k-steps)
+__global__ void im2col3x3_nchw3_packed_kernel(const float *__restrict__ in, char *__restrict__ out, int M, int H, int W,
+                                              int stride, int Ho, int Wo, int nk, int fmt, size_t total) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const size_t blk = i >> 7;
+    const int ks = (int)(blk % nk);
+    const int row = (int)(blk / nk) * 128 + (int)(i & 127);
+    float v[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) v[j] = 0.f;
+    if (row < M && ks < 2) {
+        const int ox = row % Wo, oy = (row / Wo) % Ho, n = row / (Wo * Ho);
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const int k = (ks << 4) + j;
+            if (k < 27) {
+                const int tap = k / 3, ch = k - tap * 3;
+                const int iy = oy * stride + tap / 3 - 1, ix = ox * stride + tap % 3 - 1;
+                if (iy >= 0 && iy < H && ix >= 0 && ix < W) v[j] = in[(((size_t)n * 3 + ch) * H + iy) * W + ix];
+            }
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+        x3_store_quad(out, nk, row, ks, q, make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]), fmt);
+}
+
+int launch_im2col3x3_packed(hipStream_t st, const float *in, void *out, int N, int H, int W, int C, int stride, bool nchw3,
+                            int Kp, int fmt) {
+    const int Ho = (H + 2 - 3) / stride + 1, Wo = (W + 2 - 3) / stride + 1;
+    if (N <= 0) return 0;
+    CAPDEC_CHECK((size_t)N * Ho * Wo < ((size_t)1 << 31) - 128, "im2col: too many output pixels for one launch");
+    const int M = N * Ho * Wo, nk = Kp / 16;
+    const size_t total = (size_t)((M + 127) / 128) * 128 * nk;
+    if (nchw3) {
+        CAPDEC_CHECK(Kp == 64, "im2col: the 3-channel convolution is padded to K = 64");
+        hipLaunchKernelGGL(im2col3x3_nchw3_packed_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, in,
+                           (char *)out, M, H, W, stride, Ho, Wo, nk, fmt, total);
+    } else {
+        CAPDEC_CHECK(C % 16 == 0 && Kp == 9 * C, "im2col: channel count must be a multiple of 16");
+        hipLaunchKernelGGL(im2col3x3_packed_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, in, (char *)out,
+                           M, H, W, C, stride, Ho, Wo, nk, fmt, total);
+    }
+    CAPDEC_HIP(hipGetLastError());
+    return 0;
+}
 
 // ---- im2col for a 3x3 convolution with padding 1: out[(n, oy, ox)][(ky, kx, c)] = in[n][oy*s+ky-1][ox*s+kx-1][c]
 // (NHWC input, C % 4 == 0); one thread per (output pixel, tap, 4 channels)

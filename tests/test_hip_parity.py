@@ -849,6 +849,29 @@ def test_clip_resnet_rn50x4_tower():
     _rn_check(model, sd, imgs, 5e-5)
 
 
+@pytest.mark.parametrize("precision", ["fp16", "bf16"])
+def test_clip_resnet_reduced_precision(precision):
+    """`clip.load(..., precision="fp16")` on the ResNet tower: convolutions with ONE 16-bit operand plane (the reference's
+    GPU precision class: clip.load converts the model to fp16, predictions_runner.py:218-220).  Close to the fp32 oracle at
+    the precision's level, and really reduced precision (differs from the fp32-accurate run)."""
+    from capdec_amd import clip as cclip
+    from oracle import capdec_oracle as O
+    sd = synth.hot_clip_resnet_state_dict(44, synth.CLIP_RN_TINY)
+    imgs = synth.synthetic_images(6, seed=12, size=64)
+    want = O.clip_encode_image_resnet(imgs, sd)
+    scale = float(want.abs().max())
+    full = cclip.load(sd, device=0)[0].encode_image(imgs).cpu()
+    model, _ = cclip.load(sd, device=0, precision=precision)
+    got = model.encode_image(imgs).cpu()
+    tol = {"fp16": 1e-2, "bf16": 6e-2}[precision]
+    err = float((got - want).abs().max())
+    assert err < tol * scale, (err, scale)
+    assert err > 20 * float((full - want).abs().max())
+    # cosine similarity with the exact features: what the downstream normalise -> mapper consumes
+    cos = torch.nn.functional.cosine_similarity(got, want, dim=1)
+    assert float(cos.min()) > {"fp16": 0.9999, "bf16": 0.998}[precision]
+
+
 @pytest.mark.parametrize("dims,tag", [(synth.CLIP_TINY, "tiny"), (synth.CLIP_VIT_B32, "b32")], ids=["tiny", "b32"])
 def test_clip_fp16_tower_mode(golden, dims, tag):
     """`clip.load(..., precision="fp16")`: block GEMMs with fp16 operands (the reference's GPU precision class,
