@@ -131,6 +131,7 @@ struct capdec_ctx {
     Tower clip_text, clip_vision;
     ResNet clip_resnet;
     DBuf r_a, r_b, r_c, r_d, r_e, r_f, r_col;      // ResNet activation buffers (NHWC) + im2col
+    DBuf r_pk1, r_pk2, r_xpk, r_zero;              // ... packed activations (GEMM / implicit-conv operands), zero rows
     Prof prof;
     int gemm_mode = GEMM_F16X2;
     struct Planes { void *p; size_t n; int fmt; };
@@ -911,27 +912,12 @@ static int conv_bn_forward(capdec_ctx *c, const ConvW &w, const float *in, int N
     return 0;
 }
 
-// one chunk of images: pixels [n, 3, S, S] (NCHW) -> out [n, embed]
-static int clip_resnet_chunk(capdec_ctx *c, const float *pixels, int n, float *out) {
+// stem + the four stages with fp32 NHWC activations between the convolutions (every convolution packs / im2cols its own
+// operand): the path of the bf16x3 / f32 modes.  On return x holds the [n, H, W, feat] features.
+static int resnet_body_fp32(capdec_ctx *c, const float *pixels, int n, float *&x, float *&y, float *t1, float *t2, float *xi,
+                            float *idb, int *Hp, int *Wp) {
     ResNet &r = c->clip_resnet;
-    const int S = r.image;
-    // worst-case activation sizes (floats per image): stem conv outputs at S/2, stage outputs at S/4 ... S/32
-    const size_t half = (size_t)(S / 2) * (S / 2), quarter = (size_t)(S / 4) * (S / 4);
-    size_t act = half * pad64(r.width);                                        // stem
-    int planes = r.width, sp = S / 4;
-    for (int li = 0; li < 4; ++li, planes *= 2) {
-        const int spin = sp;                                                   // spatial size entering the stage
-        if (li > 0) sp /= 2;
-        act = std::max(act, (size_t)spin * spin * pad64(planes * 4));          // identity / stage output
-        act = std::max(act, (size_t)spin * spin * pad64(planes));              // conv1 / conv2 outputs before the pool
-        act = std::max(act, (size_t)spin * spin * pad64(li ? planes * 2 : planes));   // stage input
-    }
-    act = std::max(act, quarter * pad64(r.width));
-    act = std::max(act, ((size_t)r.sp * r.sp + 1) * r.feat);                   // attention-pool tokens / keys / values
-    for (DBuf *b : {&c->r_a, &c->r_b, &c->r_c, &c->r_d, &c->r_e, &c->r_f}) CAPDEC_TRY(b->ensure((size_t)n * act * 4));
-    float *x = c->r_a.as<float>(), *y = c->r_b.as<float>(), *t1 = c->r_c.as<float>(), *t2 = c->r_d.as<float>(),
-          *xi = c->r_e.as<float>(), *idb = c->r_f.as<float>();
-    int H = S, W = S;
+    int H = *Hp, W = *Wp;
     // stem: conv3x3 stride 2 (from NCHW pixels), two conv3x3, AvgPool2d(2)
     CAPDEC_TRY(conv_bn_forward(c, r.stem[0], pixels, n, H, W, 2, true, t1, CAPDEC_ACT_RELU, nullptr, &H, &W));
     CAPDEC_TRY(conv_bn_forward(c, r.stem[1], t1, n, H, W, 1, false, t2, CAPDEC_ACT_RELU, nullptr, &H, &W));
@@ -963,6 +949,134 @@ static int clip_resnet_chunk(capdec_ctx *c, const float *pixels, int n, float *o
             std::swap(x, y);
             H = Ho; W = Wo;
         }
+    }
+    *Hp = H; *Wp = W;
+    return 0;
+}
+
+// The same with PACKED activations wherever the consumer is a GEMM operand (modes f16x2 / f16 / bf16):
+//  * a 1x1 convolution whose result feeds a 3x3 one, and a 3x3 one that feeds a 1x1 one, write their result straight as
+//    the packed operand of the consumer (GEMM epilogue packed_out: bias + ReLU + split, no fp32 copy in HBM);
+//  * a 3x3 convolution (stride 1, padding 1 -- all of them but the very first) is an IMPLICIT GEMM over that packed
+//    activation (launch_conv3x3_packed): no im2col matrix exists;
+//  * fp32 NHWC remains where it is needed as such: the residual stream (identity / residual add), the inputs of the
+//    average pools, the first convolution's pixels.
+static int conv3x3_implicit(capdec_ctx *c, const ConvW &w, const void *in_pk, int n, int H, int W, float *out,
+                            void *packed_out, int act) {
+    const int fmt = pack_fmt(c);
+    const void *pl = nullptr;
+    CAPDEC_TRY(planes_of(c, w.w, w.cout_p, w.K, true, &pl));
+    const size_t zb = (size_t)(w.cin_p / 16 + 2) * 8192;
+    if (c->r_zero.cap < zb) {
+        CAPDEC_TRY(c->r_zero.ensure(std::max<size_t>(zb, (size_t)512 << 10)));
+        CAPDEC_HIP(hipMemsetAsync(c->r_zero.p, 0, c->r_zero.cap, c->stream));
+    }
+    GemmEpilogue e;
+    e.bias = w.b;
+    e.act = act;
+    e.packed_out = packed_out;
+    ProfScope ps(c, mode_single(c) ? F_GEMM_BF16P : F_GEMM_H2P, 2.0 * n * H * W * (double)w.cout_p * w.K);
+    return launch_conv3x3_packed(c->stream, in_pk, pl, out, w.cout_p, n, H, W, w.cin_p, w.cout_p, e, fmt, c->r_zero.p,
+                                 c->r_zero.cap);
+}
+static int pack_act(capdec_ctx *c, const float *in, int M, int C, DBuf &dst) {
+    const int fmt = pack_fmt(c);
+    CAPDEC_TRY(dst.ensure(x3_packed_bytes(M, C, fmt)));
+    ProfScope ps(c, F_PACK);
+    return pack_any(c, in, M, C, fmt, dst.p);
+}
+static int resnet_body_packed(capdec_ctx *c, const float *pixels, int n, float *&x, float *&y, float *t1, float *t2,
+                              float *xi, float *idb, int *Hp, int *Wp) {
+    ResNet &r = c->clip_resnet;
+    const int fmt = pack_fmt(c);
+    int H = *Hp, W = *Wp;
+    // stem: conv1 (stride 2, 3 input channels: im2col of K = 27 -> 64 straight into the operand) -> packed; conv2 implicit ->
+    // packed; conv3 implicit -> fp32 for the average pool
+    {
+        const ConvW &s0 = r.stem[0], &s1 = r.stem[1], &s2 = r.stem[2];
+        const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1, M = n * Ho * Wo;
+        CAPDEC_TRY(c->r_col.ensure(x3_packed_bytes(M, s0.K, fmt)));
+        { ProfScope ps(c, F_PACK); CAPDEC_TRY(launch_im2col3x3_packed(c->stream, pixels, c->r_col.p, n, H, W, 3, 2, true, s0.K, fmt)); }
+        CAPDEC_TRY(c->r_pk1.ensure(x3_packed_bytes(M, std::max(s0.cout_p, s1.cout_p), fmt)));
+        CAPDEC_TRY(c->r_pk2.ensure(x3_packed_bytes(M, s1.cout_p, fmt)));
+        CAPDEC_TRY(gemm_packed(c, c->r_col.p, s0.w, nullptr, s0.cout_p, M, s0.cout_p, s0.K, s0.b, CAPDEC_ACT_RELU, nullptr, 0,
+                               c->r_pk1.p));
+        H = Ho; W = Wo;
+        CAPDEC_TRY(conv3x3_implicit(c, s1, c->r_pk1.p, n, H, W, nullptr, c->r_pk2.p, CAPDEC_ACT_RELU));
+        CAPDEC_TRY(conv3x3_implicit(c, s2, c->r_pk2.p, n, H, W, t1, nullptr, CAPDEC_ACT_RELU));
+        { ProfScope ps(c, F_OTHER); CAPDEC_TRY(launch_avgpool2(c->stream, t1, x, n, H, W, s2.cout_p)); }
+        H /= 2; W /= 2;
+    }
+    size_t bi = 0;
+    for (int li = 0; li < 4; ++li) {
+        for (int b = 0; b < r.layers[li]; ++b, bi += 4) {
+            const ConvW &c1 = r.blocks[bi], &c2 = r.blocks[bi + 1], &c3 = r.blocks[bi + 2], &ds = r.blocks[bi + 3];
+            const int stride = (b == 0 && li > 0) ? 2 : 1;
+            const int M = n * H * W;
+            CAPDEC_TRY(pack_act(c, x, M, c1.cin_p, c->r_xpk));                        // the block input as a GEMM operand
+            CAPDEC_TRY(c->r_pk1.ensure(x3_packed_bytes(M, c1.cout_p, fmt)));
+            CAPDEC_TRY(gemm_packed(c, c->r_xpk.p, c1.w, nullptr, c1.cout_p, M, c1.cout_p, c1.K, c1.b, CAPDEC_ACT_RELU, nullptr,
+                                   0, c->r_pk1.p));
+            int Ho = H, Wo = W;
+            const float *idt = x;
+            if (stride == 1) {
+                CAPDEC_TRY(c->r_pk2.ensure(x3_packed_bytes(M, c2.cout_p, fmt)));
+                CAPDEC_TRY(conv3x3_implicit(c, c2, c->r_pk1.p, n, H, W, nullptr, c->r_pk2.p, CAPDEC_ACT_RELU));
+                if (ds.w) {      // (first block of the first stage: the channel count changes, the resolution does not)
+                    CAPDEC_TRY(gemm_packed(c, c->r_xpk.p, ds.w, idb, ds.cout_p, M, ds.cout_p, ds.K, ds.b, CAPDEC_ACT_NONE));
+                    idt = idb;
+                }
+            } else {             // anti-aliased stride: average pools on the branch and in front of the downsample conv
+                CAPDEC_TRY(conv3x3_implicit(c, c2, c->r_pk1.p, n, H, W, t2, nullptr, CAPDEC_ACT_RELU));
+                {
+                    ProfScope ps(c, F_OTHER);
+                    CAPDEC_TRY(launch_avgpool2(c->stream, t2, t1, n, H, W, c2.cout_p));
+                    CAPDEC_TRY(launch_avgpool2(c->stream, x, xi, n, H, W, c1.cin_p));
+                }
+                Ho = H / 2; Wo = W / 2;
+                CAPDEC_TRY(pack_act(c, t1, n * Ho * Wo, c2.cout_p, c->r_pk2));
+                CAPDEC_CHECK(ds.w != nullptr, "clip_resnet: a strided block without a downsample branch");
+                CAPDEC_TRY(pack_act(c, xi, n * Ho * Wo, ds.cin_p, c->r_xpk));
+                CAPDEC_TRY(gemm_packed(c, c->r_xpk.p, ds.w, idb, ds.cout_p, n * Ho * Wo, ds.cout_p, ds.K, ds.b, CAPDEC_ACT_NONE));
+                idt = idb;
+            }
+            const int Mo = n * Ho * Wo;
+            CAPDEC_TRY(gemm_packed(c, c->r_pk2.p, c3.w, y, c3.cout_p, Mo, c3.cout_p, c3.K, c3.b, CAPDEC_ACT_RESID_RELU, idt,
+                                   c3.cout_p));
+            std::swap(x, y);
+            H = Ho; W = Wo;
+        }
+    }
+    *Hp = H; *Wp = W;
+    return 0;
+}
+
+// one chunk of images: pixels [n, 3, S, S] (NCHW) -> out [n, embed]
+static int clip_resnet_chunk(capdec_ctx *c, const float *pixels, int n, float *out) {
+    ResNet &r = c->clip_resnet;
+    const int S = r.image;
+    // worst-case activation sizes (floats per image): stem conv outputs at S/2, stage outputs at S/4 ... S/32
+    const size_t half = (size_t)(S / 2) * (S / 2), quarter = (size_t)(S / 4) * (S / 4);
+    size_t act = half * pad64(r.width);                                        // stem
+    int planes = r.width, sp = S / 4;
+    for (int li = 0; li < 4; ++li, planes *= 2) {
+        const int spin = sp;                                                   // spatial size entering the stage
+        if (li > 0) sp /= 2;
+        act = std::max(act, (size_t)spin * spin * pad64(planes * 4));          // identity / stage output
+        act = std::max(act, (size_t)spin * spin * pad64(planes));              // conv1 / conv2 outputs before the pool
+        act = std::max(act, (size_t)spin * spin * pad64(li ? planes * 2 : planes));   // stage input
+    }
+    act = std::max(act, quarter * pad64(r.width));
+    act = std::max(act, ((size_t)r.sp * r.sp + 1) * r.feat);                   // attention-pool tokens / keys / values
+    for (DBuf *b : {&c->r_a, &c->r_b, &c->r_c, &c->r_d, &c->r_e, &c->r_f}) CAPDEC_TRY(b->ensure((size_t)n * act * 4));
+    float *x = c->r_a.as<float>(), *y = c->r_b.as<float>(), *t1 = c->r_c.as<float>(), *t2 = c->r_d.as<float>(),
+          *xi = c->r_e.as<float>(), *idb = c->r_f.as<float>();
+    int H = S, W = S;
+    static const bool implicit_on = [] { const char *e = getenv("CAPDEC_RN_IMPLICIT"); return !(e && atoi(e) == 0); }();
+    if (implicit_on && (c->gemm_mode == GEMM_F16X2 || mode_single(c))) {
+        CAPDEC_TRY(resnet_body_packed(c, pixels, n, x, y, t1, t2, xi, idb, &H, &W));
+    } else {
+        CAPDEC_TRY(resnet_body_fp32(c, pixels, n, x, y, t1, t2, xi, idb, &H, &W));
     }
     // attention pool: tokens = [mean; features] + pos; one query (the mean token) over all tokens
     const int C = r.feat, HW = H * W, T = HW + 1;
@@ -1076,7 +1190,8 @@ void capdec_destroy(capdec_ctx *c) {
                     &c->lse, &c->topv, &c->topi, &c->kc, &c->vc, &c->tokens, &c->scores, &c->seq, &c->stopped,
                     &c->done, &c->anc, &c->next_tok, &c->alive, &c->gids, &c->glens, &c->m_hid, &c->m_lin, &c->m_seq,
                     &c->m_x, &c->m_qkv, &c->m_att, &c->m_ff, &c->t_idx, &c->t_patch, &c->t_pout, &c->xpk, &c->apk, &c->fpk, &c->cmap, &c->p_desc, &c->p_inter, &c->splitk, &c->a_tmp,
-                    &c->r_a, &c->r_b, &c->r_c, &c->r_d, &c->r_e, &c->r_f, &c->r_col};
+                    &c->r_a, &c->r_b, &c->r_c, &c->r_d, &c->r_e, &c->r_f, &c->r_col, &c->r_pk1, &c->r_pk2, &c->r_xpk,
+                    &c->r_zero};
     for (DBuf *b : bufs) b->release();
     for (auto &r : c->prof.recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
     for (auto e : c->prof.pool) (void)hipEventDestroy(e);

@@ -174,6 +174,12 @@ int launch_im2col_patches(hipStream_t st, const float *pixels, float *patches, i
 int launch_vision_assemble(hipStream_t st, const float *patch_out, const float *cls, const float *pos, float *seq,
                            int n, int ntok, int d);
 
+// gemm_f16x2.hip: implicit-GEMM 3x3 convolution (stride 1, padding 1) on the packed-operand main loop: act_pk = the input
+// activation [Nimg H W pixels][Cin] as a packed operand of format fmt (f16x2 / f16 / bf16), Bpacked = weights
+// [Cout][9 Cin] in (ky, kx, c) order; zeros = a zeroed device buffer of >= (Cin / 16 + 1) * 8 KB (the padding's rows)
+int launch_conv3x3_packed(hipStream_t st, const void *act_pk, const void *Bpacked, float *C, int ldc, int Nimg, int H,
+                          int W, int Cin, int Cout, const GemmEpilogue &epi, int fmt, const void *zeros, size_t zero_bytes);
+
 // resnet.hip: glue of CLIP's ModifiedResNet tower (NHWC fp32, channels padded to multiples of 64)
 int launch_im2col3x3(hipStream_t st, const float *in, float *out, int N, int H, int W, int C, int stride, bool nchw3,
                      int Kp);

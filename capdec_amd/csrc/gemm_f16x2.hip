@@ -86,10 +86,24 @@ __host__ __device__ constexpr int waitcnt_imm(int vm, int lgkm) {
 // PK_BF16X1: the reduced-precision modes, one MFMA per product): the same ring, DMA pieces and fragment reads, but a
 // stage holds TWO consecutive k-steps of the single plane where f16x2 holds the two planes of one k-step (both are
 // 2 x 4 KB contiguous per operand), so a stage is 32 deep and carries 8 MFMAs per wavefront instead of 12.
-template <bool TR, int NS, int ABL = 0, int KIND = 0>
+// CONV (implicit-GEMM 3x3 convolution, stride 1, padding 1; resnet.hip / capi.hip): the A operand is not an im2col
+// matrix but the ACTIVATION itself in packed form -- rows = pixels of an NHWC tensor [M = N H W][C], the very layout a
+// GEMM epilogue writes with packed_out -- and K runs over (tap, channel): K = 9 C, stage ks = tap * ncs + cs.  Row m of
+// the product is output pixel m, whose operand row for tap (ky, kx) is input pixel m + (ky - 1) W + (kx - 1) (stride 1:
+// output and input pixels share their index) or a row of zeros outside the image.  Each thread owns the same 16-byte
+// piece of the stage as in the GEMM (row t / 2, half t & 1) and re-derives its source address when the tap changes --
+// nine times per tile; a piece is a 16-byte half of a 32-byte row chunk whose position inside the chunk depends on bit 3
+// of the row (the LDS swizzle), so a piece copied from source row rs to tile row rd sits at half ^ sw(rd) ^ sw(rs).
+struct ConvGeo {
+    int H = 0, W = 0, M = 0;      // image height / width (pixels), rows of the product (= N H W)
+    int ncs = 0;                  // stages per tap: C / 16 (two-plane f16x2) or C / 32 (one-plane formats)
+    const char *zero = nullptr;   // >= ncs * 8 KB + 8 KB of zeros: the operand rows of the padding
+};
+
+template <bool TR, int NS, int ABL = 0, int KIND = 0, bool CONV = false>
 __device__ __forceinline__ void h2p_mainloop(const _Float16 *__restrict__ Apk, const _Float16 *__restrict__ Bpk, int K,
                                              int tm, int tn, char *smem, f32x16 (&am)[2][2], f32x16 (&ac)[2][2],
-                                             int ks0 = 0, int nks = -1) {
+                                             int ks0 = 0, int nks = -1, const ConvGeo cg = ConvGeo()) {
     static_assert(NS >= 3 && NS <= 9, "ring depth");
     const int t = threadIdx.x;
     const int lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -100,13 +114,48 @@ __device__ __forceinline__ void h2p_mainloop(const _Float16 *__restrict__ Apk, c
     const _Float16 *ap = Apk + ((size_t)tm * nkf + ks0) * (H2_BLOCK_B / 2) + t * 8;   // this thread's 16-B piece
     const _Float16 *bp = Bpk + ((size_t)tn * nkf + ks0) * (H2_BLOCK_B / 2) + t * 8;
     char *dst0 = smem + wave * 1024;                                           // wave-uniform LDS base of its pieces
+    // CONV: running (stage, tap, stage-in-tap) of the NEXT tile to send (the DMAs are issued in increasing stage order,
+    // clamped at the last one) and this thread's source for the current tap
+    int cv_ks = 0, cv_cs = 0, cv_tap = 0, cv_ox = 0, cv_oy = 0, cv_m = 0;
+    bool cv_ok = false;
+    const char *cv_cur = nullptr;
+    auto cv_src = [&](int tap) -> const char * {
+        const int ky = tap / 3, kx = tap - 3 * ky;
+        const int iy = cv_oy + ky - 1, ix = cv_ox + kx - 1;
+        const bool ok = cv_ok && (unsigned)iy < (unsigned)cg.H && (unsigned)ix < (unsigned)cg.W;
+        const int pin = cv_m + (ky - 1) * cg.W + (kx - 1), pr = pin & 127;
+        const size_t off = (size_t)(pin >> 7) * cg.ncs * H2_BLOCK_B + pr * X3_ROW_B +
+                           ((((t & 1) ^ ((t >> 4) & 1) ^ ((pr >> 3) & 1))) << 4);
+        return ok ? reinterpret_cast<const char *>(Apk) + off : cg.zero + ((t & 1) << 4);
+    };
+    if constexpr (CONV) {
+        cv_m = tm * GEMM_BM + (t >> 1);
+        cv_ok = cv_m < cg.M;
+        if (!cv_ok) cv_m = 0;
+        cv_ox = cv_m % cg.W;
+        cv_oy = (cv_m / cg.W) % cg.H;
+        cv_cur = cv_src(0);
+    }
 #define H2_DMA(stage, ks_)                                                                                     \
     {                                                                                                          \
-        const _Float16 *sa = ap + (size_t)(ks_) * (H2_BLOCK_B / 2), *sb = bp + (size_t)(ks_) * (H2_BLOCK_B / 2); \
         char *d = dst0 + (stage) * H2_STAGE_B;                                                                 \
-        _Pragma("unroll") for (int p = 0; p < 2; ++p) {                                                        \
-            __builtin_amdgcn_global_load_lds((glb_void_h *)(sa + p * 2048), (lds_void_h *)(d + p * X3_PLANE_B), 16, 0, 0); \
-            __builtin_amdgcn_global_load_lds((glb_void_h *)(sb + p * 2048), (lds_void_h *)(d + H2_BLOCK_B + p * X3_PLANE_B), 16, 0, 0); \
+        if constexpr (CONV) {                                                                                  \
+            const char *sa = cv_cur + (size_t)cv_cs * H2_BLOCK_B;                                              \
+            const _Float16 *sb = bp + (size_t)cv_ks * (H2_BLOCK_B / 2);                                        \
+            _Pragma("unroll") for (int p = 0; p < 2; ++p) {                                                    \
+                __builtin_amdgcn_global_load_lds((glb_void_h *)(sa + p * X3_PLANE_B), (lds_void_h *)(d + p * X3_PLANE_B), 16, 0, 0); \
+                __builtin_amdgcn_global_load_lds((glb_void_h *)(sb + p * 2048), (lds_void_h *)(d + H2_BLOCK_B + p * X3_PLANE_B), 16, 0, 0); \
+            }                                                                                                  \
+            if (cv_ks < nk - 1) {                                                                              \
+                ++cv_ks;                                                                                       \
+                if (++cv_cs == cg.ncs) { cv_cs = 0; ++cv_tap; cv_cur = cv_src(cv_tap); }                       \
+            }                                                                                                  \
+        } else {                                                                                               \
+            const _Float16 *sa = ap + (size_t)(ks_) * (H2_BLOCK_B / 2), *sb = bp + (size_t)(ks_) * (H2_BLOCK_B / 2); \
+            _Pragma("unroll") for (int p = 0; p < 2; ++p) {                                                    \
+                __builtin_amdgcn_global_load_lds((glb_void_h *)(sa + p * 2048), (lds_void_h *)(d + p * X3_PLANE_B), 16, 0, 0); \
+                __builtin_amdgcn_global_load_lds((glb_void_h *)(sb + p * 2048), (lds_void_h *)(d + H2_BLOCK_B + p * X3_PLANE_B), 16, 0, 0); \
+            }                                                                                                  \
         }                                                                                                      \
     }
 #pragma unroll
@@ -434,6 +483,56 @@ int launch_gemm_x1_topk(hipStream_t st, const void *Apacked, const void *Bpacked
         default: CAPDEC_CHECK(false, "gemm_topk: k must be in 1..8");
     }
 #undef LAUNCH_TOPKX
+    CAPDEC_HIP(hipGetLastError());
+    return 0;
+}
+
+// ---- implicit-GEMM 3x3 convolution (stride 1, padding 1) on the same main loop (CONV above).  act_pk = the input
+// activation [M = N H W pixels][Cin] as a packed operand (format fmt); Bpacked = the folded weights [Cout][9 Cin] in
+// (ky, kx, c) order; output as for the GEMMs (fp32 C with bias / activation / residual, or packed_out)
+template <int KIND>
+__global__ __launch_bounds__(256, 2) void conv3x3_packed_kernel(const _Float16 *__restrict__ Apk,
+                                                                const _Float16 *__restrict__ Bpk, float *C, int ldc, int M,
+                                                                int N, int K, const float *__restrict__ bias,
+                                                                const float *resid, int ldr, int act, int tiles_m,
+                                                                int tiles_n, char *packed_out, int fmt, ConvGeo cg) {
+    __shared__ __attribute__((aligned(16))) char smem[H2_NS * H2_STAGE_B];
+    int tm, tn;
+    tile_coords(tiles_m, tiles_n, tm, tn);
+    f32x16 am[2][2], ac[2][2];
+    h2p_mainloop<true, H2_NS, 0, KIND, true>(Apk, Bpk, K, tm, tn, smem, am, ac, 0, -1, cg);
+    if constexpr (KIND == 0) h2_join(am, ac);
+    if (packed_out)
+        epilogue_store_packed_t(am, packed_out, N >> 4, M, N, tm * GEMM_BM, tn * GEMM_BN, bias, act, fmt);
+    else
+        epilogue_store_t<true>(am, C, ldc, M, N, tm * GEMM_BM, tn * GEMM_BN, bias, resid, ldr, act);
+}
+
+int launch_conv3x3_packed(hipStream_t st, const void *act_pk, const void *Bpacked, float *C, int ldc, int Nimg, int H,
+                          int W, int Cin, int Cout, const GemmEpilogue &epi, int fmt, const void *zeros,
+                          size_t zero_bytes) {
+    CAPDEC_CHECK(fmt == PK_F16X2 || fmt == PK_F16X1 || fmt == PK_BF16X1, "conv3x3: operand format f16x2, f16 or bf16");
+    CAPDEC_CHECK(Nimg > 0 && H > 0 && W > 0 && Cin % 64 == 0 && Cout % 4 == 0, "conv3x3: Cin % 64 == 0, Cout % 4 == 0");
+    CAPDEC_CHECK((size_t)Nimg * H * W < ((size_t)1 << 31) - 256, "conv3x3: too many pixels for one launch");
+    const int M = Nimg * H * W, N = Cout, K = 9 * Cin;
+    ConvGeo cg;
+    cg.H = H; cg.W = W; cg.M = M;
+    cg.ncs = Cin / (fmt == PK_F16X2 ? 16 : 32);
+    cg.zero = (const char *)zeros;
+    CAPDEC_CHECK(zeros && zero_bytes >= (size_t)(cg.ncs + 1) * H2_BLOCK_B, "conv3x3: zero block too small");
+    CAPDEC_CHECK(epi.packed_out == nullptr || (N % 64 == 0 && epi.resid == nullptr && ((uintptr_t)epi.bias & 15) == 0),
+                 "conv3x3: packed output needs Cout % 64 == 0, a 16-byte aligned bias and no residual");
+    CAPDEC_CHECK(epi.packed_out != nullptr ||
+                     (ldc % 4 == 0 && ((uintptr_t)C & 15) == 0 && (epi.bias == nullptr || ((uintptr_t)epi.bias & 15) == 0) &&
+                      (epi.resid == nullptr || (epi.ldr % 4 == 0 && ((uintptr_t)epi.resid & 15) == 0))),
+                 "conv3x3: 16-byte aligned output rows, bias and residual");
+    const int tiles_m = (M + GEMM_BM - 1) / GEMM_BM, tiles_n = (N + GEMM_BN - 1) / GEMM_BN;
+#define LAUNCH_CONV(KD)                                                                                                  \
+    hipLaunchKernelGGL((conv3x3_packed_kernel<KD>), dim3(tiles_m * tiles_n), dim3(256), 0, st, (const _Float16 *)act_pk,   \
+                       (const _Float16 *)Bpacked, C, ldc, M, N, K, epi.bias, epi.resid, epi.ldr, epi.act, tiles_m, tiles_n, \
+                       (char *)epi.packed_out, fmt, cg)
+    if (fmt == PK_F16X2) LAUNCH_CONV(0); else if (fmt == PK_F16X1) LAUNCH_CONV(1); else LAUNCH_CONV(2);
+#undef LAUNCH_CONV
     CAPDEC_HIP(hipGetLastError());
     return 0;
 }
