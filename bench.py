@@ -120,24 +120,27 @@ def side_workload(args, world, rank, dev, emit=print):
     from capdec_amd.predictions_runner import caption_ids
     P, T = args.prefix_length, args.entry_length
     prec = {"f16": "fp16", "bf16": "bf16"}.get(args.gemm_mode or "", "fp32")      # towers: fp32-accurate unless asked
-    cm, _ = cclip.load(synth.hot_clip_state_dict(43), device=dev.index or 0, precision=prec)
     text = args.workload == "text_embed"
+    rn = args.clip == "rn50x4" and not text       # the reference's default backbone (predictions_runner.py:158): 288^2 -> 640-d
+    clip_sd = synth.hot_clip_resnet_state_dict(44, synth.CLIP_RN50X4) if rn else synth.hot_clip_state_dict(43)
+    cm, _ = cclip.load(clip_sd, device=dev.index or 0, precision=prec)
+    D = 640 if rn else 512
     mt = MappingType.MLP if text else MappingType.TransformerEncoder
-    model = ClipCaptionModel(P, clip_length=10, prefix_dim=512, num_layers=8, mapping_type=mt).to(dev).eval()
-    model.load_state_dict(synth.hot_state_dict(42, "mlp" if text else "transformer_encoder", 512, P))
+    model = ClipCaptionModel(P, clip_length=10, prefix_dim=D, num_layers=8, mapping_type=mt).to(dev).eval()
+    model.load_state_dict(synth.hot_state_dict(42, "mlp" if text else "transformer_encoder", D, P))
     if args.gemm_mode:
         model.engine.set_gemm_mode(args.gemm_mode)
     n_global = args.captions * world
     if text:
         inp = synth.synthetic_clip_tokens(n_global, seed=2).to(dev)
     else:
-        inp = synth.synthetic_images(n_global, seed=4).to(dev)
+        inp = synth.synthetic_images(n_global, seed=4, size=288 if rn else 224).to(dev)
 
     def step():
         if text:     # embeddings_generator.py:58-101 + train.py:347,253-254
             return eg.text_to_prefix(cm, model, inp, noise_variance=0.016, seed=3, rank=rank, world=world)
         emb = eg.encode_images(cm, inp, rank, world, gather=False)      # predictions_runner.py:220-232
-        full = torch.zeros(n_global, 512, device=dev)
+        full = torch.zeros(n_global, D, device=dev)
         lo, hi = cdist.shard_bounds(n_global, rank, world)
         full[lo:hi] = emb
         ids, lens, sc = caption_ids(model, full, STOP_ID, beam=True, entry_length=T, rank=rank, world=world)
@@ -161,7 +164,8 @@ def side_workload(args, world, rank, dev, emit=print):
                                                  for k, v in prof.items() if v["launches"]},
                           "value": round(n_global * args.steps / dt, 2), "unit": "items/s", "n_gpus": world,
                           "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 2),
-                          "config": {"workload": args.workload, "items_per_step": n_global, "clip_precision": prec,
+                          "config": {"workload": args.workload, "clip": "RN50x4" if rn else "ViT-B/32",
+                                     "items_per_step": n_global, "clip_precision": prec,
                                      "gemm_mode": model.engine.gemm_mode()}}))
 
 
@@ -191,6 +195,8 @@ def main():
                     help="beam_transformer = BASELINE metric config (default); greedy_mlp = configs[1] shape; "
                          "text_embed = configs[3] (CLIP ViT-B/32 encode_text + noise + mapper); "
                          "image_beam = configs[4] (ViT-B/32 encode_image + TransformerMapper + beam 5)")
+    ap.add_argument("--clip", choices=["vit_b32", "rn50x4"], default="vit_b32",
+                    help="image_beam only: the CLIP image tower (rn50x4 = the reference's default backbone, 288 x 288 -> 640-d)")
     ap.add_argument("--captions", type=int, default=5000,
                     help="captions per step: IN TOTAL with --scaling strong (default: COCO-val 5k), PER GPU with --scaling weak")
     ap.add_argument("--entry-length", type=int, default=67)

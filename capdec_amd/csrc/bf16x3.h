@@ -110,6 +110,23 @@ __device__ __forceinline__ void x3_store_quad(char *packed, int nk, int row, int
     *reinterpret_cast<bf16x4 *>(p + 2 * X3_PLANE_B) = l;
 }
 
+// the inverse for the fp16 / bf16 formats (PK_F16X2, PK_F16X1, PK_BF16X1): the four values of one quad, rejoined
+__device__ __forceinline__ float4 x3_load_quad(const char *packed, int nk, int row, int ks, int quad, int fmt) {
+    if (fmt == PK_F16X2) {
+        const char *p = packed + ((size_t)(row >> 7) * nk + ks) * H2_BLOCK_B + x3_group_offset(row & 127, quad);
+        const f16x4 h = *reinterpret_cast<const f16x4 *>(p), l = *reinterpret_cast<const f16x4 *>(p + X3_PLANE_B);
+        return make_float4((float)h[0] + (float)l[0] * (1.0f / H2_LO_SCALE), (float)h[1] + (float)l[1] * (1.0f / H2_LO_SCALE),
+                           (float)h[2] + (float)l[2] * (1.0f / H2_LO_SCALE), (float)h[3] + (float)l[3] * (1.0f / H2_LO_SCALE));
+    }
+    const char *p = packed + ((size_t)(row >> 7) * nk + ks) * X3_PLANE_B + x3_group_offset(row & 127, quad);
+    if (fmt == PK_F16X1) {
+        const f16x4 h = *reinterpret_cast<const f16x4 *>(p);
+        return make_float4((float)h[0], (float)h[1], (float)h[2], (float)h[3]);
+    }
+    const bf16x4 h = *reinterpret_cast<const bf16x4 *>(p);
+    return make_float4((float)h[0], (float)h[1], (float)h[2], (float)h[3]);
+}
+
 inline size_t x3_packed_bytes(int rows, int K, int fmt = PK_BF16X3) {
     return (size_t)((rows + X3_TILE_ROWS - 1) / X3_TILE_ROWS) * X3_TILE_ROWS * K * pk_planes(fmt) * sizeof(uint16_t);
 }

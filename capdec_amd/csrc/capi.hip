@@ -131,7 +131,7 @@ struct capdec_ctx {
     Tower clip_text, clip_vision;
     ResNet clip_resnet;
     DBuf r_a, r_b, r_c, r_d, r_e, r_f, r_col;      // ResNet activation buffers (NHWC) + im2col
-    DBuf r_pk1, r_pk2, r_xpk, r_zero;              // ... packed activations (GEMM / implicit-conv operands), zero rows
+    DBuf r_pk1, r_pk2, r_xpk, r_ypk, r_xi, r_idp, r_zero;   // ... packed activations (GEMM / implicit-conv operands), zero rows
     Prof prof;
     int gemm_mode = GEMM_F16X2;
     struct Planes { void *p; size_t n; int fmt; };
@@ -339,7 +339,7 @@ static bool use_packed_a(capdec_ctx *c, int K) {
 struct NextLn { const float *w, *b; float eps; int *done; };
 static int gemm_packed(capdec_ctx *c, const void *Apk, const float *W, float *C, int ldc, int M, int N, int K,
                        const float *bias, int act, const float *resid = nullptr, int ldr = 0,
-                       void *packed_out = nullptr, const NextLn *next_ln = nullptr) {
+                       void *packed_out = nullptr, const NextLn *next_ln = nullptr, const void *resid_packed = nullptr) {
     const void *pl = nullptr;
     CAPDEC_TRY(planes_of(c, W, N, K, true, &pl));
     GemmEpilogue e;
@@ -348,6 +348,7 @@ static int gemm_packed(capdec_ctx *c, const void *Apk, const float *W, float *C,
     e.resid = resid;
     e.ldr = ldr;
     e.packed_out = packed_out;
+    e.resid_packed = resid_packed;
     if (next_ln && next_ln->w && ldc == N && (const void *)Apk != c->xpk.p) {
         CAPDEC_TRY(c->xpk.ensure(x3_packed_bytes_host(M, N)));
         e.ln_w = next_ln->w; e.ln_b = next_ln->b; e.ln_eps = next_ln->eps; e.ln_out = c->xpk.p; e.ln_done = next_ln->done;
@@ -979,74 +980,69 @@ static int conv3x3_implicit(capdec_ctx *c, const ConvW &w, const void *in_pk, in
     return launch_conv3x3_packed(c->stream, in_pk, pl, out, w.cout_p, n, H, W, w.cin_p, w.cout_p, e, fmt, c->r_zero.p,
                                  c->r_zero.cap);
 }
-static int pack_act(capdec_ctx *c, const float *in, int M, int C, DBuf &dst) {
-    const int fmt = pack_fmt(c);
-    CAPDEC_TRY(dst.ensure(x3_packed_bytes(M, C, fmt)));
-    ProfScope ps(c, F_PACK);
-    return pack_any(c, in, M, C, fmt, dst.p);
-}
-static int resnet_body_packed(capdec_ctx *c, const float *pixels, int n, float *&x, float *&y, float *t1, float *t2,
-                              float *xi, float *idb, int *Hp, int *Wp) {
+// In this path NO fp32 activation exists between the pixels and the attention pool: every convolution writes its result as
+// the packed operand of its consumer, the residual stream included -- the last convolution of a bottleneck adds the packed
+// identity in its epilogue (GemmEpilogue::resid_packed) -- and the average pools run packed -> packed.
+static int resnet_body_packed(capdec_ctx *c, const float *pixels, int n, float *feat, int *Hp, int *Wp) {
     ResNet &r = c->clip_resnet;
     const int fmt = pack_fmt(c);
     int H = *Hp, W = *Wp;
-    // stem: conv1 (stride 2, 3 input channels: im2col of K = 27 -> 64 straight into the operand) -> packed; conv2 implicit ->
-    // packed; conv3 implicit -> fp32 for the average pool
-    {
+    DBuf *xp = &c->r_xpk, *yp = &c->r_ypk;
+    auto gemm1x1 = [&](const ConvW &w, const void *a, int M, void *dst, int act, const void *resid_pk) {
+        return gemm_packed(c, a, w.w, nullptr, w.cout_p, M, w.cout_p, w.K, w.b, act, nullptr, 0, dst, nullptr, resid_pk);
+    };
+    {   // stem: conv1 (stride 2, 3 input channels: im2col of K = 27 -> 64 straight into the operand), conv2, conv3, pool
         const ConvW &s0 = r.stem[0], &s1 = r.stem[1], &s2 = r.stem[2];
         const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1, M = n * Ho * Wo;
         CAPDEC_TRY(c->r_col.ensure(x3_packed_bytes(M, s0.K, fmt)));
         { ProfScope ps(c, F_PACK); CAPDEC_TRY(launch_im2col3x3_packed(c->stream, pixels, c->r_col.p, n, H, W, 3, 2, true, s0.K, fmt)); }
-        CAPDEC_TRY(c->r_pk1.ensure(x3_packed_bytes(M, std::max(s0.cout_p, s1.cout_p), fmt)));
+        CAPDEC_TRY(c->r_pk1.ensure(x3_packed_bytes(M, std::max(s0.cout_p, s2.cout_p), fmt)));
         CAPDEC_TRY(c->r_pk2.ensure(x3_packed_bytes(M, s1.cout_p, fmt)));
-        CAPDEC_TRY(gemm_packed(c, c->r_col.p, s0.w, nullptr, s0.cout_p, M, s0.cout_p, s0.K, s0.b, CAPDEC_ACT_RELU, nullptr, 0,
-                               c->r_pk1.p));
+        CAPDEC_TRY(gemm1x1(s0, c->r_col.p, M, c->r_pk1.p, CAPDEC_ACT_RELU, nullptr));
         H = Ho; W = Wo;
         CAPDEC_TRY(conv3x3_implicit(c, s1, c->r_pk1.p, n, H, W, nullptr, c->r_pk2.p, CAPDEC_ACT_RELU));
-        CAPDEC_TRY(conv3x3_implicit(c, s2, c->r_pk2.p, n, H, W, t1, nullptr, CAPDEC_ACT_RELU));
-        { ProfScope ps(c, F_OTHER); CAPDEC_TRY(launch_avgpool2(c->stream, t1, x, n, H, W, s2.cout_p)); }
+        CAPDEC_TRY(conv3x3_implicit(c, s2, c->r_pk2.p, n, H, W, nullptr, c->r_pk1.p, CAPDEC_ACT_RELU));
+        CAPDEC_TRY(xp->ensure(x3_packed_bytes(M / 4, s2.cout_p, fmt)));
+        { ProfScope ps(c, F_OTHER); CAPDEC_TRY(launch_avgpool2_packed(c->stream, c->r_pk1.p, xp->p, n, H, W, s2.cout_p, fmt)); }
         H /= 2; W /= 2;
     }
     size_t bi = 0;
+    int C = r.stem[2].cout_p;
     for (int li = 0; li < 4; ++li) {
         for (int b = 0; b < r.layers[li]; ++b, bi += 4) {
             const ConvW &c1 = r.blocks[bi], &c2 = r.blocks[bi + 1], &c3 = r.blocks[bi + 2], &ds = r.blocks[bi + 3];
             const int stride = (b == 0 && li > 0) ? 2 : 1;
             const int M = n * H * W;
-            CAPDEC_TRY(pack_act(c, x, M, c1.cin_p, c->r_xpk));                        // the block input as a GEMM operand
+            CAPDEC_CHECK(c1.cin_p == C, "clip_resnet: channel mismatch between consecutive blocks");
             CAPDEC_TRY(c->r_pk1.ensure(x3_packed_bytes(M, c1.cout_p, fmt)));
-            CAPDEC_TRY(gemm_packed(c, c->r_xpk.p, c1.w, nullptr, c1.cout_p, M, c1.cout_p, c1.K, c1.b, CAPDEC_ACT_RELU, nullptr,
-                                   0, c->r_pk1.p));
+            CAPDEC_TRY(c->r_pk2.ensure(x3_packed_bytes(M, c2.cout_p, fmt)));
+            CAPDEC_TRY(gemm1x1(c1, xp->p, M, c->r_pk1.p, CAPDEC_ACT_RELU, nullptr));
+            CAPDEC_TRY(conv3x3_implicit(c, c2, c->r_pk1.p, n, H, W, nullptr, c->r_pk2.p, CAPDEC_ACT_RELU));
             int Ho = H, Wo = W;
-            const float *idt = x;
-            if (stride == 1) {
-                CAPDEC_TRY(c->r_pk2.ensure(x3_packed_bytes(M, c2.cout_p, fmt)));
-                CAPDEC_TRY(conv3x3_implicit(c, c2, c->r_pk1.p, n, H, W, nullptr, c->r_pk2.p, CAPDEC_ACT_RELU));
-                if (ds.w) {      // (first block of the first stage: the channel count changes, the resolution does not)
-                    CAPDEC_TRY(gemm_packed(c, c->r_xpk.p, ds.w, idb, ds.cout_p, M, ds.cout_p, ds.K, ds.b, CAPDEC_ACT_NONE));
-                    idt = idb;
-                }
-            } else {             // anti-aliased stride: average pools on the branch and in front of the downsample conv
-                CAPDEC_TRY(conv3x3_implicit(c, c2, c->r_pk1.p, n, H, W, t2, nullptr, CAPDEC_ACT_RELU));
-                {
-                    ProfScope ps(c, F_OTHER);
-                    CAPDEC_TRY(launch_avgpool2(c->stream, t2, t1, n, H, W, c2.cout_p));
-                    CAPDEC_TRY(launch_avgpool2(c->stream, x, xi, n, H, W, c1.cin_p));
-                }
+            const void *branch = c->r_pk2.p, *idt = xp->p;
+            if (stride > 1) {    // anti-aliased stride: average pools on the branch and in front of the downsample conv
                 Ho = H / 2; Wo = W / 2;
-                CAPDEC_TRY(pack_act(c, t1, n * Ho * Wo, c2.cout_p, c->r_pk2));
                 CAPDEC_CHECK(ds.w != nullptr, "clip_resnet: a strided block without a downsample branch");
-                CAPDEC_TRY(pack_act(c, xi, n * Ho * Wo, ds.cin_p, c->r_xpk));
-                CAPDEC_TRY(gemm_packed(c, c->r_xpk.p, ds.w, idb, ds.cout_p, n * Ho * Wo, ds.cout_p, ds.K, ds.b, CAPDEC_ACT_NONE));
-                idt = idb;
+                CAPDEC_TRY(c->r_xi.ensure(x3_packed_bytes(n * Ho * Wo, C, fmt)));
+                ProfScope ps(c, F_OTHER);
+                CAPDEC_TRY(launch_avgpool2_packed(c->stream, c->r_pk2.p, c->r_pk1.p, n, H, W, c2.cout_p, fmt));
+                CAPDEC_TRY(launch_avgpool2_packed(c->stream, xp->p, c->r_xi.p, n, H, W, C, fmt));
+                branch = c->r_pk1.p;
             }
             const int Mo = n * Ho * Wo;
-            CAPDEC_TRY(gemm_packed(c, c->r_pk2.p, c3.w, y, c3.cout_p, Mo, c3.cout_p, c3.K, c3.b, CAPDEC_ACT_RESID_RELU, idt,
-                                   c3.cout_p));
-            std::swap(x, y);
+            if (ds.w) {
+                CAPDEC_TRY(c->r_idp.ensure(x3_packed_bytes(Mo, ds.cout_p, fmt)));
+                CAPDEC_TRY(gemm1x1(ds, stride > 1 ? c->r_xi.p : xp->p, Mo, c->r_idp.p, CAPDEC_ACT_NONE, nullptr));
+                idt = c->r_idp.p;
+            }
+            CAPDEC_TRY(yp->ensure(x3_packed_bytes(Mo, c3.cout_p, fmt)));
+            CAPDEC_TRY(gemm1x1(c3, branch, Mo, yp->p, CAPDEC_ACT_RESID_RELU, idt));
+            std::swap(xp, yp);
+            C = c3.cout_p;
             H = Ho; W = Wo;
         }
     }
+    { ProfScope ps(c, F_OTHER); CAPDEC_TRY(launch_unpack_rows(c->stream, xp->p, feat, n * H * W, C, fmt)); }
     *Hp = H; *Wp = W;
     return 0;
 }
@@ -1055,26 +1051,30 @@ static int resnet_body_packed(capdec_ctx *c, const float *pixels, int n, float *
 static int clip_resnet_chunk(capdec_ctx *c, const float *pixels, int n, float *out) {
     ResNet &r = c->clip_resnet;
     const int S = r.image;
-    // worst-case activation sizes (floats per image): stem conv outputs at S/2, stage outputs at S/4 ... S/32
-    const size_t half = (size_t)(S / 2) * (S / 2), quarter = (size_t)(S / 4) * (S / 4);
-    size_t act = half * pad64(r.width);                                        // stem
-    int planes = r.width, sp = S / 4;
-    for (int li = 0; li < 4; ++li, planes *= 2) {
-        const int spin = sp;                                                   // spatial size entering the stage
-        if (li > 0) sp /= 2;
-        act = std::max(act, (size_t)spin * spin * pad64(planes * 4));          // identity / stage output
-        act = std::max(act, (size_t)spin * spin * pad64(planes));              // conv1 / conv2 outputs before the pool
-        act = std::max(act, (size_t)spin * spin * pad64(li ? planes * 2 : planes));   // stage input
+    static const bool implicit_on = [] { const char *e = getenv("CAPDEC_RN_IMPLICIT"); return !(e && atoi(e) == 0); }();
+    const bool packed_path = implicit_on && (c->gemm_mode == GEMM_F16X2 || mode_single(c));
+    // fp32 buffers (floats per image): the attention pool's tokens / keys / values always; in the fp32-activation path
+    // also the worst-case activation: stem conv outputs at S/2, stage outputs at S/4 ... S/32
+    size_t act = ((size_t)r.sp * r.sp + 1) * r.feat;
+    if (!packed_path) {
+        const size_t half = (size_t)(S / 2) * (S / 2), quarter = (size_t)(S / 4) * (S / 4);
+        act = std::max(act, half * pad64(r.width));                                // stem
+        int planes = r.width, sp = S / 4;
+        for (int li = 0; li < 4; ++li, planes *= 2) {
+            const int spin = sp;                                                   // spatial size entering the stage
+            if (li > 0) sp /= 2;
+            act = std::max(act, (size_t)spin * spin * pad64(planes * 4));          // identity / stage output
+            act = std::max(act, (size_t)spin * spin * pad64(planes));              // conv1 / conv2 outputs before the pool
+            act = std::max(act, (size_t)spin * spin * pad64(li ? planes * 2 : planes));   // stage input
+        }
+        act = std::max(act, quarter * pad64(r.width));
     }
-    act = std::max(act, quarter * pad64(r.width));
-    act = std::max(act, ((size_t)r.sp * r.sp + 1) * r.feat);                   // attention-pool tokens / keys / values
     for (DBuf *b : {&c->r_a, &c->r_b, &c->r_c, &c->r_d, &c->r_e, &c->r_f}) CAPDEC_TRY(b->ensure((size_t)n * act * 4));
     float *x = c->r_a.as<float>(), *y = c->r_b.as<float>(), *t1 = c->r_c.as<float>(), *t2 = c->r_d.as<float>(),
           *xi = c->r_e.as<float>(), *idb = c->r_f.as<float>();
     int H = S, W = S;
-    static const bool implicit_on = [] { const char *e = getenv("CAPDEC_RN_IMPLICIT"); return !(e && atoi(e) == 0); }();
-    if (implicit_on && (c->gemm_mode == GEMM_F16X2 || mode_single(c))) {
-        CAPDEC_TRY(resnet_body_packed(c, pixels, n, x, y, t1, t2, xi, idb, &H, &W));
+    if (packed_path) {
+        CAPDEC_TRY(resnet_body_packed(c, pixels, n, x, &H, &W));
     } else {
         CAPDEC_TRY(resnet_body_fp32(c, pixels, n, x, y, t1, t2, xi, idb, &H, &W));
     }
@@ -1191,7 +1191,7 @@ void capdec_destroy(capdec_ctx *c) {
                     &c->done, &c->anc, &c->next_tok, &c->alive, &c->gids, &c->glens, &c->m_hid, &c->m_lin, &c->m_seq,
                     &c->m_x, &c->m_qkv, &c->m_att, &c->m_ff, &c->t_idx, &c->t_patch, &c->t_pout, &c->xpk, &c->apk, &c->fpk, &c->cmap, &c->p_desc, &c->p_inter, &c->splitk, &c->a_tmp,
                     &c->r_a, &c->r_b, &c->r_c, &c->r_d, &c->r_e, &c->r_f, &c->r_col, &c->r_pk1, &c->r_pk2, &c->r_xpk,
-                    &c->r_zero};
+                    &c->r_ypk, &c->r_xi, &c->r_idp, &c->r_zero};
     for (DBuf *b : bufs) b->release();
     for (auto &r : c->prof.recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
     for (auto e : c->prof.pool) (void)hipEventDestroy(e);

@@ -94,6 +94,8 @@ struct GemmEpilogue {
     size_t splitk_ws_bytes = 0;    // under-filled grids run unsplit
     void *packed_out = nullptr;    // bf16x3p only: write act(acc + bias) as the packed split-bf16 A operand (K = N)
                                    // of the next GEMM instead of fp32 C
+    const void *resid_packed = nullptr;   // f16x2p / x1 with packed_out only: residual [M, N] stored as a packed operand of
+                                          // the output's format (added after the activation; no split-K then)
     // Optional LayerNorm of the RESULT rows, fused into the split-K reduce pass (only when the launch splits K, C has
     // N = ldc columns and N <= 1024): ln_out receives LayerNorm(C row) as a packed operand (format of the launch);
     // *ln_done is set to 1 when the fusion happened, left untouched otherwise (the caller then runs its own LayerNorm)
@@ -187,6 +189,9 @@ int launch_im2col3x3(hipStream_t st, const float *in, float *out, int N, int H, 
 int launch_im2col3x3_packed(hipStream_t st, const float *in, void *out, int N, int H, int W, int C, int stride, bool nchw3,
                             int Kp, int fmt);
 int launch_avgpool2(hipStream_t st, const float *in, float *out, int N, int H, int W, int C);
+// AvgPool2d(2) between packed activations [N H W pixels][C] of format fmt; packed rows -> fp32 [M, C]
+int launch_avgpool2_packed(hipStream_t st, const void *in, void *out, int N, int H, int W, int C, int fmt);
+int launch_unpack_rows(hipStream_t st, const void *in, float *out, int M, int C, int fmt);
 int launch_attnpool_tokens(hipStream_t st, const float *feat, const float *pos, float *t, int N, int HW, int C);
 int launch_attnpool_attend(hipStream_t st, const float *q, const float *k, const float *v, float *out, int N, int heads,
                            int T, int C);

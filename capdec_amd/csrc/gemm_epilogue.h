@@ -143,7 +143,9 @@ __device__ __forceinline__ void epilogue_store_t(const f32x16 (&acc)[2][2], floa
 // tile never reaches HBM (or LDS).
 __device__ __forceinline__ void epilogue_store_packed_t(const f32x16 (&acc)[2][2], char *packed, int nk_out, int M,
                                                         int N, int m0, int n0, const float *__restrict__ bias,
-                                                        int act, int fmt = PK_BF16X3) {
+                                                        int act, int fmt = PK_BF16X3, const char *resid_pk = nullptr) {
+    // resid_pk: a residual [M, N] in the SAME packed format and geometry as the output (a residual stream that only ever
+    // exists as a GEMM operand: the ResNet tower), added after the activation; CAPDEC_ACT_RESID_RELU then applies
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wm = wave >> 1, wn = wave & 1, half = lane >> 5, l32 = lane & 31;
 #pragma unroll
@@ -163,6 +165,11 @@ __device__ __forceinline__ void epilogue_store_packed_t(const f32x16 (&acc)[2][2
                 }
                 v.x = act_apply(v.x, act); v.y = act_apply(v.y, act);
                 v.z = act_apply(v.z, act); v.w = act_apply(v.w, act);
+                if (resid_pk) {
+                    const float4 rr = x3_load_quad(resid_pk, nk_out, row, col >> 4, (col >> 2) & 3, fmt);
+                    v.x = post_resid(v.x + rr.x, act); v.y = post_resid(v.y + rr.y, act);
+                    v.z = post_resid(v.z + rr.z, act); v.w = post_resid(v.w + rr.w, act);
+                }
                 x3_store_quad(packed, nk_out, row, col >> 4, (col >> 2) & 3, v, fmt);
             }
     }

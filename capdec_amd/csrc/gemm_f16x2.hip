@@ -81,7 +81,7 @@ __host__ __device__ constexpr int waitcnt_imm(int vm, int lgkm) {
 // TR: MFMA operands swapped (D^T), a lane ends with four consecutive columns of one row (see gemm_bf16x3.hip).
 // am = sum hi_a hi_b, ac = sum (hi_a lo_b + lo_a hi_b) (weight 2^-11, applied by h2_join).
 // ABL (measurement only, CAPDEC_H2_ABL; results are WRONG for ABL != 0): 1 = no s_barrier in the loop, 2 = no LDS-DMA in
-// the loop, 3 = no fragment reads in the loop, 4 = neither barrier nor DMA
+// the loop, 3 = no fragment reads in the loop, 4 = neither barrier nor DMA, 5 / 6 = all blocks load the same few panels
 // KIND: 0 = f16x2 (the fp32-accurate scheme above).  1 / 2 = ONE-plane fp16 / bf16 operands (formats PK_F16X1 /
 // PK_BF16X1: the reduced-precision modes, one MFMA per product): the same ring, DMA pieces and fragment reads, but a
 // stage holds TWO consecutive k-steps of the single plane where f16x2 holds the two planes of one k-step (both are
@@ -111,8 +111,11 @@ __device__ __forceinline__ void h2p_mainloop(const _Float16 *__restrict__ Apk, c
     const int half = lane >> 5, l32 = lane & 31;
     const int nkf = K / (KIND == 0 ? X3_BK : 2 * X3_BK);                       // stages of the whole K (panel stride)
     const int nk = nks < 0 ? nkf : nks;                                        // stages of THIS block, even
-    const _Float16 *ap = Apk + ((size_t)tm * nkf + ks0) * (H2_BLOCK_B / 2) + t * 8;   // this thread's 16-B piece
-    const _Float16 *bp = Bpk + ((size_t)tn * nkf + ks0) * (H2_BLOCK_B / 2) + t * 8;
+    // (ABL 5 / 6: every block loads one of 4 x 4 / 8 x 8 panels -- a 3 MB / 6 MB working set per launch: what the loop
+    //  does when (nearly) every operand piece is an L2 hit)
+    const int tml = ABL == 5 ? (tm & 3) : ABL == 6 ? (tm & 7) : tm, tnl = ABL == 5 ? (tn & 3) : ABL == 6 ? (tn & 7) : tn;
+    const _Float16 *ap = Apk + ((size_t)tml * nkf + ks0) * (H2_BLOCK_B / 2) + t * 8;   // this thread's 16-B piece
+    const _Float16 *bp = Bpk + ((size_t)tnl * nkf + ks0) * (H2_BLOCK_B / 2) + t * 8;
     char *dst0 = smem + wave * 1024;                                           // wave-uniform LDS base of its pieces
     // CONV: running (stage, tap, stage-in-tap) of the NEXT tile to send (the DMAs are issued in increasing stage order,
     // clamped at the last one) and this thread's source for the current tap
@@ -291,7 +294,8 @@ __global__ __launch_bounds__(256, 2) void gemm_f16x2p_kernel(const _Float16 *__r
     h2p_mainloop<true, NS, ABL>(Apk, Bpk, K, tm, tn, smem, am, ac);
     h2_join(am, ac);
     if (packed_out)
-        epilogue_store_packed_t(am, packed_out, N >> 4, M, N, tm * GEMM_BM, tn * GEMM_BN, bias, act, PK_F16X2);
+        epilogue_store_packed_t(am, packed_out, N >> 4, M, N, tm * GEMM_BM, tn * GEMM_BN, bias, act, PK_F16X2,
+                                reinterpret_cast<const char *>(resid));      // (with packed_out, `resid` is a PACKED residual)
     else
         epilogue_store_t<VEC4>(am, C, ldc, M, N, tm * GEMM_BM, tn * GEMM_BN, bias, resid, ldr, act);
 }
@@ -340,7 +344,9 @@ int launch_gemm_f16x2p(hipStream_t st, const void *Apacked, const void *Bpacked,
     const bool vec4 = N % 4 == 0 && ldc % 4 == 0 && ((uintptr_t)C & 15) == 0 &&
                       (epi.bias == nullptr || ((uintptr_t)epi.bias & 15) == 0) &&
                       (epi.resid == nullptr || (epi.ldr % 4 == 0 && ((uintptr_t)epi.resid & 15) == 0));
-    const int S = (vec4 && epi.splitk_ws) ? gemm_splitk_slices(M, N, K) : 1;
+    CAPDEC_CHECK(epi.resid_packed == nullptr || epi.packed_out != nullptr, "gemm_f16x2p: a packed residual needs a packed output");
+    const float *resid_arg = epi.packed_out ? (const float *)epi.resid_packed : epi.resid;
+    const int S = (vec4 && epi.splitk_ws && !epi.resid_packed) ? gemm_splitk_slices(M, N, K) : 1;
     if (S > 1 && epi.splitk_ws_bytes >= (size_t)S * M * N * sizeof(float)) {
         float *part = (float *)epi.splitk_ws;
         hipLaunchKernelGGL(gemm_f16x2p_splitk_kernel, dim3(tiles_m * tiles_n * S), dim3(256), 0, st,
@@ -350,16 +356,17 @@ int launch_gemm_f16x2p(hipStream_t st, const void *Apacked, const void *Bpacked,
     }
 #define LAUNCH_H2(V4, NSV)                                                                                            \
     hipLaunchKernelGGL((gemm_f16x2p_kernel<V4, NSV>), dim3(tiles_m * tiles_n), dim3(256), 0, st, (const _Float16 *)Apacked, \
-                       (const _Float16 *)Bpacked, C, ldc, M, N, K, epi.bias, epi.resid, epi.ldr, epi.act, tiles_m,      \
+                       (const _Float16 *)Bpacked, C, ldc, M, N, K, epi.bias, resid_arg, epi.ldr, epi.act, tiles_m,      \
                        tiles_n, (char *)epi.packed_out)
     const int ns = h2_ns();
     static const int abl = [] { const char *e = getenv("CAPDEC_H2_ABL"); return e ? atoi(e) : 0; }();
-    if (vec4 && abl >= 1 && abl <= 4) {     // measurement only
+    if (vec4 && abl >= 1 && abl <= 6) {     // measurement only
 #define LAUNCH_H2A(A)                                                                                               \
     hipLaunchKernelGGL((gemm_f16x2p_kernel<true, H2_NS, A>), dim3(tiles_m * tiles_n), dim3(256), 0, st,               \
                        (const _Float16 *)Apacked, (const _Float16 *)Bpacked, C, ldc, M, N, K, epi.bias, epi.resid,   \
                        epi.ldr, epi.act, tiles_m, tiles_n, (char *)epi.packed_out)
-        if (abl == 1) LAUNCH_H2A(1); else if (abl == 2) LAUNCH_H2A(2); else if (abl == 3) LAUNCH_H2A(3); else LAUNCH_H2A(4);
+        if (abl == 1) LAUNCH_H2A(1); else if (abl == 2) LAUNCH_H2A(2); else if (abl == 3) LAUNCH_H2A(3);
+        else if (abl == 4) LAUNCH_H2A(4); else if (abl == 5) LAUNCH_H2A(5); else LAUNCH_H2A(6);
 #undef LAUNCH_H2A
         CAPDEC_HIP(hipGetLastError());
         return 0;
@@ -411,7 +418,8 @@ __global__ __launch_bounds__(256, (NS == 3 ? 3 : 2)) void gemm_x1_kernel(const _
     f32x16 am[2][2], ac[2][2];
     h2p_mainloop<true, NS, 0, KIND>(Apk, Bpk, K, tm, tn, smem, am, ac);
     if (packed_out)
-        epilogue_store_packed_t(am, packed_out, N >> 4, M, N, tm * GEMM_BM, tn * GEMM_BN, bias, act, out_fmt);
+        epilogue_store_packed_t(am, packed_out, N >> 4, M, N, tm * GEMM_BM, tn * GEMM_BN, bias, act, out_fmt,
+                                reinterpret_cast<const char *>(resid));      // (with packed_out, `resid` is a PACKED residual)
     else
         epilogue_store_t<VEC4>(am, C, ldc, M, N, tm * GEMM_BM, tn * GEMM_BN, bias, resid, ldr, act);
 }
@@ -446,7 +454,8 @@ int launch_gemm_x1(hipStream_t st, const void *Apacked, const void *Bpacked, flo
     static const int ns3 = [] { const char *e = getenv("CAPDEC_X1_NS"); return e && atoi(e) == 4 ? 0 : 1; }();
 #define LAUNCH_X1V(V4, KD, NSV)                                                                                         \
     hipLaunchKernelGGL((gemm_x1_kernel<V4, KD, NSV>), dim3(tiles_m * tiles_n), dim3(256), 0, st, (const _Float16 *)Apacked, \
-                       (const _Float16 *)Bpacked, C, ldc, M, N, K, epi.bias, epi.resid, epi.ldr, epi.act, tiles_m,      \
+                       (const _Float16 *)Bpacked, C, ldc, M, N, K, epi.bias,                                           \
+                       epi.packed_out ? (const float *)epi.resid_packed : epi.resid, epi.ldr, epi.act, tiles_m,       \
                        tiles_n, (char *)epi.packed_out, fmt)
 #define LAUNCH_X1K(KD)                                                                        \
     if (vec4) { if (ns3) LAUNCH_X1V(true, KD, 3); else LAUNCH_X1V(true, KD, 4); }             \

@@ -170,6 +170,64 @@ int launch_avgpool2(hipStream_t st, const float *in, float *out, int N, int H, i
     return 0;
 }
 
+// ---- AvgPool2d(2) between PACKED activations (format fmt): rows = pixels; one thread per (output pixel, k-step of 16
+// channels), the 128 threads of one (row tile, k-step) block of the output consecutive
+__global__ void avgpool2_packed_kernel(const char *__restrict__ in, char *__restrict__ out, int Mo, int H, int W, int nk,
+                                       int fmt, size_t total) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const size_t blk = i >> 7;
+    const int ks = (int)(blk % nk);
+    const int row = (int)(blk / nk) * 128 + (int)(i & 127);
+    const int Ho = H >> 1, Wo = W >> 1;
+    float4 o[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) o[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (row < Mo) {
+        const int ox = row % Wo, oy = (row / Wo) % Ho, n = row / (Wo * Ho);
+        const int p00 = (n * H + 2 * oy) * W + 2 * ox;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float4 a = x3_load_quad(in, nk, p00, ks, q, fmt), b = x3_load_quad(in, nk, p00 + 1, ks, q, fmt);
+            const float4 c = x3_load_quad(in, nk, p00 + W, ks, q, fmt), d = x3_load_quad(in, nk, p00 + W + 1, ks, q, fmt);
+            o[q] = make_float4(((a.x + b.x) + (c.x + d.x)) * 0.25f, ((a.y + b.y) + (c.y + d.y)) * 0.25f,
+                               ((a.z + b.z) + (c.z + d.z)) * 0.25f, ((a.w + b.w) + (c.w + d.w)) * 0.25f);
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) x3_store_quad(out, nk, row, ks, q, o[q], fmt);
+}
+
+int launch_avgpool2_packed(hipStream_t st, const void *in, void *out, int N, int H, int W, int C, int fmt) {
+    CAPDEC_CHECK(H % 2 == 0 && W % 2 == 0 && C % 16 == 0, "avgpool2 (packed): even spatial size, C % 16 == 0");
+    CAPDEC_CHECK(fmt == PK_F16X2 || fmt == PK_F16X1 || fmt == PK_BF16X1, "avgpool2 (packed): f16x2 / f16 / bf16 operands");
+    const int Mo = N * (H >> 1) * (W >> 1), nk = C / 16;
+    const size_t total = (size_t)((Mo + 127) / 128) * 128 * nk;
+    if (total == 0) return 0;
+    hipLaunchKernelGGL(avgpool2_packed_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, (const char *)in,
+                       (char *)out, Mo, H, W, nk, fmt, total);
+    CAPDEC_HIP(hipGetLastError());
+    return 0;
+}
+
+// ---- packed operand [M rows][C] -> fp32 [M, C] (the features in front of the attention pool)
+__global__ void unpack_rows_kernel(const char *__restrict__ in, float *__restrict__ out, int M, int C, int fmt) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;       // one thread per (row, quad)
+    const int nq = C >> 2;
+    if (i >= (size_t)M * nq) return;
+    const int row = (int)(i / nq), qd = (int)(i - (size_t)row * nq);
+    *reinterpret_cast<float4 *>(out + (size_t)row * C + 4 * qd) = x3_load_quad(in, C >> 4, row, qd >> 2, qd & 3, fmt);
+}
+
+int launch_unpack_rows(hipStream_t st, const void *in, float *out, int M, int C, int fmt) {
+    CAPDEC_CHECK(C % 16 == 0 && (fmt == PK_F16X2 || fmt == PK_F16X1 || fmt == PK_BF16X1), "unpack_rows: C % 16 == 0, fp16 / bf16 formats");
+    const size_t tot = (size_t)M * (C >> 2);
+    if (tot == 0) return 0;
+    hipLaunchKernelGGL(unpack_rows_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, (const char *)in, out, M, C, fmt);
+    CAPDEC_HIP(hipGetLastError());
+    return 0;
+}
+
 // ---- attention pool, token assembly: t[n][0] = mean over the HW feature rows, t[n][1 + i] = feature row i, + pos
 __global__ void attnpool_tokens_kernel(const float *__restrict__ feat, const float *__restrict__ pos, float *__restrict__ t,
                                        int N, int HW, int C) {

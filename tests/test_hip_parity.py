@@ -836,6 +836,12 @@ def test_clip_resnet_tiny_tower():
     np.testing.assert_allclose(eng.clip_encode_image(im2).cpu().numpy(), O.clip_encode_image(im2, vit).numpy(), atol=5e-4)
     eng.load_clip(sd, text=False, vision=True)
     assert float((eng.clip_encode_image(imgs).cpu() - got).abs().max()) == 0.0
+    # the bf16x3 / f32 modes keep fp32 activations between the convolutions (im2col + GEMM): same answer
+    for mode in ("bf16x3", "f32"):
+        eng.set_gemm_mode(mode)
+        alt = eng.clip_encode_image(imgs).cpu()
+        assert float((alt - want).abs().max()) < 2e-5 * float(want.abs().max()), mode
+    eng.set_gemm_mode("f16x2")
 
 
 def test_clip_resnet_rn50x4_tower():
