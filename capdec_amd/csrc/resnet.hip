@@ -171,7 +171,36 @@ int launch_avgpool2(hipStream_t st, const float *in, float *out, int N, int H, i
 }
 
 // ---- AvgPool2d(2) between PACKED activations (format fmt): rows = pixels; one thread per (output pixel, k-step of 16
-// channels), the 128 threads of one (row tile, k-step) block of the output consecutive
+// channels), the 128 threads of one (row tile, k-step) block of the output consecutive.  A pixel's k-step is one 32-byte
+// chunk per plane (its two 16-byte halves swapped when bit 3 of the row is set): 16-byte loads and stores throughout.
+__device__ __forceinline__ void pk_load16(const char *packed, int nk, int row, int ks, int fmt, float (&v)[16]) {
+    const int r = row & 127, sw = (r >> 3) & 1;
+    if (fmt == PK_F16X2) {
+        const char *p = packed + ((size_t)(row >> 7) * nk + ks) * H2_BLOCK_B + r * X3_ROW_B;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const f16x8 h = *reinterpret_cast<const f16x8 *>(p + j * 16), l = *reinterpret_cast<const f16x8 *>(p + X3_PLANE_B + j * 16);
+            const int k0 = (j ^ sw) * 8;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[k0 + e] = (float)h[e] + (float)l[e] * (1.0f / H2_LO_SCALE);
+        }
+    } else {
+        const char *p = packed + ((size_t)(row >> 7) * nk + ks) * X3_PLANE_B + r * X3_ROW_B;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int k0 = (j ^ sw) * 8;
+            if (fmt == PK_F16X1) {
+                const f16x8 h = *reinterpret_cast<const f16x8 *>(p + j * 16);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[k0 + e] = (float)h[e];
+            } else {
+                const bf16x8 h = *reinterpret_cast<const bf16x8 *>(p + j * 16);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[k0 + e] = (float)h[e];
+            }
+        }
+    }
+}
 __global__ void avgpool2_packed_kernel(const char *__restrict__ in, char *__restrict__ out, int Mo, int H, int W, int nk,
                                        int fmt, size_t total) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -180,22 +209,22 @@ __global__ void avgpool2_packed_kernel(const char *__restrict__ in, char *__rest
     const int ks = (int)(blk % nk);
     const int row = (int)(blk / nk) * 128 + (int)(i & 127);
     const int Ho = H >> 1, Wo = W >> 1;
-    float4 o[4];
+    float o[16];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) o[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int e = 0; e < 16; ++e) o[e] = 0.f;
     if (row < Mo) {
         const int ox = row % Wo, oy = (row / Wo) % Ho, n = row / (Wo * Ho);
         const int p00 = (n * H + 2 * oy) * W + 2 * ox;
+        float a[16], b[16], c[16], d[16];
+        pk_load16(in, nk, p00, ks, fmt, a);
+        pk_load16(in, nk, p00 + 1, ks, fmt, b);
+        pk_load16(in, nk, p00 + W, ks, fmt, c);
+        pk_load16(in, nk, p00 + W + 1, ks, fmt, d);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const float4 a = x3_load_quad(in, nk, p00, ks, q, fmt), b = x3_load_quad(in, nk, p00 + 1, ks, q, fmt);
-            const float4 c = x3_load_quad(in, nk, p00 + W, ks, q, fmt), d = x3_load_quad(in, nk, p00 + W + 1, ks, q, fmt);
-            o[q] = make_float4(((a.x + b.x) + (c.x + d.x)) * 0.25f, ((a.y + b.y) + (c.y + d.y)) * 0.25f,
-                               ((a.z + b.z) + (c.z + d.z)) * 0.25f, ((a.w + b.w) + (c.w + d.w)) * 0.25f);
-        }
+        for (int e = 0; e < 16; ++e) o[e] = ((a[e] + b[e]) + (c[e] + d[e])) * 0.25f;   // torch: window sum, one division
     }
 #pragma unroll
-    for (int q = 0; q < 4; ++q) x3_store_quad(out, nk, row, ks, q, o[q], fmt);
+    for (int q = 0; q < 4; ++q) x3_store_quad(out, nk, row, ks, q, make_float4(o[4 * q], o[4 * q + 1], o[4 * q + 2], o[4 * q + 3]), fmt);
 }
 
 int launch_avgpool2_packed(hipStream_t st, const void *in, void *out, int N, int H, int W, int C, int fmt) {

@@ -124,7 +124,7 @@ class MLP(_HipModule):
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         eng = self._owner.engine if self._owner is not None else self.engine
-        return eng.mapper_forward(x).reshape(x.shape[0], -1)   # [B, P*768] like nn.Sequential
+        return eng.mapper_forward(x).reshape(x.shape[0], self.sizes[2])   # [B, P*768] like nn.Sequential
 
 
 class ClipCaptionModel(_HipModule):

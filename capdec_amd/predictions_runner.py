@@ -61,3 +61,32 @@ def make_preds(data: Sequence[Dict], embeddings: torch.Tensor, model: ClipCaptio
         with open(out_path, 'w') as outfile:
             json.dump(new_data, outfile)
     return new_data
+
+
+def make_preds_from_images(data: Sequence[Dict], images: Sequence, clip_model, preprocess, model: ClipCaptionModel,
+                           tokenizer, out_path: Optional[str] = None, beam: bool = True, is_rn: bool = False,
+                           entry_length: int = 67, dont_normalize_prefix: bool = False,
+                           modality_offset: Optional[torch.Tensor] = None, rank: int = 0, world: int = 1,
+                           image_batch: int = 256) -> List[Dict]:
+    """The image half of the reference loop in front of ``make_preds`` (:156-161, :207-220): ``images[i]`` is what
+    ``Image.open(filename).convert("RGB")`` gave for ``data[i]`` (a PIL image or a uint8 [H, W, 3] array), or ``None``
+    for a file the reference would skip (:207-210: the entry is left out of the output).  ``preprocess`` and
+    ``clip_model.encode_image`` (``capdec_amd.clip.load``) run on the device in batches of ``image_batch``;
+    ``is_rn`` (the RN50x4 backbone) forces ``beam=True`` exactly as the reference does (:157-159)."""
+    if len(data) != len(images):
+        raise ValueError(f"make_preds_from_images: {len(data)} data entries but {len(images)} images")
+    if is_rn:
+        beam = True
+    keep = [i for i, im in enumerate(images) if im is not None]
+    feats = []
+    for b0 in range(0, len(keep), max(1, image_batch)):
+        batch = [images[i] for i in keep[b0:b0 + max(1, image_batch)]]
+        feats.append(clip_model.encode_image(preprocess.batch(batch)).float())
+    if not keep:                       # nothing to caption: the reference writes an empty list
+        if out_path and rank == 0:
+            with open(out_path, 'w') as outfile:
+                json.dump([], outfile)
+        return []
+    emb = torch.cat(feats)
+    return make_preds([data[i] for i in keep], emb, model, tokenizer, out_path, beam, entry_length, dont_normalize_prefix,
+                      modality_offset, rank, world)

@@ -855,6 +855,37 @@ def test_clip_resnet_rn50x4_tower():
     _rn_check(model, sd, imgs, 5e-5)
 
 
+def test_make_preds_from_images_rn_backbone(tmp_path):
+    """the reference's image loop (predictions_runner.py:156-161, 207-234) end to end on the device: photos ->
+    preprocess (PIL-exact) -> RN-tower encode_image -> normalise -> clip_project -> beam decode -> predictions JSON,
+    against the oracle run one image at a time the way the reference does; a missing file (None) is skipped and
+    `is_rn` forces beam search"""
+    import json
+    from capdec_amd import clip as cclip, predictions_runner as PR
+    from oracle import capdec_oracle as O
+    dims = synth.GPT2_TINY
+    clip_sd = synth.hot_clip_resnet_state_dict(44, synth.CLIP_RN_TINY)
+    clip_model, preprocess = cclip.load(clip_sd, device=0)
+    model, sd = _model(dims, "mlp", synth.CLIP_RN_TINY.embed_dim)
+    photos = [synth.synthetic_photo(h, w, 300 + i) for i, (h, w) in enumerate([(80, 100), (64, 64), (120, 70), (90, 91), (200, 150)])]
+    images = photos[:2] + [None] + photos[2:]
+    data = [{"image_id": 7 + i} for i in range(len(images))]
+    stop = dims.vocab + 5                               # never emitted: all 12 steps run
+    out = tmp_path / "p.json"
+    preds = PR.make_preds_from_images(data, images, clip_model, preprocess, model, FakeTok(stop), str(out), beam=False,
+                                      is_rn=True, entry_length=12, image_batch=2)
+    assert [p["image_id"] for p in preds] == [7, 8, 10, 11, 12] and json.load(open(out)) == preds
+    # the features: reference order of operations, one image at a time, on the oracle
+    ref = torch.cat([O.clip_encode_image_resnet(O.clip_preprocess(im, 64).unsqueeze(0), clip_sd) for im in photos])
+    feats = clip_model.encode_image(preprocess.batch(photos))
+    assert float((feats.cpu() - ref).abs().max()) < 5e-5 * float(ref.abs().max())
+    # the captions: the embedding driver (golden-tested above) on the same features; beam forced by is_rn
+    kept = [d for d, im in zip(data, images) if im is not None]
+    assert PR.make_preds(kept, feats, model, FakeTok(stop), None, beam=True, entry_length=12) == preds
+    assert PR.make_preds(kept, feats, model, FakeTok(stop), None, beam=False, entry_length=12) != preds
+    assert PR.make_preds_from_images([], [], clip_model, preprocess, model, FakeTok(stop)) == []
+
+
 @pytest.mark.parametrize("precision", ["fp16", "bf16"])
 def test_clip_resnet_reduced_precision(precision):
     """`clip.load(..., precision="fp16")` on the ResNet tower: convolutions with ONE 16-bit operand plane (the reference's
