@@ -20,6 +20,7 @@
 // kt+1 into the other fragment set), 4 LDS-DMA pieces (tile kt+NS) and 12 MFMAs (tile kt, from registers); one
 // counted s_waitcnt vmcnt(4 (NS-2)) lgkmcnt(0) + raw s_barrier per k-step.  MFMA time per k-step halves against
 // the six-product kernel, so the ring is one stage deeper to keep the same DMA lead in cycles.
+#include <algorithm>
 #include <cstdlib>
 
 #include "bf16x3.h"
@@ -288,16 +289,24 @@ __global__ __launch_bounds__(256, 2) void gemm_f16x2p_kernel(const _Float16 *__r
                                                              const float *resid, int ldr, int act, int tiles_m,
                                                              int tiles_n, char *packed_out) {
     __shared__ __attribute__((aligned(16))) char smem[NS * H2_STAGE_B];
-    int tm, tn;
-    tile_coords(tiles_m, tiles_n, tm, tn);
-    f32x16 am[2][2], ac[2][2];
-    h2p_mainloop<true, NS, ABL>(Apk, Bpk, K, tm, tn, smem, am, ac);
-    h2_join(am, ac);
-    if (packed_out)
-        epilogue_store_packed_t(am, packed_out, N >> 4, M, N, tm * GEMM_BM, tn * GEMM_BN, bias, act, PK_F16X2,
-                                reinterpret_cast<const char *>(resid));      // (with packed_out, `resid` is a PACKED residual)
-    else
-        epilogue_store_t<VEC4>(am, C, ldc, M, N, tm * GEMM_BM, tn * GEMM_BN, bias, resid, ldr, act);
+    // Persistent form: the launch has min(tiles, 512) blocks (two per CU) and block b walks tiles b, b + grid, ...  The
+    // hardware hands the blocks of a launch out breadth-first (one per CU, then the second slots), so the tiles of a
+    // partly filled last round are taken one per CU by blocks that by then have the CU to themselves -- where one block
+    // per tile lets the dispatcher put the leftovers two to a CU as slots free up (600 tiles: 2 x 37 us instead of
+    // 37 + 15).  grid % 8 == 0 keeps a block's tiles on its own XCD's slice of the tile order.
+    const int ntiles = tiles_m * tiles_n;
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        int tm, tn;
+        tile_coords(tiles_m, tiles_n, tm, tn, tile);
+        f32x16 am[2][2], ac[2][2];
+        h2p_mainloop<true, NS, ABL>(Apk, Bpk, K, tm, tn, smem, am, ac);      // ends with a barrier: the ring is free again
+        h2_join(am, ac);
+        if (packed_out)
+            epilogue_store_packed_t(am, packed_out, N >> 4, M, N, tm * GEMM_BM, tn * GEMM_BN, bias, act, PK_F16X2,
+                                    reinterpret_cast<const char *>(resid));  // (with packed_out, `resid` is a PACKED residual)
+        else
+            epilogue_store_t<VEC4>(am, C, ldc, M, N, tm * GEMM_BM, tn * GEMM_BN, bias, resid, ldr, act);
+    }
 }
 
 template <int KSEL>
@@ -354,8 +363,13 @@ int launch_gemm_f16x2p(hipStream_t st, const void *Apacked, const void *Bpacked,
         CAPDEC_HIP(hipGetLastError());
         return launch_splitk_reduce(st, part, S, M, N, epi, C, ldc, PK_F16X2);
     }
+    // persistent form for grids of up to four rounds, where the partly filled last round matters (625 captions: mlp.c_fc
+    // 600 tiles, 80 -> 70 us inside the decode loop); larger grids keep one block per tile (the dispatcher balances them:
+    // within noise either way at 25 000 rows).  CAPDEC_H2_PERSIST=<blocks> (0 = never)
+    static const int persist = [] { const char *e = getenv("CAPDEC_H2_PERSIST"); return e ? atoi(e) : 512; }();
+    const int grid_h2 = (persist > 0 && tiles_m * tiles_n <= 4 * persist) ? std::min(tiles_m * tiles_n, persist) : tiles_m * tiles_n;
 #define LAUNCH_H2(V4, NSV)                                                                                            \
-    hipLaunchKernelGGL((gemm_f16x2p_kernel<V4, NSV>), dim3(tiles_m * tiles_n), dim3(256), 0, st, (const _Float16 *)Apacked, \
+    hipLaunchKernelGGL((gemm_f16x2p_kernel<V4, NSV>), dim3(grid_h2), dim3(256), 0, st, (const _Float16 *)Apacked, \
                        (const _Float16 *)Bpacked, C, ldc, M, N, K, epi.bias, resid_arg, epi.ldr, epi.act, tiles_m,      \
                        tiles_n, (char *)epi.packed_out)
     const int ns = h2_ns();
