@@ -376,7 +376,10 @@ static int attn_decode_typed(hipStream_t st, const float *qkv, const KvCache &c,
         // waves per SIMD the register allocation is sized for: beam <= 4 fits 4 without spilling; beam 5 needs 124
         // registers at 4 waves; CAPDEC_ATT_OCC=3 / CAPDEC_ATT_NA=4 are measurement knobs (default = measured best)
         static const int occ5 = [] { const char *e = getenv("CAPDEC_ATT_OCC"); return e && atoi(e) == 3 ? 3 : 4; }();
-        static const int na4 = [] { const char *e = getenv("CAPDEC_ATT_NA"); return e && atoi(e) == 4 ? 1 : 0; }();
+        // positions per group in flight (NA): 2 when the launch is HBM-bound (5000 captions: 0.429 vs 0.435 ms), 4 when
+        // fewer than two rounds of wavefronts make it latency-bound (625 captions: 66.6 vs 68.7 us); CAPDEC_ATT_NA forces
+        static const int na_env = [] { const char *e = getenv("CAPDEC_ATT_NA"); return e ? atoi(e) : 0; }();
+        const int na4 = na_env ? (na_env == 4) : (total <= 16384);
 #define LAUNCH_BEAMS(B, OCC)                                                                                    \
     if (na4 && B <= 5)                                                                                          \
         hipLaunchKernelGGL((attn_decode_beams_kernel<B, KV, OCC, 4>), grid, block, lds, st, qkv, kl, vl, total, c.heads, \
