@@ -734,6 +734,29 @@ def test_decode_edge_cases():
         E.decode_beam_ids(model, pe, 13, 9, 5)                                   # beam > 8
 
 
+def test_decode_attention_launch_variants_agree():
+    """the decode attention keeps 2 positions per 16-lane group in flight for large launches (> 16384 (caption, head)
+    wavefronts: HBM-bound) and 4 for small ones (latency-bound); the oracle-checked tests above all sit in the small
+    regime, so decode 1500 captions in one launch (large variant) and in chunks of 250 (small variant): same beams"""
+    from capdec_amd import gpt2_prefix_eval as E
+    dims = synth.GPT2_TINY
+    model, _ = _model(dims, "mlp", 512)
+    n = 1500
+    assert n * dims.n_head > 16384 and 250 * dims.n_head <= 16384
+    x = synth.synthetic_clip_embeddings(n, 512, seed=21)
+    pe = model.clip_project(x).reshape(n, 10, -1)
+    stop = dims.vocab + 5
+    ids, lens, sc, _ = E.decode_beam_ids(model, pe, stop, 5, 24)
+    parts = [E.decode_beam_ids(model, pe[i:i + 250], stop, 5, 24) for i in range(0, n, 250)]
+    ids_c, sc_c = torch.cat([p[0] for p in parts]), torch.cat([p[2] for p in parts])
+    np.testing.assert_allclose(sc.cpu().numpy(), sc_c.cpu().numpy(), atol=2e-5)
+    same = (ids == ids_c).flatten(1).all(dim=1).float().mean()
+    assert float(same) > 0.995, float(same)              # (a near-tie may fall the other way: different summation order)
+    g, gl = E.decode_greedy_ids(model, pe, stop, 24)
+    gp = torch.cat([E.decode_greedy_ids(model, pe[i:i + 250], stop, 24)[0] for i in range(0, n, 250)])
+    assert float((g == gp).all(dim=1).float().mean()) > 0.995
+
+
 def test_full_size_properties():
     """BASELINE geometry (GPT-2 small, P = 10, T = 67, beam 5) where the oracle is too slow:
     size-independent properties -- determinism, batch-composition invariance, beam-1 == greedy,

@@ -3,6 +3,7 @@ set -u
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$R/gpurun_out; mkdir -p "$OUT"
 cd "$R"
+timeout 1200 python -m pytest tests -m gpu -x -q > "$OUT/r2_pytest_gpu.txt" 2>&1; tail -3 "$OUT/r2_pytest_gpu.txt"
 bash tools/collect_profiles.sh r2 > "$OUT/r2_collect.log" 2>&1
 cd "$R"
 timeout 300 python bench.py --cpu-seconds 0 --steps 3 --warmup 1 --captions 625 > "$OUT/r2_side_625.json" 2>/dev/null
@@ -14,6 +15,9 @@ timeout 300 python bench.py --cpu-seconds 0 --steps 2 --warmup 1 --gemm-mode bf1
 timeout 300 python bench.py --cpu-seconds 0 --steps 2 --warmup 1 --workload text_embed --captions 20000 > "$OUT/r2_side_text_f16x2.json" 2>/dev/null
 timeout 300 python bench.py --cpu-seconds 0 --steps 2 --warmup 1 --workload text_embed --captions 20000 --gemm-mode f16 > "$OUT/r2_side_text_f16.json" 2>/dev/null
 timeout 300 python bench.py --cpu-seconds 0 --steps 2 --warmup 1 --workload image_beam --captions 2014 > "$OUT/r2_side_image_f16x2.json" 2>/dev/null
+timeout 300 python bench.py --cpu-seconds 0 --steps 2 --warmup 1 --workload image_beam --clip rn50x4 --captions 2014 > "$OUT/r2_side_image_rn50x4.json" 2>/dev/null
+timeout 300 python bench.py --cpu-seconds 0 --steps 2 --warmup 1 --workload image_beam --clip rn50x4 --captions 2014 --gemm-mode f16 > "$OUT/r2_side_image_rn50x4_f16.json" 2>/dev/null
+bash tools/r2_rn50.sh > "$OUT/r2_rn50.log" 2>&1
 CAPDEC_FORCE_DIST=1 timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29513 \
    bench.py --gpus 1 --cpu-seconds 0 --steps 2 --warmup 1 > "$OUT/r2_side_dist1.json" 2>/dev/null
 python - <<'PY'

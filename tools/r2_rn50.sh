@@ -1,7 +1,7 @@
 #!/bin/bash
 # RN50x4 tower: GPU parity tests + throughput + per-family time
 export TMPDIR=/tmp
-timeout 900 python -m pytest tests -m gpu -x -q -k "resnet or from_images" > gpurun_out/r2_pytest_rn.txt 2>&1
+timeout 900 python -m pytest tests -m gpu -x -q -k "resnet" > gpurun_out/r2_pytest_rn.txt 2>&1
 tail -5 gpurun_out/r2_pytest_rn.txt
 cat > /tmp/rn_time.py <<'PY'
 import json, os, sys, time, torch
