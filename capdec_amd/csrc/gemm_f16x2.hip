@@ -427,15 +427,18 @@ __global__ __launch_bounds__(256, (NS == 3 ? 3 : 2)) void gemm_x1_kernel(const _
                                                          const float *__restrict__ bias, const float *resid, int ldr,
                                                          int act, int tiles_m, int tiles_n, char *packed_out, int out_fmt) {
     __shared__ __attribute__((aligned(16))) char smem[NS * H2_STAGE_B];
-    int tm, tn;
-    tile_coords(tiles_m, tiles_n, tm, tn);
-    f32x16 am[2][2], ac[2][2];
-    h2p_mainloop<true, NS, 0, KIND>(Apk, Bpk, K, tm, tn, smem, am, ac);
-    if (packed_out)
-        epilogue_store_packed_t(am, packed_out, N >> 4, M, N, tm * GEMM_BM, tn * GEMM_BN, bias, act, out_fmt,
-                                reinterpret_cast<const char *>(resid));      // (with packed_out, `resid` is a PACKED residual)
-    else
-        epilogue_store_t<VEC4>(am, C, ldc, M, N, tm * GEMM_BM, tn * GEMM_BN, bias, resid, ldr, act);
+    const int ntiles = tiles_m * tiles_n;
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {          // persistent form: see gemm_f16x2p_kernel
+        int tm, tn;
+        tile_coords(tiles_m, tiles_n, tm, tn, tile);
+        f32x16 am[2][2], ac[2][2];
+        h2p_mainloop<true, NS, 0, KIND>(Apk, Bpk, K, tm, tn, smem, am, ac);
+        if (packed_out)
+            epilogue_store_packed_t(am, packed_out, N >> 4, M, N, tm * GEMM_BM, tn * GEMM_BN, bias, act, out_fmt,
+                                    reinterpret_cast<const char *>(resid));  // (with packed_out, `resid` is a PACKED residual)
+        else
+            epilogue_store_t<VEC4>(am, C, ldc, M, N, tm * GEMM_BM, tn * GEMM_BN, bias, resid, ldr, act);
+    }
 }
 
 template <int KSEL, int KIND>
@@ -466,8 +469,12 @@ int launch_gemm_x1(hipStream_t st, const void *Apacked, const void *Bpacked, flo
                       (epi.resid == nullptr || (epi.ldr % 4 == 0 && ((uintptr_t)epi.resid & 15) == 0));
     // three blocks per CU measured +3 % at 25 000 rows, +1.3 % on the greedy bf16 workload; CAPDEC_X1_NS=4: two blocks
     static const int ns3 = [] { const char *e = getenv("CAPDEC_X1_NS"); return e && atoi(e) == 4 ? 0 : 1; }();
+    // persistent blocks for grids of up to four rounds (768 slots with three blocks per CU, 512 with two)
+    static const int persist = [] { const char *e = getenv("CAPDEC_H2_PERSIST"); return e ? atoi(e) : 512; }();
+    const int slots = persist > 0 ? ((vec4 && ns3) ? persist * 3 / 2 : persist) : 0;
+    const int grid_x1 = (slots > 0 && tiles_m * tiles_n <= 4 * slots) ? std::min(tiles_m * tiles_n, slots) : tiles_m * tiles_n;
 #define LAUNCH_X1V(V4, KD, NSV)                                                                                         \
-    hipLaunchKernelGGL((gemm_x1_kernel<V4, KD, NSV>), dim3(tiles_m * tiles_n), dim3(256), 0, st, (const _Float16 *)Apacked, \
+    hipLaunchKernelGGL((gemm_x1_kernel<V4, KD, NSV>), dim3(grid_x1), dim3(256), 0, st, (const _Float16 *)Apacked, \
                        (const _Float16 *)Bpacked, C, ldc, M, N, K, epi.bias,                                           \
                        epi.packed_out ? (const float *)epi.resid_packed : epi.resid, epi.ldr, epi.act, tiles_m,       \
                        tiles_n, (char *)epi.packed_out, fmt)
