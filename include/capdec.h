@@ -207,7 +207,12 @@ typedef struct {
     const float *c_w, *c_b;                            /* attnpool.c_proj: [embed_dim, 32w], [embed_dim] */
 } capdec_clip_resnet_weights;
 /* after this call capdec_clip_encode_image takes [n, 3, image_size, image_size] pixels through the ResNet tower
- * (a ViT tower loaded earlier is replaced, and vice versa) */
+ * (a ViT tower loaded earlier is replaced, and vice versa).
+ * Arithmetic: in the f16x2 / f16 / bf16 modes every activation between the pixels and the attention pool -- the residual
+ * stream included -- exists only as a packed GEMM operand of the mode (f16x2: two fp16 planes, 22 significand bits,
+ * |x| <= 65504; f16 / bf16: one 16-bit plane, what the reference's fp16 GPU model does), 3x3 convolutions are implicit
+ * GEMMs over it; the bf16x3 / f32 modes keep fp32 activations (im2col + GEMM).  Limits: width even with 32 * width a
+ * multiple of 64, image_size a multiple of 32 with at most 256 attention-pool tokens (image_size <= 480). */
 int capdec_load_clip_resnet(capdec_ctx *ctx, const capdec_clip_resnet_weights *h_weights);
 /* `clip_model.encode_text(clip.tokenize(caption))`: d_tokens int32 [n, context_length] (SOT ... EOT,
  * zero padded; the EOT row is found as argmax of the ids) -> d_out [n, embed_dim], NOT normalised */
