@@ -817,6 +817,31 @@ def test_clip_b32_towers(golden):
     _check_clip(golden("clip_b32"), synth.CLIP_VIT_B32)
 
 
+def test_clip_b32_batches_and_shards(golden):
+    """configs 4 / 5 beyond fixture size: ViT-B/32 towers on a few hundred texts / a hundred images -- the batch spans
+    several internal chunks -- must give every row what it gets alone or in another batch composition (a row's result
+    may not depend on its neighbours), and the driver's rank / world shards must concatenate to the full batch"""
+    from capdec_amd import embeddings_generator as EG
+    model, sd = _check_clip(golden("clip_b32"), synth.CLIP_VIT_B32)
+    toks = synth.synthetic_clip_tokens(301, seed=31, min_len=1, max_len=75).cuda()
+    full = model.encode_text(toks)
+    scale = float(full.abs().max())
+    pick = torch.tensor([0, 7, 150, 299, 300]).cuda()
+    sub = model.encode_text(toks[pick])
+    assert float((sub - full[pick]).abs().max()) < 2e-5 * scale           # batch-composition independent (fp32 round-off)
+    parts = [EG.encode_captions(model, toks, r, 3, gather=False) for r in range(3)]
+    assert [p.shape[0] for p in parts] == [101, 101, 99]
+    assert float((torch.cat(parts) - full).abs().max()) < 2e-5 * scale
+    imgs = synth.synthetic_images(97, seed=32).cuda()
+    fi = model.encode_image(imgs)
+    si = float(fi.abs().max())
+    assert float((model.encode_image(imgs[40:43]) - fi[40:43]).abs().max()) < 2e-5 * si
+    parts = [EG.encode_images(model, imgs, r, 2, gather=False) for r in range(2)]
+    assert float((torch.cat(parts) - fi).abs().max()) < 2e-5 * si
+    # and the rows differ from one another (no broadcasting of one row's result)
+    assert float((fi[0] - fi[1]).abs().max()) > 1e-3 * si and float((full[0] - full[1]).abs().max()) > 1e-3 * scale
+
+
 def _rn_check(model, sd, imgs, atol_rel):
     from oracle import capdec_oracle as O
     want = O.clip_encode_image_resnet(imgs, sd)
