@@ -189,11 +189,11 @@ int capdec_load_clip_vision(capdec_ctx *ctx, const capdec_clip_vision_weights *h
  * predictions_runner.py:158,220; embeddings_generator.py:89,113; train.py:445).  One entry per convolution with the
  * BatchNorm that follows it (inference statistics; folded into the convolution at load time).  Host fp32 pointers in
  * the OpenAI state-dict layouts: w [cout, cin, k, k] (k = 1, or 3 with padding 1), bn_* [cout]. */
-typedef struct {
+typedef struct capdec_conv_bn {
     const float *w, *bn_w, *bn_b, *bn_mean, *bn_var;   /* w == NULL: this convolution does not exist (no downsample) */
     int cin, cout, k;
 } capdec_conv_bn;
-typedef struct {
+typedef struct capdec_clip_resnet_weights {
     int image_size;        /* 288 for RN50x4 */
     int width;             /* 80 for RN50x4: stage planes width * {1,2,4,8}, attention-pool input 32 * width channels */
     int embed_dim;         /* 640 */

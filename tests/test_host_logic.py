@@ -62,6 +62,47 @@ def test_ctypes_signatures_match_header_prototypes():
     assert seen == len(_capi.SIGNATURES), (seen, len(_capi.SIGNATURES))
 
 
+def test_ctypes_structs_match_header_layout(tmp_path):
+    """every weight struct of include/capdec.h and its ctypes mirror agree on size, field names, field order and field
+    offsets as the C compiler lays them out (gcc on a generated program that prints sizeof / offsetof)"""
+    import ctypes as C
+    from capdec_amd import _capi
+    pairs = {"capdec_gpt2_layer": _capi.Gpt2Layer, "capdec_gpt2_weights": _capi.Gpt2Weights,
+             "capdec_tmapper_layer": _capi.TMapperLayer, "capdec_tmapper_weights": _capi.TMapperWeights,
+             "capdec_clip_block": _capi.ClipBlock, "capdec_clip_text_weights": _capi.ClipTextWeights,
+             "capdec_clip_vision_weights": _capi.ClipVisionWeights, "capdec_conv_bn": _capi.ConvBn,
+             "capdec_clip_resnet_weights": _capi.ClipResNetWeights}
+    header = open(os.path.join(ROOT, "include", "capdec.h")).read()
+    declared = set(re.findall(r"^}\s*(capdec_[a-z0-9_]+);", header, flags=re.M))
+    assert declared == set(pairs), declared ^ set(pairs)
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "capdec.h"', 'int main(void) {']
+    for cname, cls in pairs.items():
+        lines.append(f'  printf("{cname} size %zu\\n", sizeof({cname}));')
+        for fname, _ in cls._fields_:
+            lines.append(f'  printf("{cname} {fname} %zu\\n", offsetof({cname}, {fname}));')
+    lines += ['  return 0;', '}']
+    src = tmp_path / "layout.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "layout"
+    subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True)   # unknown field -> compile error
+    out = subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout
+    seen = 0
+    for line in out.splitlines():
+        cname, what, val = line.split()
+        cls = pairs[cname]
+        if what == "size":
+            assert C.sizeof(cls) == int(val), (cname, C.sizeof(cls), val)
+        else:
+            assert getattr(cls, what).offset == int(val), (cname, what, getattr(cls, what).offset, val)
+        seen += 1
+    assert seen == sum(len(c._fields_) + 1 for c in pairs.values())
+    # the header has no field the mirror lacks: count the declarators of each struct body
+    for cname, cls in pairs.items():
+        body = re.search(r"typedef struct " + cname + r" \{(.*?)\}\s*" + cname + ";", re.sub(r"/\*.*?\*/", " ", header, flags=re.S), flags=re.S).group(1)
+        n_decl = sum(len(stmt.split(",")) for stmt in body.split(";") if stmt.strip())
+        assert n_decl == len(cls._fields_), (cname, n_decl, len(cls._fields_))
+
+
 def test_no_cpu_fallback_without_gpu():
     if torch.cuda.is_available():
         pytest.skip("GPU present")
