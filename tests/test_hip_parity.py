@@ -842,9 +842,9 @@ def test_clip_b32_batches_and_shards(golden):
     assert float((fi[0] - fi[1]).abs().max()) > 1e-3 * si and float((full[0] - full[1]).abs().max()) > 1e-3 * scale
 
 
-def _rn_check(model, sd, imgs, atol_rel):
+def _rn_check(model, sd, imgs, atol_rel, fixture=None):
     from oracle import capdec_oracle as O
-    want = O.clip_encode_image_resnet(imgs, sd)
+    want = O.clip_encode_image_resnet(imgs, sd) if fixture is None else T(fixture)    # fixture: the torch.nn module witness
     got = model.encode_image(imgs).cpu()
     assert got.shape == want.shape
     scale = float(want.abs().max())
@@ -853,7 +853,7 @@ def _rn_check(model, sd, imgs, atol_rel):
     return got, want
 
 
-def test_clip_resnet_tiny_tower():
+def test_clip_resnet_tiny_tower(golden):
     """ModifiedResNet image tower (the structure of RN50x4, the reference's default backbone: predictions_runner.py:158,
     220) at a small geometry vs the oracle restatement: stem with stride-2 convolution + average pool, bottlenecks with
     anti-aliased stride and downsample branches, attention pool.  Parity vs openai/CLIP itself is UNPINNED (package
@@ -866,6 +866,9 @@ def test_clip_resnet_tiny_tower():
     assert model.input_resolution == 64 and pre.n_px == 64 and not model.has_text
     imgs = synth.synthetic_images(5, seed=12, size=64)                   # ragged: not a multiple of anything
     got, want = _rn_check(model, sd, imgs, 2e-5)
+    g = golden("clip_resnet")
+    assert synth.state_dict_checksum(sd) == int(g["crc_tiny"]), "RNG drift"
+    _rn_check(model, sd, imgs, 3e-5, g["features_tiny"])                  # same images (seed 12): the module witness
     # every image its own answer, order preserved, batch-size independent
     assert float((want[0] - want[1]).abs().max()) > 1e-2 * float(want.abs().max())
     one = model.encode_image(imgs[3:4]).cpu()
@@ -892,7 +895,7 @@ def test_clip_resnet_tiny_tower():
     eng.set_gemm_mode("f16x2")
 
 
-def test_clip_resnet_rn50x4_tower():
+def test_clip_resnet_rn50x4_tower(golden):
     """the full RN50x4 geometry (layers 4/6/10/6, width 80, 288 x 288 pixels, 2560-channel attention pool with 40 heads
     over 82 tokens, 640-d output): channel counts that need padding (40, 80, 160) included"""
     from capdec_amd import clip as cclip
@@ -900,7 +903,9 @@ def test_clip_resnet_rn50x4_tower():
     model, _ = cclip.load(sd, device=0)
     assert model.input_resolution == 288
     imgs = synth.synthetic_images(2, seed=13, size=288)
-    _rn_check(model, sd, imgs, 5e-5)
+    g = golden("clip_resnet")
+    assert synth.state_dict_checksum(sd) == int(g["crc_rn50x4"]), "RNG drift"
+    _rn_check(model, sd, imgs, 5e-5, g["features_rn50x4"])                # fixture of the torch.nn module witness
 
 
 def test_make_preds_from_images_rn_backbone(tmp_path):

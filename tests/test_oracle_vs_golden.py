@@ -344,3 +344,18 @@ def test_oracle_resnet_tower_building_blocks():
     # the tower's output depends on the image and has the embedding width
     e = O.clip_encode_image_resnet(synth.synthetic_images(2, seed=12, size=dims.image_size), sd)
     assert tuple(e.shape) == (2, dims.embed_dim) and float((e[0] - e[1]).abs().max()) > 1e-3
+
+
+@pytest.mark.parametrize("tag,dims", [("tiny", synth.CLIP_RN_TINY), ("rn50x4", synth.CLIP_RN50X4)], ids=["tiny", "rn50x4"])
+def test_oracle_resnet_tower_vs_module_witness(golden, tag, dims):
+    """the functional restatement of the ModifiedResNet tower == the torch.nn module witness of tools/gen_golden.py
+    (`_RnTower`: built as the published architecture, the synthetic weights loaded with strict=True under their OpenAI
+    names) on the committed fixture -- tiny geometry and the full RN50x4 (26 bottlenecks, 288 x 288, 640-d)"""
+    g = golden("clip_resnet")
+    sd = synth.hot_clip_resnet_state_dict(44, dims)
+    assert synth.state_dict_checksum(sd) == int(g[f"crc_{tag}"]), "RNG drift"
+    want = g[f"features_{tag}"]
+    imgs = synth.synthetic_images(want.shape[0], seed=int(g[f"image_seed_{tag}"]), size=dims.image_size)
+    got = O.clip_encode_image_resnet(imgs, sd).numpy()
+    assert got.shape == want.shape
+    assert float(np.abs(got - want).max()) < 2e-5 * float(np.abs(want).max())

@@ -439,6 +439,101 @@ def gen_clip(dims, tag, n_text, n_img):
     print(f"clip_{tag}.npz", tf.shape, vf.shape, float(tf.norm(dim=1).mean()), float(vf.norm(dim=1).mean()))
 
 
+class _RnBlock(torch.nn.Module):
+    """bottleneck of the published ModifiedResNet: 1x1 -> 3x3 -> (AvgPool2d(stride)) -> 1x1 (x4), anti-aliased strided
+    shortcut (AvgPool2d, 1x1 conv, BatchNorm) when the shape changes; submodule names = OpenAI state-dict names"""
+
+    def __init__(self, inplanes, planes, stride):
+        super().__init__()
+        nn = torch.nn
+        self.conv1, self.bn1 = nn.Conv2d(inplanes, planes, 1, bias=False), nn.BatchNorm2d(planes)
+        self.conv2, self.bn2 = nn.Conv2d(planes, planes, 3, padding=1, bias=False), nn.BatchNorm2d(planes)
+        self.avgpool = nn.AvgPool2d(stride) if stride > 1 else nn.Identity()
+        self.conv3, self.bn3 = nn.Conv2d(planes, planes * 4, 1, bias=False), nn.BatchNorm2d(planes * 4)
+        self.downsample = None
+        if stride > 1 or inplanes != planes * 4:
+            from collections import OrderedDict
+            self.downsample = nn.Sequential(OrderedDict([("-1", nn.AvgPool2d(stride)),
+                                                         ("0", nn.Conv2d(inplanes, planes * 4, 1, bias=False)),
+                                                         ("1", nn.BatchNorm2d(planes * 4))]))
+
+    def forward(self, x):
+        y = torch.relu(self.bn1(self.conv1(x)))
+        y = torch.relu(self.bn2(self.conv2(y)))
+        y = self.bn3(self.conv3(self.avgpool(y)))
+        return torch.relu(y + (x if self.downsample is None else self.downsample(x)))
+
+
+class _RnAttnPool(torch.nn.Module):
+    def __init__(self, tokens, dim, heads, out_dim):
+        super().__init__()
+        nn = torch.nn
+        self.positional_embedding = nn.Parameter(torch.zeros(tokens, dim))
+        self.q_proj, self.k_proj, self.v_proj = nn.Linear(dim, dim), nn.Linear(dim, dim), nn.Linear(dim, dim)
+        self.c_proj = nn.Linear(dim, out_dim)
+        self.heads = heads
+
+    def forward(self, x):
+        x = x.flatten(2).permute(2, 0, 1)                                   # [HW, N, C]
+        x = torch.cat([x.mean(dim=0, keepdim=True), x], dim=0) + self.positional_embedding[:, None, :]
+        out, _ = torch.nn.functional.multi_head_attention_forward(
+            query=x[:1], key=x, value=x, embed_dim_to_check=x.shape[-1], num_heads=self.heads,
+            q_proj_weight=self.q_proj.weight, k_proj_weight=self.k_proj.weight, v_proj_weight=self.v_proj.weight,
+            in_proj_weight=None, in_proj_bias=torch.cat([self.q_proj.bias, self.k_proj.bias, self.v_proj.bias]),
+            bias_k=None, bias_v=None, add_zero_attn=False, dropout_p=0.0, out_proj_weight=self.c_proj.weight,
+            out_proj_bias=self.c_proj.bias, use_separate_proj_weight=True, training=False, need_weights=False)
+        return out.squeeze(0)
+
+
+class _RnTower(torch.nn.Module):
+    """CLIP's ModifiedResNet built from torch.nn modules as published (3-convolution stem with average pool, four stages
+    of bottlenecks with strides 1/2/2/2, attention pool).  openai/CLIP is not installed here: this module is the independent
+    witness of the oracle's functional restatement, and `load_state_dict(strict=True)` of the synthetic weights is the check
+    that their names and shapes are those of an OpenAI state dict."""
+
+    def __init__(self, dims):
+        super().__init__()
+        nn, w = torch.nn, dims.width
+        self.conv1, self.bn1 = nn.Conv2d(3, w // 2, 3, stride=2, padding=1, bias=False), nn.BatchNorm2d(w // 2)
+        self.conv2, self.bn2 = nn.Conv2d(w // 2, w // 2, 3, padding=1, bias=False), nn.BatchNorm2d(w // 2)
+        self.conv3, self.bn3 = nn.Conv2d(w // 2, w, 3, padding=1, bias=False), nn.BatchNorm2d(w)
+        self.avgpool = nn.AvgPool2d(2)
+        inplanes = w
+        for li, (planes, blocks) in enumerate(zip((w, 2 * w, 4 * w, 8 * w), dims.layers), start=1):
+            layer = []
+            for b in range(blocks):
+                layer.append(_RnBlock(inplanes, planes, 2 if (b == 0 and li > 1) else 1))
+                inplanes = planes * 4
+            setattr(self, f"layer{li}", nn.Sequential(*layer))
+        sp = dims.image_size // 32
+        self.attnpool = _RnAttnPool(sp * sp + 1, dims.feat_dim, dims.heads, dims.embed_dim)
+
+    def forward(self, x):
+        for conv, bn in ((self.conv1, self.bn1), (self.conv2, self.bn2), (self.conv3, self.bn3)):
+            x = torch.relu(bn(conv(x)))
+        x = self.avgpool(x)
+        for li in (1, 2, 3, 4):
+            x = getattr(self, f"layer{li}")(x)
+        return self.attnpool(x)
+
+
+def gen_clip_resnet():
+    """RN50x4-class image towers: features of the torch.nn witness above on the synthetic OpenAI-named weights."""
+    out = {}
+    for tag, dims, n in (("tiny", synth.CLIP_RN_TINY, 5), ("rn50x4", synth.CLIP_RN50X4, 2)):
+        sd = synth.hot_clip_resnet_state_dict(44, dims)
+        tower = _RnTower(dims).eval()
+        tower.load_state_dict({k[len("visual."):]: v for k, v in sd.items()}, strict=True)
+        imgs = synth.synthetic_images(n, seed=12 if tag == "tiny" else 13, size=dims.image_size)
+        with torch.no_grad():
+            f = tower(imgs)
+        out[f"crc_{tag}"] = np.uint32(synth.state_dict_checksum(sd))
+        out[f"features_{tag}"] = f.numpy()
+        out[f"image_seed_{tag}"] = np.int64(12 if tag == "tiny" else 13)
+        print("clip_resnet", tag, tuple(f.shape), float(f.abs().max()))
+    np.savez_compressed(os.path.join(OUT, "clip_resnet.npz"), **out)
+
+
 def gen_preprocess():
     """CLIP `preprocess` (Resize(224, BICUBIC) -> CenterCrop(224) -> ToTensor -> Normalize) and the stretch variant
     `clip_transform_full` (predictions_runner.py:116-122) computed with PIL itself (torchvision is not installed: its
@@ -475,7 +570,7 @@ def main():
     args = ap.parse_args()
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(os.cpu_count() or 8)
-    refs = None if args.only == ["preprocess"] else import_reference()
+    refs = None if args.only and set(args.only) <= {"preprocess", "clip_resnet", "clip_tiny", "clip_b32"} else import_reference()
     jobs = {
         "mappers": lambda: gen_mappers(refs),
         "noise": lambda: gen_noise(refs),
@@ -490,6 +585,7 @@ def main():
         "prompt_small": lambda: gen_prompt(refs, synth.GPT2_SMALL, "small"),
         "clip_tiny": lambda: gen_clip(synth.CLIP_TINY, "tiny", 6, 3),
         "clip_b32": lambda: gen_clip(synth.CLIP_VIT_B32, "b32", 6, 3),
+        "clip_resnet": gen_clip_resnet,
         "preprocess": gen_preprocess,
     }
     for name, fn in jobs.items():
