@@ -353,8 +353,9 @@ static int gemm_packed(capdec_ctx *c, const void *Apk, const float *W, float *C,
         CAPDEC_TRY(c->xpk.ensure(x3_packed_bytes_host(M, N)));
         e.ln_w = next_ln->w; e.ln_b = next_ln->b; e.ln_eps = next_ln->eps; e.ln_out = c->xpk.p; e.ln_done = next_ln->done;
     }
-    if (c->gemm_mode == GEMM_BF16X3 || c->gemm_mode == GEMM_F16X2) {
-        const size_t wsb = gemm_splitk_ws_bytes(M, N, K);
+    if (c->gemm_mode != GEMM_F32) {
+        static const bool x1_split = [] { const char *e = getenv("CAPDEC_X1_SPLITK"); return !(e && atoi(e) == 0); }();
+        const size_t wsb = (mode_single(c) && !x1_split) ? 0 : gemm_splitk_ws_bytes(M, N, K);
         if (wsb) {
             CAPDEC_TRY(c->splitk.ensure(wsb));
             e.splitk_ws = c->splitk.p;

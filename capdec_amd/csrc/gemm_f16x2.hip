@@ -455,6 +455,23 @@ __global__ __launch_bounds__(256, 2) void gemm_x1_topk_kernel(const _Float16 *__
                                  tile_max, tile_sum, cand_val, cand_idx);
 }
 
+// split-K of the one-plane kernels (same regimes and reduce pass as the two-plane kernel: gemm_splitk_slices)
+template <int KIND>
+__global__ __launch_bounds__(256, 2) void gemm_x1_splitk_kernel(const _Float16 *__restrict__ Apk,
+                                                                const _Float16 *__restrict__ Bpk, float *part, int M, int N,
+                                                                int K, int tiles_m, int tiles_n, int S) {
+    __shared__ __attribute__((aligned(16))) char smem[H2_NS * H2_STAGE_B];
+    const int ntiles = tiles_m * tiles_n;
+    const int slice = blockIdx.x / ntiles;
+    int tm, tn;
+    tile_coords(tiles_m, tiles_n, tm, tn, blockIdx.x - slice * ntiles);
+    const int nks = K / (2 * X3_BK) / S;                 // stages (two k-steps each) of this slice
+    f32x16 am[2][2], ac[2][2];
+    h2p_mainloop<true, H2_NS, 0, KIND>(Apk, Bpk, K, tm, tn, smem, am, ac, slice * nks, nks);
+    epilogue_store_t<true>(am, part + (size_t)slice * M * N, N, M, N, tm * GEMM_BM, tn * GEMM_BN, nullptr, nullptr, 0,
+                           CAPDEC_ACT_NONE);
+}
+
 // fmt = PK_F16X1 or PK_BF16X1 (both operands; a packed output is written in the same format)
 int launch_gemm_x1(hipStream_t st, const void *Apacked, const void *Bpacked, float *C, int ldc, int M, int N, int K,
                    const GemmEpilogue &epi, int fmt) {
@@ -467,6 +484,21 @@ int launch_gemm_x1(hipStream_t st, const void *Apacked, const void *Bpacked, flo
     const bool vec4 = N % 4 == 0 && ldc % 4 == 0 && ((uintptr_t)C & 15) == 0 &&
                       (epi.bias == nullptr || ((uintptr_t)epi.bias & 15) == 0) &&
                       (epi.resid == nullptr || (epi.ldr % 4 == 0 && ((uintptr_t)epi.resid & 15) == 0));
+    {
+        int S = (vec4 && epi.splitk_ws && !epi.resid_packed) ? gemm_splitk_slices(M, N, K) : 1;
+        if (S > 1 && ((K / X3_BK / S) % 4 != 0 || epi.splitk_ws_bytes < (size_t)S * M * N * sizeof(float))) S = 1;
+        if (S > 1) {     // a slice is a whole, even number of two-k-step stages
+            float *part = (float *)epi.splitk_ws;
+            if (fmt == PK_F16X1)
+                hipLaunchKernelGGL(gemm_x1_splitk_kernel<1>, dim3(tiles_m * tiles_n * S), dim3(256), 0, st,
+                                   (const _Float16 *)Apacked, (const _Float16 *)Bpacked, part, M, N, K, tiles_m, tiles_n, S);
+            else
+                hipLaunchKernelGGL(gemm_x1_splitk_kernel<2>, dim3(tiles_m * tiles_n * S), dim3(256), 0, st,
+                                   (const _Float16 *)Apacked, (const _Float16 *)Bpacked, part, M, N, K, tiles_m, tiles_n, S);
+            CAPDEC_HIP(hipGetLastError());
+            return launch_splitk_reduce(st, part, S, M, N, epi, C, ldc, fmt);
+        }
+    }
     // three blocks per CU measured +3 % at 25 000 rows, +1.3 % on the greedy bf16 workload; CAPDEC_X1_NS=4: two blocks
     static const int ns3 = [] { const char *e = getenv("CAPDEC_X1_NS"); return e && atoi(e) == 4 ? 0 : 1; }();
     // persistent blocks for grids of up to four rounds (768 slots with three blocks per CU, 512 with two)
