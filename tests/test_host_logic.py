@@ -152,6 +152,14 @@ def test_facade_surface_matches_reference_names():
     m2 = gpt2_prefix.ClipCaptionModel(10, prefix_size=512, gpt2_dims=synth.GPT2_TINY)       # train.py spelling
     assert isinstance(m2.clip_project, transformer_mapper.TransformerMapper) and m2.prefix_dim == 512
     assert train.noise_injection(torch.ones(2, 4), 0.0).equal(torch.ones(2, 4))              # variance 0: identity
+    # the image half of the loop: argument checks happen before any device work
+    sig = inspect.signature(predictions_runner.make_preds_from_images)
+    assert list(sig.parameters)[:6] == ["data", "images", "clip_model", "preprocess", "model", "tokenizer"]
+    assert sig.parameters["is_rn"].default is False and sig.parameters["beam"].default is True
+    with pytest.raises(ValueError):
+        predictions_runner.make_preds_from_images([{"image_id": 1}], [], None, None, None, None)
+    with pytest.raises(ValueError):
+        predictions_runner.make_preds([{"image_id": 1}], torch.zeros(2, 4), None, None)
 
 
 def test_state_dict_loading_rules():
