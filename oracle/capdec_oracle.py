@@ -18,7 +18,13 @@ the GPT-2 arithmetic lives in the un-vendored dependency ``transformers`` (pinne
 reference requirments.txt:12; 5.15.0 installed here).  The oracle is therefore pinned
 against outputs of the reference itself, imported in the build container by
 ``tools/gen_golden.py`` -> ``tests/golden/*.npz`` (checked by
-``tests/test_oracle_vs_golden.py``).  CLIP towers are not restated here (package absent).
+``tests/test_oracle_vs_golden.py``).
+
+CLIP (the reference's dependency ``clip`` = openai/CLIP, NOT installed here): the towers are restated from the published
+model under OpenAI state-dict names -- PARITY UNPINNED against the package itself.  What pins them instead: the ViT-B/32
+text / image towers against ``transformers.CLIPModel`` (fp32 and fp16; ``tests/golden/clip_{tiny,b32}.npz``), the
+ModifiedResNet (RN50x4) tower against a ``torch.nn`` module witness built to the published structure into which the
+weights load with ``strict=True`` (``tools/gen_golden.py:_RnTower`` -> ``tests/golden/clip_resnet.npz``).
 """
 from __future__ import annotations
 
@@ -517,7 +523,8 @@ def clip_encode_image(image: Tensor, sd: SD, n_head: int = 12) -> Tensor:
 # CLIP ModifiedResNet image tower (`clip.load("RN50x4")`: the reference's default backbone, predictions_runner.py:158,
 # 220; embeddings_generator.py:89,113).  The `clip` package is not installed and NO stand-in for this architecture
 # exists in the container (transformers has no ModifiedResNet): the functions below restate the published openai/CLIP
-# model (clip/model.py: Bottleneck, AttentionPool2d, ModifiedResNet) -- PARITY UNPINNED, see DESIGN.md section 2.
+# model (clip/model.py: Bottleneck, AttentionPool2d, ModifiedResNet) -- PARITY UNPINNED against the package; pinned against
+# the torch.nn module witness of tools/gen_golden.py (tests/golden/clip_resnet.npz), see DESIGN.md section 2.
 #   stem: 3 x (conv3x3 -> BatchNorm -> ReLU) with the first conv at stride 2, then AvgPool2d(2);
 #   4 stages of Bottleneck blocks (1x1 -> 3x3 -> [AvgPool2d(stride)] -> 1x1 (x4 planes), BatchNorm after every conv,
 #   anti-aliased striding: the stride is an average pool, never a strided conv; downsample = AvgPool2d(stride) ->
