@@ -79,6 +79,7 @@ class ClipResNetWeights(C.Structure):
 
 #: every symbol include/capdec.h declares: name -> (restype, argtypes)
 _VP = C.c_void_p
+ABI_VERSION = 2          # include/capdec.h: CAPDEC_ABI_VERSION
 SIGNATURES = {
     "capdec_abi_version": (C.c_int, []),
     "capdec_build_id": (C.c_char_p, []),
@@ -90,6 +91,9 @@ SIGNATURES = {
     "capdec_synchronize": (C.c_int, [_VP]),
     "capdec_set_gemm_mode": (C.c_int, [_VP, C.c_int]),
     "capdec_get_gemm_mode": (C.c_int, [_VP]),
+    "capdec_set_batch_invariant": (C.c_int, [_VP, C.c_int]),
+    "capdec_set_debug_diverge": (C.c_int, [_VP, C.c_int]),
+    "capdec_decode_counters": (C.c_int, [_VP, C.POINTER(C.c_double), C.POINTER(C.c_longlong)]),
     "capdec_set_kv_budget": (C.c_int, [_VP, C.c_size_t]),
     "capdec_malloc": (C.c_int, [_VP, C.c_size_t, C.POINTER(_VP)]),
     "capdec_free": (C.c_int, [_VP, _VP]),
@@ -155,7 +159,7 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
         fn = getattr(lib, name)   # AttributeError if the symbol is not exported
         fn.restype = res
         fn.argtypes = args
-    if lib.capdec_abi_version() != 1:
+    if lib.capdec_abi_version() != ABI_VERSION:
         raise CapdecError("libcapdec_hip.so ABI version mismatch")
     if path is None and os.environ.get("CAPDEC_SKIP_BUILD_ID_CHECK") != "1":
         # stale-library guard: the id compiled into the .so must match the sources lying next to it

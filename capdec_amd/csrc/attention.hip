@@ -379,7 +379,7 @@ static int attn_decode_typed(hipStream_t st, const float *qkv, const KvCache &c,
         // positions per group in flight (NA): 2 when the launch is HBM-bound (5000 captions: 0.429 vs 0.435 ms), 4 when
         // fewer than two rounds of wavefronts make it latency-bound (625 captions: 66.6 vs 68.7 us); CAPDEC_ATT_NA forces
         static const int na_env = [] { const char *e = getenv("CAPDEC_ATT_NA"); return e ? atoi(e) : 0; }();
-        const int na4 = na_env ? (na_env == 4) : (total <= 16384);
+        const int na4 = na_env ? (na_env == 4) : (!c.fixed_variant && total <= 16384);
 #define LAUNCH_BEAMS(B, OCC)                                                                                    \
     if (na4 && B <= 5)                                                                                          \
         hipLaunchKernelGGL((attn_decode_beams_kernel<B, KV, OCC, 4>), grid, block, lds, st, qkv, kl, vl, total, c.heads, \
@@ -481,5 +481,7 @@ int launch_attn_mapper(hipStream_t st, const float *q, int ldq, const float *k, 
     CAPDEC_HIP(hipGetLastError());
     return 0;
 }
+
+CAPDEC_SAT_ACCESSOR(sat_count_attention)
 
 }  // namespace capdec

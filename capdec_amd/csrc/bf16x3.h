@@ -48,7 +48,7 @@ __device__ __forceinline__ int x3_group_offset(int r, int quad) {
 // rms 2^-24.6 |a b|, i.e. below the rounding of an fp32 multiply-add), with the 2^-11 terms summed in their own
 // accumulator.  Same tile-major layout as above with two planes: one (row_tile, k_step) block is 8 KB.
 // |a| is clamped to fp16's largest finite value 65504 (GEMM inputs of this path -- LayerNorm outputs, attention
-// outputs, GELU outputs, weights -- are orders of magnitude below it).
+// outputs, GELU outputs, weights -- are orders of magnitude below it); every clamp is counted (g_h2_saturated below).
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 // PK_BF16X1 / PK_F16X1: ONE plane -- the operand rounded to bf16 / fp16 (RNE; fp16 clamped to +-65504): the reduced-
@@ -58,11 +58,34 @@ enum PackFmt { PK_BF16X3 = 0, PK_F16X2 = 1, PK_BF16X1 = 2, PK_F16X1 = 3 };
 constexpr int H2_BLOCK_B = 2 * X3_PLANE_B;            // 8192: one (row_tile, k_step) block of the f16x2 format
 constexpr float H2_LO_SCALE = 2048.0f;                // 2^11
 
+// Range accounting of the fp16-plane formats: operands beyond fp16's largest finite value are clamped to +-65504 and
+// COUNTED (one count per saturated quad) in a per-translation-unit device counter that capdec_decode_counters sums and
+// resets -- a checkpoint whose activations leave the format's range is reported instead of silently saturating.  NaN is
+// not clamped: it goes into the high plane and propagates through the MFMAs like it would through an fp32 GEMM.
+static __device__ unsigned int g_h2_saturated;
+#define CAPDEC_SAT_ACCESSOR(fn)                                                                            \
+    unsigned long long fn(bool reset) {                                                                    \
+        unsigned int v = 0;                                                                                \
+        if (hipMemcpyFromSymbol(&v, HIP_SYMBOL(g_h2_saturated), sizeof(v)) != hipSuccess) return 0;        \
+        if (reset && v) { const unsigned int z = 0; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_h2_saturated), &z, sizeof(z)); } \
+        return v;                                                                                          \
+    }
+__device__ __forceinline__ float h2_clamp_count(const float4 v) {
+    const float m = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(v.x), __builtin_fabsf(v.y)),
+                                    __builtin_fmaxf(__builtin_fabsf(v.z), __builtin_fabsf(v.w)));
+    if (m > 65504.f) atomicAdd(&g_h2_saturated, 1u);      // rare by construction: one predicated atomic
+    return m;
+}
+__device__ __forceinline__ float h2_clamp(float a) {       // NaN-preserving (fmaxf(NaN, x) would return x)
+    return a != a ? a : __builtin_fminf(__builtin_fmaxf(a, -65504.f), 65504.f);
+}
+
 __device__ __forceinline__ void split2h(const float4 v, f16x4 &h, f16x4 &l) {
     const float a[4] = {v.x, v.y, v.z, v.w};
+    (void)h2_clamp_count(v);
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-        const float c = __builtin_fminf(__builtin_fmaxf(a[e], -65504.f), 65504.f);
+        const float c = h2_clamp(a[e]);
         const _Float16 hh = __builtin_fabsf(c) < 0x1p-14f ? (_Float16)0.f : (_Float16)c;
         const float r = c - (float)hh;                // exact
         h[e] = hh;
@@ -86,10 +109,11 @@ __device__ __forceinline__ void x3_store_quad(char *packed, int nk, int row, int
             *reinterpret_cast<bf16x4 *>(p) = h;
         } else {
             f16x4 h;
-            h[0] = (_Float16)__builtin_fminf(__builtin_fmaxf(v.x, -65504.f), 65504.f);
-            h[1] = (_Float16)__builtin_fminf(__builtin_fmaxf(v.y, -65504.f), 65504.f);
-            h[2] = (_Float16)__builtin_fminf(__builtin_fmaxf(v.z, -65504.f), 65504.f);
-            h[3] = (_Float16)__builtin_fminf(__builtin_fmaxf(v.w, -65504.f), 65504.f);
+            (void)h2_clamp_count(v);
+            h[0] = (_Float16)h2_clamp(v.x);
+            h[1] = (_Float16)h2_clamp(v.y);
+            h[2] = (_Float16)h2_clamp(v.z);
+            h[3] = (_Float16)h2_clamp(v.w);
             *reinterpret_cast<f16x4 *>(p) = h;
         }
         return;

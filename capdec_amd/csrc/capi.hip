@@ -139,13 +139,16 @@ struct capdec_ctx {
     DBuf x3_tmp, xpk, apk, fpk, a_tmp;   // scratch planes for un-cached matrices; packed LayerNorm output; packed fp32-A
     int stat_steps = 0, stat_compactions = 0;      // last decode call: steps run, compactions done,
     long long stat_row_steps = 0;                  // activation rows pushed through the GPT-2 body (prefill excluded)
+    bool batch_invariant = false;   // capdec_set_batch_invariant: no launch-size dependent summation order (no split-K, pinned kernel variants)
+    int diverge = 0;                // measurement: beams never share history (capdec_set_debug_diverge)
+    double stat_kv_slots = 0.0, stat_kv_pos = 0.0;   // last beam decode: sums behind capdec_decode_counters
     bool compact = true;       // decode: drop finished captions from the batch at the poll points (CAPDEC_COMPACT=0: off)
     bool pack_chain = true;    // ... and attention / the fc GEMM epilogue emit the packed A operand of the GEMM that follows
     bool pack_a = true;        // bf16x3 mode: LayerNorm emits the packed A operand, GEMM moves both operands by LDS-DMA
     hipEvent_t t0 = nullptr, t1 = nullptr;
     // workspaces
     DBuf h, x, qkv, att, ff, xl, tmax, tsum, cval, cidx, lse, topv, topi, kc, vc;
-    DBuf tokens, scores, seq, stopped, done, anc, next_tok, alive, gids, glens, cmap;
+    DBuf tokens, scores, seq, stopped, done, anc, next_tok, alive, gids, glens, cmap, kvstat;
     DBuf m_hid, m_lin, m_seq, m_x, m_qkv, m_att, m_ff;
     DBuf t_idx, t_patch, t_pout, p_desc, p_inter, splitk;
     int *alive_host = nullptr;   // pinned
@@ -306,7 +309,7 @@ static int gemm(capdec_ctx *c, const float *A, int lda, const float *Bt, int ldb
         CAPDEC_TRY(planes_of(c, Bt, N, K, weight, &pl, PK_F16X2));
         CAPDEC_TRY(c->a_tmp.ensure(x3_packed_bytes(M, K, PK_F16X2)));
         { ProfScope ps(c, F_PACK); CAPDEC_TRY(launch_pack_planes_h2(c->stream, A, lda, M, K, c->a_tmp.p)); }
-        const size_t wsb = gemm_splitk_ws_bytes(M, N, K);
+        const size_t wsb = c->batch_invariant ? 0 : gemm_splitk_ws_bytes(M, N, K);
         if (wsb) {
             CAPDEC_TRY(c->splitk.ensure(wsb));
             e.splitk_ws = c->splitk.p;
@@ -355,7 +358,7 @@ static int gemm_packed(capdec_ctx *c, const void *Apk, const float *W, float *C,
     }
     if (c->gemm_mode != GEMM_F32) {
         static const bool x1_split = [] { const char *e = getenv("CAPDEC_X1_SPLITK"); return !(e && atoi(e) == 0); }();
-        const size_t wsb = (mode_single(c) && !x1_split) ? 0 : gemm_splitk_ws_bytes(M, N, K);
+        const size_t wsb = ((mode_single(c) && !x1_split) || c->batch_invariant) ? 0 : gemm_splitk_ws_bytes(M, N, K);
         if (wsb) {
             CAPDEC_TRY(c->splitk.ensure(wsb));
             e.splitk_ws = c->splitk.p;
@@ -601,6 +604,7 @@ static int decode_chunk(capdec_ctx *c, const float *prefix, int nc, int P, int b
     const float inv_temp = 1.0f / (temperature > 0.f ? temperature : 1.0f);
     KvCache kv;
     CAPDEC_TRY(ensure_kv(c, kv, rows, ctx));
+    kv.fixed_variant = c->batch_invariant;
     CAPDEC_TRY(ensure_body_ws(c, std::max(nc * P, rows), d));
     CAPDEC_TRY(c->next_tok.ensure((size_t)rows * 4));
     CAPDEC_TRY(c->alive.ensure(sizeof(int)));
@@ -620,6 +624,10 @@ static int decode_chunk(capdec_ctx *c, const float *prefix, int nc, int P, int b
         bs.anc = c->anc.as<uint8_t>();
         bs.next_tok = c->next_tok.as<int>();
         bs.alive_count = c->alive.as<int>();
+        bs.diverge = c->diverge;
+        CAPDEC_TRY(c->kvstat.ensure((size_t)nc * 2 * sizeof(unsigned)));
+        bs.kv_stat = c->kvstat.as<unsigned>();
+        CAPDEC_HIP(hipMemsetAsync(bs.kv_stat, 0, (size_t)nc * 2 * sizeof(unsigned), c->stream));
         CAPDEC_HIP(hipMemsetAsync(bs.tokens, 0, (size_t)rows * T * 4, c->stream));
         CAPDEC_HIP(hipMemsetAsync(bs.anc, 0, (size_t)rows * ctx, c->stream));
     } else {
@@ -703,6 +711,12 @@ static int decode_chunk(capdec_ctx *c, const float *prefix, int nc, int P, int b
         ProfScope ps(c, F_SELECT);
         CAPDEC_TRY(launch_beam_finalize(c->stream, bs, nc, beam, T, ids, lens, scores, order));
     }
+    if (!greedy && bs.kv_stat) {     // (one small read-back per chunk, after the last kernel of the chunk was enqueued)
+        std::vector<unsigned> hs((size_t)nc * 2);
+        CAPDEC_HIP(hipMemcpyAsync(hs.data(), bs.kv_stat, hs.size() * sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
+        CAPDEC_HIP(hipStreamSynchronize(c->stream));
+        for (int i = 0; i < nc; ++i) { c->stat_kv_slots += hs[2 * i]; c->stat_kv_pos += hs[2 * i + 1]; }
+    }
     return 0;
 }
 
@@ -719,6 +733,7 @@ static int decode_common(capdec_ctx *c, const float *prefix, int n, int P, int b
     c->stat_steps = n > 0 ? 1 : 0;
     c->stat_compactions = 0;
     c->stat_row_steps = 0;
+    c->stat_kv_slots = c->stat_kv_pos = 0.0;
     if (n == 0) return 0;
     const int ctx = P + T - 1;
     const int chunk = chunk_captions(c, n, beam, ctx);
@@ -1162,8 +1177,13 @@ int capdec_create(int device_id, capdec_ctx **out) {
     if (const char *e = getenv("CAPDEC_COMPACT")) c->compact = atoi(e) != 0;
     if (const char *e = getenv("CAPDEC_GEMM_MODE")) {
         const std::string m(e);
+        if (m != "f32" && m != "bf16" && m != "bf16x3" && m != "f16" && m != "f16x2") {     // a typo must not silently select another precision
+            set_error("create: CAPDEC_GEMM_MODE=" + m + " is not one of f16x2 | bf16x3 | f32 | bf16 | f16");
+            return 1;
+        }
         c->gemm_mode = m == "f32" ? GEMM_F32 : m == "bf16" ? GEMM_BF16 : m == "bf16x3" ? GEMM_BF16X3 : m == "f16" ? GEMM_F16 : GEMM_F16X2;
     }
+    if (const char *e = getenv("CAPDEC_BATCH_INVARIANT")) c->batch_invariant = atoi(e) != 0;
     CAPDEC_HIP(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
     c->stream = c->own_stream;
     CAPDEC_HIP(hipEventCreate(&c->t0));
@@ -1190,7 +1210,7 @@ void capdec_destroy(capdec_ctx *c) {
     DBuf *bufs[] = {&c->h, &c->x, &c->qkv, &c->att, &c->ff, &c->xl, &c->tmax, &c->tsum, &c->cval, &c->cidx,
                     &c->lse, &c->topv, &c->topi, &c->kc, &c->vc, &c->tokens, &c->scores, &c->seq, &c->stopped,
                     &c->done, &c->anc, &c->next_tok, &c->alive, &c->gids, &c->glens, &c->m_hid, &c->m_lin, &c->m_seq,
-                    &c->m_x, &c->m_qkv, &c->m_att, &c->m_ff, &c->t_idx, &c->t_patch, &c->t_pout, &c->xpk, &c->apk, &c->fpk, &c->cmap, &c->p_desc, &c->p_inter, &c->splitk, &c->a_tmp,
+                    &c->m_x, &c->m_qkv, &c->m_att, &c->m_ff, &c->t_idx, &c->t_patch, &c->t_pout, &c->xpk, &c->apk, &c->fpk, &c->cmap, &c->kvstat, &c->p_desc, &c->p_inter, &c->splitk, &c->a_tmp,
                     &c->r_a, &c->r_b, &c->r_c, &c->r_d, &c->r_e, &c->r_f, &c->r_col, &c->r_pk1, &c->r_pk2, &c->r_xpk,
                     &c->r_ypk, &c->r_xi, &c->r_idp, &c->r_zero};
     for (DBuf *b : bufs) b->release();
@@ -1226,6 +1246,16 @@ int capdec_set_gemm_mode(capdec_ctx *c, int mode) {
     return 0;
 }
 int capdec_get_gemm_mode(capdec_ctx *c) { return c ? c->gemm_mode : -1; }
+int capdec_set_batch_invariant(capdec_ctx *c, int on) {
+    CAPDEC_CHECK(c, "null context");
+    c->batch_invariant = on != 0;
+    return 0;
+}
+int capdec_set_debug_diverge(capdec_ctx *c, int on) {
+    CAPDEC_CHECK(c, "null context");
+    c->diverge = on != 0;
+    return 0;
+}
 int capdec_set_kv_budget(capdec_ctx *c, size_t bytes) {
     CAPDEC_CHECK(c, "null context");
     c->kv_budget = bytes ? bytes : ((size_t)192 << 30);
@@ -1606,7 +1636,7 @@ int capdec_gemm_f32(capdec_ctx *c, const float *a, int lda, const float *bt, int
         CAPDEC_TRY(planes_of(c, bt, N, K, cache, &pb));
         GemmEpilogue e;
         e.bias = bias; e.act = act; e.resid = resid; e.ldr = ldr;
-        if (c->gemm_mode == GEMM_F16X2 || c->gemm_mode == GEMM_BF16X3) {
+        if ((c->gemm_mode == GEMM_F16X2 || c->gemm_mode == GEMM_BF16X3) && !c->batch_invariant) {
             const size_t wsb = gemm_splitk_ws_bytes(M, N, K);
             if (wsb) {
                 CAPDEC_TRY(c->splitk.ensure(wsb));
@@ -1762,6 +1792,18 @@ int capdec_decode_stats(capdec_ctx *c, int *steps, int *compactions, long long *
     return 0;
 }
 
+int capdec_decode_counters(capdec_ctx *c, double *kv_slots_per_position, long long *saturated_quads) {
+    CAPDEC_CHECK(c, "null context");
+    CAPDEC_HIP(hipSetDevice(c->device));
+    if (kv_slots_per_position) *kv_slots_per_position = c->stat_kv_pos > 0 ? c->stat_kv_slots / c->stat_kv_pos : 0.0;
+    if (saturated_quads) {
+        CAPDEC_HIP(hipStreamSynchronize(c->stream));
+        *saturated_quads = (long long)(sat_count_gemm_f16x2(true) + sat_count_gemm_h2w(true) + sat_count_gemm_bf16x3(true) +
+                                       sat_count_elementwise(true) + sat_count_attention(true) + sat_count_resnet(true));
+    }
+    return 0;
+}
+
 int capdec_timer_start(capdec_ctx *c) {
     CAPDEC_CHECK(c, "null context");
     CAPDEC_HIP(hipEventRecord(c->t0, c->stream));
@@ -1789,6 +1831,7 @@ int capdec_profile_reset(capdec_ctx *c) {
 int capdec_profile_get(capdec_ctx *c, int *count, const char **names, float *ms, int64_t *launches, double *flops,
                        int64_t *calls) {
     CAPDEC_CHECK(c && count, "null argument");
+    CAPDEC_CHECK(*count >= F_COUNT, "profile_get: *count must hold the capacity of the caller's arrays (>= 24 is always enough)");
     CAPDEC_TRY(prof_collect(c));
     *count = F_COUNT;
     for (int f = 0; f < F_COUNT; ++f) {

@@ -141,6 +141,11 @@ int launch_gemm_f16x2p(hipStream_t st, const void *Apacked, const void *Bpacked,
                        const GemmEpilogue &epi);
 int launch_gemm_f16x2p_topk(hipStream_t st, const void *Apacked, const void *Bpacked, int M, int N, int K, int k,
                             float inv_temp, float *tile_max, float *tile_sum, float *cand_val, int *cand_idx);
+// round-3 wide-tile kernels with ONE accumulator set (gemm_h2w.hip); scale = 2^(t - 11), t = pack-time pre-scale
+// exponent of the weights; `which`: 2 = 256x128 (two blocks per CU), 3 = 256x256 (8 waves), 4 / 5 = 128x128
+int h2w_choice();
+int launch_gemm_h2w(hipStream_t st, int which, const void *Apacked, const void *Bpacked, float *C, int ldc, int M, int N,
+                    int K, const GemmEpilogue &epi, float scale);
 // generic packer for any PackFmt (gemm_f16x2.hip); the one-plane formats use it
 int launch_pack_planes_fmt(hipStream_t st, const float *w, int ldw, int N, int K, void *out, int fmt);
 // round-2 one-plane kernels on the f16x2 main loop (gemm_f16x2.hip): 128x128 tile, two blocks per CU, 32-deep stages
@@ -202,6 +207,7 @@ struct KvCache {
     void *v = nullptr;
     int rows = 0, heads = 0, ctx = 0, hd = 0;
     bool bf16 = false;
+    bool fixed_variant = false;   // batch-invariant mode: the launch-size dependent kernel variants are pinned
     size_t layer_stride() const { return (size_t)rows * heads * ctx * hd; }      // elements
     size_t elem_bytes() const { return bf16 ? 2 : 4; }
     template <typename T> T *kp(int layer) const { return reinterpret_cast<T *>(k) + (size_t)layer * layer_stride(); }
@@ -238,6 +244,9 @@ struct BeamState {
     uint8_t *anc = nullptr;     // [ncap, beam, ctx]
     int *next_tok = nullptr;    // [ncap * beam]
     int *alive_count = nullptr; // [1] captions still running (device counter, polled by the host)
+    unsigned *kv_stat = nullptr;   // [ncap, 2] optional: per caption, sum over the decode steps of (distinct K/V slots the
+                                   // next step's attention reads, positions it attends to) -- what the attention roofline depends on
+    int diverge = 0;               // measurement only: every beam continues ITSELF (worst-case K/V traffic; results differ)
 };
 int launch_beam_init(hipStream_t st, const BeamState &s, const float *lse, const float *top_val, const int *top_idx,
                      int ncap, int beam, int k, int T, int ctx, int P, int stop_id);
@@ -252,6 +261,14 @@ int launch_greedy_step(hipStream_t st, const int *top_idx, int rows, int step, i
                        const float *lse = nullptr, float *stats = nullptr);
 // cmap[0..count) = indices of the captions with done[c] == 0, ascending; *count = how many (one block)
 int launch_compact_alive(hipStream_t st, const uint8_t *done, int ncap, int *cmap, int *count);
+
+// operands clamped to the fp16 range since the last reset, per translation unit (bf16x3.h: g_h2_saturated)
+unsigned long long sat_count_gemm_f16x2(bool reset);
+unsigned long long sat_count_gemm_h2w(bool reset);
+unsigned long long sat_count_gemm_bf16x3(bool reset);
+unsigned long long sat_count_elementwise(bool reset);
+unsigned long long sat_count_attention(bool reset);
+unsigned long long sat_count_resnet(bool reset);
 
 // preprocess.hip: PIL-exact bicubic resize + centre crop + ToTensor + Normalize of a batch of uint8 RGB images
 struct ImageDesc {

@@ -467,4 +467,6 @@ int launch_vision_assemble(hipStream_t st, const float *patch_out, const float *
     return 0;
 }
 
+CAPDEC_SAT_ACCESSOR(sat_count_elementwise)
+
 }  // namespace capdec

@@ -702,4 +702,6 @@ int launch_gemm_bf16x3_topk(hipStream_t st, const float *A, int lda, const void 
     return 0;
 }
 
+CAPDEC_SAT_ACCESSOR(sat_count_gemm_bf16x3)
+
 }  // namespace capdec

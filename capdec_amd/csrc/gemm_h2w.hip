@@ -1,0 +1,360 @@
+// Round 3: the fp32-accurate three-product GEMM (format PK_F16X2, see gemm_f16x2.hip) with ONE accumulator set and wide
+// wave tiles:  C[M,N] = epi( A[M,K] . Bt[N,K]^T ).
+//
+// Why: the 128x128 / 64x64-per-wave kernel of round 2 spends one s_barrier, 8 ds_read_b128 and 4 LDS-DMA pieces per
+// 12 MFMAs, and its SQ counters (profiles/r2_pmc_sq_gemm_f16x2p.txt) show the matrix pipe busy only 58-64 % with the
+// waves parked 27 % of their time: the loop is bound by what surrounds the MFMAs.  A wider wave tile amortises all of
+// it, but the second accumulator set (the 2^-11-weighted cross terms) leaves no registers for one.
+//
+// How: a b = hi_a hi_b + 2^-11 (hi_a lo'_b + lo'_a hi_b) with lo' = 2^11 lo the stored low plane.  Multiply the hi_b
+// FRAGMENT by 2^11 in registers after the ds_read (4 v_pk_mul_f16 per fragment: an exponent shift, exact while
+// |b| < 32 -- the weights carry a per-tensor power-of-two pre-scale 2^-t chosen at pack time so that it always holds):
+//     2^11 a b = hi_a (2^11 hi_b) + hi_a lo'_b + lo'_a hi_b
+// -- three MFMAs into the SAME accumulator, result scaled by 2^(t-11) in the epilogue.  No change to the operand
+// format: the activations' packers (LayerNorm, attention, fc epilogue) and the weight planes are those of round 2.
+// The 64 freed registers go to a 128x64 wave tile (TI x TJ = 4 x 2 blocks of 32x32): 12 ds_read_b128, 8 v_pk_mul_f16
+// and one barrier per 24 MFMAs, fragments of k-step kt+1 re-loaded into the registers of kt as soon as a row group's
+// MFMAs have issued (one register set + the B fragments double-buffered).
+//
+// One template serves the geometries (waves WM x WN, wave tile TI x TJ, ring depth NS):
+//   W256x128: 2x2 waves, 4x2 tiles, 256x128 block tile, 24 KB stages, NS = 3 (72 KB): two blocks per CU
+//   W256x256: 2x4 waves (512 threads), 256x256 block tile, 32 KB stages, NS = 4 (128 KB): one block per CU
+//   W128x128: 2x2 waves, 2x2 tiles (the round-2 geometry with one accumulator set): 16 KB stages, three blocks per CU
+#include <algorithm>
+#include <cstdlib>
+
+#include "bf16x3.h"
+#include "gemm_epilogue.h"
+
+namespace capdec {
+
+typedef __attribute__((address_space(3))) void lds_void_w;
+typedef const __attribute__((address_space(1))) void glb_void_w;
+
+__host__ __device__ constexpr int waitcnt_imm_w(int vm, int lgkm) {
+    return (vm & 15) | (7 << 4) | ((lgkm & 15) << 8) | ((vm >> 4) << 14);
+}
+
+template <int WM_, int WN_, int TI_, int TJ_, int NS_, int MINW_, bool ACCMAJOR_ = false>
+struct WGeo {
+    static constexpr bool ACCMAJOR = ACCMAJOR_;   // the three MFMAs of an accumulator back to back (measurement)
+    static constexpr int WM = WM_, WN = WN_, TI = TI_, TJ = TJ_, NS = NS_, MINW = MINW_;
+    static constexpr int NW = WM * WN, THREADS = 64 * NW;
+    static constexpr int BM = WM * TI * 32, BN = WN * TJ * 32;
+    static constexpr int TA = BM / 128, TB = BN / 128;           // 128-row operand tiles per block tile
+    static constexpr int STAGE_B = (TA + TB) * H2_BLOCK_B;        // one k-step of both operands
+    static constexpr int PIECES = STAGE_B / 1024, PPW = PIECES / NW;   // 1 KB LDS-DMA pieces per stage / per wavefront
+    static constexpr int SMEM_B = NS * STAGE_B;
+    static_assert(BM % 128 == 0 && BN % 128 == 0, "block tile = whole 128-row operand tiles");
+    static_assert(PIECES % NW == 0, "pieces divide evenly over the wavefronts");
+    static_assert(PPW * (NS - 2) < 64, "vmcnt range");
+    static_assert(128 % (TI * 32) == 0 && 128 % (TJ * 32) == 0, "a wavefront's rows lie in one operand tile");
+};
+
+// Issue schedule of one k-step.  The k-step is cut into TI REGIONS (one per row group of the wave tile, closed by a
+// sched_barrier so the compiler cannot merge the groups: left alone it re-sorts the MFMAs column-major and the fragment
+// re-loads land behind the last MFMA).  Slot s (1-based) of a k-step = its s-th MFMA, optionally followed by one memory
+// operation:
+//   region 0 (slots 1 .. 3 TJ): the B reads of the next tile and the A reads of its last row group (2 TJ + 2 reads)
+//   region g > 0: first the A reads of group g-1 of the next tile (their registers were freed by region g-1)
+//   the LDS-DMA pieces take the first PPW slots still free after region 0
+// kind(s): 0 = MFMA alone, 1 = + a DS read, 2 = + an LDS-DMA piece
+template <class G> struct WSched {
+    static constexpr int GM = 3 * G::TJ, NSLOT = G::TI * GM, HEAD = 2 * G::TJ + 2;
+    static_assert(HEAD <= GM, "region 0 holds the B reads");
+    static constexpr int kind(int s) {
+        int k[NSLOT + 2] = {};
+        for (int i = 1; i <= HEAD; ++i) k[i] = 1;
+        for (int g = 1; g < G::TI; ++g) k[g * GM + 1] = k[g * GM + 2] = 1;
+        int dma = G::PPW;
+        for (int i = GM + 1; i <= NSLOT && dma; ++i)
+            if (!k[i]) { k[i] = 2; --dma; }
+        return k[s];
+    }
+    static constexpr int dma_before(int g) { int n = 0; for (int i = 1; i <= g * GM; ++i) n += kind(i) == 2; return n; }
+    static_assert(dma_before(G::TI) == G::PPW, "every LDS-DMA piece of a k-step has a slot");
+};
+template <class G, int S, int END>
+__device__ __forceinline__ void w_sched_emit() {
+    if constexpr (S <= END) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        if constexpr (WSched<G>::kind(S) == 1) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        else if constexpr (WSched<G>::kind(S) == 2) __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
+        w_sched_emit<G, S + 1, END>();
+    }
+}
+
+// Main loop.  acc[i][j] (TR layout, see gemm_epilogue.h): C[m0 + wm TI 32 + i 32 + (lane & 31)]
+//                                                          [n0 + wn TJ 32 + j 32 + 8 (r >> 2) + 4 (lane >> 5) + (r & 3)]
+// scaled by 2^11.  tilesA / tilesB = number of 128-row tiles the packed operands hold (block tiles past the end re-read
+// the last one; the epilogue drops those rows / columns).
+template <class G, bool TR>
+__device__ __forceinline__ void h2w_mainloop(const _Float16 *__restrict__ Apk, const _Float16 *__restrict__ Bpk, int K,
+                                             int tm, int tn, int tilesA, int tilesB, char *smem,
+                                             f32x16 (&acc)[G::TI][G::TJ]) {
+    constexpr int TI = G::TI, TJ = G::TJ, NS = G::NS, PPW = G::PPW, TA = G::TA, SB = G::STAGE_B;
+    using SC = WSched<G>;
+    const int t = threadIdx.x;
+    const int lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wm = wave / G::WN, wn = wave % G::WN;
+    const int half = lane >> 5, l32 = lane & 31;
+    const int nk = K / X3_BK;
+    // ---- LDS-DMA: piece p = wave PPW + e of a stage; pieces 8 q .. 8 q + 7 are the 8 KB block of operand tile q
+    const char *src[PPW];
+#pragma unroll
+    for (int e = 0; e < PPW; ++e) {
+        const int p = wave * PPW + e, q = p >> 3, r = p & 7;
+        const char *base;
+        if (q < TA) base = reinterpret_cast<const char *>(Apk) + (size_t)min(tm * TA + q, tilesA - 1) * nk * H2_BLOCK_B;
+        else base = reinterpret_cast<const char *>(Bpk) + (size_t)min(tn * G::TB + (q - TA), tilesB - 1) * nk * H2_BLOCK_B;
+        src[e] = base + r * 1024 + lane * 16;
+    }
+    char *dst0 = smem + wave * (PPW * 1024);
+#define W_DMA(stage, ks_, e0, e1)                                                                               \
+    {                                                                                                           \
+        _Pragma("unroll") for (int e = (e0); e < (e1); ++e)                                                     \
+            __builtin_amdgcn_global_load_lds((glb_void_w *)(src[e] + (size_t)(ks_) * H2_BLOCK_B),                \
+                                             (lds_void_w *)(dst0 + (stage) * SB + e * 1024), 16, 0, 0);         \
+    }
+#pragma unroll
+    for (int i = 0; i < TI; ++i)
+#pragma unroll
+        for (int j = 0; j < TJ; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int swz = ((half ^ ((l32 >> 3) & 1)) << 4);
+    const int rowA0 = wm * TI * 32, colB0 = wn * TJ * 32;
+    const int a_rd = (rowA0 >> 7) * H2_BLOCK_B + ((rowA0 & 127) + l32) * X3_ROW_B + swz;
+    const int b_rd = (TA + (colB0 >> 7)) * H2_BLOCK_B + ((colB0 & 127) + l32) * X3_ROW_B + swz;
+
+    // fragment sets: a[i][plane], b[j][plane]
+    f16x8 f0a[TI][2], f0b[TJ][2], f1a[TI][2], f1b[TJ][2];
+#define W_READ_A(F, stage, i)                                                                                    \
+    {                                                                                                            \
+        F##a[i][0] = *reinterpret_cast<const f16x8 *>(smem + (stage) * SB + a_rd + (i) * 32 * X3_ROW_B);               \
+        F##a[i][1] = *reinterpret_cast<const f16x8 *>(smem + (stage) * SB + a_rd + (i) * 32 * X3_ROW_B + X3_PLANE_B);  \
+    }
+#define W_READ_B(F, stage)                                                                                         \
+    {                                                                                                              \
+        _Pragma("unroll") for (int j = 0; j < TJ; ++j) {                                                           \
+            F##b[j][0] = *reinterpret_cast<const f16x8 *>(smem + (stage) * SB + b_rd + j * 32 * X3_ROW_B);               \
+            F##b[j][1] = *reinterpret_cast<const f16x8 *>(smem + (stage) * SB + b_rd + j * 32 * X3_ROW_B + X3_PLANE_B);  \
+        }                                                                                                          \
+    }
+#define W_MM1(x, y, c) __builtin_amdgcn_mfma_f32_32x32x16_f16(x, y, c, 0, 0, 0)
+#define W_MM(x, y, c) (TR ? W_MM1(y, x, c) : W_MM1(x, y, c))
+    // the MFMAs of row group i of the tile held in fragment set F (bs[j] = 2^11 hi_b[j])
+#define W_GROUP(F, i)                                                                                      \
+    if constexpr (G::ACCMAJOR) {                                                                           \
+        _Pragma("unroll") for (int j = 0; j < TJ; ++j) {                                                   \
+            acc[i][j] = W_MM(F##a[i][1], F##b[j][0], acc[i][j]);                                           \
+            acc[i][j] = W_MM(F##a[i][0], bs[j], acc[i][j]);                                                \
+            acc[i][j] = W_MM(F##a[i][0], F##b[j][1], acc[i][j]);                                           \
+        }                                                                                                  \
+    } else {   /* term-major: consecutive MFMAs never share an accumulator */                              \
+        _Pragma("unroll") for (int j = 0; j < TJ; ++j) acc[i][j] = W_MM(F##a[i][1], F##b[j][0], acc[i][j]); \
+        _Pragma("unroll") for (int j = 0; j < TJ; ++j) acc[i][j] = W_MM(F##a[i][0], bs[j], acc[i][j]);      \
+        _Pragma("unroll") for (int j = 0; j < TJ; ++j) acc[i][j] = W_MM(F##a[i][0], F##b[j][1], acc[i][j]); \
+    }
+#define W_SYNC()                                                                       \
+    asm volatile("" ::: "memory");                                                     \
+    __builtin_amdgcn_s_waitcnt(waitcnt_imm_w(PPW * (NS - 2), 0));                      \
+    __builtin_amdgcn_s_barrier();                                                      \
+    asm volatile("" ::: "memory");                                                     \
+    __builtin_amdgcn_sched_barrier(0);     /* (the next k-step's MFMAs only read registers: keep them behind the barrier) */
+#define W_REGION(CUR, NXT, s_next, s_dma, tile_dma, g)                                                      \
+    if constexpr ((g) < TI) {                                                                               \
+        if constexpr ((g) == 0) { W_READ_B(NXT, s_next) W_READ_A(NXT, s_next, TI - 1) }                     \
+        else { W_READ_A(NXT, s_next, (g) - 1) }                                                             \
+        constexpr int e0_ = SC::dma_before(g), e1_ = SC::dma_before((g) + 1);   /* (forces compile-time evaluation) */ \
+        W_DMA(s_dma, tile_dma, e0_, e1_)                                                                    \
+        W_GROUP(CUR, g)                                                                                     \
+        w_sched_emit<G, (g) * SC::GM + 1, ((g) + 1) * SC::GM>();                                            \
+        __builtin_amdgcn_sched_barrier(0);                                                                  \
+    }
+#define W_STEP(CUR, NXT, s_next, s_dma, tile_dma)                                      \
+    {                                                                                  \
+        f16x8 bs[TJ];                                                                  \
+        _Pragma("unroll") for (int j = 0; j < TJ; ++j) bs[j] = CUR##b[j][0] * (_Float16)H2_LO_SCALE; \
+        W_REGION(CUR, NXT, s_next, s_dma, tile_dma, 0)                                 \
+        W_REGION(CUR, NXT, s_next, s_dma, tile_dma, 1)                                 \
+        W_REGION(CUR, NXT, s_next, s_dma, tile_dma, 2)                                 \
+        W_REGION(CUR, NXT, s_next, s_dma, tile_dma, 3)                                 \
+        W_SYNC()                                                                       \
+    }
+
+    // prologue: tiles 0 .. NS-1 in flight (stage s <- tile s); tile 0 landed -> fragment set f0; tile 1 landed
+#pragma unroll
+    for (int s = 0; s < NS; ++s) W_DMA(s, min(s, nk - 1), 0, PPW)
+    __builtin_amdgcn_s_waitcnt(waitcnt_imm_w(PPW * (NS - 1), 15));
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    W_READ_B(f0, 0)
+#pragma unroll
+    for (int i = 0; i < TI; ++i) W_READ_A(f0, 0, i)
+    W_SYNC()
+    // k-step kt: MFMAs of tile kt from registers, fragments of tile kt+1 read from stage (kt+1) % NS, tile kt+NS sent
+    // to stage kt % NS (its fragments were all read during k-step kt-1, before the barrier that ended it).  End of the
+    // k-step: all but the NS-2 newest tiles have landed => tile kt+2 is in LDS.
+    int s0 = 0;
+    for (int kt = 0; kt < nk; kt += 2) {
+        const int s1 = s0 + 1 == NS ? 0 : s0 + 1, s2 = s1 + 1 == NS ? 0 : s1 + 1;
+        W_STEP(f0, f1, s1, s0, min(kt + NS, nk - 1))
+        W_STEP(f1, f0, s2, s1, min(kt + 1 + NS, nk - 1))
+        s0 = s2;
+    }
+    __builtin_amdgcn_s_waitcnt(waitcnt_imm_w(0, 15));            // clamped tail pieces must land before LDS is reused
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+#undef W_DMA
+#undef W_READ_A
+#undef W_READ_B
+#undef W_MM1
+#undef W_MM
+#undef W_GROUP
+#undef W_SYNC
+#undef W_REGION
+#undef W_STEP
+}
+
+// ---- epilogues of the TR layout for a TI x TJ wave tile (generalised epilogue_store_t / epilogue_store_packed_t)
+template <class G>
+__device__ __forceinline__ void epilogue_store_tw(const f32x16 (&acc)[G::TI][G::TJ], float scale, float *C, int ldc, int M,
+                                                  int N, int m0, int n0, const float *__restrict__ bias,
+                                                  const float *resid, int ldr, int act) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wm = wave / G::WN, wn = wave % G::WN, half = lane >> 5, l32 = lane & 31;
+#pragma unroll
+    for (int i = 0; i < G::TI; ++i) {
+        const int row = m0 + (wm * G::TI + i) * 32 + l32;
+        if (row >= M) continue;
+#pragma unroll
+        for (int j = 0; j < G::TJ; ++j)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int col = n0 + (wn * G::TJ + j) * 32 + 8 * g + 4 * half;
+                if (col >= N) continue;
+                float4 v = acc_quad(acc[i][j], g);
+                v.x *= scale; v.y *= scale; v.z *= scale; v.w *= scale;
+                if (bias) {
+                    const float4 b = *reinterpret_cast<const float4 *>(bias + col);
+                    v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
+                }
+                v.x = act_apply(v.x, act); v.y = act_apply(v.y, act);
+                v.z = act_apply(v.z, act); v.w = act_apply(v.w, act);
+                if (resid) {
+                    const float4 r4 = *reinterpret_cast<const float4 *>(resid + (size_t)row * ldr + col);
+                    v.x = post_resid(v.x + r4.x, act); v.y = post_resid(v.y + r4.y, act);
+                    v.z = post_resid(v.z + r4.z, act); v.w = post_resid(v.w + r4.w, act);
+                }
+                *reinterpret_cast<float4 *>(C + (size_t)row * ldc + col) = v;
+            }
+    }
+}
+
+template <class G>
+__device__ __forceinline__ void epilogue_store_packed_tw(const f32x16 (&acc)[G::TI][G::TJ], float scale, char *packed,
+                                                         int nk_out, int M, int N, int m0, int n0,
+                                                         const float *__restrict__ bias, int act,
+                                                         const char *resid_pk) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wm = wave / G::WN, wn = wave % G::WN, half = lane >> 5, l32 = lane & 31;
+#pragma unroll
+    for (int i = 0; i < G::TI; ++i) {
+        const int row = m0 + (wm * G::TI + i) * 32 + l32;
+        if (row >= M) continue;
+#pragma unroll
+        for (int j = 0; j < G::TJ; ++j)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int col = n0 + (wn * G::TJ + j) * 32 + 8 * g + 4 * half;
+                if (col >= N) continue;
+                float4 v = acc_quad(acc[i][j], g);
+                v.x *= scale; v.y *= scale; v.z *= scale; v.w *= scale;
+                if (bias) {
+                    const float4 b = *reinterpret_cast<const float4 *>(bias + col);
+                    v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
+                }
+                v.x = act_apply(v.x, act); v.y = act_apply(v.y, act);
+                v.z = act_apply(v.z, act); v.w = act_apply(v.w, act);
+                if (resid_pk) {
+                    const float4 rr = x3_load_quad(resid_pk, nk_out, row, col >> 4, (col >> 2) & 3, PK_F16X2);
+                    v.x = post_resid(v.x + rr.x, act); v.y = post_resid(v.y + rr.y, act);
+                    v.z = post_resid(v.z + rr.z, act); v.w = post_resid(v.w + rr.w, act);
+                }
+                x3_store_quad(packed, nk_out, row, col >> 4, (col >> 2) & 3, v, PK_F16X2);
+            }
+    }
+}
+
+// persistent form: grid = min(tiles, slots) blocks, block b walks tiles b, b + grid, ... (see gemm_f16x2p_kernel)
+template <class G>
+__global__ __launch_bounds__(G::THREADS, G::MINW) void gemm_h2w_kernel(const _Float16 *__restrict__ Apk,
+                                                                      const _Float16 *__restrict__ Bpk, float *C, int ldc,
+                                                                      int M, int N, int K, const float *__restrict__ bias,
+                                                                      const float *resid, int ldr, int act, int tiles_m,
+                                                                      int tiles_n, char *packed_out, float scale) {
+    __shared__ __attribute__((aligned(16))) char smem[G::SMEM_B];
+    const int ntiles = tiles_m * tiles_n;
+    const int tilesA = (M + 127) >> 7, tilesB = (N + 127) >> 7;
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        int tm, tn;
+        tile_coords(tiles_m, tiles_n, tm, tn, tile);
+        f32x16 acc[G::TI][G::TJ];
+        h2w_mainloop<G, true>(Apk, Bpk, K, tm, tn, tilesA, tilesB, smem, acc);     // ends with a barrier: the ring is free
+        if (packed_out)
+            epilogue_store_packed_tw<G>(acc, scale, packed_out, N >> 4, M, N, tm * G::BM, tn * G::BN, bias, act,
+                                        reinterpret_cast<const char *>(resid));   // (with packed_out, `resid` is PACKED)
+        else
+            epilogue_store_tw<G>(acc, scale, C, ldc, M, N, tm * G::BM, tn * G::BN, bias, resid, ldr, act);
+    }
+}
+
+using W256x128 = WGeo<2, 2, 4, 2, 3, 2>;      // 4 waves, 72 KB, two blocks per CU
+using W256x256 = WGeo<2, 4, 4, 2, 4, 2>;      // 8 waves, 128 KB, one block per CU
+using W128x128 = WGeo<2, 2, 2, 2, 3, 3>;      // 4 waves, 48 KB, three blocks per CU
+using W128x128b = WGeo<2, 2, 2, 2, 4, 2>;     // 4 waves, 64 KB, two blocks per CU (round-2 geometry, one accumulator set)
+using W256x128a = WGeo<2, 2, 4, 2, 3, 2, true>;   // W256x128 with accumulator-major MFMA order (measurement)
+using W256x256q = WGeo<2, 2, 4, 4, 4, 1>;     // 4 waves x (128 x 128), 128 KB, ONE wavefront per SIMD (accumulators in AGPRs)
+
+// CAPDEC_H2W: 0 = round-2 kernel everywhere; 1 = automatic choice (default); 2 / 3 / 4 / 5 force W256x128 / W256x256 /
+// W128x128 / W128x128b wherever the wide kernel is applicable (measurement)
+int h2w_choice() {
+    static const int v = [] { const char *e = getenv("CAPDEC_H2W"); return e ? atoi(e) : 1; }();
+    return v;
+}
+
+template <class G>
+static int launch_h2w(hipStream_t st, const void *Apacked, const void *Bpacked, float *C, int ldc, int M, int N, int K,
+                      const GemmEpilogue &epi, float scale, int slots) {
+    const int tiles_m = (M + G::BM - 1) / G::BM, tiles_n = (N + G::BN - 1) / G::BN;
+    const int ntiles = tiles_m * tiles_n;
+    const int grid = ntiles <= 4 * slots ? std::min(ntiles, slots) : ntiles;
+    const float *resid_arg = epi.packed_out ? (const float *)epi.resid_packed : epi.resid;
+    hipLaunchKernelGGL((gemm_h2w_kernel<G>), dim3(grid), dim3(G::THREADS), 0, st, (const _Float16 *)Apacked,
+                       (const _Float16 *)Bpacked, C, ldc, M, N, K, epi.bias, resid_arg, epi.ldr, epi.act, tiles_m, tiles_n,
+                       (char *)epi.packed_out, scale);
+    CAPDEC_HIP(hipGetLastError());
+    return 0;
+}
+
+// scale = 2^(t - 11), t = the weights' pack-time pre-scale exponent.  Requires the float4 epilogue (caller checks).
+// which: 2 = W256x128, 3 = W256x256, 4 = W128x128 (three blocks per CU), 5 = W128x128b
+int launch_gemm_h2w(hipStream_t st, int which, const void *Apacked, const void *Bpacked, float *C, int ldc, int M, int N,
+                    int K, const GemmEpilogue &epi, float scale) {
+    switch (which) {
+        case 2: return launch_h2w<W256x128>(st, Apacked, Bpacked, C, ldc, M, N, K, epi, scale, 512);
+        case 3: return launch_h2w<W256x256>(st, Apacked, Bpacked, C, ldc, M, N, K, epi, scale, 256);
+        case 4: return launch_h2w<W128x128>(st, Apacked, Bpacked, C, ldc, M, N, K, epi, scale, 768);
+        case 5: return launch_h2w<W128x128b>(st, Apacked, Bpacked, C, ldc, M, N, K, epi, scale, 512);
+        case 6: return launch_h2w<W256x256q>(st, Apacked, Bpacked, C, ldc, M, N, K, epi, scale, 256);
+        case 7: return launch_h2w<W256x128a>(st, Apacked, Bpacked, C, ldc, M, N, K, epi, scale, 512);
+        default: CAPDEC_CHECK(false, "gemm_h2w: unknown geometry");
+    }
+    return 0;
+}
+
+CAPDEC_SAT_ACCESSOR(sat_count_gemm_h2w)
+
+}  // namespace capdec

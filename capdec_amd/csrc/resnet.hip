@@ -349,4 +349,6 @@ int launch_attnpool_attend(hipStream_t st, const float *q, const float *k, const
     return 0;
 }
 
+CAPDEC_SAT_ACCESSOR(sat_count_resnet)
+
 }  // namespace capdec

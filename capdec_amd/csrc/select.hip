@@ -220,6 +220,7 @@ __global__ __launch_bounds__(64) void beam_step_kernel(BeamState s, const float 
             key = (s.scores[row] + logp) / seq_new[cb];
         }
         if (key > -INFINITY || (st_old[cb] && j == 0)) flat = cb * vocab + ctok;
+        if (s.diverge && j != 0) { key = -INFINITY; flat = 0x7fffffff; }      // measurement only: each beam keeps its own lineage
     }
     for (int r = 0; r < beam; ++r) {
         float gv = key;
@@ -255,6 +256,18 @@ __global__ __launch_bounds__(64) void beam_step_kernel(BeamState s, const float 
     for (int i = lane; i < beam * (pos_cur + 1); i += 64) {
         const int b = i / (pos_cur + 1), p = i - b * (pos_cur + 1);
         s.anc[(cb0 + b) * ctx + p] = (p < pos_cur) ? anc_old[w_src[b] * SEL_CTX_MAX + p] : (uint8_t)w_src[b];
+    }
+    if (s.kv_stat) {     // distinct slots the NEXT step's attention reads at each of its pos_cur + 1 cached positions
+        int cnt = 0;
+        for (int p = lane; p <= pos_cur; p += 64) {
+            unsigned seen = 0;
+            for (int b = 0; b < beam; ++b)
+                seen |= 1u << ((p < pos_cur) ? anc_old[w_src[b] * SEL_CTX_MAX + p] : (uint8_t)w_src[b]);
+            cnt += __popc(seen);
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o, 64);
+        if (lane == 0) { s.kv_stat[2 * cap] += (unsigned)cnt; s.kv_stat[2 * cap + 1] += (unsigned)(pos_cur + 1); }
     }
     const bool all = __all(stop);
     if (lane == 0) {

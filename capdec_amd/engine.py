@@ -427,6 +427,22 @@ class Engine:
         check(self.lib.capdec_decode_stats(self._h, C.byref(a), C.byref(b), C.byref(r)), "decode_stats")
         return dict(steps=a.value, compactions=b.value, row_steps=r.value)
 
+    def decode_counters(self) -> Dict[str, float]:
+        """kv_slots_per_position: mean number of distinct K/V slots a (caption, position) of the last beam decode read
+        (1 = beams share their whole history, beam = nothing); saturated_quads: GEMM-operand quads clamped to the fp16
+        range since the last call (the call resets the counter)"""
+        kv, sat = C.c_double(0.0), C.c_longlong(0)
+        check(self.lib.capdec_decode_counters(self._h, C.byref(kv), C.byref(sat)), "decode_counters")
+        return dict(kv_slots_per_position=kv.value, saturated_quads=sat.value)
+
+    def set_batch_invariant(self, on: bool = True):
+        """results independent of batch size / chunking / sharding (no split-K, pinned kernel variants); see capdec.h"""
+        check(self.lib.capdec_set_batch_invariant(self._h, int(bool(on))), "set_batch_invariant")
+
+    def set_debug_diverge(self, on: bool = True):
+        """measurement only: beams never share history (worst-case decode-attention traffic)"""
+        check(self.lib.capdec_set_debug_diverge(self._h, int(bool(on))), "set_debug_diverge")
+
     # ------------------------------------------------------------------ hooks
     def gemm(self, a: torch.Tensor, bt: torch.Tensor, bias=None, resid=None, act: int = 0) -> torch.Tensor:
         a, bt = self._dev(a), self._dev(bt)
@@ -458,8 +474,8 @@ class Engine:
         check(self.lib.capdec_profile_reset(self._h), "profile_reset")
 
     def profile_get(self) -> Dict[str, Dict[str, float]]:
-        cnt = C.c_int(0)
-        names = (C.c_char_p * 24)()       # PROF_SLOTS of capi.hip
+        cnt = C.c_int(24)                 # in: capacity of the arrays below, out: families filled
+        names = (C.c_char_p * 24)()
         ms = (C.c_float * 24)()
         launches = (C.c_int64 * 24)()
         flops = (C.c_double * 24)()

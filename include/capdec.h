@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define CAPDEC_ABI_VERSION 1
+#define CAPDEC_ABI_VERSION 2   /* 2: capdec_profile_get takes the array capacity in *count; batch-invariant mode; decode counters */
 
 typedef struct capdec_ctx capdec_ctx;
 
@@ -67,10 +67,20 @@ int capdec_synchronize(capdec_ctx *ctx);
  * 4 = "f16": fp16 GEMM operands, fp32 everything else (KV cache included): the precision class of the reference's
  *     CLIP towers on a GPU (clip.load converts to fp16).
  * The mapper, patch-embedding and projection GEMMs are fp32-accurate in every mode.
- * The environment variable CAPDEC_GEMM_MODE=f16x2|bf16x3|f32|bf16|f16 overrides the default at capdec_create. */
+ * The environment variable CAPDEC_GEMM_MODE=f16x2|bf16x3|f32|bf16|f16 overrides the default at capdec_create (any
+ * other value makes capdec_create fail: a typo must not silently select another precision). */
 enum { CAPDEC_GEMM_F32 = 0, CAPDEC_GEMM_BF16X3 = 1, CAPDEC_GEMM_BF16 = 2, CAPDEC_GEMM_F16X2 = 3, CAPDEC_GEMM_F16 = 4 };
 int capdec_set_gemm_mode(capdec_ctx *ctx, int mode);
 int capdec_get_gemm_mode(capdec_ctx *ctx);
+/* Batch-invariant mode (default off; CAPDEC_BATCH_INVARIANT=1 sets it at capdec_create).  By default a few kernels
+ * pick a variant from the size of the launch -- split-K for under-filled GEMM grids (the K slices are summed in another
+ * order than the unsplit loop), the number of positions the decode attention keeps in flight -- so the fp32 ROUND-OFF
+ * of a row depends on how many other rows share its launch: a caption decoded alone, in a 625-caption shard or in a
+ * 5000-caption batch can differ in the last bit of a logit, and on a numerical near-tie in a token.  With this mode on,
+ * every row goes through the same summation order whatever the batch (unsplit GEMMs, pinned kernel variants): results
+ * are bit-identical across batch sizes, chunkings and multi-GPU shardings, at the price of under-filled grids for
+ * small batches. */
+int capdec_set_batch_invariant(capdec_ctx *ctx, int on);
 /* cap on bytes the decode KV cache may take (captions are processed in chunks that fit);
  * 0 = default (192 GiB of the 288 GB HBM3E) */
 int capdec_set_kv_budget(capdec_ctx *ctx, size_t bytes);
@@ -273,13 +283,26 @@ int capdec_preprocess_images(capdec_ctx *ctx, const uint8_t *d_rgb, const int64_
  * how many times finished captions were compacted out of the batch, and the activation rows pushed through the
  * GPT-2 body after the prefill (n * beam * (steps - 1) without early stopping).  CAPDEC_COMPACT=0 disables compaction. */
 int capdec_decode_stats(capdec_ctx *ctx, int *steps, int *compactions, long long *row_steps);
+/* kv_slots_per_position: over the last capdec_decode_beam call, the mean number of DISTINCT K/V cache slots one
+ * (caption, position) of the decode attention read (1.0 = all beams of a caption share their whole history, `beam` =
+ * none of it): the decode attention loads each distinct slot once, so its HBM traffic -- and its roofline -- scale with
+ * this number (0 when no beam decode ran).  saturated_quads: how many 4-element groups of GEMM operands were clamped to
+ * the +-65504 range of the fp16-plane formats since the last call (the counter is reset by the call; NaN is not
+ * clamped, it propagates) -- nonzero means the fp32-accuracy claim of the default mode does not hold for this
+ * checkpoint / input: switch to CAPDEC_GEMM_BF16X3 or CAPDEC_GEMM_F32.  Either pointer may be NULL. */
+int capdec_decode_counters(capdec_ctx *ctx, double *kv_slots_per_position, long long *saturated_quads);
+/* measurement only: every beam continues ITSELF (candidates of other parents are ignored), so no two beams of a caption
+ * share history after the first step -- the worst-case K/V traffic of the decode attention.  Results are NOT the
+ * reference's beam search. */
+int capdec_set_debug_diverge(capdec_ctx *ctx, int on);
 
 /* ---- multi-GPU: caption-batch sharding + ONE gather of the generated ids (RCCL over xGMI) ------------------------
  * The reference has no distributed code: it loops over captions one at a time (predictions_runner.py:194,
  * embeddings_generator.py:58); every caption is independent.  Rank r of R decodes the contiguous block
  * [r * ceil(N/R), (r+1) * ceil(N/R)) of the embedding matrix with replicated weights; the only exchange is an
  * all-gather of int32 token ids / lengths (+ fp32 scores, or fp32 embeddings for the embeddings_generator path),
- * in rank order, so the gathered matrix equals the single-GPU result.  One communicator per context; RCCL is
+ * in rank order, so the gathered matrix has the single-GPU layout (and, in batch-invariant mode, the single-GPU
+ * bits: by default the fp32 round-off of a row may depend on the size of its launch, see capdec_set_batch_invariant).  One communicator per context; RCCL is
  * dlopen'ed on first use (librccl.so.1), so single-GPU hosts do not need it.  A host without torch distributes the
  * 128-byte id itself (file, socket, MPI, environment ...); capdec_amd/distributed.py can use torch.distributed or
  * this communicator. */
@@ -312,7 +335,8 @@ int capdec_timer_stop_ms(capdec_ctx *ctx, float *ms);   /* records, synchronises
 /* per-kernel-family accumulated device time since the last reset (hipEvents around the timed launches).
  * on = 0: off; 1: every launch is timed; N > 1: every N-th launch of each family is timed (sampling: the
  * events of the other launches are skipped, so a timed region is barely perturbed).
- * get: caller arrays of capacity 24, *count entries are filled; ms / launches / flops cover the TIMED launches
+ * get: on entry *count = capacity of the caller's arrays (24 is always enough; a smaller capacity than the library
+ * has families is an error, never an overflow), on return the number of entries filled; ms / launches / flops cover the TIMED launches
  * (flops: algorithmic FLOPs issued, 0 for non-GEMM families), calls = all launches of the family. */
 int capdec_profile_enable(capdec_ctx *ctx, int on);
 int capdec_profile_get(capdec_ctx *ctx, int *count, const char **names, float *ms, int64_t *launches,

@@ -579,6 +579,95 @@ def test_batched_decode_vs_oracle_and_chunking():
             np.testing.assert_array_equal(i.cpu().numpy()[r], tok_o[r][od[r]].numpy())
 
 
+def _beam_rows_vs_oracle(got, sd, pe, rows, stop, T, n_head):
+    """captions `rows` of a HIP beam-5 result (ids, lens, scores, order arrays) against O.beam_cached run on those
+    captions alone (captions are independent); numerical ties (selected / rejected keys within 1e-4 of each other at
+    some step) are excluded.  Returns (compared, skipped)."""
+    from oracle import capdec_oracle as O
+    i1, l1, s1, o1 = got
+    mg = []
+    tok_o, seq_o, sc_o = O.beam_cached(sd, pe[rows], 5, stop, T, n_head=n_head, margins=mg)
+    order_o = O.beam_output_order(sc_o)
+    clear = (mg[0] > 1e-4).numpy()
+    for j, r in enumerate(rows):
+        if not clear[j]:
+            assert np.isfinite(s1[r]).all() and (np.diff(s1[r]) <= 0).all()
+            continue
+        np.testing.assert_array_equal(o1[r], order_o[j].numpy())
+        np.testing.assert_array_equal(i1[r], tok_o[j][order_o[j]].numpy())
+        np.testing.assert_array_equal(l1[r], seq_o[j][order_o[j]].numpy())
+        np.testing.assert_allclose(s1[r], sc_o[j][order_o[j]].numpy(), atol=1e-4)
+    return int(clear.sum()), int((~clear).sum())
+
+
+def _greedy_rows_vs_oracle(ids, lens, sd, pe, rows, stop, T, n_head):
+    """captions `rows` of a HIP greedy result against O.greedy_cached; a caption whose arg-max margin (top-1 minus
+    top-2 logit of the oracle, teacher-forced on its own ids) drops below 1e-4 at some step is a numerical tie"""
+    from oracle import capdec_oracle as O
+    gi, gl = O.greedy_cached(sd, pe[rows], stop_id=stop, entry_length=T, n_head=n_head)      # alt stop id 764: reference :187
+    _, st = O.greedy_forced(sd, pe[rows], gi, n_head=n_head)
+    live = torch.arange(T)[None, :] < gl[:, None]
+    gap = torch.where(live, st[:, :, 0] - st[:, :, 1], torch.full((1, 1), 1e9))
+    clear = (gap.min(dim=1).values > 1e-4).numpy()
+    for j, r in enumerate(rows):
+        if clear[j]:
+            np.testing.assert_array_equal(ids[r], gi[j].numpy())
+            assert int(lens[r]) == int(gl[j])
+    return int(clear.sum()), int((~clear).sum())
+
+
+def test_midsize_batches_vs_oracle():
+    """the regime one GPU of an 8-GPU run sits in (625 captions x beam 5 = 3125 rows): from 513 rows up the N = 768 /
+    2304 projections take the mid-size split-K path (tiles <= 256, S from the tile count) and from 1024 rows the split-K
+    reduce is fused with the LayerNorm that follows.  330 captions x beam 5 = 1650 rows and 1200 greedy rows, every
+    caption against the KV-cached oracle (ties excluded by the margin mechanism)"""
+    from capdec_amd import gpt2_prefix_eval as E
+    from oracle import capdec_oracle as O
+    dims = synth.GPT2_TINY
+    model, sd = _model(dims, "mlp", 512, seed=7)
+    n, T_ = 330, 16
+    x = synth.synthetic_clip_embeddings(n, 512, seed=21)
+    pe = O.clip_project(x, sd, "mlp", 10).reshape(n, 10, -1)
+    assert 1024 <= n * 5 and (n * 5 + 127) // 128 * 6 <= 256            # mid-size split-K + fused reduce-LN
+    i, l, s, o = E.decode_beam_ids(model, pe, 614, 5, T_)
+    got = (i.cpu().numpy(), l.cpu().numpy(), s.cpu().numpy(), o.cpu().numpy())
+    ok, ties = _beam_rows_vs_oracle(got, sd, pe, list(range(n)), 614, T_, dims.n_head)
+    assert ok >= 300, (ok, ties)
+    n = 1200
+    x = synth.synthetic_clip_embeddings(n, 512, seed=22)
+    pe = O.clip_project(x, sd, "mlp", 10).reshape(n, 10, -1)
+    ids, lens = E.decode_greedy_ids(model, pe, 443, T_)
+    ok, ties = _greedy_rows_vs_oracle(ids.cpu().numpy(), lens.cpu().numpy(), sd, pe, list(range(n)), 443, T_, dims.n_head)
+    assert ok >= 1100, (ok, ties)
+
+
+def test_large_launch_subset_vs_oracle():
+    """the regime the 5000-caption bench runs in: 3400 captions x beam 5 = 17 000 rows in ONE launch (unsplit GEMM grids
+    of several rounds of persistent blocks, the 4-rows-per-wavefront LayerNorm from 16 384 rows, the HBM-bound decode
+    attention variant from 16 384 (caption, head) wavefronts); a random subset of 32 captions is compared with the
+    oracle, and so are 32 of 17 000 greedy rows"""
+    from capdec_amd import gpt2_prefix_eval as E
+    from oracle import capdec_oracle as O
+    dims = synth.GPT2_TINY
+    model, sd = _model(dims, "mlp", 512, seed=7)
+    n, T_ = 3400, 12
+    assert n * 5 >= 16384 and n * dims.n_head > 16384
+    x = synth.synthetic_clip_embeddings(n, 512, seed=31)
+    pe = O.clip_project(x, sd, "mlp", 10).reshape(n, 10, -1)
+    i, l, s, o = E.decode_beam_ids(model, pe, 614, 5, T_)
+    got = (i.cpu().numpy(), l.cpu().numpy(), s.cpu().numpy(), o.cpu().numpy())
+    rows = sorted(np.random.default_rng(5).choice(n, 32, replace=False).tolist() + [0, n - 1])
+    ok, ties = _beam_rows_vs_oracle(got, sd, pe, rows, 614, T_, dims.n_head)
+    assert ok >= 28, (ok, ties)
+    n = 17000
+    x = synth.synthetic_clip_embeddings(n, 512, seed=32)
+    pe = O.clip_project(x, sd, "mlp", 10).reshape(n, 10, -1)
+    ids, lens = E.decode_greedy_ids(model, pe, 443, T_)
+    rows = sorted(np.random.default_rng(6).choice(n, 32, replace=False).tolist() + [0, n - 1])
+    ok, ties = _greedy_rows_vs_oracle(ids.cpu().numpy(), lens.cpu().numpy(), sd, pe, rows, 443, T_, dims.n_head)
+    assert ok >= 28, (ok, ties)
+
+
 def test_finished_caption_compaction(monkeypatch):
     """captions that stop early leave the batch at the poll points (activation rows are compacted, KV / beam state stay
     in place): with a stop id that fires at staggered steps the results still equal the oracle token for token, the

@@ -25,7 +25,7 @@ def test_c_abi_exports_every_header_symbol():
     lib = _capi.load_library()                      # binds every symbol or raises
     for name in declared:
         assert hasattr(lib, name)
-    assert lib.capdec_abi_version() == 1
+    assert lib.capdec_abi_version() == _capi.ABI_VERSION == int(re.search(r"#define CAPDEC_ABI_VERSION (\d+)", header).group(1))
     # the library is built for gfx950 and links the HIP runtime only (no torch types in the ABI)
     out = subprocess.run(["nm", "-D", "--defined-only", _capi.LIB_PATH], capture_output=True, text=True).stdout
     exported = {l.split()[-1] for l in out.splitlines() if " T " in l and "capdec_" in l.split()[-1][:7]}
