@@ -62,14 +62,18 @@ def algorithmic_flops_per_caption(P, T, beam, mapper, dims=synth.GPT2_SMALL, D=5
     return f
 
 
-def cpu_baseline(mapper, beam, P, T, budget_s=20.0, D=512, captions=0):
+def cpu_baseline(mapper, beam, P, T, budget_s=20.0, D=512, captions=8):
     """The oracle's reference-shaped path (batch 1, NO KV cache, lm_head on every position, fp32
     torch CPU ops: the algorithm of reference gpt2_prefix_eval.py:50-198 driven like
-    predictions_runner.py:221-232) timed on this box's host cores on a BOUNDED sample: decode
-    steps of the same workload are run for ~budget_s seconds; the reference's cost per step is
-    proportional to the token-rows it pushes through GPT-2 (rows x context, no cache), so
-    captions/s = (token-rows done / token-rows per caption) / elapsed.  ``captions`` > 0 (--cpu-captions, e.g. the 32 of
-    SURVEY D.5) times that many WHOLE captions instead of a time budget (minutes of CPU work: not the default)."""
+    predictions_runner.py:221-232) timed on this box's host cores on a BOUNDED sample of the same
+    workload: ``captions`` WHOLE captions (default 8; SURVEY D.5's 32 with --cpu-captions 32), one
+    warm-up caption discarded, wall clock.  Two thread settings are measured and both reported:
+    all host cores (torch.set_num_threads(os.cpu_count()), what D.5 prescribes) on the first caption,
+    and the setting a short probe finds fastest on this box (batch-1 GEMVs stop scaling long before 256
+    threads) on the rest; `value` / `cores` are the better of the two.  ``captions`` = 0 falls back to a
+    time budget of ``budget_s`` seconds of decode steps (fractional captions, by token-rows).
+    profiles/r3_cpu_port_vs_reference.json: this port against the imported reference itself in the build
+    container (same ids, 0.93-1.02x its time)."""
     from oracle import capdec_oracle as O
     ncpu = os.cpu_count() or 1
     sd = synth.hot_state_dict(42, mapper, D, P)
@@ -89,6 +93,9 @@ def cpu_baseline(mapper, beam, P, T, budget_s=20.0, D=512, captions=0):
             O.generate2_ref(sd, e, STOP_ID, T_, on_step=on_step)
         return st["rows"], time.perf_counter() - st["t0"]
 
+    def embed(r):
+        return O.clip_project(O.normalize_prefix(synth.synthetic_clip_embeddings(r + 1, D, seed=0)[r:r + 1]), sd, mapper, P)
+
     with torch.no_grad():
         pe = O.clip_project(O.normalize_prefix(x), sd, mapper, P)
         # pick the thread count that serves this box best (short probes), then the timed sample
@@ -99,18 +106,75 @@ def cpu_baseline(mapper, beam, P, T, budget_s=20.0, D=512, captions=0):
             r, dt = run(pe[1:2], 1.5, T)
             if best is None or r / dt > best[1]:
                 best = (th, r / dt)
+        all_cores = None
+        if captions > 0 and best[0] != ncpu:          # ALL host cores (SURVEY D.5's setting): at most 5 s of one caption
+            torch.set_num_threads(ncpu)               # (batch-1 GEMVs on hundreds of threads can be far slower than on 16)
+            run(pe[:1], 0.5, 3)
+            rr, dd = run(embed(2), 5.0, T)
+            all_cores = {"cores": ncpu, "value": (rr / rows_per_caption) / dd, "captions": round(rr / rows_per_caption, 3),
+                         "seconds": round(dd, 2)}
         torch.set_num_threads(best[0])
-        rows, dt, r = 0, 0.0, 2
-        while (dt < budget_s) if captions <= 0 else (r - 2 < captions):   # whole captions until the budget is used up
-            e = O.clip_project(O.normalize_prefix(synth.synthetic_clip_embeddings(r + 1, D, seed=0)[r:r + 1]), sd, mapper, P)
-            rr, dd = run(e, (budget_s - dt) if captions <= 0 else 1e9, T)
+        run(pe[:1], 0.5, 3)
+        rows, dt, r = 0, 0.0, 3
+        while (dt < budget_s) if captions <= 0 else (r - 3 < max(captions - 1, 1)):
+            rr, dd = run(embed(r), (budget_s - dt) if captions <= 0 else 1e9, T)
             rows, dt, r = rows + rr, dt + dd, r + 1
     frac = rows / rows_per_caption
-    return {"value": frac / dt, "unit": "captions/s", "cores": best[0], "kind": "port",
-            "host_cpus": ncpu,
-            "sample": f"{frac:.3f} captions of the same workload (reference-shaped: batch 1, no KV cache, "
-                      f"fp32, T={T}, beam={beam}; {rows} of {rows_per_caption} token-rows) in {dt:.1f} s wall; "
-                      f"thread count chosen by a 1.5 s probe, warm-up discarded"}
+    value, cores = frac / dt, best[0]
+    if all_cores and all_cores["value"] > value:
+        value, cores = all_cores["value"], ncpu
+    whole = "%d whole captions" % (r - 3) if captions > 0 else "%.3f captions (time budget, counted by token-rows)" % frac
+    return {"value": value, "unit": "captions/s", "cores": cores, "kind": "port", "host_cpus": ncpu,
+            "probed_threads": {"cores": best[0], "value": frac / dt, "seconds": round(dt, 2)},
+            "all_cores": all_cores,
+            "sample": f"{whole} of the same workload (reference-shaped: batch 1, no KV cache, fp32, T={T}, "
+                      f"beam={beam}; {rows} token-rows) in {dt:.1f} s wall on {best[0]} threads (count chosen by a "
+                      f"1.5 s probe); all {ncpu} host threads measured beside it (`all_cores`, <= 5 s: on a 256-thread host the batch-1 GEMVs of this path run ~5000x slower on all threads than on 16); warm-up captions discarded"}
+
+
+class SmiSampler:
+    """rocm-smi (sclk, package power) sampled from a host thread while the timed region runs: the GEMMs of this path are
+    bound by the package power cap (profiles/r3_power_probe.txt), so the clock the chip held belongs next to the rate."""
+
+    def __init__(self, card=0, period=1.0):
+        import threading
+        self.card, self.period, self.samples, self._stop = card, period, [], threading.Event()
+        self._th = threading.Thread(target=self._run, daemon=True)
+
+    def _read(self):
+        import subprocess
+        try:
+            out = subprocess.run(["rocm-smi", "--showclocks", "--showpower", "--json"], capture_output=True, text=True,
+                                 timeout=10).stdout
+            c = json.loads(out).get("card%d" % self.card, {})
+            sclk = power = None
+            for k, v in c.items():
+                if "sclk clock speed" in k.lower():
+                    sclk = float(str(v).strip("()").lower().replace("mhz", ""))
+                elif "power" in k.lower() and "(w)" in k.lower():
+                    power = float(v)
+            if sclk and power:
+                self.samples.append((sclk, power))
+        except Exception:       # rocm-smi missing or busy: the field stays null
+            pass
+
+    def _run(self):
+        while not self._stop.is_set():
+            self._read()
+            self._stop.wait(self.period)
+
+    def start(self):
+        self._th.start()
+
+    def stop(self):
+        self._stop.set()
+        self._th.join(timeout=15)
+        if not self.samples:
+            return None
+        n = len(self.samples)
+        return {"sclk_mhz": round(sum(s[0] for s in self.samples) / n, 1), "watts": round(sum(s[1] for s in self.samples) / n, 1),
+                "samples": n, "sclk_max_mhz": 2400,
+                "note": "rocm-smi during the timed region (whole step: GEMM, attention, LayerNorm phases mixed)"}
 
 
 def side_workload(args, world, rank, dev, emit=print):
@@ -214,8 +278,14 @@ def main():
                     help="hipEvent-time every N-th launch of each kernel family inside the timed region (1 = all; "
                          "7 is coprime to the 4-GEMM / 12-layer launch cycles, so every shape is sampled evenly)")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="wall-clock budget of the CPU baseline (0 = skip)")
-    ap.add_argument("--cpu-captions", type=int, default=0,
-                    help="CPU baseline on this many WHOLE captions instead of the time budget (SURVEY D.5: 32; several minutes)")
+    ap.add_argument("--cpu-captions", type=int, default=8,
+                    help="CPU baseline on this many WHOLE captions (default 8, about a minute of host time; SURVEY D.5: 32); "
+                         "0 = a --cpu-seconds time budget of decode steps instead")
+    ap.add_argument("--no-checks", action="store_true",
+                    help="skip the untimed passes after the timed region (ids_checked: 16 captions decoded alone in "
+                         "batch-invariant mode against the big batch; attn_decode_diverged: one step with beams that never "
+                         "share history)")
+    ap.add_argument("--no-smi", action="store_true", help="do not sample rocm-smi (clock / power) during the timed region")
     ap.add_argument("--dry-run", action="store_true",
                     help="launcher check without a GPU (CPU tests): join a gloo group, all-gather the ranks, print "
                          "{n_gpus, ranks} and exit")
@@ -303,19 +373,67 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         return float(tt.item())
 
+    def note(msg):
+        if rank == 0:
+            print("[bench %.1fs] %s" % (time.perf_counter() - t_start, msg), file=sys.stderr, flush=True)
+    t_start = time.perf_counter()
+    note("weights loaded, warm-up")
     for _ in range(args.warmup):
         out = step()
+    eng.decode_counters()                       # reset the saturation counter: the timed region reports its own
     eng.profile_enable(max(1, args.profile_every))
     eng.profile_reset()
+    smi = SmiSampler(local_rank) if (rank == 0 and not args.no_smi) else None
     barrier()
+    note("timed region: %d steps" % args.steps)
+    if smi:
+        smi.start()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out = step()
     barrier()
     dt = max_over_ranks(time.perf_counter() - t0)
+    note("timed region done")
+    power = smi.stop() if smi else None
     prof = eng.profile_get()
     eng.profile_enable(False)
+    counters = eng.decode_counters()
     assert out[0].shape[0] == n_global and int(out[1].min()) >= 1
+
+    # ---- untimed checks (rank 0, N = 1): (a) ids_checked -- captions [0:16] decoded ALONE in batch-invariant mode must
+    # reproduce rows [0:16] of the big batch bit for bit (at 5000 captions the default variants ARE the invariant ones:
+    # unsplit GEMM grids, the large-launch attention variant; a 16-caption batch on its own would otherwise take the
+    # split-K path); (b) one more step with beams that never share history: the worst-case K/V traffic of the decode
+    # attention (results discarded)
+    ids_check = diverged = None
+    if world == 1 and not args.no_checks and n_global >= 1400 and n_global * B >= 5400:   # (the big batch ran the unsplit / large-launch variants)
+        k16 = min(16, n_global)
+        note("ids_check")
+        eng.set_batch_invariant(True)
+        sub = run_step(emb[:k16], 0, 1)
+        eng.set_batch_invariant(False)
+        eq = (sub[0] == out[0][:k16]).flatten(1).all(1) & (sub[1] == out[1][:k16])
+        if sub[2] is not None:
+            eq = eq & (sub[2] == out[2][:k16])
+        ids_check = {"ids_checked": k16, "ids_equal": int(eq.sum()),
+                     "note": "captions [0:%d] decoded alone (batch-invariant mode) vs rows [0:%d] of the %d-caption batch: "
+                             "token ids, lengths and scores compared bit for bit" % (k16, k16, n_global)}
+        assert int(eq.sum()) == k16, ids_check
+        if beam:
+            note("diverged-beam step")
+            eng.set_debug_diverge(True)
+            eng.profile_enable(1)
+            eng.profile_reset()
+            run_step(emb, 0, 1)
+            torch.cuda.synchronize()
+            pd = eng.profile_get()["attn_decode"]
+            cd = eng.decode_counters()
+            eng.profile_enable(False)
+            eng.set_debug_diverge(False)
+            diverged = {"avg_ms": round(pd["ms"] / max(pd["launches"], 1), 4), "launches_timed": pd["launches"],
+                        "kv_slots_per_position": round(cd["kv_slots_per_position"], 3),
+                        "note": "one untimed step in which every beam continues itself (no shared history): the worst-case "
+                                "K/V traffic of the decode attention; results are not the reference's beam search"}
 
     # ---- reduced-precision modes (configs[1]: bf16): agreement with the fp32-accurate path on the same captions -- free
     # running (sequences diverge after the first flipped token) and teacher-forced (per-step arg-max given the fp32 ids)
@@ -469,11 +587,24 @@ def main():
                             **({"tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2)} if v["flops"] and v["ms"] else {})}
                         for k, v in prof.items() if v["launches"]},
             "profile_every": max(1, args.profile_every),
+            "ids_check": ids_check,
+            "power": power,
+            "saturated_operand_quads": counters["saturated_quads"],
             "scaling_check": scaling_check,
             "capi_collective": capi_collective,
             "match_vs_fp32": match,
         }
-        if world == 1 and args.cpu_seconds > 0:
+        if beam and "attn_decode" in rec["kernels"]:
+            # what the attention's HBM traffic depends on: distinct K/V slots read per (caption, position); 1 = the beams
+            # of a caption share their whole history, 5 = none of it (synthetic hot-init beams converge quickly)
+            rec["kernels"]["attn_decode"]["kv_slots_per_position"] = round(counters["kv_slots_per_position"], 3)
+            if diverged:
+                rec["kernels"]["attn_decode_diverged"] = diverged
+        if power and power.get("sclk_mhz"):
+            # the dominant kernel against the peak AT THE CLOCK THE CHIP ACTUALLY HELD (it runs at its package power cap)
+            rec["roofline"]["frac_at_measured_clock"] = round(achieved / (peak * power["sclk_mhz"] / 2400.0), 4)
+        note("cpu baseline")
+        if world == 1 and (args.cpu_seconds > 0 or args.cpu_captions > 0):
             rec["cpu_baseline"] = cpu_baseline(mapper, B, P, T, args.cpu_seconds, captions=args.cpu_captions)
         else:
             rec["cpu_baseline"] = None

@@ -78,15 +78,32 @@ def make_preds_from_images(data: Sequence[Dict], images: Sequence, clip_model, p
     if is_rn:
         beam = True
     keep = [i for i, im in enumerate(images) if im is not None]
-    feats = []
-    for b0 in range(0, len(keep), max(1, image_batch)):
-        batch = [images[i] for i in keep[b0:b0 + max(1, image_batch)]]
-        feats.append(clip_model.encode_image(preprocess.batch(batch)).float())
     if not keep:                       # nothing to caption: the reference writes an empty list
         if out_path and rank == 0:
             with open(out_path, 'w') as outfile:
                 json.dump([], outfile)
         return []
-    emb = torch.cat(feats)
-    return make_preds([data[i] for i in keep], emb, model, tokenizer, out_path, beam, entry_length, dont_normalize_prefix,
-                      modality_offset, rank, world)
+    # the image tower is the expensive half of this path (RN50x4: ~10x a caption's decode), so it is sharded like the
+    # decode: rank r preprocesses / encodes / decodes only ITS block of the kept images; the ids are gathered at the end
+    cdist.check_world(rank, world)
+    lo, hi = cdist.shard_bounds(len(keep), rank, world)
+    mine = keep[lo:hi]
+    feats = []
+    for b0 in range(0, len(mine), max(1, image_batch)):
+        batch = [images[i] for i in mine[b0:b0 + max(1, image_batch)]]
+        feats.append(clip_model.encode_image(preprocess.batch(batch)).float())
+    stop = tokenizer.encode('.')[0]
+    T = entry_length
+    if feats:
+        ids, lens, _ = caption_ids(model, torch.cat(feats), stop, beam, 5, T, dont_normalize_prefix, modality_offset)
+    else:                              # an empty shard (more ranks than images) still takes part in the gather
+        dev = next(model.parameters()).device
+        ids, lens = torch.zeros(0, T, dtype=torch.int32, device=dev), torch.zeros(0, dtype=torch.int32, device=dev)
+    ids, lens, _ = cdist.gather_ids(ids, lens, len(keep))
+    ids, lens = ids.cpu().numpy(), lens.cpu().numpy()
+    new_data = [{"caption": tokenizer.decode(list(ids[j, :int(lens[j])])).lower(), "image_id": data[i]["image_id"]}
+                for j, i in enumerate(keep)]
+    if out_path and rank == 0:
+        with open(out_path, 'w') as outfile:
+            json.dump(new_data, outfile)
+    return new_data

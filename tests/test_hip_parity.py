@@ -668,6 +668,100 @@ def test_large_launch_subset_vs_oracle():
     assert ok >= 28, (ok, ties)
 
 
+def test_batch_invariant_mode_bit_identical_across_batch_sizes():
+    """capdec_set_batch_invariant: no launch-size dependent summation order (no split-K, pinned attention variant), so a
+    caption's ids AND scores are bit-identical whether it is decoded alone, in a 330-caption shard (the mid-size
+    split-K regime by default) or in a 1500-caption batch -- mapper included; and at 1500 captions the default mode
+    already runs those variants (what bench.py's `ids_check` relies on)"""
+    from capdec_amd import gpt2_prefix_eval as E
+    dims = synth.GPT2_TINY
+    model, sd = _model(dims, "transformer_encoder", 512, seed=7, num_layers=2)
+    eng = model.engine
+    n, T_ = 1500, 12
+    assert n * 5 > 42 * 128 and n * dims.n_head > 16384
+    x = synth.synthetic_clip_embeddings(n, 512, seed=41)
+
+    def beams(xs):
+        pe = model.clip_project(xs).reshape(xs.shape[0], 10, -1)
+        i, l, s, _ = E.decode_beam_ids(model, pe, dims.vocab + 5, 5, T_)
+        g, gl = E.decode_greedy_ids(model, pe, dims.vocab + 5, T_, alt_stop_id=-1)
+        return i, l, s, g, gl
+    default_big = beams(x)
+    eng.set_batch_invariant(True)
+    try:
+        big, small, mid = beams(x), beams(x[:16]), beams(x[100:430])
+    finally:
+        eng.set_batch_invariant(False)
+    for a, b in zip(big, default_big):
+        assert torch.equal(a, b)
+    for a, b in zip(big, small):
+        assert torch.equal(a[:16], b)
+    for a, b in zip(big, mid):
+        assert torch.equal(a[100:430], b)
+
+
+def test_operand_range_counter_and_nan_propagation():
+    """GEMM operands beyond fp16's range are clamped AND counted (capdec_decode_counters resets the count); NaN is not
+    clamped: it propagates to its output row like in an fp32 GEMM (round-2 review: a corrupt weight must not yield a
+    plausible-looking caption)"""
+    from capdec_amd.engine import Engine
+    e = Engine(0)
+    e.decode_counters()
+    K = 64
+    a = torch.ones(4, K)
+    bt = torch.ones(8, K)
+    e.gemm(a, bt)
+    assert e.decode_counters()["saturated_quads"] == 0
+    a[1, 3] = 1e6
+    a[2, 5] = float("inf")
+    a[3, 7] = float("nan")
+    out = e.gemm(a, bt).cpu()
+    c = e.decode_counters()
+    assert c["saturated_quads"] >= 2, c
+    assert e.decode_counters()["saturated_quads"] == 0                          # reset by the read
+    assert torch.isfinite(out[:3]).all() and torch.isnan(out[3]).all()
+    assert abs(float(out[0, 0]) - K) < 1e-3 and abs(float(out[1, 0]) - (65504.0 + K - 1)) < 1.0
+    e.close()
+
+
+def test_kv_slot_statistic_and_diverged_beams():
+    """capdec_decode_counters: distinct K/V slots per (caption, position) of a beam decode -- between 1 (all beams share
+    their history) and the beam width; with the debug switch that makes every beam continue itself it is exactly
+    (P + 5 i) / (P + i) summed over the steps"""
+    from capdec_amd import gpt2_prefix_eval as E
+    dims = synth.GPT2_TINY
+    model, sd = _model(dims, "mlp", 512, seed=7)
+    eng = model.engine
+    n, P, T_ = 40, 10, 14
+    x = synth.synthetic_clip_embeddings(n, 512, seed=5)
+    pe = model.clip_project(x).reshape(n, P, -1)
+    i0, _, s0, _ = E.decode_beam_ids(model, pe, dims.vocab + 5, 5, T_)
+    kv = eng.decode_counters()["kv_slots_per_position"]
+    assert 1.0 <= kv <= 5.0
+    eng.set_debug_diverge(True)
+    try:
+        E.decode_beam_ids(model, pe, dims.vocab + 5, 5, T_)
+        kvd = eng.decode_counters()["kv_slots_per_position"]
+    finally:
+        eng.set_debug_diverge(False)
+    want = sum(P + 5 * i for i in range(1, T_)) / sum(P + i for i in range(1, T_))
+    assert abs(kvd - want) < 1e-6 and kvd > kv
+    i1, _, s1, _ = E.decode_beam_ids(model, pe, dims.vocab + 5, 5, T_)           # the switch is really off again
+    assert torch.equal(i0, i1) and torch.equal(s0, s1)
+
+
+def test_unknown_gemm_mode_is_an_error(monkeypatch):
+    from capdec_amd.engine import Engine
+    from capdec_amd._capi import CapdecError
+    monkeypatch.setenv("CAPDEC_GEMM_MODE", "fp16")          # a typo of "f16"
+    with pytest.raises(CapdecError, match="CAPDEC_GEMM_MODE"):
+        Engine(0)
+    monkeypatch.setenv("CAPDEC_GEMM_MODE", "f16")
+    e = Engine(0)
+    assert e.gemm_mode() == "f16"
+    e.close()
+
+
 def test_finished_caption_compaction(monkeypatch):
     """captions that stop early leave the batch at the poll points (activation rows are compacted, KV / beam state stay
     in place): with a stop id that fires at staggered steps the results still equal the oracle token for token, the
