@@ -134,7 +134,7 @@ struct capdec_ctx {
     DBuf r_pk1, r_pk2, r_xpk, r_ypk, r_xi, r_idp, r_zero;   // ... packed activations (GEMM / implicit-conv operands), zero rows
     Prof prof;
     int gemm_mode = GEMM_F16X2;
-    struct Planes { void *p; size_t n; int fmt; };
+    struct Planes { void *p; size_t n; int fmt; bool wide_ok; };   // wide_ok: max |w| < 16 (see GemmEpilogue::wide_ok)
     std::unordered_map<const void *, Planes> planes;   // fp32 weight -> (packed planes, elements, PackFmt)
     DBuf x3_tmp, xpk, apk, fpk, a_tmp;   // scratch planes for un-cached matrices; packed LayerNorm output; packed fp32-A
     int stat_steps = 0, stat_compactions = 0;      // last decode call: steps run, compactions done,
@@ -150,7 +150,7 @@ struct capdec_ctx {
     DBuf h, x, qkv, att, ff, xl, tmax, tsum, cval, cidx, lse, topv, topi, kc, vc;
     DBuf tokens, scores, seq, stopped, done, anc, next_tok, alive, gids, glens, cmap, kvstat;
     DBuf m_hid, m_lin, m_seq, m_x, m_qkv, m_att, m_ff;
-    DBuf t_idx, t_patch, t_pout, p_desc, p_inter, splitk;
+    DBuf t_idx, t_patch, t_pout, p_desc, p_inter, splitk, absmax;
     int *alive_host = nullptr;   // pinned
     // caption-shard communicator (RCCL), see capdec_comm_init
     ncclComm_t comm = nullptr;
@@ -268,14 +268,29 @@ static int pack_any(capdec_ctx *c, const float *W, int N, int K, int fmt, void *
     if (fmt == PK_BF16X3) return launch_pack_planes(c->stream, W, N, K, out);
     return launch_pack_planes_fmt(c->stream, W, K, N, K, out, fmt);
 }
-static int planes_of(capdec_ctx *c, const float *W, int N, int K, bool cache, const void **out, int fmt_override = -1) {
+// max |w| < 16 ?  (one tiny reduction + a 4-byte read-back, once per cached weight)
+static int weight_wide_ok(capdec_ctx *c, const float *W, size_t n, bool *ok) {
+    CAPDEC_TRY(c->absmax.ensure(sizeof(unsigned)));
+    CAPDEC_TRY(launch_absmax_bits(c->stream, W, n, c->absmax.as<unsigned>()));
+    unsigned bits = 0;
+    CAPDEC_HIP(hipMemcpyAsync(&bits, c->absmax.p, sizeof(bits), hipMemcpyDeviceToHost, c->stream));
+    CAPDEC_HIP(hipStreamSynchronize(c->stream));
+    float m;
+    memcpy(&m, &bits, sizeof(m));
+    *ok = m < 16.0f;
+    return 0;
+}
+static int planes_of(capdec_ctx *c, const float *W, int N, int K, bool cache, const void **out, int fmt_override = -1,
+                     bool *wide_ok = nullptr) {
     const int fmt = fmt_override >= 0 ? fmt_override : pack_fmt(c);
     const size_t n = (size_t)N * K, bytes = x3_packed_bytes(N, K, fmt);
+    if (wide_ok) *wide_ok = false;
     if (cache) {
         auto it = c->planes.find(W);
         if (it != c->planes.end()) {
             if (it->second.n == n && it->second.fmt == fmt) {
                 *out = it->second.p;
+                if (wide_ok) *wide_ok = it->second.wide_ok;
                 return 0;
             }
             (void)hipFree(it->second.p);      // same address, different matrix (or the GEMM mode changed)
@@ -283,9 +298,12 @@ static int planes_of(capdec_ctx *c, const float *W, int N, int K, bool cache, co
         }
         void *p = nullptr;
         CAPDEC_HIP(hipMalloc(&p, bytes));
-        c->planes[W] = capdec_ctx::Planes{p, n, fmt};
+        bool ok = false;
+        if (fmt == PK_F16X2) CAPDEC_TRY(weight_wide_ok(c, W, n, &ok));
+        c->planes[W] = capdec_ctx::Planes{p, n, fmt, ok};
         CAPDEC_TRY(pack_any(c, W, N, K, fmt, p));
         *out = p;
+        if (wide_ok) *wide_ok = ok;
         return 0;
     }
     CAPDEC_TRY(c->x3_tmp.ensure(bytes));
@@ -306,7 +324,7 @@ static int gemm(capdec_ctx *c, const float *A, int lda, const float *Bt, int ldb
         // per element), then the packed LDS-DMA kernel -- fp32-accurate (f16x2) also in the reduced-precision modes,
         // whose 16-bit operands are confined to the GPT-2 / CLIP block stacks and the lm_head
         const void *pl = nullptr;
-        CAPDEC_TRY(planes_of(c, Bt, N, K, weight, &pl, PK_F16X2));
+        CAPDEC_TRY(planes_of(c, Bt, N, K, weight, &pl, PK_F16X2, &e.wide_ok));
         CAPDEC_TRY(c->a_tmp.ensure(x3_packed_bytes(M, K, PK_F16X2)));
         { ProfScope ps(c, F_PACK); CAPDEC_TRY(launch_pack_planes_h2(c->stream, A, lda, M, K, c->a_tmp.p)); }
         const size_t wsb = c->batch_invariant ? 0 : gemm_splitk_ws_bytes(M, N, K);
@@ -344,8 +362,8 @@ static int gemm_packed(capdec_ctx *c, const void *Apk, const float *W, float *C,
                        const float *bias, int act, const float *resid = nullptr, int ldr = 0,
                        void *packed_out = nullptr, const NextLn *next_ln = nullptr, const void *resid_packed = nullptr) {
     const void *pl = nullptr;
-    CAPDEC_TRY(planes_of(c, W, N, K, true, &pl));
     GemmEpilogue e;
+    CAPDEC_TRY(planes_of(c, W, N, K, true, &pl, -1, &e.wide_ok));
     e.bias = bias;
     e.act = act;
     e.resid = resid;
@@ -506,9 +524,17 @@ static int lm_head_select(capdec_ctx *c, const float *h0, int ldh, int R, int k,
         CAPDEC_TRY(c->xpk.ensure(x3_packed_bytes_host(R, d)));
         { ProfScope ps(c, F_LN); CAPDEC_TRY(launch_layernorm_packed(c->stream, h0, ldh, g.lnfw, g.lnfb, g.eps, c->xpk.p, R, d, pack_fmt(c))); }
         const void *pl = nullptr;
-        CAPDEC_TRY(planes_of(c, g.wte, g.vocab, d, true, &pl));
+        bool wide_ok = false;
+        CAPDEC_TRY(planes_of(c, g.wte, g.vocab, d, true, &pl, -1, &wide_ok));
         if (c->gemm_mode == GEMM_F16X2) {
             ProfScope ps(c, F_LMHEAD_H2, 2.0 * R * (double)g.vocab * d);
+            // 256 x 128 tiles with one accumulator set once the grid is many rounds deep (each wte panel is then fetched
+            // by half as many row tiles); small row counts keep the 128-row tile (more blocks, the same partial lists)
+            static const int lm_wide = [] { const char *e = getenv("CAPDEC_LMHEAD_WIDE"); return e ? atoi(e) : 1; }();
+            if (wide_ok && ((lm_wide && h2w_choice() >= 1 && R >= 2048) || h2w_choice() >= 2))   // (CAPDEC_H2W >= 2: forced, tests)
+                CAPDEC_TRY(launch_gemm_h2w_topk(c->stream, c->xpk.p, pl, R, g.vocab, d, k, inv_temp, c->tmax.as<float>(),
+                                                c->tsum.as<float>(), c->cval.as<float>(), c->cidx.as<int>()));
+            else
             CAPDEC_TRY(launch_gemm_f16x2p_topk(c->stream, c->xpk.p, pl, R, g.vocab, d, k, inv_temp, c->tmax.as<float>(),
                                                c->tsum.as<float>(), c->cval.as<float>(), c->cidx.as<int>()));
         } else if (mode_single(c)) {
@@ -1210,7 +1236,7 @@ void capdec_destroy(capdec_ctx *c) {
     DBuf *bufs[] = {&c->h, &c->x, &c->qkv, &c->att, &c->ff, &c->xl, &c->tmax, &c->tsum, &c->cval, &c->cidx,
                     &c->lse, &c->topv, &c->topi, &c->kc, &c->vc, &c->tokens, &c->scores, &c->seq, &c->stopped,
                     &c->done, &c->anc, &c->next_tok, &c->alive, &c->gids, &c->glens, &c->m_hid, &c->m_lin, &c->m_seq,
-                    &c->m_x, &c->m_qkv, &c->m_att, &c->m_ff, &c->t_idx, &c->t_patch, &c->t_pout, &c->xpk, &c->apk, &c->fpk, &c->cmap, &c->kvstat, &c->p_desc, &c->p_inter, &c->splitk, &c->a_tmp,
+                    &c->m_x, &c->m_qkv, &c->m_att, &c->m_ff, &c->t_idx, &c->t_patch, &c->t_pout, &c->xpk, &c->apk, &c->fpk, &c->cmap, &c->kvstat, &c->p_desc, &c->p_inter, &c->splitk, &c->absmax, &c->a_tmp,
                     &c->r_a, &c->r_b, &c->r_c, &c->r_d, &c->r_e, &c->r_f, &c->r_col, &c->r_pk1, &c->r_pk2, &c->r_xpk,
                     &c->r_ypk, &c->r_xi, &c->r_idp, &c->r_zero};
     for (DBuf *b : bufs) b->release();
@@ -1633,8 +1659,9 @@ int capdec_gemm_f32(capdec_ctx *c, const float *a, int lda, const float *bt, int
             CAPDEC_TRY(pack_any(c, a, M, K, pack_fmt(c), c->xpk.p));
             pa = c->xpk.p;
         }
-        CAPDEC_TRY(planes_of(c, bt, N, K, cache, &pb));
         GemmEpilogue e;
+        CAPDEC_TRY(planes_of(c, bt, N, K, cache, &pb, -1, &e.wide_ok));
+        if (!cache && pack_fmt(c) == PK_F16X2) CAPDEC_TRY(weight_wide_ok(c, bt, (size_t)N * K, &e.wide_ok));
         e.bias = bias; e.act = act; e.resid = resid; e.ldr = ldr;
         if ((c->gemm_mode == GEMM_F16X2 || c->gemm_mode == GEMM_BF16X3) && !c->batch_invariant) {
             const size_t wsb = gemm_splitk_ws_bytes(M, N, K);

@@ -94,6 +94,8 @@ struct GemmEpilogue {
     size_t splitk_ws_bytes = 0;    // under-filled grids run unsplit
     void *packed_out = nullptr;    // bf16x3p only: write act(acc + bias) as the packed split-bf16 A operand (K = N)
                                    // of the next GEMM instead of fp32 C
+    bool wide_ok = false;          // f16x2p only: the B operand is a weight with max |w| < 16, so its high plane can be scaled
+                                   // by 2^11 in fp16 registers (the single-accumulator kernels of gemm_h2w.hip)
     const void *resid_packed = nullptr;   // f16x2p / x1 with packed_out only: residual [M, N] stored as a packed operand of
                                           // the output's format (added after the activation; no split-K then)
     // Optional LayerNorm of the RESULT rows, fused into the split-K reduce pass (only when the launch splits K, C has
@@ -144,8 +146,12 @@ int launch_gemm_f16x2p_topk(hipStream_t st, const void *Apacked, const void *Bpa
 // round-3 wide-tile kernels with ONE accumulator set (gemm_h2w.hip); scale = 2^(t - 11), t = pack-time pre-scale
 // exponent of the weights; `which`: 2 = 256x128 (two blocks per CU), 3 = 256x256 (8 waves), 4 / 5 = 128x128
 int h2w_choice();
+int h2w_plan(int M, int N, int K);
+int launch_absmax_bits(hipStream_t st, const float *w, size_t n, unsigned *d_out);
 int launch_gemm_h2w(hipStream_t st, int which, const void *Apacked, const void *Bpacked, float *C, int ldc, int M, int N,
                     int K, const GemmEpilogue &epi, float scale);
+int launch_gemm_h2w_topk(hipStream_t st, const void *Apacked, const void *Bpacked, int M, int N, int K, int k,
+                         float inv_temp, float *tile_max, float *tile_sum, float *cand_val, int *cand_idx);
 // generic packer for any PackFmt (gemm_f16x2.hip); the one-plane formats use it
 int launch_pack_planes_fmt(hipStream_t st, const float *w, int ldw, int N, int K, void *out, int fmt);
 // round-2 one-plane kernels on the f16x2 main loop (gemm_f16x2.hip): 128x128 tile, two blocks per CU, 32-deep stages

@@ -366,7 +366,10 @@ int launch_gemm_f16x2p(hipStream_t st, const void *Apacked, const void *Bpacked,
     // persistent form for grids of up to four rounds, where the partly filled last round matters (625 captions: mlp.c_fc
     // 600 tiles, 80 -> 70 us inside the decode loop); larger grids keep one block per tile (the dispatcher balances them:
     // within noise either way at 25 000 rows).  CAPDEC_H2_PERSIST=<blocks> (0 = never)
-    if (vec4 && h2w_choice() >= 2) return launch_gemm_h2w(st, h2w_choice(), Apacked, Bpacked, C, ldc, M, N, K, epi, 1.0f / H2_LO_SCALE);
+    if (vec4 && epi.wide_ok && h2w_choice() >= 1) {      // round-3 single-accumulator geometries where they remove a round
+        const int which = h2w_choice() >= 2 ? h2w_choice() : h2w_plan(M, N, K);
+        if (which) return launch_gemm_h2w(st, which, Apacked, Bpacked, C, ldc, M, N, K, epi, 1.0f / H2_LO_SCALE);
+    }
     static const int persist = [] { const char *e = getenv("CAPDEC_H2_PERSIST"); return e ? atoi(e) : 512; }();
     const int grid_h2 = (persist > 0 && tiles_m * tiles_n <= 4 * persist) ? std::min(tiles_m * tiles_n, persist) : tiles_m * tiles_n;
 #define LAUNCH_H2(V4, NSV)                                                                                            \

@@ -41,14 +41,14 @@ struct WGeo {
     static constexpr int WM = WM_, WN = WN_, TI = TI_, TJ = TJ_, NS = NS_, MINW = MINW_;
     static constexpr int NW = WM * WN, THREADS = 64 * NW;
     static constexpr int BM = WM * TI * 32, BN = WN * TJ * 32;
-    static constexpr int TA = BM / 128, TB = BN / 128;           // 128-row operand tiles per block tile
-    static constexpr int STAGE_B = (TA + TB) * H2_BLOCK_B;        // one k-step of both operands
-    static constexpr int PIECES = STAGE_B / 1024, PPW = PIECES / NW;   // 1 KB LDS-DMA pieces per stage / per wavefront
+    // operands move in CHUNKS of 32 rows (one 1 KB LDS-DMA piece per plane): a block tile may start anywhere on a
+    // 32-row boundary of the 128-row packed tiles, so BN = 192 is as good as 128 or 256
+    static constexpr int CA = BM / 32, CB = BN / 32;
+    static constexpr int PIECES = 2 * (CA + CB), PPW = PIECES / NW;      // pieces per stage / per wavefront
+    static constexpr int STAGE_B = PIECES * 1024;                        // one k-step of both operands
     static constexpr int SMEM_B = NS * STAGE_B;
-    static_assert(BM % 128 == 0 && BN % 128 == 0, "block tile = whole 128-row operand tiles");
     static_assert(PIECES % NW == 0, "pieces divide evenly over the wavefronts");
     static_assert(PPW * (NS - 2) < 64, "vmcnt range");
-    static_assert(128 % (TI * 32) == 0 && 128 % (TJ * 32) == 0, "a wavefront's rows lie in one operand tile");
 };
 
 // Issue schedule of one k-step.  The k-step is cut into TI REGIONS (one per row group of the wave tile, closed by a
@@ -86,28 +86,30 @@ __device__ __forceinline__ void w_sched_emit() {
 
 // Main loop.  acc[i][j] (TR layout, see gemm_epilogue.h): C[m0 + wm TI 32 + i 32 + (lane & 31)]
 //                                                          [n0 + wn TJ 32 + j 32 + 8 (r >> 2) + 4 (lane >> 5) + (r & 3)]
-// scaled by 2^11.  tilesA / tilesB = number of 128-row tiles the packed operands hold (block tiles past the end re-read
-// the last one; the epilogue drops those rows / columns).
+// scaled by 2^11.  chunksA / chunksB = number of 32-row chunks the packed operands hold (rows padded to 128: block tiles
+// past the end re-read the last chunk; the epilogue drops those rows / columns).
 template <class G, bool TR>
 __device__ __forceinline__ void h2w_mainloop(const _Float16 *__restrict__ Apk, const _Float16 *__restrict__ Bpk, int K,
-                                             int tm, int tn, int tilesA, int tilesB, char *smem,
+                                             int tm, int tn, int chunksA, int chunksB, char *smem,
                                              f32x16 (&acc)[G::TI][G::TJ]) {
-    constexpr int TI = G::TI, TJ = G::TJ, NS = G::NS, PPW = G::PPW, TA = G::TA, SB = G::STAGE_B;
+    constexpr int TI = G::TI, TJ = G::TJ, NS = G::NS, PPW = G::PPW, SB = G::STAGE_B;
     using SC = WSched<G>;
     const int t = threadIdx.x;
     const int lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int wm = wave / G::WN, wn = wave % G::WN;
     const int half = lane >> 5, l32 = lane & 31;
     const int nk = K / X3_BK;
-    // ---- LDS-DMA: piece p = wave PPW + e of a stage; pieces 8 q .. 8 q + 7 are the 8 KB block of operand tile q
+    // ---- LDS-DMA: piece p = wave PPW + e of a stage = plane (p & 1) of chunk (p >> 1); chunks 0 .. CA-1 are the A rows
+    // of the block tile, CA .. CA+CB-1 its B rows.  Global chunk g of a packed operand = piece (g & 3) of each plane of
+    // its 128-row tile g >> 2.  The LDS image is chunk-major: [chunk][plane][32 rows x 32 B].
     const char *src[PPW];
 #pragma unroll
     for (int e = 0; e < PPW; ++e) {
-        const int p = wave * PPW + e, q = p >> 3, r = p & 7;
-        const char *base;
-        if (q < TA) base = reinterpret_cast<const char *>(Apk) + (size_t)min(tm * TA + q, tilesA - 1) * nk * H2_BLOCK_B;
-        else base = reinterpret_cast<const char *>(Bpk) + (size_t)min(tn * G::TB + (q - TA), tilesB - 1) * nk * H2_BLOCK_B;
-        src[e] = base + r * 1024 + lane * 16;
+        const int p = wave * PPW + e, c = p >> 1, pl = p & 1;
+        const bool isA = c < G::CA;
+        const int g = isA ? min(tm * G::CA + c, chunksA - 1) : min(tn * G::CB + (c - G::CA), chunksB - 1);
+        const char *base = reinterpret_cast<const char *>(isA ? Apk : Bpk);
+        src[e] = base + (size_t)(g >> 2) * nk * H2_BLOCK_B + pl * X3_PLANE_B + (g & 3) * 1024 + lane * 16;
     }
     char *dst0 = smem + wave * (PPW * 1024);
 #define W_DMA(stage, ks_, e0, e1)                                                                               \
@@ -124,22 +126,21 @@ __device__ __forceinline__ void h2w_mainloop(const _Float16 *__restrict__ Apk, c
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     const int swz = ((half ^ ((l32 >> 3) & 1)) << 4);
-    const int rowA0 = wm * TI * 32, colB0 = wn * TJ * 32;
-    const int a_rd = (rowA0 >> 7) * H2_BLOCK_B + ((rowA0 & 127) + l32) * X3_ROW_B + swz;
-    const int b_rd = (TA + (colB0 >> 7)) * H2_BLOCK_B + ((colB0 & 127) + l32) * X3_ROW_B + swz;
+    const int a_rd = (2 * wm * TI) * 1024 + l32 * X3_ROW_B + swz;                  // chunk wm TI + i, plane p: + (2 i + p) KB
+    const int b_rd = (2 * (G::CA + wn * TJ)) * 1024 + l32 * X3_ROW_B + swz;
 
     // fragment sets: a[i][plane], b[j][plane]
     f16x8 f0a[TI][2], f0b[TJ][2], f1a[TI][2], f1b[TJ][2];
 #define W_READ_A(F, stage, i)                                                                                    \
     {                                                                                                            \
-        F##a[i][0] = *reinterpret_cast<const f16x8 *>(smem + (stage) * SB + a_rd + (i) * 32 * X3_ROW_B);               \
-        F##a[i][1] = *reinterpret_cast<const f16x8 *>(smem + (stage) * SB + a_rd + (i) * 32 * X3_ROW_B + X3_PLANE_B);  \
+        F##a[i][0] = *reinterpret_cast<const f16x8 *>(smem + (stage) * SB + a_rd + (2 * (i)) * 1024);       \
+        F##a[i][1] = *reinterpret_cast<const f16x8 *>(smem + (stage) * SB + a_rd + (2 * (i) + 1) * 1024);   \
     }
 #define W_READ_B(F, stage)                                                                                         \
     {                                                                                                              \
         _Pragma("unroll") for (int j = 0; j < TJ; ++j) {                                                           \
-            F##b[j][0] = *reinterpret_cast<const f16x8 *>(smem + (stage) * SB + b_rd + j * 32 * X3_ROW_B);               \
-            F##b[j][1] = *reinterpret_cast<const f16x8 *>(smem + (stage) * SB + b_rd + j * 32 * X3_ROW_B + X3_PLANE_B);  \
+            F##b[j][0] = *reinterpret_cast<const f16x8 *>(smem + (stage) * SB + b_rd + (2 * j) * 1024);       \
+            F##b[j][1] = *reinterpret_cast<const f16x8 *>(smem + (stage) * SB + b_rd + (2 * j + 1) * 1024);   \
         }                                                                                                          \
     }
 #define W_MM1(x, y, c) __builtin_amdgcn_mfma_f32_32x32x16_f16(x, y, c, 0, 0, 0)
@@ -297,12 +298,12 @@ __global__ __launch_bounds__(G::THREADS, G::MINW) void gemm_h2w_kernel(const _Fl
                                                                       int tiles_n, char *packed_out, float scale) {
     __shared__ __attribute__((aligned(16))) char smem[G::SMEM_B];
     const int ntiles = tiles_m * tiles_n;
-    const int tilesA = (M + 127) >> 7, tilesB = (N + 127) >> 7;
+    const int chunksA = ((M + 127) >> 7) * 4, chunksB = ((N + 127) >> 7) * 4;
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         int tm, tn;
         tile_coords(tiles_m, tiles_n, tm, tn, tile);
         f32x16 acc[G::TI][G::TJ];
-        h2w_mainloop<G, true>(Apk, Bpk, K, tm, tn, tilesA, tilesB, smem, acc);     // ends with a barrier: the ring is free
+        h2w_mainloop<G, true>(Apk, Bpk, K, tm, tn, chunksA, chunksB, smem, acc);     // ends with a barrier: the ring is free
         if (packed_out)
             epilogue_store_packed_tw<G>(acc, scale, packed_out, N >> 4, M, N, tm * G::BM, tn * G::BN, bias, act,
                                         reinterpret_cast<const char *>(resid));   // (with packed_out, `resid` is PACKED)
@@ -311,15 +312,156 @@ __global__ __launch_bounds__(G::THREADS, G::MINW) void gemm_h2w_kernel(const _Fl
     }
 }
 
+// lm_head epilogue on a G::BM x 128 block tile (non-TR accumulator layout: acc[i][j][r] = C[wm TI 32 + i 32 + (r & 3) +
+// 8 (r >> 2) + 4 (lane >> 5)][wn TJ 32 + j 32 + (lane & 31)]): the logits go through LDS in slabs of 128 rows (66 KB,
+// re-using the ring) and leave as per-(row, 128-column tile) max, sum exp(x - max) and top-k (value, column) -- the
+// arithmetic and the tie rules of epilogue_topk (gemm_epilogue.h), so the merge kernel sees the same partial lists
+// whichever tile height produced them.
+template <class G, int KSEL>
+__device__ __forceinline__ void epilogue_topk_w(const f32x16 (&acc)[G::TI][G::TJ], float scale, float *Ct, int M, int N,
+                                                int m0, int n0, int tn, int tiles_n, float *tile_max, float *tile_sum,
+                                                float *cand_val, int *cand_idx) {
+    static_assert(G::BN == 128 && G::NW == 4 && G::SMEM_B >= 128 * CT_LD * 4, "top-k epilogue: 128-column tiles, 4 waves");
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wm = wave / G::WN, wn = wave % G::WN, half = lane >> 5, l32 = lane & 31;
+    const int grp = lane >> 4, sub = lane & 15;
+    constexpr int SLABS = G::BM / 128, WROWS = G::TI * 32;       // rows of one wavefront's tile
+    for (int hh = 0; hh < SLABS; ++hh) {
+        if ((wm * WROWS) / 128 == hh) {
+            const int r0 = (wm * WROWS) % 128;
+#pragma unroll
+            for (int i = 0; i < G::TI; ++i)
+#pragma unroll
+                for (int j = 0; j < G::TJ; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int row = r0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                        Ct[row * CT_LD + (wn * G::TJ + j) * 32 + l32] = acc[i][j][r] * scale;
+                    }
+        }
+        __syncthreads();
+        for (int it = 0; it < 8; ++it) {
+            const int rl = wave * 32 + it * 4 + grp;              // row within the slab
+            const int row = m0 + hh * 128 + rl;
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int cl = sub + 16 * j;
+                v[j] = (n0 + cl < N) ? Ct[rl * CT_LD + cl] : -INFINITY;
+            }
+            float mx = v[0];
+#pragma unroll
+            for (int j = 1; j < 8; ++j) mx = fmaxf(mx, v[j]);
+            mx = row16_max(mx);
+            float se = 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) se += __expf(v[j] - mx);
+            se = row16_sum(se);
+            const size_t tbase = (size_t)row * tiles_n + tn;
+            if (row < M && sub == 0) {
+                tile_max[tbase] = mx;
+                tile_sum[tbase] = se;
+            }
+#pragma unroll
+            for (int kk = 0; kk < KSEL; ++kk) {
+                float bv = v[0];
+                int bj = 0;
+#pragma unroll
+                for (int j = 1; j < 8; ++j)
+                    if (v[j] > bv) { bv = v[j]; bj = j; }
+                const int bc = sub + 16 * bj;
+                float gv = bv;
+                int gc = bc;
+#define TOPKW_STEP(CTRL)                                                      \
+    {                                                                          \
+        const float ov = dpp_f<CTRL>(gv);                                      \
+        const int oc = dpp_i<CTRL>(gc);                                        \
+        if (ov > gv || (ov == gv && oc < gc)) { gv = ov; gc = oc; }            \
+    }
+                TOPKW_STEP(DPP_XOR1) TOPKW_STEP(DPP_XOR2) TOPKW_STEP(DPP_HALF_MIRROR) TOPKW_STEP(DPP_MIRROR)
+#undef TOPKW_STEP
+                if (gc == bc) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j)
+                        if (j == bj) v[j] = -INFINITY;
+                }
+                if (row < M && sub == kk) {
+                    cand_val[tbase * KSEL + kk] = gv;
+                    cand_idx[tbase * KSEL + kk] = n0 + gc;
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+template <class G, int KSEL>
+__global__ __launch_bounds__(G::THREADS, G::MINW) void gemm_h2w_topk_kernel(const _Float16 *__restrict__ Apk,
+                                                                           const _Float16 *__restrict__ Bpk, int M, int N,
+                                                                           int K, float scale, float *tile_max,
+                                                                           float *tile_sum, float *cand_val, int *cand_idx,
+                                                                           int tiles_m, int tiles_n) {
+    __shared__ __attribute__((aligned(16))) char smem[G::SMEM_B];
+    int tm, tn;
+    tile_coords(tiles_m, tiles_n, tm, tn);
+    f32x16 acc[G::TI][G::TJ];
+    h2w_mainloop<G, false>(Apk, Bpk, K, tm, tn, ((M + 127) >> 7) * 4, ((N + 127) >> 7) * 4, smem, acc);   // ends with a barrier
+    epilogue_topk_w<G, KSEL>(acc, scale, reinterpret_cast<float *>(smem), M, N, tm * G::BM, tn * G::BN, tn, tiles_n, tile_max,
+                             tile_sum, cand_val, cand_idx);
+}
+
 using W256x128 = WGeo<2, 2, 4, 2, 3, 2>;      // 4 waves, 72 KB, two blocks per CU
 using W256x256 = WGeo<2, 4, 4, 2, 4, 2>;      // 8 waves, 128 KB, one block per CU
 using W128x128 = WGeo<2, 2, 2, 2, 3, 3>;      // 4 waves, 48 KB, three blocks per CU
 using W128x128b = WGeo<2, 2, 2, 2, 4, 2>;     // 4 waves, 64 KB, two blocks per CU (round-2 geometry, one accumulator set)
 using W256x128a = WGeo<2, 2, 4, 2, 3, 2, true>;   // W256x128 with accumulator-major MFMA order (measurement)
 using W256x256q = WGeo<2, 2, 4, 4, 4, 1>;     // 4 waves x (128 x 128), 128 KB, ONE wavefront per SIMD (accumulators in AGPRs)
+using W128x192 = WGeo<2, 2, 2, 3, 4, 2>;      // 4 waves x (64 x 96), 80 KB, two blocks per CU: column tiles of 192
 
-// CAPDEC_H2W: 0 = round-2 kernel everywhere; 1 = automatic choice (default); 2 / 3 / 4 / 5 force W256x128 / W256x256 /
-// W128x128 / W128x128b wherever the wide kernel is applicable (measurement)
+// max |w| of a device matrix as the bit pattern of a non-negative float (atomicMax on the bits is order preserving)
+__global__ void absmax_bits_kernel(const float *__restrict__ w, size_t n, unsigned *__restrict__ out) {
+    float m = 0.f;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const float a = __builtin_fabsf(w[i]);
+        m = (a > m || a != a) ? a : m;                          // a NaN weight poisons the maximum: not "wide ok"
+    }
+    m = wave_max(m == m ? m : __builtin_inff());
+    if ((threadIdx.x & 63) == 0) atomicMax(out, __builtin_bit_cast(unsigned, m));
+}
+int launch_absmax_bits(hipStream_t st, const float *w, size_t n, unsigned *d_out) {
+    CAPDEC_HIP(hipMemsetAsync(d_out, 0, sizeof(unsigned), st));
+    const unsigned blocks = (unsigned)std::min<size_t>((n + 255) / 256, 1024);
+    hipLaunchKernelGGL(absmax_bits_kernel, dim3(blocks ? blocks : 1), dim3(256), 0, st, w, n, d_out);
+    CAPDEC_HIP(hipGetLastError());
+    return 0;
+}
+
+// Which kernel for an f16x2 GEMM [M, N, K] whose grid is not split along K: 0 = the round-2 128x128 two-accumulator
+// kernel, else a WGeo id of launch_gemm_h2w.  Estimated time = (full rounds of 512 blocks + what the partly filled last
+// round costs) x tile area / relative loop efficiency; a block alone on its CU runs ~1.64x faster than one of a pair
+// (measured: one block per CU = 0.82 of two), so a last round of <= 256 tiles costs 0.61.  The wide tiles only win
+// where they remove a round: at 25 000 rows the estimates tie (measured: within +-3 %, profiles/r3_gemm_geometries.txt)
+// and the round-2 kernel stays; at a few thousand rows mlp.c_fc (600 tiles of 128x128 = 1.17 rounds) takes the
+// 128x192 tile (400 tiles, one round).
+int h2w_plan(int M, int N, int K) {
+    (void)K;
+    auto cost = [&](int bm, int bn, double eff) {
+        const long tiles = (long)((M + bm - 1) / bm) * ((N + bn - 1) / bn);
+        const long full = tiles / 512, rem = tiles % 512;
+        const double rounds = (double)full + (rem == 0 ? 0.0 : rem <= 256 ? 0.61 : 1.0);
+        return rounds * bm * bn / eff;
+    };
+    const double c0 = cost(128, 128, 1.0), c8 = cost(128, 192, 1.04), c2 = cost(256, 128, 1.05);
+    int best = 0;
+    double cb = c0 * 0.97;                       // the wide kernel must be worth >= 3 %
+    if (c8 < cb) { best = 8; cb = c8; }
+    if (c2 < cb) { best = 2; cb = c2; }
+    return best;
+}
+
+// CAPDEC_H2W: 0 = round-2 kernels everywhere; 1 = automatic (default: the wide kernel where it measured faster);
+// 2 .. 8 force one geometry wherever the wide kernel is applicable (measurement): 2 = W256x128, 3 = W256x256,
+// 4 = W128x128, 5 = W128x128b, 6 = W256x256q, 7 = W256x128a, 8 = W128x192
 int h2w_choice() {
     static const int v = [] { const char *e = getenv("CAPDEC_H2W"); return e ? atoi(e) : 1; }();
     return v;
@@ -339,8 +481,8 @@ static int launch_h2w(hipStream_t st, const void *Apacked, const void *Bpacked, 
     return 0;
 }
 
-// scale = 2^(t - 11), t = the weights' pack-time pre-scale exponent.  Requires the float4 epilogue (caller checks).
-// which: 2 = W256x128, 3 = W256x256, 4 = W128x128 (three blocks per CU), 5 = W128x128b
+// scale = 2^-11 (x 2^t for weights packed with a pre-scale 2^-t; t = 0 today: weights with |w| >= 16 keep the
+// two-accumulator kernel, see planes_of in capi.hip).  Requires the float4 epilogue (caller checks).
 int launch_gemm_h2w(hipStream_t st, int which, const void *Apacked, const void *Bpacked, float *C, int ldc, int M, int N,
                     int K, const GemmEpilogue &epi, float scale) {
     switch (which) {
@@ -350,8 +492,36 @@ int launch_gemm_h2w(hipStream_t st, int which, const void *Apacked, const void *
         case 5: return launch_h2w<W128x128b>(st, Apacked, Bpacked, C, ldc, M, N, K, epi, scale, 512);
         case 6: return launch_h2w<W256x256q>(st, Apacked, Bpacked, C, ldc, M, N, K, epi, scale, 256);
         case 7: return launch_h2w<W256x128a>(st, Apacked, Bpacked, C, ldc, M, N, K, epi, scale, 512);
+        case 8: return launch_h2w<W128x192>(st, Apacked, Bpacked, C, ldc, M, N, K, epi, scale, 512);
         default: CAPDEC_CHECK(false, "gemm_h2w: unknown geometry");
     }
+    return 0;
+}
+
+// fused lm_head on the 256 x 128 tile: same partial lists per (row, 128-column tile) as launch_gemm_f16x2p_topk
+int launch_gemm_h2w_topk(hipStream_t st, const void *Apacked, const void *Bpacked, int M, int N, int K, int k,
+                         float inv_temp, float *tile_max, float *tile_sum, float *cand_val, int *cand_idx) {
+    CAPDEC_CHECK(M > 0 && N > 0 && K > 0 && K % 64 == 0, "gemm_h2w_topk: K must be a multiple of 64");
+    using G = W256x128;
+    const int tiles_m = (M + G::BM - 1) / G::BM, tiles_n = (N + G::BN - 1) / G::BN;
+    dim3 grid(tiles_m * tiles_n), block(G::THREADS);
+    const float scale = inv_temp / H2_LO_SCALE;
+#define LAUNCH_TOPKW(KS)                                                                                           \
+    hipLaunchKernelGGL((gemm_h2w_topk_kernel<G, KS>), grid, block, 0, st, (const _Float16 *)Apacked,                \
+                       (const _Float16 *)Bpacked, M, N, K, scale, tile_max, tile_sum, cand_val, cand_idx, tiles_m, tiles_n)
+    switch (k) {
+        case 1: LAUNCH_TOPKW(1); break;
+        case 2: LAUNCH_TOPKW(2); break;
+        case 3: LAUNCH_TOPKW(3); break;
+        case 4: LAUNCH_TOPKW(4); break;
+        case 5: LAUNCH_TOPKW(5); break;
+        case 6: LAUNCH_TOPKW(6); break;
+        case 7: LAUNCH_TOPKW(7); break;
+        case 8: LAUNCH_TOPKW(8); break;
+        default: CAPDEC_CHECK(false, "gemm_topk: k must be in 1..8");
+    }
+#undef LAUNCH_TOPKW
+    CAPDEC_HIP(hipGetLastError());
     return 0;
 }
 

@@ -762,6 +762,23 @@ def test_unknown_gemm_mode_is_an_error(monkeypatch):
     e.close()
 
 
+@pytest.mark.parametrize("geometry", ["2", "8"], ids=["w256x128", "w128x192"])
+def test_wide_single_accumulator_kernels_against_goldens(geometry):
+    """the round-3 GEMM geometries (gemm_h2w.hip: one accumulator set, 256x128 / 128x192 block tiles, and the fused
+    lm_head on the 256-row tile) are chosen by a planner only where they remove a round of blocks, so most parity
+    tests never reach them: re-run the GEMM-vs-fp64, reference-golden (logits, greedy ids, beams) and batched
+    oracle tests in a child process with CAPDEC_H2W forcing the geometry everywhere"""
+    import os, subprocess, sys
+    env = dict(os.environ, CAPDEC_H2W=geometry)
+    sel = ("test_gemm_packed_a_path or test_gpt2_logits or test_decode_small_vs_reference_golden or "
+           "test_decode_tiny or test_batched_decode_vs_oracle_and_chunking or test_midsize_batches_vs_oracle or "
+           "test_mlp_mapper or test_transformer_mapper")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-m", "gpu", "-k", sel,
+                        "-p", "no:cacheprovider"], env=env, capture_output=True, text=True, timeout=1500)
+    tail = r.stdout[-1500:]
+    assert r.returncode == 0 and " passed" in tail and "failed" not in tail, tail
+
+
 def test_finished_caption_compaction(monkeypatch):
     """captions that stop early leave the batch at the poll points (activation rows are compacted, KV / beam state stay
     in place): with a stop id that fires at staggered steps the results still equal the oracle token for token, the
