@@ -1608,6 +1608,17 @@ int capdec_gpt2_logits(capdec_ctx *c, const float *embeds, int n, int L, int all
     return 0;
 }
 
+int capdec_cross_entropy(capdec_ctx *c, const float *logits, int ld, const int32_t *labels, int rows, int vocab,
+                         int ignore_index, float *loss) {
+    CAPDEC_CHECK(c && loss && (rows == 0 || (logits && labels)), "cross_entropy: null argument");
+    CAPDEC_CHECK(rows >= 0 && vocab > 0 && ld >= vocab, "cross_entropy: bad sizes");
+    CAPDEC_HIP(hipSetDevice(c->device));
+    if (rows == 0) return 0;
+    CAPDEC_TRY(c->xl.ensure((size_t)rows * sizeof(float)));
+    ProfScope ps(c, F_SELECT);
+    return launch_cross_entropy_mean(c->stream, logits, ld, labels, rows, vocab, ignore_index, c->xl.as<float>(), loss);
+}
+
 int capdec_wte_lookup(capdec_ctx *c, const int32_t *ids, int n, float *out) {
     CAPDEC_CHECK(c && c->gpt.loaded, "wte_lookup: GPT-2 weights not loaded");
     CAPDEC_HIP(hipSetDevice(c->device));

@@ -265,6 +265,9 @@ int launch_greedy_step(hipStream_t st, const int *top_idx, int rows, int step, i
                        int *ids, int *lens, uint8_t *done, int *next_tok, int *alive_count,
                        const int *cmap = nullptr, int k = 1, const int *forced = nullptr, const float *top_val = nullptr,
                        const float *lse = nullptr, float *stats = nullptr);
+// mean over the rows with label != ignore_index of logsumexp(logits[row]) - logits[row][label]; nll_ws: rows floats
+int launch_cross_entropy_mean(hipStream_t st, const float *logits, int ld, const int *labels, int rows, int V,
+                              int ignore_index, float *nll_ws, float *out);
 // cmap[0..count) = indices of the captions with done[c] == 0, ascending; *count = how many (one block)
 int launch_compact_alive(hipStream_t st, const uint8_t *done, int ncap, int *cmap, int *count);
 

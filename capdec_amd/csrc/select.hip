@@ -360,4 +360,51 @@ int launch_compact_alive(hipStream_t st, const uint8_t *done, int ncap, int *cma
     return 0;
 }
 
+// ---- token cross-entropy of a logits matrix (the loss of the train step's forward: reference train.py:349 /
+// GPT2LMHeadModel's `labels=`): nll[row] = logsumexp(logits[row]) - logits[row][label[row]], one wavefront per row
+// (max, then sum of exp(x - max): the order torch's log_softmax uses), rows whose label == ignore_index contribute
+// nothing; the mean over the counted rows is taken by ONE block in a fixed order (deterministic).
+__global__ __launch_bounds__(256) void token_nll_kernel(const float *__restrict__ logits, int ld, const int *__restrict__ labels,
+                                                        int rows, int V, int ignore_index, float *__restrict__ nll) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int lab = labels[row];
+    if (lab == ignore_index || lab < 0 || lab >= V) { if (lane == 0) nll[row] = -1.f; return; }     // -1 = not counted
+    const float *x = logits + (size_t)row * ld;
+    float mx = -INFINITY;
+    for (int c = lane; c < V; c += 64) mx = fmaxf(mx, x[c]);
+    mx = wave_max(mx);
+    float se = 0.f;
+    for (int c = lane; c < V; c += 64) se += expf(x[c] - mx);
+    se = wave_sum(se);
+    if (lane == 0) nll[row] = (mx + logf(se)) - x[lab];
+}
+__global__ __launch_bounds__(256) void nll_mean_kernel(const float *__restrict__ nll, int rows, float *__restrict__ out) {
+    __shared__ double part[256];
+    __shared__ int cnt[256];
+    double s = 0.0;
+    int n = 0;
+    for (int r = threadIdx.x; r < rows; r += 256) {
+        const float v = nll[r];
+        if (v >= 0.f || v != v) { s += (double)v; ++n; }          // (a NaN loss must stay visible)
+    }
+    part[threadIdx.x] = s;
+    cnt[threadIdx.x] = n;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) { part[threadIdx.x] += part[threadIdx.x + o]; cnt[threadIdx.x] += cnt[threadIdx.x + o]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[0] = cnt[0] > 0 ? (float)(part[0] / cnt[0]) : nanf("");    // torch: mean over nothing = nan
+}
+int launch_cross_entropy_mean(hipStream_t st, const float *logits, int ld, const int *labels, int rows, int V,
+                              int ignore_index, float *nll_ws, float *out) {
+    if (rows <= 0) return 0;
+    hipLaunchKernelGGL(token_nll_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, logits, ld, labels, rows, V, ignore_index, nll_ws);
+    hipLaunchKernelGGL(nll_mean_kernel, dim3(1), dim3(256), 0, st, nll_ws, rows, out);
+    CAPDEC_HIP(hipGetLastError());
+    return 0;
+}
+
 }  // namespace capdec

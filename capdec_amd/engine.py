@@ -311,6 +311,18 @@ class Engine:
               "capdec_gpt2_logits")
         return out
 
+    def cross_entropy(self, logits: torch.Tensor, labels: torch.Tensor, ignore_index: int = -100) -> torch.Tensor:
+        """mean token cross-entropy of ``logits`` [..., V] against ``labels`` [...] on the device (capdec_cross_entropy);
+        rows with ``labels == ignore_index`` are skipped -- what ``nnf.cross_entropy`` computes at train.py:349"""
+        V = logits.shape[-1]
+        lg = self._dev(logits).reshape(-1, V)
+        lab = self._dev(labels.reshape(-1), torch.int32)
+        out = torch.empty(1, device=self.device, dtype=torch.float32)
+        self._sync_stream()
+        check(self.lib.capdec_cross_entropy(self._h, lg.data_ptr(), V, lab.data_ptr(), lg.shape[0], V, int(ignore_index),
+                                            out.data_ptr()), "capdec_cross_entropy")
+        return out[0]
+
     def wte(self, ids: torch.Tensor) -> torch.Tensor:
         shape = tuple(ids.shape)
         i = self._dev(ids.reshape(-1), torch.int32)

@@ -3,8 +3,9 @@
 
 Same names, constructor arguments and attribute surface (``.clip_project``, ``.gpt``,
 ``.gpt.transformer.wte``, ``.prefix_length``, ``.load_state_dict``, ``.eval``, ``.to``,
-``.parameters``), but the arithmetic runs in libcapdec_hip.so on an MI355X.  The training
-forward/backward (reference :145-155) is out of scope: ``forward`` raises.
+``.parameters``), but the arithmetic runs in libcapdec_hip.so on an MI355X.  ``forward`` is the
+forward pass of the reference's train step (:145-155; train.py:251-260) -- logits and loss, inference
+only: backward and the optimiser are outside this path.
 """
 from __future__ import annotations
 
@@ -203,7 +204,7 @@ class ClipCaptionModel(_HipModule):
         if labels is not None:
             dummy_token = self.get_dummy_token(tokens.shape[0], tokens.device)
             lab = torch.cat((dummy_token, tokens.long()), dim=1)
-            loss = torch.nn.functional.cross_entropy(logits[:, :-1].reshape(-1, logits.shape[-1]), lab[:, 1:].reshape(-1))
+            loss = self.engine.cross_entropy(logits[:, :-1], lab[:, 1:])          # device kernel (capdec_cross_entropy)
         return SimpleNamespace(logits=logits, loss=loss)
 
     def __call__(self, *args, **kwargs):

@@ -237,6 +237,12 @@ int capdec_clip_encode_image(capdec_ctx *ctx, const float *d_pixels, int n, floa
  * materialises); 0 -> d_logits [n, vocab], last position only (what it uses). */
 int capdec_gpt2_logits(capdec_ctx *ctx, const float *d_embeds, int n, int L, int all_positions,
                        float *d_logits);
+/* The loss of the train step's forward (reference train.py:349 `nnf.cross_entropy(logits, tokens, ignore_index=0)`,
+ * and GPT2LMHeadModel's shifted `labels=` loss used by gpt2_prefix.py:154): mean over the rows whose label differs
+ * from ignore_index of logsumexp(d_logits[row, 0..vocab)) - d_logits[row, label].  d_logits: device fp32 [rows, ld],
+ * d_labels: device int32 [rows], d_loss: device fp32 [1] (NaN when no row counts, like torch). */
+int capdec_cross_entropy(capdec_ctx *ctx, const float *d_logits, int ld, const int32_t *d_labels, int rows, int vocab,
+                         int ignore_index, float *d_loss);
 /* `model.gpt.transformer.wte(ids)` (reference gpt2_prefix_eval.py:105,181): d_out [n, d] */
 int capdec_wte_lookup(capdec_ctx *ctx, const int32_t *d_ids, int n, float *d_out);
 

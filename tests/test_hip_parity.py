@@ -351,6 +351,12 @@ def test_train_step_forward_vs_reference_golden(golden, dims, tag):
     # rows without padding: GPT2LMHeadModel's own `labels=` loss is reproduced as well
     full = model(tokens[:1], prefix[:1], mask[:1], labels=tokens[:1])
     assert full.loss is not None and torch.isfinite(full.loss)
+    lab = torch.cat((torch.zeros(1, 10, dtype=torch.int64), tokens[:1].long()), 1)[:, 1:]
+    want = torch.nn.functional.cross_entropy(full.logits[:, :-1].reshape(-1, dims.vocab).cpu(), lab.reshape(-1))
+    assert abs(float(full.loss) - float(want)) < 1e-4
+    # the device cross-entropy is the train loss of train.py:349 (ignore_index = 0) when handed its slice and labels
+    dl = model.engine.cross_entropy(out.logits[:, 9:-1], tokens, ignore_index=0)
+    assert abs(float(dl) - float(g["train_loss"])) < 1e-4
     bad = mask.clone()
     bad[1, 12] = 0                                               # a hole in the middle: not the dataset's mask
     with pytest.raises(CapdecError):
@@ -721,6 +727,32 @@ def test_operand_range_counter_and_nan_propagation():
     assert e.decode_counters()["saturated_quads"] == 0                          # reset by the read
     assert torch.isfinite(out[:3]).all() and torch.isnan(out[3]).all()
     assert abs(float(out[0, 0]) - K) < 1e-3 and abs(float(out[1, 0]) - (65504.0 + K - 1)) < 1.0
+    e.close()
+
+
+def test_activation_range_probe_reports_saturation():
+    """a checkpoint whose activations leave the fp16-plane range of the default GEMM mode must be REPORTED, not silently
+    saturated: the hot-init weights stay far inside the range (counter 0 over a whole decode); the same model with
+    mlp.c_fc blown up by 3e4 drives the GELU output past 65504 and the counter says so; bf16x3 mode (no such limit)
+    counts nothing on the blown-up model"""
+    from capdec_amd.engine import Engine
+    dims = synth.GPT2_TINY
+    sd = synth.hot_gpt2_state_dict(42, dims)
+    g = torch.Generator().manual_seed(8)
+    pe = torch.randn(3, 10, dims.n_embd, generator=g) * 0.3
+    e = Engine(0)
+    e.load_gpt2(sd)
+    e.decode_counters()
+    e.decode_greedy(pe, dims.vocab + 5, 6)
+    assert e.decode_counters()["saturated_quads"] == 0
+    big = {k: (v * 3e4 if k.endswith("mlp.c_fc.weight") else v) for k, v in sd.items()}
+    e.load_gpt2(big)
+    e.decode_greedy(pe, dims.vocab + 5, 6)
+    assert e.decode_counters()["saturated_quads"] > 0
+    e.set_gemm_mode("bf16x3")
+    e.load_gpt2(big)
+    e.decode_greedy(pe, dims.vocab + 5, 6)
+    assert e.decode_counters()["saturated_quads"] == 0
     e.close()
 
 

@@ -186,6 +186,57 @@ def test_state_dict_loading_rules():
         mm.load_state_dict(sd)
 
 
+@pytest.mark.skipif(not os.path.isdir("/root/reference"), reason="needs the reference checkout (build container only)")
+@pytest.mark.parametrize("variant", ["train_mlp", "eval_transformer"])
+def test_loads_checkpoint_written_by_the_reference(tmp_path, variant):
+    """Real-artefact readiness without the artefacts: a checkpoint written the way the reference writes it --
+    instantiate ITS ClipCaptionModel (train.py:246-284 with ``prefix_size`` / gpt2_prefix.py:139-171 with ``prefix_dim``),
+    ``torch.save(model.state_dict(), path)`` (train.py:359-371) -- is read back with ``torch.load(map_location=...)``
+    (predictions_runner.py:461) and loaded STRICT by ``capdec_amd.gpt2_prefix.ClipCaptionModel``: every tensor the
+    reference saved arrives bit for bit, the tied ``gpt.lm_head.weight`` is accepted, and the transformers-4.24 buffers
+    (``attn.bias`` / ``attn.masked_bias``; 5.x no longer writes them) are tolerated when present"""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import gen_golden as G
+    from transformers import GPT2Config, GPT2LMHeadModel
+    from capdec_amd import synth
+    from capdec_amd import gpt2_prefix as ours
+    refs = G.import_reference()
+    ref_gpt2_prefix, ref_train = refs[0], refs[3]
+    dims = synth.GPT2Dims(n_layer=2, vocab=1531, n_pos=128)
+    cfg = GPT2Config(n_layer=dims.n_layer, n_head=dims.n_head, n_embd=dims.n_embd, vocab_size=dims.vocab, n_positions=dims.n_pos)
+    GPT2LMHeadModel.from_pretrained = staticmethod(lambda name, *a, **k: GPT2LMHeadModel(cfg))
+    torch.manual_seed(3)
+    if variant == "train_mlp":
+        ref = ref_train.ClipCaptionModel(10, clip_length=10, prefix_size=512, num_layers=8, mapping_type=ref_train.MappingType.MLP)
+        mine = ours.ClipCaptionModel(10, clip_length=10, prefix_size=512, mapping_type=ours.MappingType.MLP, gpt2_dims=dims)
+    else:
+        ref = ref_gpt2_prefix.ClipCaptionModel(10, clip_length=10, prefix_dim=640, num_layers=3,
+                                               mapping_type=ref_gpt2_prefix.MappingType.TransformerEncoder)
+        mine = ours.ClipCaptionModel(10, clip_length=10, prefix_dim=640, num_layers=3,
+                                     mapping_type=ours.MappingType.TransformerEncoder, gpt2_dims=dims)
+    path = str(tmp_path / "coco_prefix_latest.pt")
+    torch.save(ref.state_dict(), path)                                      # train.py:359-371
+    sd = torch.load(path, map_location=torch.device("cpu"))                 # predictions_runner.py:461
+    assert "gpt.lm_head.weight" in sd or "gpt.transformer.wte.weight" in sd
+    res = mine.load_state_dict(sd)                                          # strict
+    assert res.missing_keys == [] and res.unexpected_keys == []
+    got = mine.state_dict()
+    for k, v in sd.items():
+        assert k in got, k
+        assert torch.equal(got[k], v.float()), k
+    # the same checkpoint as transformers 4.24 (the reference's pin) wrote it: causal-mask buffers in every block
+    sd24 = dict(sd)
+    for i in range(dims.n_layer):
+        sd24[f"gpt.transformer.h.{i}.attn.bias"] = torch.tril(torch.ones(dims.n_pos, dims.n_pos, dtype=torch.uint8)).view(1, 1, dims.n_pos, dims.n_pos)
+        sd24[f"gpt.transformer.h.{i}.attn.masked_bias"] = torch.tensor(-1e4)
+    res = mine.load_state_dict(sd24)
+    assert res.unexpected_keys == []
+    # an fp16 checkpoint (a user's `.half()` export) is upcast; a key the model does not know is refused
+    mine.load_state_dict({k: (v.half() if v.is_floating_point() else v) for k, v in sd.items()})
+    with pytest.raises(RuntimeError):
+        mine.load_state_dict(dict(sd, **{"bridger.0.weight": torch.zeros(2, 2)}))
+
+
 def test_synth_recipe_is_deterministic():
     from capdec_amd import synth
     a = synth.hot_state_dict(42, "mlp", 640, 10, dims=synth.GPT2_TINY)
