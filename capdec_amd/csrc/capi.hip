@@ -325,6 +325,7 @@ static int gemm(capdec_ctx *c, const float *A, int lda, const float *Bt, int ldb
         // whose 16-bit operands are confined to the GPT-2 / CLIP block stacks and the lm_head
         const void *pl = nullptr;
         CAPDEC_TRY(planes_of(c, Bt, N, K, weight, &pl, PK_F16X2, &e.wide_ok));
+        if (c->batch_invariant) e.wide_ok = false;      // (the geometry planner looks at M)
         CAPDEC_TRY(c->a_tmp.ensure(x3_packed_bytes(M, K, PK_F16X2)));
         { ProfScope ps(c, F_PACK); CAPDEC_TRY(launch_pack_planes_h2(c->stream, A, lda, M, K, c->a_tmp.p)); }
         const size_t wsb = c->batch_invariant ? 0 : gemm_splitk_ws_bytes(M, N, K);
@@ -364,6 +365,7 @@ static int gemm_packed(capdec_ctx *c, const void *Apk, const float *W, float *C,
     const void *pl = nullptr;
     GemmEpilogue e;
     CAPDEC_TRY(planes_of(c, W, N, K, true, &pl, -1, &e.wide_ok));
+    if (c->batch_invariant) e.wide_ok = false;          // (the geometry planner looks at M)
     e.bias = bias;
     e.act = act;
     e.resid = resid;
@@ -531,7 +533,7 @@ static int lm_head_select(capdec_ctx *c, const float *h0, int ldh, int R, int k,
             // 256 x 128 tiles with one accumulator set once the grid is many rounds deep (each wte panel is then fetched
             // by half as many row tiles); small row counts keep the 128-row tile (more blocks, the same partial lists)
             static const int lm_wide = [] { const char *e = getenv("CAPDEC_LMHEAD_WIDE"); return e ? atoi(e) : 1; }();
-            if (wide_ok && ((lm_wide && h2w_choice() >= 1 && R >= 2048) || h2w_choice() >= 2))   // (CAPDEC_H2W >= 2: forced, tests)
+            if (wide_ok && !c->batch_invariant && ((lm_wide && h2w_choice() >= 1 && R >= 2048) || h2w_choice() >= 2))   // (CAPDEC_H2W >= 2: forced, tests)
                 CAPDEC_TRY(launch_gemm_h2w_topk(c->stream, c->xpk.p, pl, R, g.vocab, d, k, inv_temp, c->tmax.as<float>(),
                                                 c->tsum.as<float>(), c->cval.as<float>(), c->cidx.as<int>()));
             else

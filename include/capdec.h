@@ -74,12 +74,13 @@ int capdec_set_gemm_mode(capdec_ctx *ctx, int mode);
 int capdec_get_gemm_mode(capdec_ctx *ctx);
 /* Batch-invariant mode (default off; CAPDEC_BATCH_INVARIANT=1 sets it at capdec_create).  By default a few kernels
  * pick a variant from the size of the launch -- split-K for under-filled GEMM grids (the K slices are summed in another
- * order than the unsplit loop), the number of positions the decode attention keeps in flight -- so the fp32 ROUND-OFF
+ * order than the unsplit loop), the block-tile geometry of a GEMM (one or two accumulator sets), the fused lm_head's
+ * tile height, the number of positions the decode attention keeps in flight -- so the fp32 ROUND-OFF
  * of a row depends on how many other rows share its launch: a caption decoded alone, in a 625-caption shard or in a
  * 5000-caption batch can differ in the last bit of a logit, and on a numerical near-tie in a token.  With this mode on,
- * every row goes through the same summation order whatever the batch (unsplit GEMMs, pinned kernel variants): results
- * are bit-identical across batch sizes, chunkings and multi-GPU shardings, at the price of under-filled grids for
- * small batches. */
+ * every row goes through the same summation order whatever the batch (unsplit 128x128 GEMMs, pinned kernel variants):
+ * results are bit-identical across batch sizes, chunkings and multi-GPU shardings, at the price of under-filled grids
+ * for small batches (and they may differ in the last bit from the default mode's). */
 int capdec_set_batch_invariant(capdec_ctx *ctx, int on);
 /* cap on bytes the decode KV cache may take (captions are processed in chunks that fit);
  * 0 = default (192 GiB of the 288 GB HBM3E) */

@@ -675,10 +675,9 @@ def test_large_launch_subset_vs_oracle():
 
 
 def test_batch_invariant_mode_bit_identical_across_batch_sizes():
-    """capdec_set_batch_invariant: no launch-size dependent summation order (no split-K, pinned attention variant), so a
-    caption's ids AND scores are bit-identical whether it is decoded alone, in a 330-caption shard (the mid-size
-    split-K regime by default) or in a 1500-caption batch -- mapper included; and at 1500 captions the default mode
-    already runs those variants (what bench.py's `ids_check` relies on)"""
+    """capdec_set_batch_invariant: no launch-size dependent summation order (no split-K, one GEMM geometry, pinned
+    attention variant), so a caption's ids AND scores are bit-identical whether it is decoded alone, in a 330-caption
+    shard (the mid-size split-K regime by default) or in a 1500-caption batch -- mapper included"""
     from capdec_amd import gpt2_prefix_eval as E
     dims = synth.GPT2_TINY
     model, sd = _model(dims, "transformer_encoder", 512, seed=7, num_layers=2)
@@ -698,8 +697,9 @@ def test_batch_invariant_mode_bit_identical_across_batch_sizes():
         big, small, mid = beams(x), beams(x[:16]), beams(x[100:430])
     finally:
         eng.set_batch_invariant(False)
-    for a, b in zip(big, default_big):
-        assert torch.equal(a, b)
+    # (the default mode may pick other kernel variants: same captions up to fp32 round-off -- near-ties aside)
+    assert float((big[0] == default_big[0]).flatten(1).all(1).float().mean()) > 0.99
+    np.testing.assert_allclose(big[2].cpu().numpy(), default_big[2].cpu().numpy(), atol=2e-5)
     for a, b in zip(big, small):
         assert torch.equal(a[:16], b)
     for a, b in zip(big, mid):
