@@ -65,7 +65,10 @@ __device__ __forceinline__ float att_exp2(float x) { return __builtin_amdgcn_exp
 // trips of the former scores -> LDS -> softmax -> P.V structure), no score ever goes through LDS and there is no
 // block barrier in the loop; the four partial softmaxes are merged once at the end (max / rescale / sum across the
 // groups).  LDS only holds the caption's ancestor-slot table.
-template <int BEAM, typename KV, int OCC, int NA = 2>
+// CUR (round 3): the rows' own K / V are ALREADY in the cache at position L-1 (the qkv GEMM's epilogue wrote them there,
+// QkvScatter): the current token is then just the last cached position (slot = the beam itself) -- no own-token loads
+// from the qkv activations, no append stores, no special first term of the running softmax.
+template <int BEAM, typename KV, int OCC, int NA = 2, bool CUR = false>
 __global__ __launch_bounds__(256, OCC) void attn_decode_beams_kernel(const float *__restrict__ qkv, KV *__restrict__ kc,
                                                                 KV *__restrict__ vc, int total, int heads,
                                                                 int ctx, int d, int L,
@@ -84,13 +87,13 @@ __global__ __launch_bounds__(256, OCC) void attn_decode_beams_kernel(const float
     const size_t hstride = (size_t)ctx * 64;
     const int row0 = cap * BEAM;                                   // activation rows (compact)
     const int srow0 = (cmap ? cmap[cap] : cap) * BEAM;             // state rows: KV cache / ancestor table (original)
-    const int Lpast = L - 1;
+    const int Lpast = CUR ? L : L - 1;                              // cached positions this step attends to
 
     // ancestor slots of this caption -> LDS (removes the dependent byte load in front of every K/V load)
     // (anc == nullptr: greedy decode -- one row per caption, everything in its own slot 0)
     for (int i = lane; i < BEAM * Lpast; i += 64) {
         const int b = i / Lpast, p = i - b * Lpast;
-        sl[b * L + p] = anc ? anc[(size_t)(srow0 + b) * anc_stride + p] : 0;
+        sl[b * L + p] = (CUR && p == L - 1) ? b : (anc ? anc[(size_t)(srow0 + b) * anc_stride + p] : 0);
     }
 
     float4 q[BEAM], acc[BEAM];
@@ -103,6 +106,12 @@ __global__ __launch_bounds__(256, OCC) void attn_decode_beams_kernel(const float
         // v_exp_f32 each (2^x, ~1 ulp) instead of an expf call -- every lane of a 16-lane group evaluates its group's
         // weights, so the exponential is the dominant VALU cost of this kernel
         q[b].x *= ATT_QSCALE; q[b].y *= ATT_QSCALE; q[b].z *= ATT_QSCALE; q[b].w *= ATT_QSCALE;
+        if constexpr (CUR) {
+            mrun[b] = ATT_NEG;
+            lrun[b] = 0.f;
+            acc[b] = make_float4(0.f, 0.f, 0.f, 0.f);
+            continue;
+        }
         // the row's own key / value: appended to the cache at its own slot; group 0 starts its running softmax with it
         const float4 kcur = KvIo<KV>::round4(reinterpret_cast<const float4 *>(qrow + d + head * 64)[sub]);
         const float4 vcur = KvIo<KV>::round4(reinterpret_cast<const float4 *>(qrow + 2 * d + head * 64)[sub]);
@@ -366,7 +375,7 @@ int launch_attn_prefill(hipStream_t st, const float *qkv, const KvCache &c, int 
 template <typename KV>
 static int attn_decode_typed(hipStream_t st, const float *qkv, const KvCache &c, int layer, int rows, int beam, int L,
                              const uint8_t *anc, int anc_stride, float *out, void *packed_out, const int *cmap,
-                             int fmt) {
+                             int fmt, bool cur_cached) {
     KV *kl = c.kp<KV>(layer), *vl = c.vp<KV>(layer);
     {
         const int ncap = rows / beam, total = ncap * c.heads;
@@ -380,13 +389,14 @@ static int attn_decode_typed(hipStream_t st, const float *qkv, const KvCache &c,
         // fewer than two rounds of wavefronts make it latency-bound (625 captions: 66.6 vs 68.7 us); CAPDEC_ATT_NA forces
         static const int na_env = [] { const char *e = getenv("CAPDEC_ATT_NA"); return e ? atoi(e) : 0; }();
         const int na4 = na_env ? (na_env == 4) : (!c.fixed_variant && total <= 16384);
+#define LAUNCH_BEAMS_V(B, OCC, NAV, CURV)                                                                       \
+    hipLaunchKernelGGL((attn_decode_beams_kernel<B, KV, OCC, NAV, CURV>), grid, block, lds, st, qkv, kl, vl, total, c.heads, \
+                       c.ctx, c.heads * c.hd, L, anc, anc_stride, out, (char *)packed_out, cmap, fmt)
 #define LAUNCH_BEAMS(B, OCC)                                                                                    \
-    if (na4 && B <= 5)                                                                                          \
-        hipLaunchKernelGGL((attn_decode_beams_kernel<B, KV, OCC, 4>), grid, block, lds, st, qkv, kl, vl, total, c.heads, \
-                           c.ctx, c.heads * c.hd, L, anc, anc_stride, out, (char *)packed_out, cmap, fmt);       \
-    else                                                                                                        \
-        hipLaunchKernelGGL((attn_decode_beams_kernel<B, KV, OCC>), grid, block, lds, st, qkv, kl, vl, total, c.heads, \
-                           c.ctx, c.heads * c.hd, L, anc, anc_stride, out, (char *)packed_out, cmap, fmt)
+    if (cur_cached && (B == 1 || B == 5)) {       /* (the widths the decode drivers use most: greedy and beam 5) */ \
+        if (na4) LAUNCH_BEAMS_V(B, OCC, 4, true); else LAUNCH_BEAMS_V(B, OCC, 2, true);                          \
+    } else if (na4 && B <= 5) LAUNCH_BEAMS_V(B, OCC, 4, false);                                                 \
+    else LAUNCH_BEAMS_V(B, OCC, 2, false)
         switch (beam) {
             case 1: LAUNCH_BEAMS(1, 4); break;      // greedy: the same single-pass kernel with one row per caption
             case 2: LAUNCH_BEAMS(2, 4); break;
@@ -399,17 +409,20 @@ static int attn_decode_typed(hipStream_t st, const float *qkv, const KvCache &c,
             default: CAPDEC_CHECK(false, "attention: beam must be in 1..8");
         }
 #undef LAUNCH_BEAMS
+#undef LAUNCH_BEAMS_V
         CAPDEC_HIP(hipGetLastError());
         return 0;
     }
 }
 
 int launch_attn_decode(hipStream_t st, const float *qkv, const KvCache &c, int layer, int rows, int beam, int L,
-                       const uint8_t *anc, int anc_stride, float *out, void *packed_out, const int *cmap, int fmt) {
+                       const uint8_t *anc, int anc_stride, float *out, void *packed_out, const int *cmap, int fmt,
+                       bool cur_cached) {
     CAPDEC_CHECK(c.hd == 64, "attention: head_dim must be 64");
     CAPDEC_CHECK(L >= 1 && L <= ATT_CTX_MAX && L <= c.ctx, "attention: context length out of range");
-    return c.bf16 ? attn_decode_typed<__bf16>(st, qkv, c, layer, rows, beam, L, anc, anc_stride, out, packed_out, cmap, fmt)
-                  : attn_decode_typed<float>(st, qkv, c, layer, rows, beam, L, anc, anc_stride, out, packed_out, cmap, fmt);
+    CAPDEC_CHECK(!cur_cached || (!c.bf16 && (beam == 1 || beam == 5)), "attention: cur_cached needs an fp32 cache and beam 1 or 5");
+    return c.bf16 ? attn_decode_typed<__bf16>(st, qkv, c, layer, rows, beam, L, anc, anc_stride, out, packed_out, cmap, fmt, false)
+                  : attn_decode_typed<float>(st, qkv, c, layer, rows, beam, L, anc, anc_stride, out, packed_out, cmap, fmt, cur_cached);
 }
 
 // ---------------------------------------------------------------------------------------------

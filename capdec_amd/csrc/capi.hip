@@ -361,9 +361,11 @@ static bool use_packed_a(capdec_ctx *c, int K) {
 struct NextLn { const float *w, *b; float eps; int *done; };
 static int gemm_packed(capdec_ctx *c, const void *Apk, const float *W, float *C, int ldc, int M, int N, int K,
                        const float *bias, int act, const float *resid = nullptr, int ldr = 0,
-                       void *packed_out = nullptr, const NextLn *next_ln = nullptr, const void *resid_packed = nullptr) {
+                       void *packed_out = nullptr, const NextLn *next_ln = nullptr, const void *resid_packed = nullptr,
+                       const QkvScatter *qkv_scatter = nullptr) {
     const void *pl = nullptr;
     GemmEpilogue e;
+    e.qkv_scatter = qkv_scatter;
     CAPDEC_TRY(planes_of(c, W, N, K, true, &pl, -1, &e.wide_ok));
     if (c->batch_invariant) e.wide_ok = false;          // (the geometry planner looks at M)
     e.bias = bias;
@@ -378,7 +380,7 @@ static int gemm_packed(capdec_ctx *c, const void *Apk, const float *W, float *C,
     }
     if (c->gemm_mode != GEMM_F32) {
         static const bool x1_split = [] { const char *e = getenv("CAPDEC_X1_SPLITK"); return !(e && atoi(e) == 0); }();
-        const size_t wsb = ((mode_single(c) && !x1_split) || c->batch_invariant) ? 0 : gemm_splitk_ws_bytes(M, N, K);
+        const size_t wsb = ((mode_single(c) && !x1_split) || c->batch_invariant || qkv_scatter) ? 0 : gemm_splitk_ws_bytes(M, N, K);
         if (wsb) {
             CAPDEC_TRY(c->splitk.ensure(wsb));
             e.splitk_ws = c->splitk.p;
@@ -400,13 +402,13 @@ static int gemm_packed(capdec_ctx *c, const void *Apk, const float *W, float *C,
 // (ln_ready: c->xpk already holds LayerNorm(h) -- written by the fused split-K reduce of the previous GEMM)
 static int ln_gemm_packed(capdec_ctx *c, const float *h, int ldh, const float *lnw, const float *lnb, float eps,
                           const float *W, float *C, int ldc, int M, int N, int K, const float *bias, int act,
-                          void *packed_out = nullptr, bool ln_ready = false) {
+                          void *packed_out = nullptr, bool ln_ready = false, const QkvScatter *qkv_scatter = nullptr) {
     CAPDEC_TRY(c->xpk.ensure(x3_packed_bytes_host(M, K)));
     if (!ln_ready) {
         ProfScope ps(c, F_LN);
         CAPDEC_TRY(launch_layernorm_packed(c->stream, h, ldh, lnw, lnb, eps, c->xpk.p, M, K, pack_fmt(c)));
     }
-    return gemm_packed(c, c->xpk.p, W, C, ldc, M, N, K, bias, act, nullptr, 0, packed_out);
+    return gemm_packed(c, c->xpk.p, W, C, ldc, M, N, K, bias, act, nullptr, 0, packed_out, nullptr, nullptr, qkv_scatter);
 }
 
 // ---------------------------------------------------------------------------- GPT-2 body
@@ -446,6 +448,7 @@ static int stack_body(capdec_ctx *c, const StackCfg &g, const StepShape &s, cons
     // [packed] -> fc GEMM + act -> [packed] -> mlp c_proj (+h): every GEMM operand moves by LDS-DMA, and the
     // attention / MLP intermediates never exist in fp32 in HBM.
     const bool chain = use_packed_a(c, d) && c->pack_chain;
+    static const bool kv_direct = [] { const char *e = getenv("CAPDEC_KV_DIRECT"); return !(e && atoi(e) == 0); }();
     void *apk = nullptr, *fpk = nullptr;
     if (chain) {
         CAPDEC_TRY(c->apk.ensure(x3_packed_bytes_host(M, d)));
@@ -457,9 +460,19 @@ static int stack_body(capdec_ctx *c, const StackCfg &g, const StepShape &s, cons
     for (int l = 0; l < g.n_layer; ++l) {
         const Gpt2Layer &w = (*g.layers)[l];
         const int kl = g.keep_kv ? l : 0;
+        // decode steps in the default mode: K / V of the new token go from the qkv GEMM's epilogue straight into the cache
+        // (QkvScatter) when that GEMM runs unsplit -- the attention then reads them like any other position
+        QkvScatter sc;
+        const bool scatter = kv_direct && !s.prefill && g.keep_kv && c->gemm_mode == GEMM_F16X2 && !kv.bf16 && w.bqkv &&
+                             d % GEMM_BN == 0 && (s.beam == 1 || s.beam == 5) &&
+                             (c->batch_invariant || gemm_splitk_slices(M, 3 * d, d) == 1);
+        if (scatter) {
+            sc.kc = kv.kp<float>(kl); sc.vc = kv.vp<float>(kl); sc.cmap = s.cmap;
+            sc.beam = s.beam; sc.heads = kv.heads; sc.ctx = kv.ctx; sc.pos = s.L - 1; sc.d = d;
+        }
         if (use_packed_a(c, d)) {
             CAPDEC_TRY(ln_gemm_packed(c, h, d, w.ln1w, w.ln1b, g.eps, w.wqkv, qkv, 3 * d, M, 3 * d, d, w.bqkv, CAPDEC_ACT_NONE,
-                                      nullptr, ln1_ready != 0));
+                                      nullptr, ln1_ready != 0, scatter ? &sc : nullptr));
             ln1_ready = 0;
         } else {
             { ProfScope ps(c, F_LN); CAPDEC_TRY(launch_layernorm(c->stream, h, d, w.ln1w, w.ln1b, g.eps, x, d, M, d)); }
@@ -472,7 +485,8 @@ static int stack_body(capdec_ctx *c, const StackCfg &g, const StepShape &s, cons
             CAPDEC_TRY(launch_attn_prefill(c->stream, qkv, kv, kl, s.ncap, s.P, s.beam, att, g.causal, apk, pack_fmt(c)));
         } else {
             ProfScope ps(c, F_ATTN_DEC);
-            CAPDEC_TRY(launch_attn_decode(c->stream, qkv, kv, kl, s.rows, s.beam, s.L, s.anc, s.anc_stride, att, apk, s.cmap, pack_fmt(c)));
+            CAPDEC_TRY(launch_attn_decode(c->stream, qkv, kv, kl, s.rows, s.beam, s.L, s.anc, s.anc_stride, att, apk, s.cmap, pack_fmt(c),
+                                          scatter));
         }
         int ln2_ready = 0;
         if (chain) {

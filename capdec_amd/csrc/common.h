@@ -84,6 +84,17 @@ __device__ __forceinline__ float wave_max(float v) {
 constexpr int GEMM_BM = 128, GEMM_BN = 128, GEMM_BK = 32;
 constexpr int TOPK_MAX = 8;
 
+// Decode-step qkv projection (f16x2 mode, fp32 KV cache): the K and V thirds of the result go STRAIGHT into the KV cache
+// at the position being decoded -- activation row r (caption cmap[r / beam] after compaction) -> cache row
+// caption * beam + r % beam, [head][pos][64] -- instead of into the qkv activation buffer, so the attention kernel
+// neither re-writes them (154 MB per layer-step at 25 000 rows) nor treats the current token apart: it is simply the
+// last cached position.  The q third still goes to C.
+struct QkvScatter {
+    float *kc = nullptr, *vc = nullptr;     // this layer's K / V cache (fp32)
+    const int *cmap = nullptr;
+    int beam = 1, heads = 0, ctx = 0, pos = 0, d = 0;
+};
+
 // gemm_f32.hip
 struct GemmEpilogue {
     const float *bias = nullptr;   // [N]
@@ -94,6 +105,7 @@ struct GemmEpilogue {
     size_t splitk_ws_bytes = 0;    // under-filled grids run unsplit
     void *packed_out = nullptr;    // bf16x3p only: write act(acc + bias) as the packed split-bf16 A operand (K = N)
                                    // of the next GEMM instead of fp32 C
+    const QkvScatter *qkv_scatter = nullptr;   // f16x2p, unsplit grids only (see QkvScatter)
     bool wide_ok = false;          // f16x2p only: the B operand is a weight with max |w| < 16, so its high plane can be scaled
                                    // by 2^11 in fp16 registers (the single-accumulator kernels of gemm_h2w.hip)
     const void *resid_packed = nullptr;   // f16x2p / x1 with packed_out only: residual [M, N] stored as a packed operand of
@@ -229,7 +241,9 @@ int launch_attn_prefill(hipStream_t st, const float *qkv, const KvCache &c, int 
 // at phys row r), positions p < L-1 from phys row caption*beam + anc[r][p] (anc == nullptr -> r itself)
 int launch_attn_decode(hipStream_t st, const float *qkv, const KvCache &c, int layer, int rows, int beam, int L,
                        const uint8_t *anc, int anc_stride, float *out, void *packed_out = nullptr,
-                       const int *cmap = nullptr, int fmt = 0);
+                       const int *cmap = nullptr, int fmt = 0, bool cur_cached = false);
+// (cur_cached: the rows' own K / V are already in the cache at position L-1 -- written by the qkv GEMM's epilogue,
+//  QkvScatter -- so the kernel neither reads them from `qkv` nor appends them)
 // (cmap != nullptr: finished captions were compacted away -- activation row r belongs to caption cmap[r / beam];
 //  KV cache, ancestor table and beam state stay indexed by the original caption)
 // (packed_out != nullptr: the attention rows are written as the packed split-bf16 A operand of c_proj, K = d,

@@ -287,7 +287,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f16x2p_kernel(const _Float16 *__r
                                                              const _Float16 *__restrict__ Bpk, float *C, int ldc, int M,
                                                              int N, int K, const float *__restrict__ bias,
                                                              const float *resid, int ldr, int act, int tiles_m,
-                                                             int tiles_n, char *packed_out) {
+                                                             int tiles_n, char *packed_out, QkvScatter sc) {
     __shared__ __attribute__((aligned(16))) char smem[NS * H2_STAGE_B];
     // Persistent form: the launch has min(tiles, 512) blocks (two per CU) and block b walks tiles b, b + grid, ...  The
     // hardware hands the blocks of a launch out breadth-first (one per CU, then the second slots), so the tiles of a
@@ -304,6 +304,8 @@ __global__ __launch_bounds__(256, 2) void gemm_f16x2p_kernel(const _Float16 *__r
         if (packed_out)
             epilogue_store_packed_t(am, packed_out, N >> 4, M, N, tm * GEMM_BM, tn * GEMM_BN, bias, act, PK_F16X2,
                                     reinterpret_cast<const char *>(resid));  // (with packed_out, `resid` is a PACKED residual)
+        else if (VEC4 && sc.kc && tn * GEMM_BN >= sc.d)                      // K / V third of a decode-step qkv projection
+            epilogue_store_kv_t(am, M, tm * GEMM_BM, tn * GEMM_BN, bias, sc);
         else
             epilogue_store_t<VEC4>(am, C, ldc, M, N, tm * GEMM_BM, tn * GEMM_BN, bias, resid, ldr, act);
     }
@@ -355,6 +357,10 @@ int launch_gemm_f16x2p(hipStream_t st, const void *Apacked, const void *Bpacked,
                       (epi.resid == nullptr || (epi.ldr % 4 == 0 && ((uintptr_t)epi.resid & 15) == 0));
     CAPDEC_CHECK(epi.resid_packed == nullptr || epi.packed_out != nullptr, "gemm_f16x2p: a packed residual needs a packed output");
     const float *resid_arg = epi.packed_out ? (const float *)epi.resid_packed : epi.resid;
+    const QkvScatter sc = epi.qkv_scatter ? *epi.qkv_scatter : QkvScatter();
+    CAPDEC_CHECK(!sc.kc || (vec4 && epi.bias && !epi.resid && !epi.packed_out && epi.act == CAPDEC_ACT_NONE && N == 3 * sc.d &&
+                            sc.d % GEMM_BN == 0 && !epi.splitk_ws),
+                 "gemm_f16x2p: the qkv scatter epilogue needs an unsplit, biased, plain [M, 3d] projection");
     const int S = (vec4 && epi.splitk_ws && !epi.resid_packed) ? gemm_splitk_slices(M, N, K) : 1;
     if (S > 1 && epi.splitk_ws_bytes >= (size_t)S * M * N * sizeof(float)) {
         float *part = (float *)epi.splitk_ws;
@@ -366,7 +372,7 @@ int launch_gemm_f16x2p(hipStream_t st, const void *Apacked, const void *Bpacked,
     // persistent form for grids of up to four rounds, where the partly filled last round matters (625 captions: mlp.c_fc
     // 600 tiles, 80 -> 70 us inside the decode loop); larger grids keep one block per tile (the dispatcher balances them:
     // within noise either way at 25 000 rows).  CAPDEC_H2_PERSIST=<blocks> (0 = never)
-    if (vec4 && epi.wide_ok && h2w_choice() >= 1) {      // round-3 single-accumulator geometries where they remove a round
+    if (vec4 && epi.wide_ok && h2w_choice() >= 1 && !sc.kc) {      // round-3 single-accumulator geometries where they remove a round
         const int which = h2w_choice() >= 2 ? h2w_choice() : h2w_plan(M, N, K);
         if (which) return launch_gemm_h2w(st, which, Apacked, Bpacked, C, ldc, M, N, K, epi, 1.0f / H2_LO_SCALE);
     }
@@ -375,14 +381,14 @@ int launch_gemm_f16x2p(hipStream_t st, const void *Apacked, const void *Bpacked,
 #define LAUNCH_H2(V4, NSV)                                                                                            \
     hipLaunchKernelGGL((gemm_f16x2p_kernel<V4, NSV>), dim3(grid_h2), dim3(256), 0, st, (const _Float16 *)Apacked, \
                        (const _Float16 *)Bpacked, C, ldc, M, N, K, epi.bias, resid_arg, epi.ldr, epi.act, tiles_m,      \
-                       tiles_n, (char *)epi.packed_out)
+                       tiles_n, (char *)epi.packed_out, sc)
     const int ns = h2_ns();
     static const int abl = [] { const char *e = getenv("CAPDEC_H2_ABL"); return e ? atoi(e) : 0; }();
     if (vec4 && abl >= 1 && abl <= 6) {     // measurement only
 #define LAUNCH_H2A(A)                                                                                               \
     hipLaunchKernelGGL((gemm_f16x2p_kernel<true, H2_NS, A>), dim3(tiles_m * tiles_n), dim3(256), 0, st,               \
                        (const _Float16 *)Apacked, (const _Float16 *)Bpacked, C, ldc, M, N, K, epi.bias, epi.resid,   \
-                       epi.ldr, epi.act, tiles_m, tiles_n, (char *)epi.packed_out)
+                       epi.ldr, epi.act, tiles_m, tiles_n, (char *)epi.packed_out, sc)
         if (abl == 1) LAUNCH_H2A(1); else if (abl == 2) LAUNCH_H2A(2); else if (abl == 3) LAUNCH_H2A(3);
         else if (abl == 4) LAUNCH_H2A(4); else if (abl == 5) LAUNCH_H2A(5); else LAUNCH_H2A(6);
 #undef LAUNCH_H2A

@@ -794,14 +794,16 @@ def test_unknown_gemm_mode_is_an_error(monkeypatch):
     e.close()
 
 
-@pytest.mark.parametrize("geometry", ["2", "8"], ids=["w256x128", "w128x192"])
+@pytest.mark.parametrize("geometry", ["2", "8", "invariant"], ids=["w256x128", "w128x192", "batch_invariant"])
 def test_wide_single_accumulator_kernels_against_goldens(geometry):
     """the round-3 GEMM geometries (gemm_h2w.hip: one accumulator set, 256x128 / 128x192 block tiles, and the fused
     lm_head on the 256-row tile) are chosen by a planner only where they remove a round of blocks, so most parity
     tests never reach them: re-run the GEMM-vs-fp64, reference-golden (logits, greedy ids, beams) and batched
     oracle tests in a child process with CAPDEC_H2W forcing the geometry everywhere"""
     import os, subprocess, sys
-    env = dict(os.environ, CAPDEC_H2W=geometry)
+    # ("invariant": the same tests with CAPDEC_BATCH_INVARIANT=1 -- unsplit 128x128 GEMMs at every size, which also puts
+    #  the small reference goldens on the decode path of the big batches: K / V written by the qkv GEMM's epilogue)
+    env = dict(os.environ, CAPDEC_BATCH_INVARIANT="1") if geometry == "invariant" else dict(os.environ, CAPDEC_H2W=geometry)
     sel = ("test_gemm_packed_a_path or test_gpt2_logits or test_decode_small_vs_reference_golden or "
            "test_decode_tiny or test_batched_decode_vs_oracle_and_chunking or test_midsize_batches_vs_oracle or "
            "test_mlp_mapper or test_transformer_mapper")
