@@ -75,7 +75,7 @@ __global__ __launch_bounds__(256, OCC) void attn_decode_beams_kernel(const float
                                                                 const uint8_t *__restrict__ anc, int anc_stride,
                                                                 float *__restrict__ out,
                                                                 char *__restrict__ packed_out,
-                                                                const int *__restrict__ cmap, int fmt) {
+                                                                const int *__restrict__ cmap, int fmt, int npre) {
     extern __shared__ __attribute__((aligned(16))) int sl_all[];      // [4 waves][BEAM][L] ancestor slots
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int grp = lane >> 4, sub = lane & 15;
@@ -89,6 +89,22 @@ __global__ __launch_bounds__(256, OCC) void attn_decode_beams_kernel(const float
     const int srow0 = (cmap ? cmap[cap] : cap) * BEAM;             // state rows: KV cache / ancestor table (original)
     const int Lpast = CUR ? L : L - 1;                              // cached positions this step attends to
 
+    // The first `npre` positions (the CLIP prefix) live in slot 0 for every beam whatever the ancestor table says: their
+    // K / V loads are issued FIRST, so they fly together with the table's and the q rows' loads instead of one memory
+    // round trip behind them (a wavefront lives for ~25 us; the round trip is ~1-2 of them)
+    const int npe = min(4 * NA, (min(npre, Lpast) >> 2) << 2);     // positions [0, npe) are peeled off phase A
+    float4 kk0[NA], vv0[NA];
+    {
+        const KV *kb0 = kc + ((size_t)srow0 * heads + head) * hstride + sub * 4;
+        const KV *vb0 = vc + ((size_t)srow0 * heads + head) * hstride + sub * 4;
+#pragma unroll
+        for (int j = 0; j < NA; ++j) {
+            const int pj = 4 * j + grp;
+            const bool v = active && pj < npe;
+            kk0[j] = KvIo<KV>::ld4(v ? kb0 + pj * 64 : kb0);
+            vv0[j] = KvIo<KV>::ld4(v ? vb0 + pj * 64 : kb0);
+        }
+    }
     // ancestor slots of this caption -> LDS (removes the dependent byte load in front of every K/V load)
     // (anc == nullptr: greedy decode -- one row per caption, everything in its own slot 0)
     for (int i = lane; i < BEAM * Lpast; i += 64) {
@@ -161,7 +177,19 @@ __global__ __launch_bounds__(256, OCC) void attn_decode_beams_kernel(const float
         mrun[b] = mx_; lrun[b] = ls_; acc[b] = a_;                                                       \
     }
     // ---- phase A: converged prefix, NA positions per group per iteration: NA K + NA V loads in flight per lane
-    for (int p0 = 0; p0 < nconv; p0 += 4 * NA) {
+    if (npe > 0) {                                                 // the peeled positions: loaded before the table arrived
+#pragma unroll
+        for (int b = 0; b < BEAM; ++b) {
+            float sv[NA];
+#pragma unroll
+            for (int j = 0; j < NA; ++j) {
+                const float t = group16_sum(dot4(q[b], kk0[j]));
+                sv[j] = 4 * j + grp < npe ? t : -INFINITY;
+            }
+            ATT_UPDATE(b, NA, sv, vv0)
+        }
+    }
+    for (int p0 = npe; p0 < nconv; p0 += 4 * NA) {
         int pp[NA];
         float4 kk[NA], vv[NA];
 #pragma unroll
@@ -377,6 +405,10 @@ static int attn_decode_typed(hipStream_t st, const float *qkv, const KvCache &c,
                              const uint8_t *anc, int anc_stride, float *out, void *packed_out, const int *cmap,
                              int fmt, bool cur_cached) {
     KV *kl = c.kp<KV>(layer), *vl = c.vp<KV>(layer);
+    // positions known to sit in slot 0 whatever the table says: the whole history for greedy rows, the CLIP prefix for
+    // beams (c.prefix_len; 0 = unknown)
+    static const int pre_on = [] { const char *e = getenv("CAPDEC_ATT_PRELOAD"); return e ? atoi(e) : 1; }();
+    const int npre = !pre_on ? 0 : (anc == nullptr ? L : c.prefix_len);
     {
         const int ncap = rows / beam, total = ncap * c.heads;
         if (total <= 0) return 0;
@@ -391,7 +423,7 @@ static int attn_decode_typed(hipStream_t st, const float *qkv, const KvCache &c,
         const int na4 = na_env ? (na_env == 4) : (!c.fixed_variant && total <= 16384);
 #define LAUNCH_BEAMS_V(B, OCC, NAV, CURV)                                                                       \
     hipLaunchKernelGGL((attn_decode_beams_kernel<B, KV, OCC, NAV, CURV>), grid, block, lds, st, qkv, kl, vl, total, c.heads, \
-                       c.ctx, c.heads * c.hd, L, anc, anc_stride, out, (char *)packed_out, cmap, fmt)
+                       c.ctx, c.heads * c.hd, L, anc, anc_stride, out, (char *)packed_out, cmap, fmt, npre)
 #define LAUNCH_BEAMS(B, OCC)                                                                                    \
     if (cur_cached && (B == 1 || B == 5)) {       /* (the widths the decode drivers use most: greedy and beam 5) */ \
         if (na4) LAUNCH_BEAMS_V(B, OCC, 4, true); else LAUNCH_BEAMS_V(B, OCC, 2, true);                          \

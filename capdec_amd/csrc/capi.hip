@@ -647,6 +647,7 @@ static int decode_chunk(capdec_ctx *c, const float *prefix, int nc, int P, int b
     KvCache kv;
     CAPDEC_TRY(ensure_kv(c, kv, rows, ctx));
     kv.fixed_variant = c->batch_invariant;
+    kv.prefix_len = P;
     CAPDEC_TRY(ensure_body_ws(c, std::max(nc * P, rows), d));
     CAPDEC_TRY(c->next_tok.ensure((size_t)rows * 4));
     CAPDEC_TRY(c->alive.ensure(sizeof(int)));

@@ -225,6 +225,7 @@ struct KvCache {
     void *v = nullptr;
     int rows = 0, heads = 0, ctx = 0, hd = 0;
     bool bf16 = false;
+    int prefix_len = 0;           // decode: positions [0, prefix_len) of every row live in slot 0 (the CLIP prefix)
     bool fixed_variant = false;   // batch-invariant mode: the launch-size dependent kernel variants are pinned
     size_t layer_stride() const { return (size_t)rows * heads * ctx * hd; }      // elements
     size_t elem_bytes() const { return bf16 ? 2 : 4; }
