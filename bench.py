@@ -39,7 +39,7 @@ from capdec_amd import synth  # noqa: E402
 PEAK_F32_MFMA_TFLOPS = 157.3    # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 PEAK_BF16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA (not the 2:1-sparse marketing figure)
 STOP_ID, D_EMB = 13, 768
-PMC_TRAFFIC_FILE = "r2_pmc_traffic.json"   # rocprofv3 --pmc summary the `roofline.traffic` field is read from
+PMC_TRAFFIC_FILE = "r3_pmc_traffic.json"   # rocprofv3 --pmc summary the `roofline.traffic` field is read from
 
 
 def algorithmic_flops_per_caption(P, T, beam, mapper, dims=synth.GPT2_SMALL, D=512, clip_len=10):
