@@ -44,10 +44,11 @@ for h in ("0", "2"):
         acc = collections.defaultdict(lambda: collections.defaultdict(lambda: [0, 0.0]))
         for p in glob.glob(f"{out}/{tag}_pmc_sq_{h}_{data}/**/*counter_collection.csv", recursive=True):
             for row in csv.DictReader(open(p, newline="")):
-                k = row["Kernel_Name"].split("(")[0][-60:]
+                k = row["Kernel_Name"].split("(")[0]
+                if "gemm" not in k: continue                 # (rocprofv3 leaves template kernels mangled)
+                k = k[:72]
                 a = acc[k][row["Counter_Name"]]; a[0] += 1; a[1] += float(row["Counter_Value"])
         for k, cs in acc.items():
-            if "mm_" not in k: continue                      # (rocprofv3 leaves template kernels mangled; the name is cut to 60 chars)
             print(f"h2w={h} data={data} {k}")
             for c, (n, s) in sorted(cs.items()):
                 print(f"   {c:36s} n={n:4d} avg={s/n:16.1f}")
@@ -56,9 +57,9 @@ for h in ("0", "2"):
         for p in glob.glob(f"{out}/{tag}_pmc_sq_{h}_{data}/**/*kernel_trace.csv", recursive=True):
             dur = collections.defaultdict(list)
             for row in csv.DictReader(open(p, newline="")):
-                dur[row["Kernel_Name"].split("(")[0][-60:]].append(int(row["End_Timestamp"]) - int(row["Start_Timestamp"]))
+                dur[row["Kernel_Name"].split("(")[0][:72]].append(int(row["End_Timestamp"]) - int(row["Start_Timestamp"]))
             for k, v in dur.items():
-                if "mm_" in k: print("   duration_ns", k, "n=%d avg=%.0f min=%d" % (len(v), sum(v) / len(v), min(v)))
+                if "gemm" in k: print("   duration_ns", k, "n=%d avg=%.0f min=%d" % (len(v), sum(v) / len(v), min(v)))
 PY
 find "$OUT" -name "*counter_collection.csv" -delete
 find "$OUT" -name "*kernel_trace.csv" -delete
