@@ -806,7 +806,7 @@ def test_wide_single_accumulator_kernels_against_goldens(geometry):
     env = dict(os.environ, CAPDEC_BATCH_INVARIANT="1") if geometry == "invariant" else dict(os.environ, CAPDEC_H2W=geometry)
     sel = ("test_gemm_packed_a_path or test_gpt2_logits or test_decode_small_vs_reference_golden or "
            "test_decode_tiny or test_batched_decode_vs_oracle_and_chunking or test_midsize_batches_vs_oracle or "
-           "test_mlp_mapper or test_transformer_mapper")
+           "test_mlp_mapper or test_transformer_mapper or test_finished_caption_compaction or test_prompt_and_tokens")
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-m", "gpu", "-k", sel,
                         "-p", "no:cacheprovider"], env=env, capture_output=True, text=True, timeout=1500)
     tail = r.stdout[-1500:]
