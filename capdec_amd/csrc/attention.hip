@@ -68,15 +68,22 @@ __device__ __forceinline__ float att_exp2(float x) { return __builtin_amdgcn_exp
 // CUR (round 3): the rows' own K / V are ALREADY in the cache at position L-1 (the qkv GEMM's epilogue wrote them there,
 // QkvScatter): the current token is then just the last cached position (slot = the beam itself) -- no own-token loads
 // from the qkv activations, no append stores, no special first term of the running softmax.
-template <int BEAM, typename KV, int OCC, int NA = 2, bool CUR = false>
+// DMA (round 3, fp32 cache): the converged prefix is streamed through a per-wavefront LDS double buffer by LDS-DMA
+// (global_load_lds: no destination registers), so the K / V of the NEXT 4 NA positions are in flight while the current
+// ones are reduced -- the register-landed loop has one iteration's loads in flight only while it waits for them, and
+// the converged case is latency-bound (5.4 TB/s; the diverged tail with its 2 BEAM loads per lane reaches 5.8-6.2).
+// Every lane reads back exactly the 16 bytes it asked for (LDS image = lane order): the LDS is a landing buffer, not a
+// sharing stage -- each key / value is still used by one wavefront only.
+template <int BEAM, typename KV, int OCC, int NA = 2, bool CUR = false, bool DMA = false>
 __global__ __launch_bounds__(256, OCC) void attn_decode_beams_kernel(const float *__restrict__ qkv, KV *__restrict__ kc,
                                                                 KV *__restrict__ vc, int total, int heads,
                                                                 int ctx, int d, int L,
                                                                 const uint8_t *__restrict__ anc, int anc_stride,
                                                                 float *__restrict__ out,
                                                                 char *__restrict__ packed_out,
-                                                                const int *__restrict__ cmap, int fmt, int npre) {
-    extern __shared__ __attribute__((aligned(16))) int sl_all[];      // [4 waves][BEAM][L] ancestor slots
+                                                                const int *__restrict__ cmap, int fmt, int npre,
+                                                                int ring_off) {
+    extern __shared__ __attribute__((aligned(16))) int sl_all[];      // [4 waves][BEAM][L] ancestor slots (+ DMA ring at ring_off)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int grp = lane >> 4, sub = lane & 15;
     const int gw = blockIdx.x * 4 + wave;
@@ -189,6 +196,63 @@ __global__ __launch_bounds__(256, OCC) void attn_decode_beams_kernel(const float
             ATT_UPDATE(b, NA, sv, vv0)
         }
     }
+    if constexpr (DMA) {
+        typedef __attribute__((address_space(3))) void lds_void_a;
+        typedef const __attribute__((address_space(1))) void glb_void_a;
+        constexpr int BUF = 2 * NA * 1024;                        // one iteration: NA K pieces + NA V pieces of 1 KB
+        char *ring = reinterpret_cast<char *>(sl_all) + ring_off + __builtin_amdgcn_readfirstlane(wave) * (2 * BUF);
+        const int n_it = (nconv - npe + 4 * NA - 1) / (4 * NA);
+#define ATT_ISSUE(it_)                                                                                          \
+        {                                                                                                       \
+            char *dst = ring + ((it_) & 1) * BUF;                                                               \
+            _Pragma("unroll") for (int j = 0; j < NA; ++j) {                                                    \
+                const int pj = npe + (it_) * 4 * NA + 4 * j + grp;                                              \
+                const bool v = pj < nconv;                                                                      \
+                const int o = v ? sl[pj] * slot_stride + pj * 64 : 0;                                           \
+                __builtin_amdgcn_global_load_lds((glb_void_a *)(v ? kbase + o : dummy), (lds_void_a *)(dst + j * 1024), 16, 0, 0);             \
+                __builtin_amdgcn_global_load_lds((glb_void_a *)(v ? vbase + o : dummy), (lds_void_a *)(dst + (NA + j) * 1024), 16, 0, 0);      \
+            }                                                                                                   \
+        }
+        if (n_it > 0) ATT_ISSUE(0)
+        for (int it = 0; it < n_it; ++it) {
+            if (it + 1 < n_it) {
+                ATT_ISSUE(it + 1)
+                asm volatile("" ::: "memory");
+                __builtin_amdgcn_s_waitcnt(0x0F70 | (2 * NA));    // vmcnt(2 NA): this iteration's pieces have landed
+            } else {
+                asm volatile("" ::: "memory");
+                __builtin_amdgcn_s_waitcnt(0x0F70);               // vmcnt(0)
+            }
+            asm volatile("" ::: "memory");
+            // the landed pieces come back through inline-asm ds_reads: for a compiler-visible LDS load hipcc's waitcnt
+            // pass cannot tell which LDS-DMA it may alias and waits vmcnt(0) -- the very drain the double buffer avoids
+            static_assert(NA == 2, "the LDS-DMA variant reads two K and two V pieces per iteration");
+            typedef float f4v __attribute__((ext_vector_type(4)));
+            const unsigned laddr = (unsigned)(uintptr_t)(ring + (it & 1) * BUF + lane * 16);
+            f4v k0, k1, v0, v1;
+            asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:1024\n\tds_read_b128 %2, %4 offset:2048\n\t"
+                         "ds_read_b128 %3, %4 offset:3072\n\ts_waitcnt lgkmcnt(0)"
+                         : "=&v"(k0), "=&v"(k1), "=&v"(v0), "=&v"(v1) : "v"(laddr) : "memory");
+            int pp[NA];
+            float4 kk[NA], vv[NA];
+            kk[0] = make_float4(k0[0], k0[1], k0[2], k0[3]); kk[1] = make_float4(k1[0], k1[1], k1[2], k1[3]);
+            vv[0] = make_float4(v0[0], v0[1], v0[2], v0[3]); vv[1] = make_float4(v1[0], v1[1], v1[2], v1[3]);
+#pragma unroll
+            for (int j = 0; j < NA; ++j) pp[j] = npe + it * 4 * NA + 4 * j + grp;
+#pragma unroll
+            for (int b = 0; b < BEAM; ++b) {
+                float sv[NA];
+#pragma unroll
+                for (int j = 0; j < NA; ++j) {
+                    const float t = group16_sum(dot4(q[b], kk[j]));
+                    sv[j] = pp[j] < nconv ? t : -INFINITY;
+                }
+                ATT_UPDATE(b, NA, sv, vv)
+            }
+            asm volatile("" ::: "memory");                        // (the buffer is re-filled by the next ATT_ISSUE)
+        }
+#undef ATT_ISSUE
+    } else
     for (int p0 = npe; p0 < nconv; p0 += 4 * NA) {
         int pp[NA];
         float4 kk[NA], vv[NA];
@@ -412,7 +476,8 @@ static int attn_decode_typed(hipStream_t st, const float *qkv, const KvCache &c,
     {
         const int ncap = rows / beam, total = ncap * c.heads;
         if (total <= 0) return 0;
-        size_t lds = (size_t)4 * beam * L * sizeof(int);   // ancestor slots
+        size_t lds = ((size_t)4 * beam * L * sizeof(int) + 1023) & ~(size_t)1023;   // ancestor slots (the DMA ring, if any, follows)
+        static const int dma_on = [] { const char *e = getenv("CAPDEC_ATT_DMA"); return e ? atoi(e) : 1; }();
         dim3 grid((total + 3) / 4), block(256);
         // waves per SIMD the register allocation is sized for: beam <= 4 fits 4 without spilling; beam 5 needs 124
         // registers at 4 waves; CAPDEC_ATT_OCC=3 / CAPDEC_ATT_NA=4 are measurement knobs (default = measured best)
@@ -422,11 +487,18 @@ static int attn_decode_typed(hipStream_t st, const float *qkv, const KvCache &c,
         static const int na_env = [] { const char *e = getenv("CAPDEC_ATT_NA"); return e ? atoi(e) : 0; }();
         const int na4 = na_env ? (na_env == 4) : (!c.fixed_variant && total <= 16384);
 #define LAUNCH_BEAMS_V(B, OCC, NAV, CURV)                                                                       \
-    hipLaunchKernelGGL((attn_decode_beams_kernel<B, KV, OCC, NAV, CURV>), grid, block, lds, st, qkv, kl, vl, total, c.heads, \
-                       c.ctx, c.heads * c.hd, L, anc, anc_stride, out, (char *)packed_out, cmap, fmt, npre)
+    hipLaunchKernelGGL((attn_decode_beams_kernel<B, KV, OCC, NAV, CURV, false>), grid, block, lds, st, qkv, kl, vl, total, \
+                       c.heads, c.ctx, c.heads * c.hd, L, anc, anc_stride, out, (char *)packed_out, cmap, fmt, npre, 0)
+    // (LDS-DMA variant: NA = 2 for every launch size -- with its double buffer 16 positions per group are in flight, what
+    //  NA = 4 gives the register-landed loop, and 38 KB of LDS per block still lets four blocks share a CU)
+#define LAUNCH_BEAMS_DMA(B, OCC)                                                                                \
+    hipLaunchKernelGGL((attn_decode_beams_kernel<B, float, OCC, 2, true, true>), grid, block, lds + 4 * 2 * (2 * 2 * 1024), st, \
+                       qkv, (float *)kl, (float *)vl, total, c.heads, c.ctx, c.heads * c.hd, L, anc, anc_stride, out,  \
+                       (char *)packed_out, cmap, fmt, npre, (int)lds)
 #define LAUNCH_BEAMS(B, OCC)                                                                                    \
     if (cur_cached && (B == 1 || B == 5)) {       /* (the widths the decode drivers use most: greedy and beam 5) */ \
-        if (na4) LAUNCH_BEAMS_V(B, OCC, 4, true); else LAUNCH_BEAMS_V(B, OCC, 2, true);                          \
+        if (dma_on) LAUNCH_BEAMS_DMA(B, OCC);                                                                   \
+        else if (na4) LAUNCH_BEAMS_V(B, OCC, 4, true); else LAUNCH_BEAMS_V(B, OCC, 2, true);                     \
     } else if (na4 && B <= 5) LAUNCH_BEAMS_V(B, OCC, 4, false);                                                 \
     else LAUNCH_BEAMS_V(B, OCC, 2, false)
         switch (beam) {
@@ -441,6 +513,7 @@ static int attn_decode_typed(hipStream_t st, const float *qkv, const KvCache &c,
             default: CAPDEC_CHECK(false, "attention: beam must be in 1..8");
         }
 #undef LAUNCH_BEAMS
+#undef LAUNCH_BEAMS_DMA
 #undef LAUNCH_BEAMS_V
         CAPDEC_HIP(hipGetLastError());
         return 0;
