@@ -156,7 +156,7 @@ int launch_gemm_f16x2p(hipStream_t st, const void *Apacked, const void *Bpacked,
 int launch_gemm_f16x2p_topk(hipStream_t st, const void *Apacked, const void *Bpacked, int M, int N, int K, int k,
                             float inv_temp, float *tile_max, float *tile_sum, float *cand_val, int *cand_idx);
 // round-3 wide-tile kernels with ONE accumulator set (gemm_h2w.hip); scale = 2^(t - 11), t = pack-time pre-scale
-// exponent of the weights; `which`: 2 = 256x128 (two blocks per CU), 3 = 256x256 (8 waves), 4 / 5 = 128x128
+// exponent of the weights; `which`: 2 = 256x128 (two blocks per CU), 3 = 256x256 (8 waves), 6 = 256x256 (4 waves), 8 = 128x192
 int h2w_choice();
 int h2w_plan(int M, int N, int K);
 int launch_absmax_bits(hipStream_t st, const float *w, size_t n, unsigned *d_out);

@@ -19,7 +19,8 @@
 // One template serves the geometries (waves WM x WN, wave tile TI x TJ, ring depth NS):
 //   W256x128: 2x2 waves, 4x2 tiles, 256x128 block tile, 24 KB stages, NS = 3 (72 KB): two blocks per CU
 //   W256x256: 2x4 waves (512 threads), 256x256 block tile, 32 KB stages, NS = 4 (128 KB): one block per CU
-//   W128x128: 2x2 waves, 2x2 tiles (the round-2 geometry with one accumulator set): 16 KB stages, three blocks per CU
+//   W128x192: 2x2 waves, 2x3 tiles, 20 KB stages, NS = 4 (80 KB): two blocks per CU -- column tiles of 192
+//   W256x256q: 2x2 waves, 4x4 tiles (128x128 per wavefront, AGPR accumulators), one wavefront per SIMD (measurement)
 #include <algorithm>
 #include <cstdlib>
 
@@ -412,9 +413,8 @@ __global__ __launch_bounds__(G::THREADS, G::MINW) void gemm_h2w_topk_kernel(cons
 
 using W256x128 = WGeo<2, 2, 4, 2, 3, 2>;      // 4 waves, 72 KB, two blocks per CU
 using W256x256 = WGeo<2, 4, 4, 2, 4, 2>;      // 8 waves, 128 KB, one block per CU
-using W128x128 = WGeo<2, 2, 2, 2, 3, 3>;      // 4 waves, 48 KB, three blocks per CU
-using W128x128b = WGeo<2, 2, 2, 2, 4, 2>;     // 4 waves, 64 KB, two blocks per CU (round-2 geometry, one accumulator set)
-using W256x128a = WGeo<2, 2, 4, 2, 3, 2, true>;   // W256x128 with accumulator-major MFMA order (measurement)
+// (measured and removed from the build, profiles/r3_gemm_geometries.txt: WGeo<2,2,2,2,3,3> = 128x128 at three blocks per CU
+//  and WGeo<2,2,2,2,4,2> at two: +-0 against the round-2 kernel; WGeo<2,2,4,2,3,2,true>, accumulator-major MFMA order: -4 %)
 using W256x256q = WGeo<2, 2, 4, 4, 4, 1>;     // 4 waves x (128 x 128), 128 KB, ONE wavefront per SIMD (accumulators in AGPRs)
 using W128x192 = WGeo<2, 2, 2, 3, 4, 2>;      // 4 waves x (64 x 96), 80 KB, two blocks per CU: column tiles of 192
 
@@ -460,8 +460,8 @@ int h2w_plan(int M, int N, int K) {
 }
 
 // CAPDEC_H2W: 0 = round-2 kernels everywhere; 1 = automatic (default: the wide kernel where it measured faster);
-// 2 .. 8 force one geometry wherever the wide kernel is applicable (measurement): 2 = W256x128, 3 = W256x256,
-// 4 = W128x128, 5 = W128x128b, 6 = W256x256q, 7 = W256x128a, 8 = W128x192
+// 2, 3, 6, 8 force one geometry wherever the wide kernel is applicable (measurement / tests): 2 = W256x128,
+// 3 = W256x256, 6 = W256x256q, 8 = W128x192
 int h2w_choice() {
     static const int v = [] { const char *e = getenv("CAPDEC_H2W"); return e ? atoi(e) : 1; }();
     return v;
@@ -488,10 +488,7 @@ int launch_gemm_h2w(hipStream_t st, int which, const void *Apacked, const void *
     switch (which) {
         case 2: return launch_h2w<W256x128>(st, Apacked, Bpacked, C, ldc, M, N, K, epi, scale, 512);
         case 3: return launch_h2w<W256x256>(st, Apacked, Bpacked, C, ldc, M, N, K, epi, scale, 256);
-        case 4: return launch_h2w<W128x128>(st, Apacked, Bpacked, C, ldc, M, N, K, epi, scale, 768);
-        case 5: return launch_h2w<W128x128b>(st, Apacked, Bpacked, C, ldc, M, N, K, epi, scale, 512);
         case 6: return launch_h2w<W256x256q>(st, Apacked, Bpacked, C, ldc, M, N, K, epi, scale, 256);
-        case 7: return launch_h2w<W256x128a>(st, Apacked, Bpacked, C, ldc, M, N, K, epi, scale, 512);
         case 8: return launch_h2w<W128x192>(st, Apacked, Bpacked, C, ldc, M, N, K, epi, scale, 512);
         default: CAPDEC_CHECK(false, "gemm_h2w: unknown geometry");
     }
