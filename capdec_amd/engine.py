@@ -433,6 +433,17 @@ class Engine:
             "capdec_preprocess_images")
         return out
 
+    def timer_start(self):
+        """hipEvent on the engine's stream (capdec_timer_start): the reference Timer's ``starter.record()``"""
+        self._sync_stream()
+        check(self.lib.capdec_timer_start(self._h), "timer_start")
+
+    def timer_stop_ms(self) -> float:
+        """records the end event, synchronises, returns the elapsed milliseconds (capdec_timer_stop_ms)"""
+        ms = C.c_float(0.0)
+        check(self.lib.capdec_timer_stop_ms(self._h, C.byref(ms)), "timer_stop_ms")
+        return float(ms.value)
+
     def decode_stats(self) -> Dict[str, int]:
         """steps run / compactions / activation row-steps of the last decode call"""
         a, b, r = C.c_int(0), C.c_int(0), C.c_longlong(0)

@@ -16,6 +16,46 @@ from .gpt2_prefix_eval import (decode_beam_ids, decode_greedy_ids, generate2, ge
                                generate_beam, generate_beam_batch)
 
 
+class Timer:
+    """reference predictions_runner.py:125-150 (``with timer: ...`` around the work of one image, ``print(timer)`` every 99
+    images, :214,:233,:253): here the events are the C ABI's hipEvent pair on the engine's stream (capdec_timer_start /
+    capdec_timer_stop_ms) and one interval covers one BATCH; ``per_item`` divides by the batch size so that the printed
+    mean / std stay "ms per image" like the reference's."""
+
+    def __init__(self, model: Optional[ClipCaptionModel] = None):
+        self.sum = 0.0
+        self.count = 0
+        self.timings: List[float] = []
+        self.items = 0
+        self._model = model
+
+    def bind(self, model: ClipCaptionModel):
+        self._model = model
+        return self
+
+    def __enter__(self):
+        self._model.engine.timer_start()
+        return self
+
+    def __exit__(self, *args):
+        interval = self._model.engine.timer_stop_ms()
+        self.timings.append(interval)
+        self.sum += interval
+        self.count += 1
+
+    def add_items(self, n: int):
+        self.items += int(n)
+
+    def __str__(self):
+        import numpy as np
+        if self.count == 0:
+            return "mean: nan ms, std: nan ms"
+        s = f"mean: {self.sum / self.count:.2f} ms, std: {float(np.std(self.timings)):.2f} ms"
+        if self.items:
+            s += f" per batch; {self.sum / self.items:.4f} ms per image over {self.items} images"
+        return s
+
+
 def prefix_from_embeddings(model: ClipCaptionModel, embeddings: torch.Tensor, dont_normalize_prefix: bool = False,
                            modality_offset: Optional[torch.Tensor] = None) -> torch.Tensor:
     """reference :221-228 for a batch: ``prefix / prefix.norm(2,-1)``; ``+ offset``;
@@ -43,7 +83,7 @@ def caption_ids(model: ClipCaptionModel, embeddings: torch.Tensor, stop_token_in
 def make_preds(data: Sequence[Dict], embeddings: torch.Tensor, model: ClipCaptionModel, tokenizer,
                out_path: Optional[str] = None, beam: bool = True, entry_length: int = 67,
                dont_normalize_prefix: bool = False, modality_offset: Optional[torch.Tensor] = None,
-               rank: int = 0, world: int = 1) -> List[Dict]:
+               rank: int = 0, world: int = 1, timer: Optional[Timer] = None) -> List[Dict]:
     """``data[i]`` = {"image_id": ...}; ``embeddings[i]`` its CLIP embedding.  Writes the
     reference's predictions JSON (``[{"caption": lower-cased text, "image_id": id}]``, :260-261,
     :301) -- the whole list, not only every 99th flush."""
@@ -51,8 +91,16 @@ def make_preds(data: Sequence[Dict], embeddings: torch.Tensor, model: ClipCaptio
     if len(data) != embeddings.shape[0]:
         raise ValueError(f"make_preds: {len(data)} data entries but {embeddings.shape[0]} embeddings")
     stop = tokenizer.encode('.')[0]
-    ids, lens, _ = caption_ids(model, embeddings, stop, beam, 5, entry_length, dont_normalize_prefix,
-                               modality_offset, rank, world)
+    if timer is not None:           # the reference's `with timer:` (:214-233) around this rank's share of the batch
+        with timer.bind(model):
+            ids, lens, _ = caption_ids(model, embeddings, stop, beam, 5, entry_length, dont_normalize_prefix,
+                                       modality_offset, rank, world)
+        lo, hi = cdist.shard_bounds(embeddings.shape[0], rank, world)
+        timer.add_items(hi - lo)
+        print(timer)                # (:253)
+    else:
+        ids, lens, _ = caption_ids(model, embeddings, stop, beam, 5, entry_length, dont_normalize_prefix,
+                                   modality_offset, rank, world)
     ids, lens, _ = cdist.gather_ids(ids, lens, embeddings.shape[0])
     ids, lens = ids.cpu().numpy(), lens.cpu().numpy()
     new_data = [{"caption": tokenizer.decode(list(ids[i, :int(lens[i])])).lower(), "image_id": d["image_id"]}

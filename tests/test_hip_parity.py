@@ -312,6 +312,12 @@ def test_make_preds_driver_vs_reference_golden(golden, dims, tag, tmp_path):
     want = [{"caption": " ".join(str(int(v)) for v in gt[r][go[r][0]][:int(gl[r][go[r][0]])]), "image_id": 100 + r}
             for r in range(nb)]
     assert preds == want and json.load(open(out)) == want
+    # the reference's Timer (predictions_runner.py:125-150) on the C ABI's hipEvent pair: one interval per batch
+    timer = PR.Timer()
+    for _ in range(2):
+        assert PR.make_preds(data, x, model, FakeTok(st), None, beam=True, entry_length=12, timer=timer) == want
+    assert timer.count == 2 and timer.items == 2 * nb and all(t > 0 for t in timer.timings)
+    assert str(timer).startswith("mean: ") and " ms, std: " in str(timer)
     # ---- greedy (config 1 shape: 8 x 640-d, MLP mapper)
     model, _ = _model(dims, "mlp", 640)
     x = T(g["greedy_x"])

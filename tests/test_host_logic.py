@@ -162,6 +162,17 @@ def test_facade_surface_matches_reference_names():
         predictions_runner.make_preds([{"image_id": 1}], torch.zeros(2, 4), None, None)
 
 
+def test_timer_matches_the_reference_timer_text():
+    """capdec_amd.predictions_runner.Timer prints what the reference's Timer prints (predictions_runner.py:146-149)"""
+    from capdec_amd.predictions_runner import Timer
+    t = Timer()
+    assert str(t) == "mean: nan ms, std: nan ms"
+    t.timings, t.sum, t.count = [1.0, 3.0], 4.0, 2
+    assert str(t) == "mean: 2.00 ms, std: 1.00 ms"
+    t.add_items(8)
+    assert str(t).startswith("mean: 2.00 ms, std: 1.00 ms per batch; 0.5000 ms per image over 8 images")
+
+
 def test_state_dict_loading_rules():
     from capdec_amd import synth
     from capdec_amd.gpt2_prefix import ClipCaptionModel, MappingType
