@@ -148,7 +148,16 @@ __global__ __launch_bounds__(256, OCC) void attn_decode_beams_kernel(const float
         lrun[b] = grp == 0 ? 1.f : 0.f;
         acc[b] = grp == 0 ? vcur : make_float4(0.f, 0.f, 0.f, 0.f);
     }
-    __syncthreads();                                               // slot table visible
+    // slot table visible: the table (and the DMA ring) are PRIVATE to the wavefront and a wavefront's LDS operations
+    // complete in order, so a wavefront-scope fence is all the ordering needed -- a block barrier would make every
+    // wavefront wait for the slowest of four unrelated (caption, head) pairs' first loads
+    if (ring_off < 0) {                                            // (CAPDEC_ATT_WSYNC=0: the round-2 block barrier, for A/B)
+        __syncthreads();
+    } else {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
     const KV *kbase = kc + ((size_t)srow0 * heads + head) * hstride + sub * 4;
     const KV *vbase = vc + ((size_t)srow0 * heads + head) * hstride + sub * 4;
     const int slot_stride = heads * ctx * 64;      // offsets inside one caption's K / V region fit 32 bits (<= 8 x 16 x 256 x 64)
@@ -477,7 +486,8 @@ static int attn_decode_typed(hipStream_t st, const float *qkv, const KvCache &c,
         const int ncap = rows / beam, total = ncap * c.heads;
         if (total <= 0) return 0;
         size_t lds = ((size_t)4 * beam * L * sizeof(int) + 1023) & ~(size_t)1023;   // ancestor slots (the DMA ring, if any, follows)
-        static const int dma_on = [] { const char *e = getenv("CAPDEC_ATT_DMA"); return e ? atoi(e) : 1; }();
+        static const int wsync = [] { const char *e = getenv("CAPDEC_ATT_WSYNC"); return e ? atoi(e) : 1; }();
+        static const int dma_on = [] { const char *e = getenv("CAPDEC_ATT_DMA"); return (e ? atoi(e) : 1) && wsync; }();
         dim3 grid((total + 3) / 4), block(256);
         // waves per SIMD the register allocation is sized for: beam <= 4 fits 4 without spilling; beam 5 needs 124
         // registers at 4 waves; CAPDEC_ATT_OCC=3 / CAPDEC_ATT_NA=4 are measurement knobs (default = measured best)
@@ -488,7 +498,7 @@ static int attn_decode_typed(hipStream_t st, const float *qkv, const KvCache &c,
         const int na4 = na_env ? (na_env == 4) : (!c.fixed_variant && total <= 16384);
 #define LAUNCH_BEAMS_V(B, OCC, NAV, CURV)                                                                       \
     hipLaunchKernelGGL((attn_decode_beams_kernel<B, KV, OCC, NAV, CURV, false>), grid, block, lds, st, qkv, kl, vl, total, \
-                       c.heads, c.ctx, c.heads * c.hd, L, anc, anc_stride, out, (char *)packed_out, cmap, fmt, npre, 0)
+                       c.heads, c.ctx, c.heads * c.hd, L, anc, anc_stride, out, (char *)packed_out, cmap, fmt, npre, wsync ? 0 : -1)
     // (LDS-DMA variant: NA = 2 for every launch size -- with its double buffer 16 positions per group are in flight, what
     //  NA = 4 gives the register-landed loop, and 38 KB of LDS per block still lets four blocks share a CU)
 #define LAUNCH_BEAMS_DMA(B, OCC)                                                                                \
