@@ -463,7 +463,7 @@ static int stack_body(capdec_ctx *c, const StackCfg &g, const StepShape &s, cons
         // decode steps in the default mode: K / V of the new token go from the qkv GEMM's epilogue straight into the cache
         // (QkvScatter) when that GEMM runs unsplit -- the attention then reads them like any other position
         QkvScatter sc;
-        const bool scatter = kv_direct && !s.prefill && g.keep_kv && c->gemm_mode == GEMM_F16X2 && !kv.bf16 && w.bqkv &&
+        const bool scatter = kv_direct && !s.prefill && g.keep_kv && c->gemm_mode == GEMM_F16X2 && use_packed_a(c, d) && !kv.bf16 && w.bqkv &&
                              d % GEMM_BN == 0 && (s.beam == 1 || s.beam == 5) &&
                              (c->batch_invariant || gemm_splitk_slices(M, 3 * d, d) == 1);
         if (scatter) {

@@ -5,12 +5,15 @@
 // 12 MFMAs, and its SQ counters (profiles/r2_pmc_sq_gemm_f16x2p.txt) show the matrix pipe busy only 58-64 % with the
 // waves parked 27 % of their time: the loop is bound by what surrounds the MFMAs.  A wider wave tile amortises all of
 // it, but the second accumulator set (the 2^-11-weighted cross terms) leaves no registers for one.
+// (What it bought, profiles/r3_gemm_geometries.txt / r3_pmc_sq_gemm.txt: -4..8 % cycles, pipe busy 51 -> 54 %, +6 % at the
+//  package power cap where the grid is whole rounds -- so a planner uses these kernels only where they remove a round.)
 //
 // How: a b = hi_a hi_b + 2^-11 (hi_a lo'_b + lo'_a hi_b) with lo' = 2^11 lo the stored low plane.  Multiply the hi_b
 // FRAGMENT by 2^11 in registers after the ds_read (4 v_pk_mul_f16 per fragment: an exponent shift, exact while
-// |b| < 32 -- the weights carry a per-tensor power-of-two pre-scale 2^-t chosen at pack time so that it always holds):
+// |b| < 32 -- B is always a weight matrix here; max |w| is measured once when its planes are packed and a matrix with
+// max |w| >= 16 simply keeps the two-accumulator kernel, GemmEpilogue::wide_ok):
 //     2^11 a b = hi_a (2^11 hi_b) + hi_a lo'_b + lo'_a hi_b
-// -- three MFMAs into the SAME accumulator, result scaled by 2^(t-11) in the epilogue.  No change to the operand
+// -- three MFMAs into the SAME accumulator, result scaled by 2^-11 in the epilogue.  No change to the operand
 // format: the activations' packers (LayerNorm, attention, fc epilogue) and the weight planes are those of round 2.
 // The 64 freed registers go to a 128x64 wave tile (TI x TJ = 4 x 2 blocks of 32x32): 12 ds_read_b128, 8 v_pk_mul_f16
 // and one barrier per 24 MFMAs, fragments of k-step kt+1 re-loaded into the registers of kt as soon as a row group's
