@@ -323,6 +323,70 @@ def test_gather_ids_gloo_world_size_2(tmp_path):
     assert all("OK" in o for o in outs)
 
 
+_IMG_WORKER = r"""
+import os, sys, json, torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+from capdec_amd import predictions_runner as PR
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{sys.argv[2]}", rank=rank, world_size=world)
+# fakes for the device pieces: an "image" is an int, its embedding is [v, v, v, v], its caption ids are [v, v + 1, v + 2]
+encoded = []
+class Pre:
+    def batch(self, imgs): return torch.tensor(imgs, dtype=torch.float32)
+class Clip:
+    def encode_image(self, px):
+        encoded.extend(int(v) for v in px.tolist())
+        return px[:, None].repeat(1, 4)
+class Model:
+    prefix_length = 10
+    def parameters(self): yield torch.zeros(0)
+def fake_caption_ids(model, emb, stop, beam, beam_size, T, dont_norm, off, rank=0, world=1):
+    v = emb[:, 0].to(torch.int32)
+    ids = torch.zeros(emb.shape[0], T, dtype=torch.int32)
+    ids[:, 0], ids[:, 1], ids[:, 2] = v, v + 1, v + 2
+    return ids, torch.full((emb.shape[0],), 3, dtype=torch.int32), None
+PR.caption_ids = fake_caption_ids
+class Tok:
+    def encode(self, s): return [13]
+    def decode(self, ids): return " ".join(str(int(i)) for i in ids)
+images = [10, None, 30, 40, None, 60, 70]                  # two files the reference would skip (:207-210)
+data = [{"image_id": 100 + i} for i in range(len(images))]
+out = sys.argv[3]
+preds = PR.make_preds_from_images(data, images, Clip(), Pre(), Model(), Tok(), out if rank == 0 else None, beam=True,
+                                  entry_length=5, rank=rank, world=world, image_batch=2)
+keep = [i for i, im in enumerate(images) if im is not None]
+want = [{"caption": f"{images[i]} {images[i] + 1} {images[i] + 2}", "image_id": 100 + i} for i in keep]
+assert preds == want, (rank, preds)
+# the tower ran on THIS rank's block of the kept images only (5 kept images over 2 ranks: 3 + 2)
+lo, hi = (0, 3) if rank == 0 else (3, 5)
+assert encoded == [images[i] for i in keep[lo:hi]], (rank, encoded)
+if rank == 0:
+    assert json.load(open(out)) == want
+# more ranks than images: the empty shard still takes part in the gather
+one = PR.make_preds_from_images(data[:1], images[:1], Clip(), Pre(), Model(), Tok(), None, entry_length=5, rank=rank, world=world)
+assert one == want[:1], (rank, one)
+dist.destroy_process_group()
+print("OK", rank)
+"""
+
+
+def test_image_driver_shards_the_tower_gloo_world_size_2(tmp_path):
+    """round-2 advisor finding: make_preds_from_images ran preprocess + encode_image for ALL images on every rank.  Two
+    gloo ranks, fake device pieces: each rank encodes only its block of the kept images, the gathered predictions equal
+    the single-process list, skipped files stay skipped, an empty shard still joins the gather"""
+    script = tmp_path / "img_worker.py"
+    script.write_text(_IMG_WORKER)
+    port = 31500 + (os.getpid() % 2000)
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, str(script), ROOT, str(port), str(tmp_path / "preds.json")], env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=180)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    assert all("OK" in o for o in outs)
+
+
 def test_shard_consistency_checks():
     """a partial shard without a process group must not be returned as if it were the whole result"""
     from capdec_amd import distributed as cd
