@@ -38,6 +38,9 @@ from capdec_amd import synth  # noqa: E402
 
 PEAK_F32_MFMA_TFLOPS = 157.3    # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 PEAK_BF16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA (not the 2:1-sparse marketing figure)
+# what the 1400 W package cap leaves of the fp16 matrix pipe on random (full-entropy) operands: a registers-only stream of
+# back-to-back MFMAs sustains 1650 TFLOP/s (profiles/r3_mfma_power_ceiling.txt, tools/probes/mfma_energy.hip; zeros: 2451)
+F16_MFMA_AT_POWER_CAP_TFLOPS = 1650.0
 STOP_ID, D_EMB = 13, 768
 PMC_TRAFFIC_FILE = "r3_pmc_traffic.json"   # rocprofv3 --pmc summary the `roofline.traffic` field is read from
 
@@ -592,6 +595,9 @@ def main():
                          "mfma_tflops_executed": round(achieved * products, 1) if products else None,
                          "mfma_frac_of_dense_peak": round(achieved * products / PEAK_BF16_MFMA_TFLOPS, 4) if products else None,
                          "vs_native_f32_mfma_peak": round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
+                         # against the power-capped ceiling of a PURE MFMA stream on random fp16 operands (measured, see the
+                         # constant above): what is left between this kernel and it is the energy of everything around the MFMAs
+                         "frac_of_power_capped_mfma_stream": round(achieved * products / F16_MFMA_AT_POWER_CAP_TFLOPS, 4) if products in (1, 3) else None,
                          # the same achieved rate against round 1's ceiling (six bf16 MFMAs per fp32 product: 2500 / 6)
                          "vs_six_product_ceiling_416_7": round(achieved / (PEAK_BF16_MFMA_TFLOPS / 6.0), 4),
                          "whole_path_tflops": round(alg / dt / 1e12, 2)},
