@@ -325,7 +325,7 @@ static int gemm(capdec_ctx *c, const float *A, int lda, const float *Bt, int ldb
         // whose 16-bit operands are confined to the GPT-2 / CLIP block stacks and the lm_head
         const void *pl = nullptr;
         CAPDEC_TRY(planes_of(c, Bt, N, K, weight, &pl, PK_F16X2, &e.wide_ok));
-        if (c->batch_invariant) e.wide_ok = false;      // (the geometry planner looks at M)
+        if (c->batch_invariant) { e.wide_ok = false; e.invariant = true; }      // (the geometry planners look at M)
         CAPDEC_TRY(c->a_tmp.ensure(x3_packed_bytes(M, K, PK_F16X2)));
         { ProfScope ps(c, F_PACK); CAPDEC_TRY(launch_pack_planes_h2(c->stream, A, lda, M, K, c->a_tmp.p)); }
         const size_t wsb = c->batch_invariant ? 0 : gemm_splitk_ws_bytes(M, N, K);
@@ -367,7 +367,7 @@ static int gemm_packed(capdec_ctx *c, const void *Apk, const float *W, float *C,
     GemmEpilogue e;
     e.qkv_scatter = qkv_scatter;
     CAPDEC_TRY(planes_of(c, W, N, K, true, &pl, -1, &e.wide_ok));
-    if (c->batch_invariant) e.wide_ok = false;          // (the geometry planner looks at M)
+    if (c->batch_invariant) { e.wide_ok = false; e.invariant = true; }          // (the geometry planners look at M)
     e.bias = bias;
     e.act = act;
     e.resid = resid;
@@ -1853,7 +1853,7 @@ int capdec_decode_counters(capdec_ctx *c, double *kv_slots_per_position, long lo
     if (kv_slots_per_position) *kv_slots_per_position = c->stat_kv_pos > 0 ? c->stat_kv_slots / c->stat_kv_pos : 0.0;
     if (saturated_quads) {
         CAPDEC_HIP(hipStreamSynchronize(c->stream));
-        *saturated_quads = (long long)(sat_count_gemm_f16x2(true) + sat_count_gemm_h2w(true) + sat_count_gemm_bf16x3(true) +
+        *saturated_quads = (long long)(sat_count_gemm_f16x2(true) + sat_count_gemm_h2w(true) + sat_count_gemm_pp(true) + sat_count_gemm_bf16x3(true) +
                                        sat_count_elementwise(true) + sat_count_attention(true) + sat_count_resnet(true));
     }
     return 0;

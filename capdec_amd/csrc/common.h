@@ -106,6 +106,7 @@ struct GemmEpilogue {
     void *packed_out = nullptr;    // bf16x3p only: write act(acc + bias) as the packed split-bf16 A operand (K = N)
                                    // of the next GEMM instead of fp32 C
     const QkvScatter *qkv_scatter = nullptr;   // f16x2p, unsplit grids only (see QkvScatter)
+    bool invariant = false;        // batch-invariant mode: the unsplit 128 x 128 kernel whatever M is (no planner, no split-K)
     bool wide_ok = false;          // f16x2p only: the B operand is a weight with max |w| < 16, so its high plane can be scaled
                                    // by 2^11 in fp16 registers (the single-accumulator kernels of gemm_h2w.hip)
     const void *resid_packed = nullptr;   // f16x2p / x1 with packed_out only: residual [M, N] stored as a packed operand of
@@ -164,6 +165,13 @@ int launch_gemm_h2w(hipStream_t st, int which, const void *Apacked, const void *
                     int K, const GemmEpilogue &epi, float scale);
 int launch_gemm_h2w_topk(hipStream_t st, const void *Apacked, const void *Bpacked, int M, int N, int K, int k,
                          float inv_temp, float *tile_max, float *tile_sum, float *cand_val, int *cand_idx);
+// round-4 ping-pong kernels (gemm_pp.hip): ONE 8-wavefront block per CU, the two wavefronts of a SIMD alternate between a
+// load phase and a matrix phase; `which`: 10 = 256x128 (two accumulator sets), 11 = 256x128, 12 = 256x256, 13 = 128x256 (one set)
+int launch_gemm_pp(hipStream_t st, int which, const void *Apacked, const void *Bpacked, float *C, int ldc, int M, int N,
+                   int K, const GemmEpilogue &epi, float scale);
+// planner: 0 = keep the kernels of rounds 2-3, else a ping-pong geometry (10 = 256x128, 14 = 256x192, 12 = 256x256)
+int pp_plan(int M, int N, int K, bool wide_ok, bool can_split, int mode = 2);
+size_t pp_splitk_ws_bytes(int which, int M, int N, int K);
 // generic packer for any PackFmt (gemm_f16x2.hip); the one-plane formats use it
 int launch_pack_planes_fmt(hipStream_t st, const float *w, int ldw, int N, int K, void *out, int fmt);
 // round-2 one-plane kernels on the f16x2 main loop (gemm_f16x2.hip): 128x128 tile, two blocks per CU, 32-deep stages
@@ -289,6 +297,7 @@ int launch_compact_alive(hipStream_t st, const uint8_t *done, int ncap, int *cma
 // operands clamped to the fp16 range since the last reset, per translation unit (bf16x3.h: g_h2_saturated)
 unsigned long long sat_count_gemm_f16x2(bool reset);
 unsigned long long sat_count_gemm_h2w(bool reset);
+unsigned long long sat_count_gemm_pp(bool reset);
 unsigned long long sat_count_gemm_bf16x3(bool reset);
 unsigned long long sat_count_elementwise(bool reset);
 unsigned long long sat_count_attention(bool reset);

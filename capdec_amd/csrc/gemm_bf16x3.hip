@@ -584,7 +584,9 @@ int gemm_splitk_slices(int M, int N, int K) {
 //  round they save: 3125 x 3072 x 768: 55 -> 68 us, 25000 x 768 x 3072: 393 -> 440 us.  DESIGN.md section 5.)
 size_t gemm_splitk_ws_bytes(int M, int N, int K) {
     const int s = gemm_splitk_slices(M, N, K);
-    return s > 1 ? (size_t)s * M * N * sizeof(float) : 0;
+    size_t b = s > 1 ? (size_t)s * M * N * sizeof(float) : 0;
+    for (int which : {10, 12, 14}) b = std::max(b, pp_splitk_ws_bytes(which, M, N, K));     // (the ping-pong kernels' own split)
+    return b;
 }
 
 int launch_gemm_bf16x3p(hipStream_t st, const void *Apacked, const void *Bpacked, float *C, int ldc, int M, int N, int K,

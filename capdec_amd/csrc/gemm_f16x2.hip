@@ -25,6 +25,7 @@
 
 #include "bf16x3.h"
 #include "gemm_epilogue.h"
+#include "gemm_epilogue_lds.h"
 
 namespace capdec {
 
@@ -276,6 +277,34 @@ __device__ __forceinline__ void h2_join(f32x16 (&am)[2][2], const f32x16 (&ac)[2
 }
 
 constexpr int H2_NS = 4;
+// CAPDEC_PP=0: the ping-pong kernels of round 4 are never planned (A/B against rounds 2-3)
+static int pp_enabled() {      // 0 = never, 2 = mid-size launches only (default), 1 = mid-size and large, 3 = large only
+    static const int on = [] { const char *e = getenv("CAPDEC_PP"); return e ? atoi(e) : 2; }();
+    return on;
+}
+// wave grid of the 128 x 128 kernels for the coalesced epilogues (gemm_epilogue_lds.h): 2 x 2 wavefronts of 64 x 64
+struct H2Tile { static constexpr int WN = 2, TI = 2, TJ = 2; };
+// end of a persistent block's tile: the next tile's LDS-DMA pieces land in the epilogue's slabs
+__device__ __forceinline__ void h2_slab_release(bool more) {
+    if (more) {
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_s_waitcnt(waitcnt_imm(63, 0));
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    }
+}
+__device__ __forceinline__ EpiArgs h2_epi_args(float *C, int ldc, int M, int N, int m0, int n0, const float *bias,
+                                               const float *resid, int ldr, int act, char *packed_out, int fmt,
+                                               const QkvScatter *sc) {
+    EpiArgs ea;
+    ea.C = C; ea.ldc = ldc; ea.M = M; ea.N = N; ea.m0 = m0; ea.n0 = n0;
+    ea.bias = bias; ea.act = act; ea.ldr = ldr; ea.fmt = fmt;
+    ea.packed = packed_out;
+    if (packed_out) ea.resid_pk = reinterpret_cast<const char *>(resid);      // (with packed_out, `resid` is a PACKED residual)
+    else ea.resid = resid;
+    ea.sc = sc;
+    return ea;
+}
 // ring depth of the plain kernel: CAPDEC_H2_NS = 3 | 4 | 5 (measurement knob; the default is the measured-fastest)
 static int h2_ns() {
     static const int ns = [] { const char *e = getenv("CAPDEC_H2_NS"); const int v = e ? atoi(e) : H2_NS; return v == 3 || v == 5 ? v : H2_NS; }();
@@ -301,13 +330,16 @@ __global__ __launch_bounds__(256, 2) void gemm_f16x2p_kernel(const _Float16 *__r
         f32x16 am[2][2], ac[2][2];
         h2p_mainloop<true, NS, ABL>(Apk, Bpk, K, tm, tn, smem, am, ac);      // ends with a barrier: the ring is free again
         h2_join(am, ac);
-        if (packed_out)
+        if constexpr (VEC4) {
+            const EpiArgs ea = h2_epi_args(C, ldc, M, N, tm * GEMM_BM, tn * GEMM_BN, bias, resid, ldr, act, packed_out, PK_F16X2, &sc);
+            epilogue_lds<H2Tile>(am, smem, ea);
+            h2_slab_release(tile + (int)gridDim.x < ntiles);
+        } else if (packed_out) {
             epilogue_store_packed_t(am, packed_out, N >> 4, M, N, tm * GEMM_BM, tn * GEMM_BN, bias, act, PK_F16X2,
                                     reinterpret_cast<const char *>(resid));  // (with packed_out, `resid` is a PACKED residual)
-        else if (VEC4 && sc.kc && tn * GEMM_BN >= sc.d)                      // K / V third of a decode-step qkv projection
-            epilogue_store_kv_t(am, M, tm * GEMM_BM, tn * GEMM_BN, bias, sc);
-        else
-            epilogue_store_t<VEC4>(am, C, ldc, M, N, tm * GEMM_BM, tn * GEMM_BN, bias, resid, ldr, act);
+        } else {
+            epilogue_store_t<false>(am, C, ldc, M, N, tm * GEMM_BM, tn * GEMM_BN, bias, resid, ldr, act);
+        }
     }
 }
 
@@ -341,8 +373,10 @@ __global__ __launch_bounds__(256, 2) void gemm_f16x2p_splitk_kernel(const _Float
     f32x16 am[2][2], ac[2][2];
     h2p_mainloop<true, H2_NS>(Apk, Bpk, K, tm, tn, smem, am, ac, slice * nks, nks);
     h2_join(am, ac);
-    epilogue_store_t<true>(am, part + (size_t)slice * M * N, N, M, N, tm * GEMM_BM, tn * GEMM_BN, nullptr, nullptr, 0,
-                           CAPDEC_ACT_NONE);
+    const EpiArgs ea = h2_epi_args(part + (size_t)slice * M * N, N, M, N, tm * GEMM_BM, tn * GEMM_BN, nullptr, nullptr, 0,
+                                   CAPDEC_ACT_NONE, nullptr, PK_F16X2, nullptr);
+    epilogue_lds_wave<2, 2, 0, CAPDEC_ACT_NONE>(am, reinterpret_cast<float *>(smem + (threadIdx.x >> 6) * EpiSlab<2>::BYTES),
+                                                ea.m0 + (threadIdx.x >> 7) * 64, ea.n0 + ((threadIdx.x >> 6) & 1) * 64, ea);
 }
 
 int launch_gemm_f16x2p(hipStream_t st, const void *Apacked, const void *Bpacked, float *C, int ldc, int M, int N, int K,
@@ -361,6 +395,15 @@ int launch_gemm_f16x2p(hipStream_t st, const void *Apacked, const void *Bpacked,
     CAPDEC_CHECK(!sc.kc || (vec4 && epi.bias && !epi.resid && !epi.packed_out && epi.act == CAPDEC_ACT_NONE && N == 3 * sc.d &&
                             sc.d % GEMM_BN == 0 && !epi.splitk_ws),
                  "gemm_f16x2p: the qkv scatter epilogue needs an unsplit, biased, plain [M, 3d] projection");
+    // round-4 ping-pong kernels (gemm_pp.hip): forced (CAPDEC_H2W >= 10) or where the planner expects >= 5 % from them
+    // (mid-size and large launches; the small-batch regime M <= 512 keeps its batch-size independent split-K)
+    if (vec4 && !epi.invariant) {
+        const bool can_split = epi.splitk_ws && !epi.resid_packed && !epi.packed_out && !sc.kc;
+        int which = 0;
+        if (h2w_choice() >= 10) which = (h2w_choice() == 10 || epi.wide_ok) ? h2w_choice() : 0;
+        else if (h2w_choice() == 1 && pp_enabled() && M > 4 * GEMM_BM) which = pp_plan(M, N, K, epi.wide_ok, can_split, pp_enabled());
+        if (which) return launch_gemm_pp(st, which, Apacked, Bpacked, C, ldc, M, N, K, epi, 1.0f / H2_LO_SCALE);
+    }
     const int S = (vec4 && epi.splitk_ws && !epi.resid_packed) ? gemm_splitk_slices(M, N, K) : 1;
     if (S > 1 && epi.splitk_ws_bytes >= (size_t)S * M * N * sizeof(float)) {
         float *part = (float *)epi.splitk_ws;
@@ -372,7 +415,7 @@ int launch_gemm_f16x2p(hipStream_t st, const void *Apacked, const void *Bpacked,
     // persistent form for grids of up to four rounds, where the partly filled last round matters (625 captions: mlp.c_fc
     // 600 tiles, 80 -> 70 us inside the decode loop); larger grids keep one block per tile (the dispatcher balances them:
     // within noise either way at 25 000 rows).  CAPDEC_H2_PERSIST=<blocks> (0 = never)
-    if (vec4 && epi.wide_ok && h2w_choice() >= 1 && !sc.kc) {      // round-3 single-accumulator geometries where they remove a round
+    if (vec4 && epi.wide_ok && h2w_choice() >= 1 && h2w_choice() < 10 && !sc.kc) {      // round-3 single-accumulator geometries where they remove a round
         const int which = h2w_choice() >= 2 ? h2w_choice() : h2w_plan(M, N, K);
         if (which) return launch_gemm_h2w(st, which, Apacked, Bpacked, C, ldc, M, N, K, epi, 1.0f / H2_LO_SCALE);
     }
@@ -443,11 +486,16 @@ __global__ __launch_bounds__(256, (NS == 3 ? 3 : 2)) void gemm_x1_kernel(const _
         tile_coords(tiles_m, tiles_n, tm, tn, tile);
         f32x16 am[2][2], ac[2][2];
         h2p_mainloop<true, NS, 0, KIND>(Apk, Bpk, K, tm, tn, smem, am, ac);
-        if (packed_out)
+        if constexpr (VEC4) {
+            const EpiArgs ea = h2_epi_args(C, ldc, M, N, tm * GEMM_BM, tn * GEMM_BN, bias, resid, ldr, act, packed_out, out_fmt, nullptr);
+            epilogue_lds<H2Tile>(am, smem, ea);
+            h2_slab_release(tile + (int)gridDim.x < ntiles);
+        } else if (packed_out) {
             epilogue_store_packed_t(am, packed_out, N >> 4, M, N, tm * GEMM_BM, tn * GEMM_BN, bias, act, out_fmt,
                                     reinterpret_cast<const char *>(resid));  // (with packed_out, `resid` is a PACKED residual)
-        else
-            epilogue_store_t<VEC4>(am, C, ldc, M, N, tm * GEMM_BM, tn * GEMM_BN, bias, resid, ldr, act);
+        } else {
+            epilogue_store_t<false>(am, C, ldc, M, N, tm * GEMM_BM, tn * GEMM_BN, bias, resid, ldr, act);
+        }
     }
 }
 
@@ -478,8 +526,10 @@ __global__ __launch_bounds__(256, 2) void gemm_x1_splitk_kernel(const _Float16 *
     const int nks = K / (2 * X3_BK) / S;                 // stages (two k-steps each) of this slice
     f32x16 am[2][2], ac[2][2];
     h2p_mainloop<true, H2_NS, 0, KIND>(Apk, Bpk, K, tm, tn, smem, am, ac, slice * nks, nks);
-    epilogue_store_t<true>(am, part + (size_t)slice * M * N, N, M, N, tm * GEMM_BM, tn * GEMM_BN, nullptr, nullptr, 0,
-                           CAPDEC_ACT_NONE);
+    const EpiArgs ea = h2_epi_args(part + (size_t)slice * M * N, N, M, N, tm * GEMM_BM, tn * GEMM_BN, nullptr, nullptr, 0,
+                                   CAPDEC_ACT_NONE, nullptr, PK_F16X2, nullptr);
+    epilogue_lds_wave<2, 2, 0, CAPDEC_ACT_NONE>(am, reinterpret_cast<float *>(smem + (threadIdx.x >> 6) * EpiSlab<2>::BYTES),
+                                                ea.m0 + (threadIdx.x >> 7) * 64, ea.n0 + ((threadIdx.x >> 6) & 1) * 64, ea);
 }
 
 // fmt = PK_F16X1 or PK_BF16X1 (both operands; a packed output is written in the same format)
@@ -574,10 +624,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_packed_kernel(const _Float16 *
     f32x16 am[2][2], ac[2][2];
     h2p_mainloop<true, H2_NS, 0, KIND, true>(Apk, Bpk, K, tm, tn, smem, am, ac, 0, -1, cg);
     if constexpr (KIND == 0) h2_join(am, ac);
-    if (packed_out)
-        epilogue_store_packed_t(am, packed_out, N >> 4, M, N, tm * GEMM_BM, tn * GEMM_BN, bias, act, fmt);
-    else
-        epilogue_store_t<true>(am, C, ldc, M, N, tm * GEMM_BM, tn * GEMM_BN, bias, resid, ldr, act);
+    const EpiArgs ea = h2_epi_args(C, ldc, M, N, tm * GEMM_BM, tn * GEMM_BN, bias, packed_out ? nullptr : resid, ldr, act, packed_out,
+                                   fmt, nullptr);
+    epilogue_lds<H2Tile>(am, smem, ea);
 }
 
 int launch_conv3x3_packed(hipStream_t st, const void *act_pk, const void *Bpacked, float *C, int ldc, int Nimg, int H,

@@ -680,6 +680,43 @@ def test_large_launch_subset_vs_oracle():
     assert ok >= 28, (ok, ties)
 
 
+def test_headline_configuration_vs_oracle_at_its_own_size(capsys):
+    """BASELINE metric configuration at the size bench.py times it: GPT-2 small (12 layers, V = 50 257 -> the 393-tile
+    fused lm_head), 5000 x 512-d embeddings -> TransformerMapper(8) -> beam 5, P = 10, T = 67, DEFAULT mode, ONE launch of
+    25 000 rows; 24 seeded captions of it against the KV-cached oracle (reference gpt2_prefix_eval.py:50-115), and 32 of
+    a 25 000-row greedy batch against O.greedy_cached (reference :118-198).  The numbers of clear / tied captions are
+    printed and asserted (observed: no ties on these seeds)"""
+    from capdec_amd import gpt2_prefix_eval as E
+    from oracle import capdec_oracle as O
+    dims = synth.GPT2_SMALL
+    model, sd = _model(dims, "transformer_encoder", 512, seed=42)
+    n, T_, stop = 5000, 67, 13
+    x = synth.synthetic_clip_embeddings(n, 512, seed=0)
+    pe = model.clip_project(x).reshape(n, 10, -1)
+    rows = sorted(np.random.default_rng(11).choice(n, 22, replace=False).tolist() + [0, n - 1])
+    pe_rows = O.clip_project(x[rows], sd, "transformer_encoder", 10).reshape(len(rows), 10, -1)
+    np.testing.assert_allclose(pe[rows].cpu().numpy(), pe_rows.numpy(), atol=2e-4, rtol=2e-4)
+    i, l, s, o = E.decode_beam_ids(model, pe, stop, 5, T_)
+    assert model.engine.decode_stats()["row_steps"] == n * 5 * (T_ - 1)           # one launch of 25 000 rows per step, all 67 steps
+    got = (i.cpu().numpy(), l.cpu().numpy(), s.cpu().numpy(), o.cpu().numpy())
+    pe_cpu = pe.cpu()
+    ok, ties = _beam_rows_vs_oracle(got, sd, pe_cpu, rows, stop, T_, dims.n_head)
+    with capsys.disabled():
+        print(f"\n[headline vs oracle] beam 5, 5000 captions in one launch: {ok} captions identical to the oracle, {ties} numerical ties skipped")
+    assert ok >= 23 and ties <= 1, (ok, ties)
+    del i, l, s, o
+    # 25 000 greedy rows (the same 25 000-row launches, k = 1): 32 of them
+    n = 25000
+    x = synth.synthetic_clip_embeddings(n, 512, seed=1)
+    pe = model.clip_project(x).reshape(n, 10, -1)
+    ids, lens = E.decode_greedy_ids(model, pe, stop, T_)
+    rows = sorted(np.random.default_rng(12).choice(n, 30, replace=False).tolist() + [0, n - 1])
+    ok, ties = _greedy_rows_vs_oracle(ids.cpu().numpy(), lens.cpu().numpy(), sd, pe.cpu(), rows, stop, T_, dims.n_head)
+    with capsys.disabled():
+        print(f"[headline vs oracle] greedy, 25000 rows in one launch: {ok} captions identical to the oracle, {ties} numerical ties skipped")
+    assert ok >= 31 and ties <= 1, (ok, ties)
+
+
 def test_batch_invariant_mode_bit_identical_across_batch_sizes():
     """capdec_set_batch_invariant: no launch-size dependent summation order (no split-K, one GEMM geometry, pinned
     attention variant), so a caption's ids AND scores are bit-identical whether it is decoded alone, in a 330-caption

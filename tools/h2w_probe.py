@@ -28,8 +28,9 @@ def main():
     res["max_err_over_scale"] = worst
     os.environ["CAPDEC_HOOK_CACHE"] = "1"
     Ms = [int(v) for v in sys.argv[1:]] or [25000]
-    for M in Ms:
-        for (m, n, k) in [(M, 2304, 768), (M, 768, 768), (M, 3072, 768), (M, 768, 3072), (M, 50257, 768)]:
+    custom = [tuple(int(x) for x in t.split(",")) for t in os.environ.get("PROBE_SHAPES", "").split(";") if t]
+    for M in ([0] if custom else Ms):
+        for (m, n, k) in custom or ([(M, 2304, 768), (M, 768, 768), (M, 3072, 768), (M, 768, 3072)] + ([(M, 50257, 768)] if os.environ.get('PROBE_LMHEAD') else [])):
             a = (torch.rand(m, k, generator=g) * 2 - 1).cuda()
             bt = (torch.rand(n, k, generator=g) * 2 - 1).cuda()
             for _ in range(2):
