@@ -65,6 +65,52 @@ def algorithmic_flops_per_caption(P, T, beam, mapper, dims=synth.GPT2_SMALL, D=5
     return f
 
 
+def oracle_compare(model, emb, out, mapper, beam, P, T, rows):
+    """captions `rows` of a timed step's result against the CPU oracle run on their own prefixes (the oracle is the checker,
+    never the thing measured).  Every caption is compared; a difference is tolerated only on a numerical tie -- selected /
+    rejected candidate keys (beam) or top-1 / top-2 logits (greedy) within 1e-4 of each other at some step: which side of
+    fp32 round-off wins there is not defined -- and counted separately"""
+    import numpy as np
+    import torch
+    from capdec_amd import synth
+    from capdec_amd.predictions_runner import prefix_from_embeddings
+    from oracle import capdec_oracle as O
+    sd = synth.hot_state_dict(42, mapper, 512, P)
+    rows = sorted(set(int(r) for r in rows))
+    pe = prefix_from_embeddings(model, emb[rows]).float().cpu()
+    ids, lens = out[0][rows].cpu().numpy(), out[1][rows].cpu().numpy()
+    t0 = time.perf_counter()
+    equal = ties = 0
+    if beam:
+        mg = []
+        tok, seq, sc = O.beam_cached(sd, pe, 5, STOP_ID, T, margins=mg)
+        order = O.beam_output_order(sc)
+        clear = (mg[0] > 1e-4).numpy()
+        scores = out[2][rows].cpu().numpy()
+        for j in range(len(rows)):
+            b = int(order[j][0])
+            good = (np.array_equal(ids[j].reshape(-1)[:T], tok[j][b].numpy()) and int(np.asarray(lens[j]).reshape(-1)[0]) == int(seq[j][b])
+                    and abs(float(np.asarray(scores[j]).reshape(-1)[0]) - float(sc[j][b])) <= 1e-4)
+            equal += int(good)
+            ties += int((not good) and (not clear[j]))
+    else:
+        gi, gl = O.greedy_cached(sd, pe, stop_id=STOP_ID, entry_length=T)
+        _, st = O.greedy_forced(sd, pe, gi)
+        live = torch.arange(T)[None, :] < gl[:, None]
+        gap = torch.where(live, st[:, :, 0] - st[:, :, 1], torch.full((1, 1), 1e9))
+        clear = (gap.min(dim=1).values > 1e-4).numpy()
+        for j in range(len(rows)):
+            good = np.array_equal(ids[j], gi[j].numpy()) and int(lens[j]) == int(gl[j])
+            equal += int(good)
+            ties += int((not good) and (not clear[j]))
+    n = len(rows)
+    return {"oracle_checked": n, "oracle_equal": equal, "differ_on_a_numerical_tie": ties, "ok": equal == n - ties,
+            "captions_with_a_near_tie_step": int((~clear).sum()),
+            "rows": rows, "seconds": round(time.perf_counter() - t0, 1),
+            "note": "rows of the timed default-mode step vs oracle/capdec_oracle.py (beam: best beam's ids, length, mean log-prob "
+                    "within 1e-4; greedy: ids and length) on the prefixes the HIP mapper produced"}
+
+
 def cpu_baseline(mapper, beam, P, T, budget_s=20.0, D=512, captions=8):
     """The oracle's reference-shaped path (batch 1, NO KV cache, lm_head on every position, fp32
     torch CPU ops: the algorithm of reference gpt2_prefix_eval.py:50-198 driven like
@@ -236,6 +282,97 @@ def side_workload(args, world, rank, dev, emit=print):
                                      "gemm_mode": model.engine.gemm_mode()}}))
 
 
+class Watchdog:
+    """Every rank of a multi-GPU run carries one: if the run is still going after `limit_s` seconds the rank says WHERE it
+    is stuck on stderr and exits with status 3 (torchrun then takes the other ranks down) -- an unattended 8-GPU run must
+    end with a readable line, not with the driver's clock."""
+
+    def __init__(self, rank, world, limit_s):
+        import threading
+        self.rank, self.world, self.limit, self.phase, self.t0 = rank, world, float(limit_s), "start", time.perf_counter()
+        self._done = threading.Event()
+        if self.limit > 0:
+            threading.Thread(target=self._run, daemon=True).start()
+
+    def note(self, phase):
+        self.phase = phase
+
+    def _run(self):
+        if not self._done.wait(self.limit):
+            print("bench.py: rank %d of %d still in phase '%s' after %.0f s (--rank-timeout): aborting this rank"
+                  % (self.rank, self.world, self.phase, time.perf_counter() - self.t0), file=sys.stderr, flush=True)
+            os._exit(3)
+
+    def stop(self):
+        self._done.set()
+
+
+def per_rank_table(world, rank, n_local, seconds, device, all_gather_floats):
+    """[{rank, device, captions, seconds, captions_per_s}] on every rank: what each rank did in the timed region (the
+    driver can see that N ranks really decoded, and which one was slowest)"""
+    rows = all_gather_floats([float(rank), float(device), float(n_local), float(seconds)])
+    return [{"rank": int(r[0]), "device": int(r[1]), "captions_per_step": int(r[2]), "seconds": round(r[3], 4),
+             "captions_per_s": round(r[2] / r[3], 2) if r[3] > 0 else None} for r in rows]
+
+
+def dry_run(args, world, rank, emit):
+    """--dry-run: the N-rank control flow of this file on CPU -- gloo process group, caption sharding, a fake decode
+    (token ids are a function of the caption index), the id gather, barrier + max-over-ranks timing, the per-rank table,
+    the scaling check against a one-rank pass, the watchdog -- everything except the GPU work.  tests/test_host_logic.py
+    runs it with 2 and with 8 ranks."""
+    import torch.distributed as dist
+    from capdec_amd import distributed as cdist
+    wd = Watchdog(rank, world, args.rank_timeout)
+    if world > 1:
+        wd.note("init_process_group(gloo)")
+        dist.init_process_group("gloo")
+    n_global, T = args.captions, args.entry_length
+
+    def fake_step(r, w):
+        lo, hi = cdist.shard_bounds(n_global, r, w)
+        idx = torch.arange(lo, hi, dtype=torch.int32)
+        ids = (idx[:, None] * 7 + torch.arange(T, dtype=torch.int32)[None, :]) % 50257
+        lens = (idx % T + 1).to(torch.int32)
+        scores = -(idx.float() + 1.0) / 100.0
+        return cdist.gather_ids(ids, lens, n_global, scores) if w > 1 else (ids, lens, scores)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    def all_gather_floats(vals):
+        t = torch.tensor(vals, dtype=torch.float64)
+        if world == 1:
+            return [t.tolist()]
+        parts = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(parts, t)
+        return [p.tolist() for p in parts]
+
+    wd.note("timed region")
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = fake_step(rank, world)
+    t_local = time.perf_counter() - t0
+    barrier()
+    mx = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+    lo, hi = cdist.shard_bounds(n_global, rank, world)
+    table = per_rank_table(world, rank, hi - lo, t_local / max(args.steps, 1), rank, all_gather_floats)
+    wd.note("scaling check")
+    one = fake_step(0, 1)
+    same = all(bool((a == b).all()) for a, b in zip(one, out))
+    barrier()
+    if world > 1:
+        dist.destroy_process_group()
+    wd.stop()
+    if rank == 0:
+        emit(json.dumps({"dry_run": True, "n_gpus": world, "ranks": [r["rank"] for r in table], "per_rank": table,
+                          "captions_per_step": n_global, "ids_equal_to_1gpu": same, "ms_per_step": round(float(mx) / args.steps * 1e3, 3),
+                          "backend": "gloo" if world > 1 else None}))
+
+
 def respawn_under_torchrun(n):
     """`python bench.py --gpus N` without a launcher: start N ranks (one per GPU) with torch.distributed.run and
     pass the same arguments through; the JSON line is printed by rank 0 of that job."""
@@ -280,8 +417,9 @@ def main():
     ap.add_argument("--profile-every", type=int, default=7,
                     help="hipEvent-time every N-th launch of each kernel family inside the timed region (1 = all; "
                          "7 is coprime to the 4-GEMM / 12-layer launch cycles, so every shape is sampled evenly)")
-    ap.add_argument("--cpu-seconds", type=float, default=20.0, help="wall-clock budget of the CPU baseline (0 = skip)")
-    ap.add_argument("--cpu-captions", type=int, default=8,
+    ap.add_argument("--cpu-seconds", type=float, default=20.0,
+                    help="wall-clock budget of the CPU baseline; 0 = SKIP the CPU baseline (unless --cpu-captions is given explicitly)")
+    ap.add_argument("--cpu-captions", type=int, default=None,
                     help="CPU baseline on this many WHOLE captions (default 8, about a minute of host time; SURVEY D.5: 32); "
                          "0 = a --cpu-seconds time budget of decode steps instead")
     ap.add_argument("--no-checks", action="store_true",
@@ -289,6 +427,9 @@ def main():
                          "batch-invariant mode against the big batch; attn_decode_diverged: one step with beams that never "
                          "share history)")
     ap.add_argument("--no-smi", action="store_true", help="do not sample rocm-smi (clock / power) during the timed region")
+    ap.add_argument("--rank-timeout", type=float, default=1500.0,
+                    help="N > 1: a rank still running after this many seconds prints the phase it is stuck in and exits "
+                         "with status 3 (0 = no watchdog)")
     ap.add_argument("--dry-run", action="store_true",
                     help="launcher check without a GPU (CPU tests): join a gloo group, all-gather the ranks, print "
                          "{n_gpus, ranks} and exit")
@@ -314,17 +455,9 @@ def main():
     if world != args.gpus:
         raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
     if args.dry_run:
-        import torch.distributed as dist
-        seen = [rank]
-        if world > 1:
-            dist.init_process_group("gloo")
-            parts = [torch.zeros(1, dtype=torch.int64) for _ in range(world)]
-            dist.all_gather(parts, torch.tensor([rank]))
-            seen = [int(p) for p in parts]
-            dist.destroy_process_group()
-        if rank == 0:
-            emit(json.dumps({"dry_run": True, "n_gpus": world, "ranks": seen}))
-        return
+        return dry_run(args, world, rank, emit)
+    wd = Watchdog(rank, world, args.rank_timeout if world > 1 else 0)
+    wd.note("init_process_group(nccl)")
     if use_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -377,8 +510,18 @@ def main():
         return float(tt.item())
 
     def note(msg):
+        wd.note(msg)
         if rank == 0:
             print("[bench %.1fs] %s" % (time.perf_counter() - t_start, msg), file=sys.stderr, flush=True)
+
+    def all_gather_floats(vals):
+        t = torch.tensor(vals, dtype=torch.float64, device=dev)
+        if not use_dist:
+            return [t.tolist()]
+        import torch.distributed as dist
+        parts = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(parts, t)
+        return [p.tolist() for p in parts]
     t_start = time.perf_counter()
     note("weights loaded, warm-up")
     for _ in range(args.warmup):
@@ -394,9 +537,13 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out = step()
+    torch.cuda.synchronize()
+    t_local = time.perf_counter() - t0           # this rank's own time (the metric uses the max over ranks, after the barrier)
     barrier()
     dt = max_over_ranks(time.perf_counter() - t0)
     note("timed region done")
+    lo_r, hi_r = cdist.shard_bounds(n_global, rank, world)
+    per_rank = per_rank_table(world, rank, hi_r - lo_r, t_local / max(args.steps, 1), local_rank, all_gather_floats)
     power = smi.stop() if smi else None
     prof = eng.profile_get()
     eng.profile_enable(False)
@@ -408,7 +555,7 @@ def main():
     # rows [0:16] of the big batch bit for bit (ids, lengths, scores), and the timed (default-mode) batch is compared
     # with the invariant one caption by caption (other kernel variants: same captions up to fp32 round-off);
     # (b) one more step with beams that never share history: the worst-case K/V traffic of the decode attention
-    ids_check = diverged = None
+    ids_check = diverged = oracle_check = None
     if world == 1 and not args.no_checks:
         try:        # (an extra measurement must never take the metric line down: failures are reported in the record)
             k16 = min(16, n_global)
@@ -432,26 +579,16 @@ def main():
         except Exception as ex:
             eng.set_batch_invariant(False)
             ids_check = {"ok": False, "error": str(ex)[:300]}
+        # (c) oracle_check: four captions of the TIMED default-mode batch against the CPU oracle (KV-cached restatement of
+        # reference gpt2_prefix_eval.py:50-115 / :118-198) run on exactly their prefixes -- the headline configuration
+        # compared at its own size on every bench run (tests/test_hip_parity.py does 24 + 32 of them)
         try:
-            if beam:
-                note("diverged-beam step")
-                eng.set_debug_diverge(True)
-                eng.profile_enable(1)
-                eng.profile_reset()
-                run_step(emb, 0, 1)
-                torch.cuda.synchronize()
-                pd = eng.profile_get()["attn_decode"]
-                cd = eng.decode_counters()
-                diverged = {"avg_ms": round(pd["ms"] / max(pd["launches"], 1), 4), "launches_timed": pd["launches"],
-                            "kv_slots_per_position": round(cd["kv_slots_per_position"], 3),
-                            "note": "one untimed step in which every beam continues itself (no shared history): the worst-case "
-                                    "K/V traffic of the decode attention; results are not the reference's beam search"}
+            note("oracle_check")
+            oracle_check = oracle_compare(model, emb, out, mapper, beam, P, T, rows=[0, n_global // 3, (2 * n_global) // 3, n_global - 1])
+            if not oracle_check.get("ok"):
+                print("bench.py: oracle_check FAILED: %s" % oracle_check, file=sys.stderr)
         except Exception as ex:
-            diverged = {"error": str(ex)[:300]}
-        finally:
-            eng.profile_enable(False)
-            eng.set_debug_diverge(False)
-
+            oracle_check = {"ok": False, "error": str(ex)[:300]}
     # ---- reduced-precision modes (configs[1]: bf16): agreement with the fp32-accurate path on the same captions -- free
     # running (sequences diverge after the first flipped token) and teacher-forced (per-step arg-max given the fp32 ids)
     match = None
@@ -482,6 +619,7 @@ def main():
     if use_dist:
         try:
             cdist.capi_comm_from_torch(eng)
+            rccl_rank, rccl_ranks = eng.comm_info()          # ncclCommUserRank / ncclCommCount: what RCCL itself reports
             lo, hi = cdist.shard_bounds(n_global, rank, world)
             g_ids = eng.gather_rows(out[0][lo:hi].contiguous(), n_global)
             g_sc = eng.gather_rows(out[2][lo:hi].contiguous(), n_global) if out[2] is not None else None
@@ -491,7 +629,8 @@ def main():
             for _ in range(10):
                 eng.gather_rows(out[0][lo:hi].contiguous(), n_global)
             torch.cuda.synchronize()
-            capi_collective = {"ok": ok, "ranks": world, "ms_per_gather": round((time.perf_counter() - t0c) * 100, 3)}
+            capi_collective = {"ok": ok and rccl_ranks == world and rccl_rank == rank, "ranks": world, "rccl_ranks": rccl_ranks,
+                               "ms_per_gather": round((time.perf_counter() - t0c) * 100, 3)}
             eng.comm_destroy()
         except Exception as ex:          # never let the optional check take the metric line down
             capi_collective = {"ok": False, "error": str(ex)[:300]}
@@ -525,9 +664,35 @@ def main():
                              "weak_value": round(vw, 2), "weak_captions_per_gpu": args.captions,
                              "weak_efficiency": round(vw / (world * v1), 4)}
 
+    mode_name = eng.gemm_mode()
+    # ---- one more step with beams that never share history: the worst-case K/V traffic of the decode attention.  The hook
+    # lives in the MEASUREMENT build of the library only (libcapdec_hip_measure.so, -DCAPDEC_MEASURE): the model moves to
+    # a context of that library for this last, untimed step (the product context and its KV cache are released first)
+    if world == 1 and not args.no_checks and beam:
+        try:
+            note("diverged-beam step (measurement build)")
+            model.use_measurement_build(True)
+            engm = model.engine
+            engm.set_gemm_mode(mode_name)
+            engm.set_debug_diverge(True)
+            engm.profile_enable(1)
+            engm.profile_reset()
+            run_step(emb, 0, 1)
+            torch.cuda.synchronize()
+            pd = engm.profile_get()["attn_decode"]
+            cd = engm.decode_counters()
+            diverged = {"avg_ms": round(pd["ms"] / max(pd["launches"], 1), 4), "launches_timed": pd["launches"],
+                        "kv_slots_per_position": round(cd["kv_slots_per_position"], 3),
+                        "note": "one untimed step in which every beam continues itself (no shared history): the worst-case "
+                                "K/V traffic of the decode attention; run in the measurement build of the library (the "
+                                "shipped one has no such hook); results are not the reference's beam search"}
+            engm.set_debug_diverge(False)
+        except Exception as ex:
+            diverged = {"error": str(ex)[:300]}
+
     if rank == 0:
         value = n_global * args.steps / dt
-        mode = eng.gemm_mode()
+        mode = mode_name
         est = lambda f: f["ms"] * f["calls"] / f["launches"] if f and f["launches"] else 0.0
         if mode in ("bf16", "f16"):
             fam, kname, peak = prof["gemm_x1"], "gemm_x1_kernel", PEAK_BF16_MFMA_TFLOPS
@@ -611,6 +776,8 @@ def main():
             "power": power,
             "saturated_operand_quads": counters["saturated_quads"],
             "scaling_check": scaling_check,
+            "per_rank": per_rank,
+            "rccl_ranks": (capi_collective or {}).get("rccl_ranks") if use_dist else None,
             "capi_collective": capi_collective,
             "match_vs_fp32": match,
         }
@@ -620,10 +787,13 @@ def main():
             rec["kernels"]["attn_decode"]["kv_slots_per_position"] = round(counters["kv_slots_per_position"], 3)
             if diverged:
                 rec["kernels"]["attn_decode_diverged"] = diverged
+        rec["oracle_check"] = oracle_check
         if power and power.get("sclk_mhz"):
             # the dominant kernel against the peak AT THE CLOCK THE CHIP ACTUALLY HELD (it runs at its package power cap)
             rec["roofline"]["frac_at_measured_clock"] = round(achieved / (peak * power["sclk_mhz"] / 2400.0), 4)
         note("cpu baseline")
+        if args.cpu_captions is None:      # not given: whole captions by default, nothing at all with --cpu-seconds 0
+            args.cpu_captions = 8 if args.cpu_seconds > 0 else 0
         if world == 1 and (args.cpu_seconds > 0 or args.cpu_captions > 0):
             try:
                 rec["cpu_baseline"] = cpu_baseline(mapper, B, P, T, args.cpu_seconds, captions=args.cpu_captions)
@@ -634,8 +804,10 @@ def main():
         emit(json.dumps(rec))
     if use_dist:
         import torch.distributed as dist
+        wd.note("final barrier")
         dist.barrier()
         dist.destroy_process_group()
+    wd.stop()
 
 
 if __name__ == "__main__":

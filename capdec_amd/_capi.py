@@ -79,7 +79,7 @@ class ClipResNetWeights(C.Structure):
 
 #: every symbol include/capdec.h declares: name -> (restype, argtypes)
 _VP = C.c_void_p
-ABI_VERSION = 2          # include/capdec.h: CAPDEC_ABI_VERSION
+ABI_VERSION = 3          # include/capdec.h: CAPDEC_ABI_VERSION
 SIGNATURES = {
     "capdec_abi_version": (C.c_int, []),
     "capdec_build_id": (C.c_char_p, []),
@@ -92,7 +92,6 @@ SIGNATURES = {
     "capdec_set_gemm_mode": (C.c_int, [_VP, C.c_int]),
     "capdec_get_gemm_mode": (C.c_int, [_VP]),
     "capdec_set_batch_invariant": (C.c_int, [_VP, C.c_int]),
-    "capdec_set_debug_diverge": (C.c_int, [_VP, C.c_int]),
     "capdec_cross_entropy": (C.c_int, [_VP, _VP, C.c_int, _VP, C.c_int, C.c_int, C.c_int, _VP]),
     "capdec_decode_counters": (C.c_int, [_VP, C.POINTER(C.c_double), C.POINTER(C.c_longlong)]),
     "capdec_set_kv_budget": (C.c_int, [_VP, C.c_size_t]),
@@ -125,6 +124,7 @@ SIGNATURES = {
     "capdec_comm_unique_id": (C.c_int, [C.c_char_p]),
     "capdec_comm_init": (C.c_int, [_VP, C.c_int, C.c_int, C.c_char_p]),
     "capdec_comm_destroy": (C.c_int, [_VP]),
+    "capdec_comm_info": (C.c_int, [_VP, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "capdec_shard_bounds": (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "capdec_gather_rows": (C.c_int, [_VP, _VP, C.c_int, C.c_int, C.c_int, _VP]),
     "capdec_gather_ids": (C.c_int, [_VP, _VP, _VP, _VP, C.c_int, C.c_int, C.c_int, _VP, _VP, _VP]),
@@ -136,6 +136,12 @@ SIGNATURES = {
     "capdec_profile_get": (C.c_int, [_VP, C.POINTER(C.c_int), C.POINTER(C.c_char_p), c_float_p,
                                      C.POINTER(C.c_int64), C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
 }
+
+#: exported by measurement builds only (libcapdec_hip_measure.so, -DCAPDEC_MEASURE): bound when present
+MEASURE_SIGNATURES = {
+    "capdec_set_debug_diverge": (C.c_int, [_VP, C.c_int]),
+}
+MEASURE_LIB_PATH = os.path.join(_HERE, "lib", "libcapdec_hip_measure.so")
 
 _lib: Optional[C.CDLL] = None
 
@@ -160,9 +166,14 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
         fn = getattr(lib, name)   # AttributeError if the symbol is not exported
         fn.restype = res
         fn.argtypes = args
+    for name, (res, args) in MEASURE_SIGNATURES.items():
+        fn = getattr(lib, name, None)
+        if fn is not None:
+            fn.restype = res
+            fn.argtypes = args
     if lib.capdec_abi_version() != ABI_VERSION:
         raise CapdecError("libcapdec_hip.so ABI version mismatch")
-    if path is None and os.environ.get("CAPDEC_SKIP_BUILD_ID_CHECK") != "1":
+    if (path is None or os.path.abspath(p) == os.path.abspath(MEASURE_LIB_PATH)) and os.environ.get("CAPDEC_SKIP_BUILD_ID_CHECK") != "1":
         # stale-library guard: the id compiled into the .so must match the sources lying next to it
         try:
             from .build import source_hash
@@ -178,7 +189,7 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     return lib
 
 
-def check(rc: int, what: str = "") -> None:
+def check(rc: int, what: str = "", lib: Optional[C.CDLL] = None) -> None:
     if rc != 0:
-        msg = load_library().capdec_last_error()
+        msg = (lib or load_library()).capdec_last_error()
         raise CapdecError(f"{what}: {msg.decode() if msg else 'unknown error'}")

@@ -480,21 +480,22 @@ static int attn_decode_typed(hipStream_t st, const float *qkv, const KvCache &c,
     KV *kl = c.kp<KV>(layer), *vl = c.vp<KV>(layer);
     // positions known to sit in slot 0 whatever the table says: the whole history for greedy rows, the CLIP prefix for
     // beams (c.prefix_len; 0 = unknown)
-    static const int pre_on = [] { const char *e = getenv("CAPDEC_ATT_PRELOAD"); return e ? atoi(e) : 1; }();
+    const Tuning &tn = c.tune ? *c.tune : default_tuning();     // (the overrides below exist in measurement builds only)
+    const int pre_on = tn.att_preload;
     const int npre = !pre_on ? 0 : (anc == nullptr ? L : c.prefix_len);
     {
         const int ncap = rows / beam, total = ncap * c.heads;
         if (total <= 0) return 0;
         size_t lds = ((size_t)4 * beam * L * sizeof(int) + 1023) & ~(size_t)1023;   // ancestor slots (the DMA ring, if any, follows)
-        static const int wsync = [] { const char *e = getenv("CAPDEC_ATT_WSYNC"); return e ? atoi(e) : 1; }();
-        static const int dma_on = [] { const char *e = getenv("CAPDEC_ATT_DMA"); return (e ? atoi(e) : 1) && wsync; }();
+        const int wsync = tn.att_wsync;
+        const int dma_on = tn.att_dma && wsync;
         dim3 grid((total + 3) / 4), block(256);
         // waves per SIMD the register allocation is sized for: beam <= 4 fits 4 without spilling; beam 5 needs 124
         // registers at 4 waves; CAPDEC_ATT_OCC=3 / CAPDEC_ATT_NA=4 are measurement knobs (default = measured best)
-        static const int occ5 = [] { const char *e = getenv("CAPDEC_ATT_OCC"); return e && atoi(e) == 3 ? 3 : 4; }();
+        const int occ5 = tn.att_occ == 3 ? 3 : 4;
         // positions per group in flight (NA): 2 when the launch is HBM-bound (5000 captions: 0.429 vs 0.435 ms), 4 when
         // fewer than two rounds of wavefronts make it latency-bound (625 captions: 66.6 vs 68.7 us); CAPDEC_ATT_NA forces
-        static const int na_env = [] { const char *e = getenv("CAPDEC_ATT_NA"); return e ? atoi(e) : 0; }();
+        const int na_env = tn.att_na;
         const int na4 = na_env ? (na_env == 4) : (!c.fixed_variant && total <= 16384);
 #define LAUNCH_BEAMS_V(B, OCC, NAV, CURV)                                                                       \
     hipLaunchKernelGGL((attn_decode_beams_kernel<B, KV, OCC, NAV, CURV, false>), grid, block, lds, st, qkv, kl, vl, total, \

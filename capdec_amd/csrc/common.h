@@ -6,6 +6,7 @@
 #include <vector>
 
 #include "../../include/capdec.h"
+#include "config.h"
 
 namespace capdec {
 
@@ -105,6 +106,7 @@ struct GemmEpilogue {
     size_t splitk_ws_bytes = 0;    // under-filled grids run unsplit
     void *packed_out = nullptr;    // bf16x3p only: write act(acc + bias) as the packed split-bf16 A operand (K = N)
                                    // of the next GEMM instead of fp32 C
+    const Tuning *tune = nullptr;  // the context's environment knobs (config.h); nullptr = every default
     const QkvScatter *qkv_scatter = nullptr;   // f16x2p, unsplit grids only (see QkvScatter)
     bool invariant = false;        // batch-invariant mode: the unsplit 128 x 128 kernel whatever M is (no planner, no split-K)
     bool wide_ok = false;          // f16x2p only: the B operand is a weight with max |w| < 16, so its high plane can be scaled
@@ -119,12 +121,14 @@ struct GemmEpilogue {
     void *ln_out = nullptr;
     int *ln_done = nullptr;
 };
+inline const Tuning &tuning_of(const GemmEpilogue &e) { return e.tune ? *e.tune : default_tuning(); }
 int launch_gemm_f32(hipStream_t st, const float *A, int lda, const float *Bt, int ldb, float *C, int ldc,
                     int M, int N, int K, const GemmEpilogue &epi);
 // lm_head: logits tile never leaves the CU; per (row, 128-column tile) emits max, sum exp(x - max)
 // and the top-k (value, column) pairs.
 int launch_gemm_f32_topk(hipStream_t st, const float *A, int lda, const float *Bt, int ldb, int M, int N, int K,
-                         int k, float inv_temp, float *tile_max, float *tile_sum, float *cand_val, int *cand_idx);
+                         int k, float inv_temp, float *tile_max, float *tile_sum, float *cand_val, int *cand_idx,
+                         const Tuning *tune = nullptr);
 inline int gemm_tiles_n(int N) { return (N + GEMM_BN - 1) / GEMM_BN; }
 
 // gemm_bf16x3.hip: the same two GEMMs on the bf16 matrix cores with operands split into three bf16
@@ -143,8 +147,8 @@ int launch_gemm_bf16x3p(hipStream_t st, const void *Apacked, const void *Bpacked
 int launch_gemm_bf16x3p_topk(hipStream_t st, const void *Apacked, const void *Bpacked, int M, int N, int K, int k,
                              float inv_temp, float *tile_max, float *tile_sum, float *cand_val, int *cand_idx);
 // split-K of the packed-A kernel for under-filled grids: number of K slices (1 = none) and the workspace it needs
-int gemm_splitk_slices(int M, int N, int K);
-size_t gemm_splitk_ws_bytes(int M, int N, int K);
+int gemm_splitk_slices(int M, int N, int K, const Tuning &t = default_tuning());
+size_t gemm_splitk_ws_bytes(int M, int N, int K, const Tuning &t = default_tuning());
 // adds the S partial tiles of a split-K launch in slice order and applies the epilogue (fmt: packed output format)
 int launch_splitk_reduce(hipStream_t st, const float *part, int S, int M, int N, const GemmEpilogue &epi, float *C,
                          int ldc, int fmt);
@@ -158,13 +162,13 @@ int launch_gemm_f16x2p_topk(hipStream_t st, const void *Apacked, const void *Bpa
                             float inv_temp, float *tile_max, float *tile_sum, float *cand_val, int *cand_idx);
 // round-3 wide-tile kernels with ONE accumulator set (gemm_h2w.hip); scale = 2^(t - 11), t = pack-time pre-scale
 // exponent of the weights; `which`: 2 = 256x128 (two blocks per CU), 3 = 256x256 (8 waves), 6 = 256x256 (4 waves), 8 = 128x192
-int h2w_choice();
 int h2w_plan(int M, int N, int K);
 int launch_absmax_bits(hipStream_t st, const float *w, size_t n, unsigned *d_out);
 int launch_gemm_h2w(hipStream_t st, int which, const void *Apacked, const void *Bpacked, float *C, int ldc, int M, int N,
                     int K, const GemmEpilogue &epi, float scale);
 int launch_gemm_h2w_topk(hipStream_t st, const void *Apacked, const void *Bpacked, int M, int N, int K, int k,
-                         float inv_temp, float *tile_max, float *tile_sum, float *cand_val, int *cand_idx);
+                         float inv_temp, float *tile_max, float *tile_sum, float *cand_val, int *cand_idx,
+                         const Tuning *tune = nullptr);
 // round-4 ping-pong kernels (gemm_pp.hip): ONE 8-wavefront block per CU, the two wavefronts of a SIMD alternate between a
 // load phase and a matrix phase; `which`: 10 = 256x128 (two accumulator sets), 11 = 256x128, 12 = 256x256, 13 = 128x256 (one set)
 int launch_gemm_pp(hipStream_t st, int which, const void *Apacked, const void *Bpacked, float *C, int ldc, int M, int N,
@@ -235,6 +239,7 @@ struct KvCache {
     bool bf16 = false;
     int prefix_len = 0;           // decode: positions [0, prefix_len) of every row live in slot 0 (the CLIP prefix)
     bool fixed_variant = false;   // batch-invariant mode: the launch-size dependent kernel variants are pinned
+    const Tuning *tune = nullptr; // the context's environment knobs (measurement builds read the attention overrides)
     size_t layer_stride() const { return (size_t)rows * heads * ctx * hd; }      // elements
     size_t elem_bytes() const { return bf16 ? 2 : 4; }
     template <typename T> T *kp(int layer) const { return reinterpret_cast<T *>(k) + (size_t)layer * layer_stride(); }

@@ -533,7 +533,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_ln_kernel(const float *__re
 
 int launch_splitk_reduce(hipStream_t st, const float *part, int S, int M, int N, const GemmEpilogue &epi, float *C,
                          int ldc, int fmt) {
-    static const int fuse_off = [] { const char *e = getenv("CAPDEC_FUSE_LN"); return e && atoi(e) == 0 ? 1 : 0; }();
+    const bool fuse_off = !tuning_of(epi).fuse_ln;
     // (below ~1000 rows the element-parallel reduce + a separate LayerNorm keep more loads in flight than one wavefront
     //  per row: 8 captions x beam 5 measured 74 vs 81 ms per pass)
     if (!fuse_off && M >= 1024 && epi.ln_out && epi.ln_w && epi.ln_b && epi.packed_out == nullptr && epi.act == CAPDEC_ACT_NONE &&
@@ -560,9 +560,8 @@ int launch_splitk_reduce(hipStream_t st, const float *part, int S, int M, int N,
 //      k-steps per slice.  mlp.c_proj (K = 3072, 150 tiles walking 192 k-steps each): 58 -> ~35 us.
 // Across a regime / S boundary the fp32 summation order of a row changes (round-off level; the unsplit regime above is
 // again batch-size independent).  CAPDEC_SPLITK=0 disables both, CAPDEC_SPLITK_MID=0 only (b).
-int gemm_splitk_slices(int M, int N, int K) {
-    static const int off = [] { const char *e = getenv("CAPDEC_SPLITK"); return e && atoi(e) == 0 ? 1 : 0; }();
-    static const int mid_off = [] { const char *e = getenv("CAPDEC_SPLITK_MID"); return e && atoi(e) == 0 ? 1 : 0; }();
+int gemm_splitk_slices(int M, int N, int K, const Tuning &t) {
+    const bool off = !t.splitk, mid_off = !t.splitk_mid;
     const int nk = K / X3_BK;
     if (off || N % 4 != 0) return 1;
     int best = 1;
@@ -582,8 +581,8 @@ int gemm_splitk_slices(int M, int N, int K) {
 //  the same launch, summed by the last piece to arrive at a per-tile counter.  Device-scope fences cost an L2 write-back +
 //  invalidate per piece; with sc1 write-through dumps instead, the dump + arrival + re-read still cost more than the
 //  round they save: 3125 x 3072 x 768: 55 -> 68 us, 25000 x 768 x 3072: 393 -> 440 us.  DESIGN.md section 5.)
-size_t gemm_splitk_ws_bytes(int M, int N, int K) {
-    const int s = gemm_splitk_slices(M, N, K);
+size_t gemm_splitk_ws_bytes(int M, int N, int K, const Tuning &t) {
+    const int s = gemm_splitk_slices(M, N, K, t);
     size_t b = s > 1 ? (size_t)s * M * N * sizeof(float) : 0;
     for (int which : {10, 12, 14}) b = std::max(b, pp_splitk_ws_bytes(which, M, N, K));     // (the ping-pong kernels' own split)
     return b;
@@ -600,7 +599,7 @@ int launch_gemm_bf16x3p(hipStream_t st, const void *Apacked, const void *Bpacked
     const bool vec4 = N % 4 == 0 && ldc % 4 == 0 && ((uintptr_t)C & 15) == 0 &&
                       (epi.bias == nullptr || ((uintptr_t)epi.bias & 15) == 0) &&
                       (epi.resid == nullptr || (epi.ldr % 4 == 0 && ((uintptr_t)epi.resid & 15) == 0));
-    const int S = (vec4 && epi.splitk_ws) ? gemm_splitk_slices(M, N, K) : 1;
+    const int S = (vec4 && epi.splitk_ws) ? gemm_splitk_slices(M, N, K, tuning_of(epi)) : 1;
     if (S > 1 && epi.splitk_ws_bytes >= (size_t)S * M * N * sizeof(float)) {
         float *part = (float *)epi.splitk_ws;
         hipLaunchKernelGGL(gemm_bf16x3p_splitk_kernel, dim3(tiles_m * tiles_n * S), dim3(256), 0, st,
@@ -608,7 +607,7 @@ int launch_gemm_bf16x3p(hipStream_t st, const void *Apacked, const void *Bpacked
         CAPDEC_HIP(hipGetLastError());
         return launch_splitk_reduce(st, part, S, M, N, epi, C, ldc, PK_BF16X3);
     }
-    static const int dbg = [] { const char *e = getenv("CAPDEC_ABL_DMA"); return e ? atoi(e) : 0; }();
+    const int dbg = tuning_of(epi).x3_abl_dma;      // (measurement builds only: 0 otherwise)
     if (vec4)
         hipLaunchKernelGGL(gemm_bf16x3p_kernel<true>, dim3(tiles_m * tiles_n), dim3(256), 0, st, (const __bf16 *)Apacked,
                            (const __bf16 *)Bpacked, C, ldc, M, N, K, epi.bias, epi.resid, epi.ldr, epi.act, tiles_m,
@@ -645,8 +644,8 @@ int launch_gemm_bf16x3p_topk(hipStream_t st, const void *Apacked, const void *Bp
     return 0;
 }
 
-static bool x3_use_small_tile(int M, int tiles_n) {
-    static const int force = [] { const char *e = getenv("CAPDEC_X3_TILE_M"); return e ? atoi(e) : 0; }();
+static bool x3_use_small_tile(int M, int tiles_n, const Tuning &t) {
+    const int force = t.x3_tile_m;
     // Measured on MI355X (M = 3125 / 5000 decode rows): the 64-row tile doubles the blocks of an under-filled
     // grid but also doubles the B bytes per FLOP, and comes out 6-10 % SLOWER than 128-row tiles even at
     // 150 blocks on 256 CUs -- so it is opt-in only (CAPDEC_X3_TILE_M=64), e.g. for M <= 64.
@@ -661,7 +660,7 @@ int launch_gemm_bf16x3(hipStream_t st, const float *A, int lda, const void *Bpac
     CAPDEC_CHECK((((uintptr_t)A | (uintptr_t)Bpacked) & 15) == 0, "gemm_bf16x3: operands must be 16-byte aligned");
     // 64-row tiles when the 128-row grid would leave the chip (256 CUs x 2 blocks) under-filled
     const int tiles_n = (N + GEMM_BN - 1) / GEMM_BN;
-    const bool small = x3_use_small_tile(M, tiles_n);
+    const bool small = x3_use_small_tile(M, tiles_n, tuning_of(epi));
     const int bm = small ? 64 : 128, tiles_m = (M + bm - 1) / bm;
     if (small)
         hipLaunchKernelGGL(gemm_bf16x3_kernel<1>, dim3(tiles_m * tiles_n), dim3(256), 0, st, A, lda, (const __bf16 *)Bpacked,
@@ -678,7 +677,7 @@ int launch_gemm_bf16x3_topk(hipStream_t st, const float *A, int lda, const void 
     CAPDEC_CHECK(M > 0 && N > 0 && K > 0, "gemm_topk: empty problem");
     CAPDEC_CHECK(K % 64 == 0 && lda % 4 == 0, "gemm_bf16x3_topk: K must be a multiple of 64");
     const int tiles_n = (N + GEMM_BN - 1) / GEMM_BN;
-    const bool small = x3_use_small_tile(M, tiles_n);
+    const bool small = x3_use_small_tile(M, tiles_n, default_tuning());
     const int bm = small ? 64 : 128, tiles_m = (M + bm - 1) / bm;
     dim3 grid(tiles_m * tiles_n), block(256);
 #define LAUNCH_TOPK(KS)                                                                                               \

@@ -277,11 +277,6 @@ __device__ __forceinline__ void h2_join(f32x16 (&am)[2][2], const f32x16 (&ac)[2
 }
 
 constexpr int H2_NS = 4;
-// CAPDEC_PP=0: the ping-pong kernels of round 4 are never planned (A/B against rounds 2-3)
-static int pp_enabled() {      // 0 = never, 2 = mid-size launches only (default), 1 = mid-size and large, 3 = large only
-    static const int on = [] { const char *e = getenv("CAPDEC_PP"); return e ? atoi(e) : 2; }();
-    return on;
-}
 // wave grid of the 128 x 128 kernels for the coalesced epilogues (gemm_epilogue_lds.h): 2 x 2 wavefronts of 64 x 64
 struct H2Tile { static constexpr int WN = 2, TI = 2, TJ = 2; };
 // end of a persistent block's tile: the next tile's LDS-DMA pieces land in the epilogue's slabs
@@ -304,11 +299,6 @@ __device__ __forceinline__ EpiArgs h2_epi_args(float *C, int ldc, int M, int N, 
     else ea.resid = resid;
     ea.sc = sc;
     return ea;
-}
-// ring depth of the plain kernel: CAPDEC_H2_NS = 3 | 4 | 5 (measurement knob; the default is the measured-fastest)
-static int h2_ns() {
-    static const int ns = [] { const char *e = getenv("CAPDEC_H2_NS"); const int v = e ? atoi(e) : H2_NS; return v == 3 || v == 5 ? v : H2_NS; }();
-    return ns;
 }
 
 template <bool VEC4, int NS, int ABL = 0>
@@ -395,16 +385,17 @@ int launch_gemm_f16x2p(hipStream_t st, const void *Apacked, const void *Bpacked,
     CAPDEC_CHECK(!sc.kc || (vec4 && epi.bias && !epi.resid && !epi.packed_out && epi.act == CAPDEC_ACT_NONE && N == 3 * sc.d &&
                             sc.d % GEMM_BN == 0 && !epi.splitk_ws),
                  "gemm_f16x2p: the qkv scatter epilogue needs an unsplit, biased, plain [M, 3d] projection");
-    // round-4 ping-pong kernels (gemm_pp.hip): forced (CAPDEC_H2W >= 10) or where the planner expects >= 5 % from them
-    // (mid-size and large launches; the small-batch regime M <= 512 keeps its batch-size independent split-K)
+    const Tuning &tn = tuning_of(epi);
+    // round-4 ping-pong kernels (gemm_pp.hip): forced (CAPDEC_H2W >= 10) or where the planner expects a gain from them
+    // (mid-size launches; the small-batch regime M <= 512 keeps its batch-size independent split-K)
     if (vec4 && !epi.invariant) {
         const bool can_split = epi.splitk_ws && !epi.resid_packed && !epi.packed_out && !sc.kc;
         int which = 0;
-        if (h2w_choice() >= 10) which = (h2w_choice() == 10 || epi.wide_ok) ? h2w_choice() : 0;
-        else if (h2w_choice() == 1 && pp_enabled() && M > 4 * GEMM_BM) which = pp_plan(M, N, K, epi.wide_ok, can_split, pp_enabled());
+        if (tn.h2w >= 10) which = (tn.h2w == 10 || tn.h2w == 11 || epi.wide_ok) ? tn.h2w : 0;
+        else if (tn.h2w == 1 && tn.pp && M > 4 * GEMM_BM) which = pp_plan(M, N, K, epi.wide_ok, can_split, tn.pp);
         if (which) return launch_gemm_pp(st, which, Apacked, Bpacked, C, ldc, M, N, K, epi, 1.0f / H2_LO_SCALE);
     }
-    const int S = (vec4 && epi.splitk_ws && !epi.resid_packed) ? gemm_splitk_slices(M, N, K) : 1;
+    const int S = (vec4 && epi.splitk_ws && !epi.resid_packed) ? gemm_splitk_slices(M, N, K, tn) : 1;
     if (S > 1 && epi.splitk_ws_bytes >= (size_t)S * M * N * sizeof(float)) {
         float *part = (float *)epi.splitk_ws;
         hipLaunchKernelGGL(gemm_f16x2p_splitk_kernel, dim3(tiles_m * tiles_n * S), dim3(256), 0, st,
@@ -412,37 +403,43 @@ int launch_gemm_f16x2p(hipStream_t st, const void *Apacked, const void *Bpacked,
         CAPDEC_HIP(hipGetLastError());
         return launch_splitk_reduce(st, part, S, M, N, epi, C, ldc, PK_F16X2);
     }
+    if (vec4 && epi.wide_ok && tn.h2w >= 1 && tn.h2w < 10 && !sc.kc) {      // round-3 single-accumulator geometries where they remove a round
+        const int which = tn.h2w >= 2 ? tn.h2w : h2w_plan(M, N, K);
+        if (which) return launch_gemm_h2w(st, which, Apacked, Bpacked, C, ldc, M, N, K, epi, 1.0f / H2_LO_SCALE);
+    }
     // persistent form for grids of up to four rounds, where the partly filled last round matters (625 captions: mlp.c_fc
     // 600 tiles, 80 -> 70 us inside the decode loop); larger grids keep one block per tile (the dispatcher balances them:
     // within noise either way at 25 000 rows).  CAPDEC_H2_PERSIST=<blocks> (0 = never)
-    if (vec4 && epi.wide_ok && h2w_choice() >= 1 && h2w_choice() < 10 && !sc.kc) {      // round-3 single-accumulator geometries where they remove a round
-        const int which = h2w_choice() >= 2 ? h2w_choice() : h2w_plan(M, N, K);
-        if (which) return launch_gemm_h2w(st, which, Apacked, Bpacked, C, ldc, M, N, K, epi, 1.0f / H2_LO_SCALE);
-    }
-    static const int persist = [] { const char *e = getenv("CAPDEC_H2_PERSIST"); return e ? atoi(e) : 512; }();
+    const int persist = tn.h2_persist;
     const int grid_h2 = (persist > 0 && tiles_m * tiles_n <= 4 * persist) ? std::min(tiles_m * tiles_n, persist) : tiles_m * tiles_n;
 #define LAUNCH_H2(V4, NSV)                                                                                            \
     hipLaunchKernelGGL((gemm_f16x2p_kernel<V4, NSV>), dim3(grid_h2), dim3(256), 0, st, (const _Float16 *)Apacked, \
                        (const _Float16 *)Bpacked, C, ldc, M, N, K, epi.bias, resid_arg, epi.ldr, epi.act, tiles_m,      \
                        tiles_n, (char *)epi.packed_out, sc)
-    const int ns = h2_ns();
-    static const int abl = [] { const char *e = getenv("CAPDEC_H2_ABL"); return e ? atoi(e) : 0; }();
-    if (vec4 && abl >= 1 && abl <= 6) {     // measurement only
+#ifdef CAPDEC_MEASURE
+    // CAPDEC_H2_ABL 1..6: ablations of the main loop (WRONG results); CAPDEC_H2_NS: ring depth 3 / 5
+    if (vec4 && tn.h2_abl >= 1 && tn.h2_abl <= 6) {
 #define LAUNCH_H2A(A)                                                                                               \
     hipLaunchKernelGGL((gemm_f16x2p_kernel<true, H2_NS, A>), dim3(tiles_m * tiles_n), dim3(256), 0, st,               \
                        (const _Float16 *)Apacked, (const _Float16 *)Bpacked, C, ldc, M, N, K, epi.bias, epi.resid,   \
                        epi.ldr, epi.act, tiles_m, tiles_n, (char *)epi.packed_out, sc)
-        if (abl == 1) LAUNCH_H2A(1); else if (abl == 2) LAUNCH_H2A(2); else if (abl == 3) LAUNCH_H2A(3);
-        else if (abl == 4) LAUNCH_H2A(4); else if (abl == 5) LAUNCH_H2A(5); else LAUNCH_H2A(6);
+        switch (tn.h2_abl) {
+            case 1: LAUNCH_H2A(1); break;
+            case 2: LAUNCH_H2A(2); break;
+            case 3: LAUNCH_H2A(3); break;
+            case 4: LAUNCH_H2A(4); break;
+            case 5: LAUNCH_H2A(5); break;
+            default: LAUNCH_H2A(6);
+        }
 #undef LAUNCH_H2A
         CAPDEC_HIP(hipGetLastError());
         return 0;
     }
-    if (vec4) {
-        if (ns == 3) LAUNCH_H2(true, 3); else if (ns == 5) LAUNCH_H2(true, 5); else LAUNCH_H2(true, H2_NS);
-    } else {
-        LAUNCH_H2(false, H2_NS);
-    }
+    if (vec4 && tn.h2_ns == 3) { LAUNCH_H2(true, 3); CAPDEC_HIP(hipGetLastError()); return 0; }
+    if (vec4 && tn.h2_ns == 5) { LAUNCH_H2(true, 5); CAPDEC_HIP(hipGetLastError()); return 0; }
+#endif
+    if (vec4) LAUNCH_H2(true, H2_NS);
+    else LAUNCH_H2(false, H2_NS);
 #undef LAUNCH_H2
     CAPDEC_HIP(hipGetLastError());
     return 0;
@@ -545,7 +542,7 @@ int launch_gemm_x1(hipStream_t st, const void *Apacked, const void *Bpacked, flo
                       (epi.bias == nullptr || ((uintptr_t)epi.bias & 15) == 0) &&
                       (epi.resid == nullptr || (epi.ldr % 4 == 0 && ((uintptr_t)epi.resid & 15) == 0));
     {
-        int S = (vec4 && epi.splitk_ws && !epi.resid_packed) ? gemm_splitk_slices(M, N, K) : 1;
+        int S = (vec4 && epi.splitk_ws && !epi.resid_packed) ? gemm_splitk_slices(M, N, K, tuning_of(epi)) : 1;
         if (S > 1 && ((K / X3_BK / S) % 4 != 0 || epi.splitk_ws_bytes < (size_t)S * M * N * sizeof(float))) S = 1;
         if (S > 1) {     // a slice is a whole, even number of two-k-step stages
             float *part = (float *)epi.splitk_ws;
@@ -560,9 +557,9 @@ int launch_gemm_x1(hipStream_t st, const void *Apacked, const void *Bpacked, flo
         }
     }
     // three blocks per CU measured +3 % at 25 000 rows, +1.3 % on the greedy bf16 workload; CAPDEC_X1_NS=4: two blocks
-    static const int ns3 = [] { const char *e = getenv("CAPDEC_X1_NS"); return e && atoi(e) == 4 ? 0 : 1; }();
+    const int ns3 = tuning_of(epi).x1_ns == 4 ? 0 : 1;
     // persistent blocks for grids of up to four rounds (768 slots with three blocks per CU, 512 with two)
-    static const int persist = [] { const char *e = getenv("CAPDEC_H2_PERSIST"); return e ? atoi(e) : 512; }();
+    const int persist = tuning_of(epi).h2_persist;
     const int slots = persist > 0 ? ((vec4 && ns3) ? persist * 3 / 2 : persist) : 0;
     const int grid_x1 = (slots > 0 && tiles_m * tiles_n <= 4 * slots) ? std::min(tiles_m * tiles_n, slots) : tiles_m * tiles_n;
 #define LAUNCH_X1V(V4, KD, NSV)                                                                                         \

@@ -174,8 +174,8 @@ int launch_gemm_f32(hipStream_t st, const float *A, int lda, const float *Bt, in
     CAPDEC_CHECK((((uintptr_t)A | (uintptr_t)Bt) & 15) == 0, "gemm: operands must be 16-byte aligned");
     const int tiles_m = (M + GEMM_BM - 1) / GEMM_BM, tiles_n = (N + GEMM_BN - 1) / GEMM_BN;
     // BK 16 (40 KB LDS, 3-4 blocks per CU) measured faster on the wide / deep projections, BK 32 on the
-    // N = K = 768 ones; CAPDEC_GEMM_BK overrides (tuning knob)
-    static const int bk_env = [] { const char *e = getenv("CAPDEC_GEMM_BK"); return e ? atoi(e) : 0; }();
+    // N = K = 768 ones (measurement builds: CAPDEC_GEMM_BK overrides)
+    const int bk_env = tuning_of(epi).f32_bk;
     const int bk = bk_env ? bk_env : ((N >= 3072 || K >= 2048) ? 16 : 32);
     if (bk == 16)
         hipLaunchKernelGGL((gemm_f32_kernel<16, 3>), dim3(tiles_m * tiles_n), dim3(256), 0, st, A, lda, Bt, ldb, C, ldc, M,
@@ -188,13 +188,14 @@ int launch_gemm_f32(hipStream_t st, const float *A, int lda, const float *Bt, in
 }
 
 int launch_gemm_f32_topk(hipStream_t st, const float *A, int lda, const float *Bt, int ldb, int M, int N, int K,
-                         int k, float inv_temp, float *tile_max, float *tile_sum, float *cand_val, int *cand_idx) {
+                         int k, float inv_temp, float *tile_max, float *tile_sum, float *cand_val, int *cand_idx,
+                         const Tuning *tune) {
     CAPDEC_CHECK(M > 0 && N > 0 && K > 0, "gemm_topk: empty problem");
     CAPDEC_CHECK(K % GEMM_BK == 0, "gemm_topk: K must be a multiple of 32");
     CAPDEC_CHECK(lda % 4 == 0 && ldb % 4 == 0, "gemm_topk: lda/ldb must be multiples of 4");
     const int tiles_m = (M + GEMM_BM - 1) / GEMM_BM, tiles_n = (N + GEMM_BN - 1) / GEMM_BN;
     dim3 grid(tiles_m * tiles_n), block(256);
-    static const int bk = [] { const char *e = getenv("CAPDEC_LMHEAD_BK"); return e ? atoi(e) : 16; }();
+    const int bk = (tune ? *tune : default_tuning()).f32_lmhead_bk;
 #define LAUNCH_TOPK(KS)                                                                                          \
     if (bk == 16)                                                                                                \
         hipLaunchKernelGGL((gemm_f32_topk_kernel<KS, 16, 3>), grid, block, 0, st, A, lda, Bt, ldb, M, N, K, inv_temp, \

@@ -271,10 +271,12 @@ __global__ __launch_bounds__(G::THREADS, G::MINW) void gemm_h2w_topk_kernel(cons
 }
 
 using W256x128 = WGeo<2, 2, 4, 2, 3, 2>;      // 4 waves, 72 KB, two blocks per CU
-using W256x256 = WGeo<2, 4, 4, 2, 4, 2>;      // 8 waves, 128 KB, one block per CU
+#ifdef CAPDEC_MEASURE
+using W256x256 = WGeo<2, 4, 4, 2, 4, 2>;      // 8 waves, 128 KB, one block per CU (measured: -4 .. -27 %)
 // (measured and removed from the build, profiles/r3_gemm_geometries.txt: WGeo<2,2,2,2,3,3> = 128x128 at three blocks per CU
 //  and WGeo<2,2,2,2,4,2> at two: +-0 against the round-2 kernel; WGeo<2,2,4,2,3,2,true>, accumulator-major MFMA order: -4 %)
-using W256x256q = WGeo<2, 2, 4, 4, 4, 1>;     // 4 waves x (128 x 128), 128 KB, ONE wavefront per SIMD (accumulators in AGPRs)
+using W256x256q = WGeo<2, 2, 4, 4, 4, 1>;     // 4 waves x (128 x 128), 128 KB, ONE wavefront per SIMD (accumulators in AGPRs: -40 %)
+#endif
 using W128x192 = WGeo<2, 2, 2, 3, 4, 2>;      // 4 waves x (64 x 96), 80 KB, two blocks per CU: column tiles of 192
 
 // max |w| of a device matrix as the bit pattern of a non-negative float (atomicMax on the bits is order preserving)
@@ -318,14 +320,6 @@ int h2w_plan(int M, int N, int K) {
     return best;
 }
 
-// CAPDEC_H2W: 0 = round-2 kernels everywhere; 1 = automatic (default: the wide kernel where it measured faster);
-// 2, 3, 6, 8 force one geometry wherever the wide kernel is applicable (measurement / tests): 2 = W256x128,
-// 3 = W256x256, 6 = W256x256q, 8 = W128x192
-int h2w_choice() {
-    static const int v = [] { const char *e = getenv("CAPDEC_H2W"); return e ? atoi(e) : 1; }();
-    return v;
-}
-
 template <class G>
 static int launch_h2w(hipStream_t st, const void *Apacked, const void *Bpacked, float *C, int ldc, int M, int N, int K,
                       const GemmEpilogue &epi, float scale, int slots) {
@@ -346,8 +340,10 @@ int launch_gemm_h2w(hipStream_t st, int which, const void *Apacked, const void *
                     int K, const GemmEpilogue &epi, float scale) {
     switch (which) {
         case 2: return launch_h2w<W256x128>(st, Apacked, Bpacked, C, ldc, M, N, K, epi, scale, 512);
+#ifdef CAPDEC_MEASURE
         case 3: return launch_h2w<W256x256>(st, Apacked, Bpacked, C, ldc, M, N, K, epi, scale, 256);
         case 6: return launch_h2w<W256x256q>(st, Apacked, Bpacked, C, ldc, M, N, K, epi, scale, 256);
+#endif
         case 8: return launch_h2w<W128x192>(st, Apacked, Bpacked, C, ldc, M, N, K, epi, scale, 512);
         default: CAPDEC_CHECK(false, "gemm_h2w: unknown geometry");
     }
@@ -356,12 +352,19 @@ int launch_gemm_h2w(hipStream_t st, int which, const void *Apacked, const void *
 
 // fused lm_head on the 256 x 128 tile: same partial lists per (row, 128-column tile) as launch_gemm_f16x2p_topk
 int launch_gemm_h2w_topk(hipStream_t st, const void *Apacked, const void *Bpacked, int M, int N, int K, int k,
-                         float inv_temp, float *tile_max, float *tile_sum, float *cand_val, int *cand_idx) {
+                         float inv_temp, float *tile_max, float *tile_sum, float *cand_val, int *cand_idx,
+                         const Tuning *tune) {
     CAPDEC_CHECK(M > 0 && N > 0 && K > 0 && K % 64 == 0, "gemm_h2w_topk: K must be a multiple of 64");
     using G = W256x128;
     const int tiles_m = (M + G::BM - 1) / G::BM, tiles_n = (N + G::BN - 1) / G::BN;
     dim3 grid(tiles_m * tiles_n), block(G::THREADS);
     const float scale = inv_temp / H2_LO_SCALE;
+#ifdef CAPDEC_MEASURE
+    // CAPDEC_LMHEAD_K1=1 (WRONG results): run the k = 1 epilogue whatever k is -- what the top-k selection rounds cost
+    if (tune && tune->lmhead_k1) k = 1;
+#else
+    (void)tune;
+#endif
 #define LAUNCH_TOPKW(KS)                                                                                           \
     hipLaunchKernelGGL((gemm_h2w_topk_kernel<G, KS>), grid, block, 0, st, (const _Float16 *)Apacked,                \
                        (const _Float16 *)Bpacked, M, N, K, scale, tile_max, tile_sum, cand_val, cand_idx, tiles_m, tiles_n)

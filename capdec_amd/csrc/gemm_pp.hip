@@ -350,20 +350,22 @@ static int launch_pp(hipStream_t st, const void *Apacked, const void *Bpacked, f
     const QkvScatter sc = epi.qkv_scatter ? *epi.qkv_scatter : QkvScatter();
     long long *stamps = nullptr;
 #define LAUNCH_PP(A)                                                                                                  \
-    hipLaunchKernelGGL((gemm_pp_kernel<G, A>), dim3(grid), dim3(G::THREADS), 0, st, (const _Float16 *)Apacked,        \
+    hipLaunchKernelGGL((gemm_pp_kernel<G, (G::BM == 256 && G::BN == 128 && G::TWOACC) ? A : 0>), dim3(grid), dim3(G::THREADS), 0, st, (const _Float16 *)Apacked, \
                        (const _Float16 *)Bpacked, C, ldc, M, N, K, epi.bias, resid_arg, epi.ldr, epi.act, tiles_m, tiles_n, \
                        (char *)epi.packed_out, kscale, sc, stamps)
 #ifdef CAPDEC_MEASURE
     // CAPDEC_PP_ABL (WRONG results for 1..5): 1 = no LDS-DMA in the loop, 2 = no fragment reads, 3 = no MFMAs, 4 = no
     // barriers, 5 = neither DMA nor reads, 8 = direct epilogue; CAPDEC_PP_STAMPS=<file>: per-block phase stamps, appended
-    static const int abl = [] { const char *e = getenv("CAPDEC_PP_ABL"); return e ? atoi(e) : 0; }();
-    static const char *stamp_path = getenv("CAPDEC_PP_STAMPS");
+    const Tuning &tn = tuning_of(epi);
+    const int abl = tn.pp_abl;
+    const char *stamp_path = tn.pp_stamps.empty() ? nullptr : tn.pp_stamps.c_str();
     static long long *d_stamps = nullptr;
     if (stamp_path) {
         if (!d_stamps) CAPDEC_HIP(hipMalloc(&d_stamps, 4096 * 4 * sizeof(long long)));
         if (grid <= 4096) { stamps = d_stamps; CAPDEC_HIP(hipMemsetAsync(d_stamps, 0, 4096 * 4 * sizeof(long long), st)); }
     }
-    switch (abl) {
+    constexpr bool kAbl = G::BM == 256 && G::BN == 128 && G::TWOACC;     // (ablation variants: geometry 10 only)
+    switch (kAbl ? abl : 0) {
         case 1: LAUNCH_PP(1); break;
         case 2: LAUNCH_PP(2); break;
         case 3: LAUNCH_PP(3); break;

@@ -370,7 +370,11 @@ __global__ __launch_bounds__(256) void token_nll_kernel(const float *__restrict_
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
     const int lab = labels[row];
-    if (lab == ignore_index || lab < 0 || lab >= V) { if (lane == 0) nll[row] = -1.f; return; }     // -1 = not counted
+    if (lab == ignore_index) { if (lane == 0) nll[row] = -1.f; return; }     // -1 = not counted
+    // a label outside [0, V) that is not ignore_index is an ERROR in torch's cross_entropy (and in the reference's
+    // train.py:350 / GPT2LMHeadModel labels path): a wrong tokenizer or vocabulary must not yield a plausible mean over
+    // fewer rows -- the row becomes NaN, so the loss is NaN (capdec.h)
+    if (lab < 0 || lab >= V) { if (lane == 0) nll[row] = nanf(""); return; }
     const float *x = logits + (size_t)row * ld;
     float mx = -INFINITY;
     for (int c = lane; c < V; c += 64) mx = fmaxf(mx, x[c]);

@@ -4,6 +4,7 @@ arithmetic happens in libcapdec_hip.so."""
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Dict, Optional, Tuple
 
 import numpy as np
@@ -26,20 +27,31 @@ def _fp(a: np.ndarray):
 class Engine:
     """One context per GPU / rank."""
 
-    def __init__(self, device: int = 0, kv_budget_bytes: int = 0):
+    def __init__(self, device: int = 0, kv_budget_bytes: int = 0, measure: bool = False):
+        """measure=True: the context lives in libcapdec_hip_measure.so (built with -DCAPDEC_MEASURE: ablation / override
+        knobs, the diverged-beam hook) -- tools/ and bench.py's untimed tail only, never the product path"""
         if not torch.cuda.is_available():
             raise CapdecError("capdec_amd needs a HIP device (MI355X); none is visible and there is no CPU fallback")
-        self.lib = _capi.load_library()
+        if measure:
+            if not os.path.exists(_capi.MEASURE_LIB_PATH):
+                raise CapdecError(f"{_capi.MEASURE_LIB_PATH} is missing: run `python -m capdec_amd.build --measure`")
+            self.lib = _capi.load_library(_capi.MEASURE_LIB_PATH)
+        else:
+            self.lib = _capi.load_library()
+        self.measure = bool(measure)
         self.device_index = int(device)
         self.device = torch.device("cuda", self.device_index)
         h = C.c_void_p()
-        check(self.lib.capdec_create(self.device_index, C.byref(h)), "capdec_create")
+        self._chk(self.lib.capdec_create(self.device_index, C.byref(h)), "capdec_create")
         self._h = h
         if kv_budget_bytes:
-            check(self.lib.capdec_set_kv_budget(self._h, kv_budget_bytes), "set_kv_budget")
+            self._chk(self.lib.capdec_set_kv_budget(self._h, kv_budget_bytes), "set_kv_budget")
         self.gpt_dims: Optional[Dict[str, int]] = None
         self.mapper: Optional[Dict[str, int]] = None
         self.comm: Optional[Tuple[int, int]] = None          # (rank, world) of the C-ABI RCCL communicator, if any
+
+    def _chk(self, rc: int, what: str = ""):
+        check(rc, what, self.lib)
 
     # ------------------------------------------------------------------ lifetime
     def close(self):
@@ -56,10 +68,10 @@ class Engine:
     def _sync_stream(self):
         """run on torch's current stream so torch copies and our kernels stay ordered"""
         s = torch.cuda.current_stream(self.device).cuda_stream
-        check(self.lib.capdec_set_stream(self._h, C.c_void_p(s)), "set_stream")
+        self._chk(self.lib.capdec_set_stream(self._h, C.c_void_p(s)), "set_stream")
 
     def synchronize(self):
-        check(self.lib.capdec_synchronize(self._h), "synchronize")
+        self._chk(self.lib.capdec_synchronize(self._h), "synchronize")
 
     def _dev(self, t: torch.Tensor, dtype=torch.float32) -> torch.Tensor:
         return t.to(device=self.device, dtype=dtype).contiguous()
@@ -99,7 +111,7 @@ class Engine:
         keep += [lnw, lnb]
         w = _capi.Gpt2Weights(n_layer, n_head, d, wte.shape[0], wpe.shape[0], ln_eps, _fp(wte), _fp(wpe), layers,
                               _fp(lnw), _fp(lnb))
-        check(self.lib.capdec_load_gpt2(self._h, C.byref(w)), "capdec_load_gpt2")
+        self._chk(self.lib.capdec_load_gpt2(self._h, C.byref(w)), "capdec_load_gpt2")
         self.gpt_dims = dict(n_layer=n_layer, n_head=n_head, d=d, vocab=wte.shape[0], n_pos=wpe.shape[0])
 
     def load_mapper_mlp(self, sd: Dict[str, torch.Tensor], prefix: str = "clip_project."):
@@ -108,7 +120,7 @@ class Engine:
         d = self.gpt_dims["d"] if self.gpt_dims else 768
         hidden, D = w1.shape
         P = w2.shape[0] // d
-        check(self.lib.capdec_load_mapper_mlp(self._h, D, P, hidden, _fp(w1), _fp(b1), _fp(w2), _fp(b2)),
+        self._chk(self.lib.capdec_load_mapper_mlp(self._h, D, P, hidden, _fp(w1), _fp(b1), _fp(w2), _fp(b2)),
               "capdec_load_mapper_mlp")
         self.mapper = dict(kind="mlp", D=D, P=P, d=d)
 
@@ -134,7 +146,7 @@ class Engine:
                 setattr(layers[i], field, _fp(a))
         hid = _f32(sd[f"{prefix}transformer.layers.0.mlp.fc1.weight"]).shape[0]
         w = _capi.TMapperWeights(lw.shape[1], P, clip_len, n_layers, num_heads, d, hid, _fp(lw), _fp(lb), _fp(pc), layers)
-        check(self.lib.capdec_load_mapper_transformer(self._h, C.byref(w)), "capdec_load_mapper_transformer")
+        self._chk(self.lib.capdec_load_mapper_transformer(self._h, C.byref(w)), "capdec_load_mapper_transformer")
         self.mapper = dict(kind="transformer", D=lw.shape[1], P=P, d=d, clip_length=clip_len, num_layers=n_layers)
 
     # ------------------------------------------------------------------ prefix stage
@@ -146,7 +158,7 @@ class Engine:
             return out
         off = self._dev(offset).reshape(-1) if offset is not None else None
         self._sync_stream()
-        check(self.lib.capdec_normalize_prefix(self._h, x.data_ptr(), n, dim, int(normalize),
+        self._chk(self.lib.capdec_normalize_prefix(self._h, x.data_ptr(), n, dim, int(normalize),
                                                off.data_ptr() if off is not None else None, out.data_ptr()),
               "capdec_normalize_prefix")
         return out
@@ -163,7 +175,7 @@ class Engine:
         nz = self._dev(noise) if noise is not None else None
         uu = self._dev(u) if u is not None else None
         self._sync_stream()
-        check(self.lib.capdec_noise_inject(self._h, x.data_ptr(), n, dim, float(variance),
+        self._chk(self.lib.capdec_noise_inject(self._h, x.data_ptr(), n, dim, float(variance),
                                            off.data_ptr() if off is not None else None, int(uniform), int(dont_norm),
                                            int(seed) & 0xFFFFFFFFFFFFFFFF, nz.data_ptr() if nz is not None else None,
                                            uu.data_ptr() if uu is not None else None, out.data_ptr()),
@@ -180,7 +192,7 @@ class Engine:
         out = torch.empty(n, self.mapper["P"], self.mapper["d"], device=self.device, dtype=torch.float32)
         if n:
             self._sync_stream()
-            check(self.lib.capdec_mapper_forward(self._h, x.data_ptr(), n, out.data_ptr()), "capdec_mapper_forward")
+            self._chk(self.lib.capdec_mapper_forward(self._h, x.data_ptr(), n, out.data_ptr()), "capdec_mapper_forward")
         return out
 
     # ------------------------------------------------------------------ CLIP towers
@@ -219,7 +231,7 @@ class Engine:
             width = te.shape[1]
             w = _capi.ClipTextWeights(pe.shape[0], te.shape[0], width, width // 64, layers, proj.shape[1], _fp(te),
                                       _fp(pe), self._clip_blocks(sd, "", layers, keep), _fp(lw), _fp(lb), _fp(proj))
-            check(self.lib.capdec_load_clip_text(self._h, C.byref(w)), "capdec_load_clip_text")
+            self._chk(self.lib.capdec_load_clip_text(self._h, C.byref(w)), "capdec_load_clip_text")
             self.clip_text = dict(context_length=pe.shape[0], embed_dim=proj.shape[1], vocab=te.shape[0])
         if vision and "visual.layer1.0.conv1.weight" in sd:
             self._load_clip_resnet(sd)
@@ -238,7 +250,7 @@ class Engine:
             w = _capi.ClipVisionWeights(image, patch, width, width // 64, layers, proj.shape[1], _fp(cw), _fp(ce), _fp(pe),
                                         _fp(l1w), _fp(l1b), self._clip_blocks(sd, "visual.", layers, keep), _fp(l2w),
                                         _fp(l2b), _fp(proj))
-            check(self.lib.capdec_load_clip_vision(self._h, C.byref(w)), "capdec_load_clip_vision")
+            self._chk(self.lib.capdec_load_clip_vision(self._h, C.byref(w)), "capdec_load_clip_vision")
             self.clip_vision = dict(image_size=image, embed_dim=proj.shape[1])
 
     def _load_clip_resnet(self, sd: Dict[str, torch.Tensor]):
@@ -275,7 +287,7 @@ class Engine:
         embed = proj[3][0].shape[0]
         w = _capi.ClipResNetWeights(image, width, embed, (C.c_int * 4)(*layers), stem, barr, _fp(pos),
                                     *[_fp(t) for pr in proj for t in pr])
-        check(self.lib.capdec_load_clip_resnet(self._h, C.byref(w)), "capdec_load_clip_resnet")
+        self._chk(self.lib.capdec_load_clip_resnet(self._h, C.byref(w)), "capdec_load_clip_resnet")
         self.clip_vision = dict(image_size=image, embed_dim=embed, kind="resnet")
 
     def clip_encode_text(self, tokens: torch.Tensor) -> torch.Tensor:
@@ -286,7 +298,7 @@ class Engine:
         out = torch.empty(n, self.clip_text["embed_dim"], device=self.device, dtype=torch.float32)
         if n:
             self._sync_stream()
-            check(self.lib.capdec_clip_encode_text(self._h, t.data_ptr(), n, out.data_ptr()), "capdec_clip_encode_text")
+            self._chk(self.lib.capdec_clip_encode_text(self._h, t.data_ptr(), n, out.data_ptr()), "capdec_clip_encode_text")
         return out
 
     def clip_encode_image(self, pixels: torch.Tensor) -> torch.Tensor:
@@ -297,7 +309,7 @@ class Engine:
         out = torch.empty(n, self.clip_vision["embed_dim"], device=self.device, dtype=torch.float32)
         if n:
             self._sync_stream()
-            check(self.lib.capdec_clip_encode_image(self._h, x.data_ptr(), n, out.data_ptr()), "capdec_clip_encode_image")
+            self._chk(self.lib.capdec_clip_encode_image(self._h, x.data_ptr(), n, out.data_ptr()), "capdec_clip_encode_image")
         return out
 
     # ------------------------------------------------------------------ GPT-2
@@ -307,7 +319,7 @@ class Engine:
         V = self.gpt_dims["vocab"]
         out = torch.empty((n, L, V) if all_positions else (n, V), device=self.device, dtype=torch.float32)
         self._sync_stream()
-        check(self.lib.capdec_gpt2_logits(self._h, e.data_ptr(), n, L, int(all_positions), out.data_ptr()),
+        self._chk(self.lib.capdec_gpt2_logits(self._h, e.data_ptr(), n, L, int(all_positions), out.data_ptr()),
               "capdec_gpt2_logits")
         return out
 
@@ -319,7 +331,7 @@ class Engine:
         lab = self._dev(labels.reshape(-1), torch.int32)
         out = torch.empty(1, device=self.device, dtype=torch.float32)
         self._sync_stream()
-        check(self.lib.capdec_cross_entropy(self._h, lg.data_ptr(), V, lab.data_ptr(), lg.shape[0], V, int(ignore_index),
+        self._chk(self.lib.capdec_cross_entropy(self._h, lg.data_ptr(), V, lab.data_ptr(), lg.shape[0], V, int(ignore_index),
                                             out.data_ptr()), "capdec_cross_entropy")
         return out[0]
 
@@ -328,7 +340,7 @@ class Engine:
         i = self._dev(ids.reshape(-1), torch.int32)
         out = torch.empty(i.numel(), self.gpt_dims["d"], device=self.device, dtype=torch.float32)
         self._sync_stream()
-        check(self.lib.capdec_wte_lookup(self._h, i.data_ptr(), i.numel(), out.data_ptr()), "capdec_wte_lookup")
+        self._chk(self.lib.capdec_wte_lookup(self._h, i.data_ptr(), i.numel(), out.data_ptr()), "capdec_wte_lookup")
         return out.view(*shape, -1)
 
     # ------------------------------------------------------------------ decode
@@ -339,7 +351,7 @@ class Engine:
         ids = torch.empty(n, entry_length, device=self.device, dtype=torch.int32)
         lens = torch.empty(n, device=self.device, dtype=torch.int32)
         self._sync_stream()
-        check(self.lib.capdec_decode_greedy(self._h, p.data_ptr(), n, P, int(stop_id), int(alt_stop_id),
+        self._chk(self.lib.capdec_decode_greedy(self._h, p.data_ptr(), n, P, int(stop_id), int(alt_stop_id),
                                             int(entry_length), ids.data_ptr(), lens.data_ptr()), "capdec_decode_greedy")
         return ids, lens
 
@@ -353,7 +365,7 @@ class Engine:
         ids = torch.empty(n, T, device=self.device, dtype=torch.int32)
         stats = torch.empty(n, T, 3, device=self.device, dtype=torch.float32)
         self._sync_stream()
-        check(self.lib.capdec_decode_greedy_forced(self._h, p.data_ptr(), n, P, T, f.data_ptr(), ids.data_ptr(),
+        self._chk(self.lib.capdec_decode_greedy_forced(self._h, p.data_ptr(), n, P, T, f.data_ptr(), ids.data_ptr(),
                                                    stats.data_ptr()), "capdec_decode_greedy_forced")
         return ids, stats
 
@@ -369,7 +381,7 @@ class Engine:
         scores = torch.empty(n, beam_size, device=self.device, dtype=torch.float32)
         order = torch.empty(n, beam_size, device=self.device, dtype=torch.int32)
         self._sync_stream()
-        check(self.lib.capdec_decode_beam(self._h, p.data_ptr(), n, P, int(beam_size), int(stop_id), int(entry_length),
+        self._chk(self.lib.capdec_decode_beam(self._h, p.data_ptr(), n, P, int(beam_size), int(stop_id), int(entry_length),
                                           float(temperature), ids.data_ptr(), lens.data_ptr(), scores.data_ptr(),
                                           order.data_ptr()), "capdec_decode_beam")
         return ids, lens, scores, order
@@ -378,17 +390,24 @@ class Engine:
     def comm_unique_id(self) -> bytes:
         """rank 0: the 128-byte communicator id every rank passes to :meth:`comm_init`"""
         buf = C.create_string_buffer(128)
-        check(self.lib.capdec_comm_unique_id(buf), "capdec_comm_unique_id")
+        self._chk(self.lib.capdec_comm_unique_id(buf), "capdec_comm_unique_id")
         return buf.raw
 
     def comm_init(self, rank: int, world: int, comm_id: bytes):
         if len(comm_id) != 128:
             raise CapdecError("comm_init: the communicator id is 128 bytes")
-        check(self.lib.capdec_comm_init(self._h, int(rank), int(world), comm_id), "capdec_comm_init")
+        self._chk(self.lib.capdec_comm_init(self._h, int(rank), int(world), comm_id), "capdec_comm_init")
         self.comm = (int(rank), int(world))
 
+    def comm_info(self) -> Tuple[int, int]:
+        """(rank, ranks) as RCCL itself reports them for the C-ABI communicator (ncclCommUserRank / ncclCommCount);
+        (0, 1) without one"""
+        r, n = C.c_int(0), C.c_int(1)
+        self._chk(self.lib.capdec_comm_info(self._h, C.byref(r), C.byref(n)), "capdec_comm_info")
+        return r.value, n.value
+
     def comm_destroy(self):
-        check(self.lib.capdec_comm_destroy(self._h), "capdec_comm_destroy")
+        self._chk(self.lib.capdec_comm_destroy(self._h), "capdec_comm_destroy")
         self.comm = None
 
     def gather_rows(self, local: torch.Tensor, n_total: int) -> torch.Tensor:
@@ -399,7 +418,7 @@ class Engine:
         row = int(np.prod(t.shape[1:])) if t.dim() > 1 else 1
         out = torch.empty((n_total,) + tuple(t.shape[1:]), dtype=t.dtype, device=self.device)
         self._sync_stream()
-        check(self.lib.capdec_gather_rows(self._h, t.data_ptr() if t.numel() else None, t.shape[0], max(row, 1),
+        self._chk(self.lib.capdec_gather_rows(self._h, t.data_ptr() if t.numel() else None, t.shape[0], max(row, 1),
                                           int(n_total), out.data_ptr() if out.numel() else None), "capdec_gather_rows")
         return out
 
@@ -427,7 +446,7 @@ class Engine:
         m = np.asarray(mean, dtype=np.float32)
         sd = np.asarray(std, dtype=np.float32)
         self._sync_stream()
-        check(self.lib.capdec_preprocess_images(
+        self._chk(self.lib.capdec_preprocess_images(
             self._h, flat.data_ptr(), offs.ctypes.data_as(C.POINTER(C.c_int64)), hs.ctypes.data_as(C.POINTER(C.c_int32)),
             ws.ctypes.data_as(C.POINTER(C.c_int32)), n, int(n_px), int(bool(stretch)), _fp(m), _fp(sd), out.data_ptr()),
             "capdec_preprocess_images")
@@ -436,18 +455,18 @@ class Engine:
     def timer_start(self):
         """hipEvent on the engine's stream (capdec_timer_start): the reference Timer's ``starter.record()``"""
         self._sync_stream()
-        check(self.lib.capdec_timer_start(self._h), "timer_start")
+        self._chk(self.lib.capdec_timer_start(self._h), "timer_start")
 
     def timer_stop_ms(self) -> float:
         """records the end event, synchronises, returns the elapsed milliseconds (capdec_timer_stop_ms)"""
         ms = C.c_float(0.0)
-        check(self.lib.capdec_timer_stop_ms(self._h, C.byref(ms)), "timer_stop_ms")
+        self._chk(self.lib.capdec_timer_stop_ms(self._h, C.byref(ms)), "timer_stop_ms")
         return float(ms.value)
 
     def decode_stats(self) -> Dict[str, int]:
         """steps run / compactions / activation row-steps of the last decode call"""
         a, b, r = C.c_int(0), C.c_int(0), C.c_longlong(0)
-        check(self.lib.capdec_decode_stats(self._h, C.byref(a), C.byref(b), C.byref(r)), "decode_stats")
+        self._chk(self.lib.capdec_decode_stats(self._h, C.byref(a), C.byref(b), C.byref(r)), "decode_stats")
         return dict(steps=a.value, compactions=b.value, row_steps=r.value)
 
     def decode_counters(self) -> Dict[str, float]:
@@ -455,16 +474,19 @@ class Engine:
         (1 = beams share their whole history, beam = nothing); saturated_quads: GEMM-operand quads clamped to the fp16
         range since the last call (the call resets the counter)"""
         kv, sat = C.c_double(0.0), C.c_longlong(0)
-        check(self.lib.capdec_decode_counters(self._h, C.byref(kv), C.byref(sat)), "decode_counters")
+        self._chk(self.lib.capdec_decode_counters(self._h, C.byref(kv), C.byref(sat)), "decode_counters")
         return dict(kv_slots_per_position=kv.value, saturated_quads=sat.value)
 
     def set_batch_invariant(self, on: bool = True):
         """results independent of batch size / chunking / sharding (no split-K, pinned kernel variants); see capdec.h"""
-        check(self.lib.capdec_set_batch_invariant(self._h, int(bool(on))), "set_batch_invariant")
+        self._chk(self.lib.capdec_set_batch_invariant(self._h, int(bool(on))), "set_batch_invariant")
 
     def set_debug_diverge(self, on: bool = True):
-        """measurement only: beams never share history (worst-case decode-attention traffic)"""
-        check(self.lib.capdec_set_debug_diverge(self._h, int(bool(on))), "set_debug_diverge")
+        """measurement builds only (Engine(measure=True)): beams never share history -- the worst-case decode-attention
+        traffic; the shipped library does not export the hook"""
+        if not hasattr(self.lib, "capdec_set_debug_diverge") or not self.measure:
+            raise CapdecError("capdec_set_debug_diverge exists only in the measurement build: Engine(measure=True)")
+        self._chk(self.lib.capdec_set_debug_diverge(self._h, int(bool(on))), "set_debug_diverge")
 
     # ------------------------------------------------------------------ hooks
     def gemm(self, a: torch.Tensor, bt: torch.Tensor, bias=None, resid=None, act: int = 0) -> torch.Tensor:
@@ -475,7 +497,7 @@ class Engine:
         b = self._dev(bias) if bias is not None else None
         r = self._dev(resid) if resid is not None else None
         self._sync_stream()
-        check(self.lib.capdec_gemm_f32(self._h, a.data_ptr(), K, bt.data_ptr(), K, out.data_ptr(), N, M, N, K,
+        self._chk(self.lib.capdec_gemm_f32(self._h, a.data_ptr(), K, bt.data_ptr(), K, out.data_ptr(), N, M, N, K,
                                        b.data_ptr() if b is not None else None,
                                        r.data_ptr() if r is not None else None, N, act), "capdec_gemm_f32")
         return out
@@ -484,17 +506,17 @@ class Engine:
         """'f16x2' (default: fp32-accurate, operands as two fp16 planes, 3 MFMAs per product), 'bf16x3' (fp32-accurate,
         three bf16 planes, 6 MFMAs per product), 'f32' (native fp32 MFMA), 'bf16' (bf16 GEMM operands and KV cache, fp32
         accumulate: BASELINE configs[1]) or 'f16' (fp16 GEMM operands: the reference's CLIP-tower arithmetic on a GPU)"""
-        check(self.lib.capdec_set_gemm_mode(self._h, {"f32": 0, "bf16x3": 1, "bf16": 2, "f16x2": 3, "f16": 4}[mode]), "set_gemm_mode")
+        self._chk(self.lib.capdec_set_gemm_mode(self._h, {"f32": 0, "bf16x3": 1, "bf16": 2, "f16x2": 3, "f16": 4}[mode]), "set_gemm_mode")
 
     def gemm_mode(self) -> str:
         return ["f32", "bf16x3", "bf16", "f16x2", "f16"][self.lib.capdec_get_gemm_mode(self._h)]
 
     def profile_enable(self, on=True):
         """True / 1: time every launch; N > 1: every N-th launch of each kernel family (sampling); False: off"""
-        check(self.lib.capdec_profile_enable(self._h, int(on)), "profile_enable")
+        self._chk(self.lib.capdec_profile_enable(self._h, int(on)), "profile_enable")
 
     def profile_reset(self):
-        check(self.lib.capdec_profile_reset(self._h), "profile_reset")
+        self._chk(self.lib.capdec_profile_reset(self._h), "profile_reset")
 
     def profile_get(self) -> Dict[str, Dict[str, float]]:
         cnt = C.c_int(24)                 # in: capacity of the arrays below, out: families filled
@@ -503,7 +525,7 @@ class Engine:
         launches = (C.c_int64 * 24)()
         flops = (C.c_double * 24)()
         calls = (C.c_int64 * 24)()
-        check(self.lib.capdec_profile_get(self._h, C.byref(cnt), names, ms, launches, flops, calls), "profile_get")
+        self._chk(self.lib.capdec_profile_get(self._h, C.byref(cnt), names, ms, launches, flops, calls), "profile_get")
         return {names[i].decode(): dict(ms=float(ms[i]), launches=int(launches[i]), flops=float(flops[i]),
                                         calls=int(calls[i]))
                 for i in range(cnt.value)}

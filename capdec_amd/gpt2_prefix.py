@@ -47,6 +47,7 @@ class _HipModule:
         self._engine: Optional[Engine] = None
         self._device_index = 0
         self._dirty = True
+        self._measure = False
         self.training = False
 
     # --- nn.Module-ish API the reference's callers use
@@ -82,10 +83,22 @@ class _HipModule:
         for v in self._sd.values():
             yield torch.empty(0, device=dev, dtype=torch.float32)
 
+    def use_measurement_build(self, on: bool = True):
+        """measurement tooling only (bench.py's untimed tail, tools/): move this module to a context of the library's
+        -DCAPDEC_MEASURE build (ablation / override knobs, the diverged-beam hook).  The current context -- weights, KV
+        cache, workspaces -- is released; the weights are uploaded again on the next use."""
+        if bool(on) != self._measure:
+            if self._engine is not None:
+                self._engine.close()
+                self._engine = None
+            self._measure = bool(on)
+            self._dirty = True
+        return self
+
     @property
     def engine(self) -> Engine:
         if self._engine is None:
-            self._engine = Engine(self._device_index)
+            self._engine = Engine(self._device_index, measure=self._measure)
             self._dirty = True
         if self._dirty:
             self._upload(self._engine)

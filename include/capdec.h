@@ -31,7 +31,8 @@
 extern "C" {
 #endif
 
-#define CAPDEC_ABI_VERSION 2   /* 2: capdec_profile_get takes the array capacity in *count; batch-invariant mode; decode counters */
+#define CAPDEC_ABI_VERSION 3   /* 3: the diverged-beam debug hook left the shipped library (measurement builds only);
+                                  2: capdec_profile_get takes the array capacity in *count; batch-invariant mode; decode counters */
 
 typedef struct capdec_ctx capdec_ctx;
 
@@ -241,7 +242,8 @@ int capdec_gpt2_logits(capdec_ctx *ctx, const float *d_embeds, int n, int L, int
 /* The loss of the train step's forward (reference train.py:349 `nnf.cross_entropy(logits, tokens, ignore_index=0)`,
  * and GPT2LMHeadModel's shifted `labels=` loss used by gpt2_prefix.py:154): mean over the rows whose label differs
  * from ignore_index of logsumexp(d_logits[row, 0..vocab)) - d_logits[row, label].  d_logits: device fp32 [rows, ld],
- * d_labels: device int32 [rows], d_loss: device fp32 [1] (NaN when no row counts, like torch). */
+ * d_labels: device int32 [rows], d_loss: device fp32 [1] (NaN when no row counts, like torch).  A label outside
+ * [0, vocab) other than ignore_index -- an error in torch -- makes the loss NaN instead of being skipped silently. */
 int capdec_cross_entropy(capdec_ctx *ctx, const float *d_logits, int ld, const int32_t *d_labels, int rows, int vocab,
                          int ignore_index, float *d_loss);
 /* `model.gpt.transformer.wte(ids)` (reference gpt2_prefix_eval.py:105,181): d_out [n, d] */
@@ -296,12 +298,17 @@ int capdec_decode_stats(capdec_ctx *ctx, int *steps, int *compactions, long long
  * this number (0 when no beam decode ran).  saturated_quads: how many 4-element groups of GEMM operands were clamped to
  * the +-65504 range of the fp16-plane formats since the last call (the counter is reset by the call; NaN is not
  * clamped, it propagates) -- nonzero means the fp32-accuracy claim of the default mode does not hold for this
- * checkpoint / input: switch to CAPDEC_GEMM_BF16X3 or CAPDEC_GEMM_F32.  Either pointer may be NULL. */
+ * checkpoint / input: switch to CAPDEC_GEMM_BF16X3 or CAPDEC_GEMM_F32.  The saturation counter is kept PER DEVICE (one
+ * counter per GPU, shared by every context on it): with several contexts on one GPU the call returns -- and resets --
+ * the clamps of all of them.  Either pointer may be NULL; the K/V statistic is accumulated on the device and read back
+ * (one small copy + a stream synchronisation) only by this call. */
 int capdec_decode_counters(capdec_ctx *ctx, double *kv_slots_per_position, long long *saturated_quads);
-/* measurement only: every beam continues ITSELF (candidates of other parents are ignored), so no two beams of a caption
- * share history after the first step -- the worst-case K/V traffic of the decode attention.  Results are NOT the
- * reference's beam search. */
+#ifdef CAPDEC_MEASURE
+/* MEASUREMENT BUILDS ONLY (libcapdec_hip_measure.so, compiled with -DCAPDEC_MEASURE; the shipped library does not export
+ * it): every beam continues ITSELF (candidates of other parents are ignored), so no two beams of a caption share history
+ * after the first step -- the worst-case K/V traffic of the decode attention.  Results are NOT the reference's beam search. */
 int capdec_set_debug_diverge(capdec_ctx *ctx, int on);
+#endif
 
 /* ---- multi-GPU: caption-batch sharding + ONE gather of the generated ids (RCCL over xGMI) ------------------------
  * The reference has no distributed code: it loops over captions one at a time (predictions_runner.py:194,
@@ -319,6 +326,9 @@ int capdec_comm_unique_id(char *id /* [CAPDEC_COMM_ID_BYTES] */);
 /* every rank, after capdec_create on its own GPU: join (ncclCommInitRank).  nranks == 1 is allowed. */
 int capdec_comm_init(capdec_ctx *ctx, int rank, int nranks, const char *id /* [CAPDEC_COMM_ID_BYTES] */);
 int capdec_comm_destroy(capdec_ctx *ctx);
+/* what RCCL reports for the context's communicator (ncclCommUserRank / ncclCommCount): *rank = 0, *nranks = 1 when the
+ * context has none.  A launcher can check that N ranks really joined (bench.py prints it as `rccl_ranks`). */
+int capdec_comm_info(capdec_ctx *ctx, int *rank, int *nranks);
 /* the shard of rank `rank`: [*lo, *hi) of n_total rows (trailing ranks may get an empty block) */
 int capdec_shard_bounds(int n_total, int rank, int nranks, int *lo, int *hi);
 /* all-gather of row blocks laid out by capdec_shard_bounds: d_local [n_local, row_elems] 4-byte elements (int32 or

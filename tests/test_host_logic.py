@@ -18,6 +18,10 @@ def test_c_abi_exports_every_header_symbol():
     if not os.path.exists(_capi.LIB_PATH):
         build.build()
     header = open(os.path.join(ROOT, "include", "capdec.h")).read()
+    # what only the measurement build declares (#ifdef CAPDEC_MEASURE ... #endif) must NOT be in the shipped library
+    measure_only = set(re.findall(r"\b(capdec_[a-z0-9_]+)\s*\(", " ".join(re.findall(r"#ifdef CAPDEC_MEASURE(.*?)#endif", header, flags=re.S))))
+    assert measure_only == set(_capi.MEASURE_SIGNATURES) == {"capdec_set_debug_diverge"}
+    header = re.sub(r"#ifdef CAPDEC_MEASURE.*?#endif", " ", header, flags=re.S)
     declared = set(re.findall(r"\b(capdec_[a-z0-9_]+)\s*\(", header))
     declared -= {"capdec_ctx"}
     assert len(declared) >= 25
@@ -29,7 +33,12 @@ def test_c_abi_exports_every_header_symbol():
     # the library is built for gfx950 and links the HIP runtime only (no torch types in the ABI)
     out = subprocess.run(["nm", "-D", "--defined-only", _capi.LIB_PATH], capture_output=True, text=True).stdout
     exported = {l.split()[-1] for l in out.splitlines() if " T " in l and "capdec_" in l.split()[-1][:7]}
-    assert declared <= exported
+    assert declared == exported, declared ^ exported           # nothing undeclared leaves the library: no debug hooks
+    # ... and no measurement code is compiled in: no ablation / override knob is even named in the binary
+    strs = subprocess.run(["strings", _capi.LIB_PATH], capture_output=True, text=True).stdout
+    knobs = set(re.findall(r"CAPDEC_[A-Z0-9_]+", strs))
+    assert not {k for k in knobs if "ABL" in k or k in ("CAPDEC_H2_NS", "CAPDEC_X1_NS", "CAPDEC_ATT_OCC", "CAPDEC_ATT_NA",
+                                                        "CAPDEC_PP_STAMPS", "CAPDEC_LMHEAD_K1", "CAPDEC_GEMM_BK")}, knobs
 
 
 def test_ctypes_signatures_match_header_prototypes():
@@ -40,6 +49,7 @@ def test_ctypes_signatures_match_header_prototypes():
     from capdec_amd import _capi
     header = open(os.path.join(ROOT, "include", "capdec.h")).read()
     header = re.sub(r"/\*.*?\*/", " ", header, flags=re.S)                       # strip comments
+    header = re.sub(r"#ifdef CAPDEC_MEASURE.*?#endif", " ", header, flags=re.S)   # (measurement builds only)
     protos = re.findall(r"\b(?:int|void|const char \*)\s*(capdec_[a-z0-9_]+)\s*\(([^;{]*?)\)\s*;", header, flags=re.S)
     seen = 0
     for name, params in protos:
@@ -401,20 +411,35 @@ def test_shard_consistency_checks():
     assert [cd.shard_bounds(5, r, 4) for r in range(4)] == [(0, 2), (2, 4), (4, 5), (5, 5)]
 
 
-def test_bench_spawns_its_own_ranks():
-    """`python bench.py --gpus N` (the driver's form) must start N ranks itself; --dry-run checks the launcher path
-    on CPU (gloo) without touching a GPU"""
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run"],
-                         capture_output=True, text=True, timeout=300)
-    assert out.returncode == 0, out.stderr[-2000:]
+@pytest.mark.parametrize("n", [2, 8])
+def test_bench_spawns_its_own_ranks(n):
+    """`python bench.py --gpus N` (the driver's form) must start N ranks itself; --dry-run rehearses the whole N-rank
+    control flow on CPU (gloo): sharding, a fake decode, the id gather, barrier + max-over-ranks timing, the per-rank
+    table, the comparison with a one-rank pass -- with 2 ranks and with the 8 of a full node"""
     import json
-    line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
-    rec = json.loads(line)
-    assert rec == {"dry_run": True, "n_gpus": 2, "ranks": [0, 1]}
-    # a launcher that started the wrong number of ranks is an error, not a silent mismatch
-    bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run"],
-                         capture_output=True, text=True, timeout=120, env=dict(os.environ, RANK="0", WORLD_SIZE="1"))
-    assert bad.returncode != 0 and "WORLD_SIZE=1" in (bad.stderr + bad.stdout)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--dry-run", "--captions", "5000"],
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]                        # stdout carries exactly one JSON line
+    rec = json.loads(lines[0])
+    assert rec["dry_run"] and rec["n_gpus"] == n and rec["ranks"] == list(range(n)) and rec["ids_equal_to_1gpu"]
+    per = -(-5000 // n)
+    assert [r["captions_per_step"] for r in rec["per_rank"]] == [min(per, max(0, 5000 - r * per)) for r in range(n)]
+    assert sum(r["captions_per_step"] for r in rec["per_rank"]) == 5000 and all(r["seconds"] > 0 for r in rec["per_rank"])
+    if n == 2:
+        # a launcher that started the wrong number of ranks is an error, not a silent mismatch
+        bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run"],
+                             capture_output=True, text=True, timeout=120, env=dict(os.environ, RANK="0", WORLD_SIZE="1"))
+        assert bad.returncode != 0 and "WORLD_SIZE=1" in (bad.stderr + bad.stdout)
+
+
+def test_bench_watchdog_names_the_phase_a_rank_is_stuck_in():
+    """an unattended multi-GPU run must not end silently: a rank that overruns --rank-timeout says where it is and exits 3"""
+    code = ("import sys, time; sys.path.insert(0, %r); import bench; w = bench.Watchdog(3, 8, 0.3); w.note('timed region'); "
+            "time.sleep(5); print('not reached')" % ROOT)
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 3 and "rank 3 of 8" in out.stderr and "timed region" in out.stderr and "not reached" not in out.stdout
 
 
 def test_formats_round_trip(tmp_path):

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Reproduce everything under profiles/ on an MI355X box (one gpurun call):
-#   gpurun --timeout 1500 -- 'bash tools/collect_profiles.sh r3'
+#   gpurun --timeout 1500 -- 'bash tools/collect_profiles.sh r4'
 # then copy gpurun_out/<tag>_* into profiles/.  Steps: the driver-style bench line (with the CPU baseline), the same
 # command under rocprofv3 --kernel-trace --stats (kernel averages must agree with the hipEvent averages of the bench
 # line), the FETCH_SIZE / WRITE_SIZE counters in their own passes (never combined with tracing), summarised per kernel,
@@ -9,14 +9,19 @@
 # chip runs at its package power cap: zeros show the loop's structure at 2.4 GHz, random what the cap leaves), and the
 # 625-caption line (the per-GPU shard of the metric at 8 GPUs).
 set -u
-TAG=${1:-r3}
+TAG=${1:-r4}
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$R/gpurun_out
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 cd "$R"
 timeout 400 python bench.py --steps 20 --warmup 5 > "$OUT/${TAG}_bench.json" 2> "$OUT/${TAG}_bench.err"
-timeout 300 python bench.py --captions 625 --steps 20 --warmup 5 --cpu-captions 0 --cpu-seconds 0 > "$OUT/${TAG}_bench_625.json" 2> "$OUT/${TAG}_bench_625.err"
+timeout 300 python bench.py --captions 625 --steps 20 --warmup 5 --cpu-seconds 0 > "$OUT/${TAG}_bench_625.json" 2> "$OUT/${TAG}_bench_625.err"
+# what one decode step of the 625-caption shard is made of: per-(kernel, grid) table of a traced pass
+timeout 300 rocprofv3 --kernel-trace --output-format csv -d "$OUT/${TAG}_kt625" -- python bench.py --cpu-seconds 0 --no-checks --no-smi --captions 625 --steps 1 --warmup 1 \
+    > "$OUT/${TAG}_kt625.json" 2> "$OUT/${TAG}_kt625.err"
+python tools/trace_summary.py "$OUT/${TAG}_kt625" "$OUT/${TAG}_625_kernels.txt" --title "bench.py --captions 625 --steps 1 --warmup 1 under rocprofv3 --kernel-trace (two passes of 67 steps + mapper + prefill)"
+find "$OUT/${TAG}_kt625" -name "*.csv" -delete
 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/${TAG}_kt" -- python bench.py --cpu-seconds 0 --cpu-captions 0 --no-checks --no-smi \
     > "$OUT/${TAG}_bench_under_rocprof.json" 2> "$OUT/${TAG}_kt.err"
 find "$OUT/${TAG}_kt" -name "*kernel_stats.csv" -exec cp {} "$OUT/${TAG}_bench_kernel_stats.csv" \;

@@ -7,7 +7,7 @@ import torch
 from capdec_amd.engine import Engine
 
 def main():
-    eng = Engine(0)
+    eng = Engine(0, measure=os.environ.get("CAPDEC_MEASURE_LIB") == "1")   # CAPDEC_MEASURE_LIB=1: the -DCAPDEC_MEASURE build (ablation knobs)
     Ms = [int(v) for v in sys.argv[1:]] or [25000]
     g = torch.Generator().manual_seed(0)
     res = {"mode": eng.gemm_mode()}

@@ -6,7 +6,7 @@ import sys, os, json
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from capdec_amd.engine import Engine
-eng = Engine(0)
+eng = Engine(0, measure=os.environ.get("CAPDEC_MEASURE_LIB") == "1")   # CAPDEC_MEASURE_LIB=1: the -DCAPDEC_MEASURE build (ablation knobs)
 M = int(sys.argv[1]) if len(sys.argv) > 1 else 3125
 g = torch.Generator().manual_seed(0)
 res = {}

@@ -10,7 +10,7 @@ from capdec_amd.engine import Engine
 
 
 def main():
-    eng = Engine(0)
+    eng = Engine(0, measure=os.environ.get("CAPDEC_MEASURE_LIB") == "1")   # CAPDEC_MEASURE_LIB=1: the -DCAPDEC_MEASURE build (ablation knobs)
     res = {"h2w": os.environ.get("CAPDEC_H2W", "default"), "mode": eng.gemm_mode()}
     g = torch.Generator().manual_seed(1)
     worst = 0.0

@@ -9,7 +9,7 @@ os.environ["CAPDEC_HOOK_CACHE"] = "1"
 import torch
 from capdec_amd.engine import Engine
 
-eng = Engine(0)
+eng = Engine(0, measure=os.environ.get("CAPDEC_MEASURE_LIB") == "1")   # CAPDEC_MEASURE_LIB=1: the -DCAPDEC_MEASURE build (ablation knobs)
 g = torch.Generator().manual_seed(1)
 m, n, k = (int(v) for v in (sys.argv[1:4] if len(sys.argv) > 3 else (25000, 2304, 768)))
 kinds = sys.argv[4].split(",") if len(sys.argv) > 4 else ["random", "fp16_exact", "small_int", "zeros", "random"]

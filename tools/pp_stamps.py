@@ -5,6 +5,7 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 path = "/tmp/pp_stamps.txt"
 os.environ["CAPDEC_PP_STAMPS"] = path
+os.environ["CAPDEC_MEASURE_LIB"] = "1"
 os.environ.setdefault("CAPDEC_HOOK_PACKA", "1")
 os.environ["CAPDEC_HOOK_CACHE"] = "1"
 os.environ.setdefault("CAPDEC_SPLITK", "0")
@@ -12,7 +13,7 @@ import numpy as np
 import torch
 from capdec_amd.engine import Engine
 
-eng = Engine(0)
+eng = Engine(0, measure=os.environ.get("CAPDEC_MEASURE_LIB") == "1")   # CAPDEC_MEASURE_LIB=1: the -DCAPDEC_MEASURE build (ablation knobs)
 g = torch.Generator().manual_seed(0)
 for t in sys.argv[1].split(";"):
     m, n, k = (int(v) for v in t.split(","))

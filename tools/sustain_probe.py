@@ -9,7 +9,7 @@ os.environ["CAPDEC_HOOK_CACHE"] = "1"
 import torch
 from capdec_amd.engine import Engine
 
-eng = Engine(0)
+eng = Engine(0, measure=os.environ.get("CAPDEC_MEASURE_LIB") == "1")   # CAPDEC_MEASURE_LIB=1: the -DCAPDEC_MEASURE build (ablation knobs)
 g = torch.Generator().manual_seed(1)
 
 
