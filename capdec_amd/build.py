@@ -84,4 +84,9 @@ def build(force: bool = False, verbose: bool = True, measure: bool = False) -> s
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, measure="--measure" in sys.argv))
+    # both variants by default (a measurement library older than the sources is refused like a stale product library);
+    # --product / --measure build one of them
+    if "--measure" not in sys.argv:
+        print(build(force="--force" in sys.argv))
+    if "--product" not in sys.argv:
+        print(build(force="--force" in sys.argv, measure=True))

@@ -204,6 +204,42 @@ __device__ __forceinline__ void epilogue_store_packed_t(const f32x16 (&acc)[2][2
     }
 }
 
+// top-KSEL (value, column) of one row's 128 logits held by a 16-lane group, 8 per lane (lane `sub` holds columns
+// sub + 16 j): descending value, equal values in ascending column order -- the order topk_merge and the reference's
+// torch.topk walk expect.  Round 4 form: per round the VALUE of the best remaining logit comes from a max3 tree and
+// four v_max_f32 DPP steps, its lowest COLUMN from an equality scan and four v_min_u32 DPP steps, then the winner is
+// retired -- ~45 VALU instructions where the former (value, column) pair tournament with its two-key comparisons took
+// ~80; the selection rounds were a fifth of the fused lm_head's time (CAPDEC_LMHEAD_K1 measurement).
+__device__ __forceinline__ int row16_min_i(int v) {
+    v = min(v, dpp_i<DPP_XOR1>(v));
+    v = min(v, dpp_i<DPP_XOR2>(v));
+    v = min(v, dpp_i<DPP_HALF_MIRROR>(v));
+    v = min(v, dpp_i<DPP_MIRROR>(v));
+    return v;
+}
+template <int KSEL>
+__device__ __forceinline__ void row_tile_topk(float (&v)[8], float row_max, int sub, int n0, bool write, size_t tbase,
+                                              float *__restrict__ cand_val, int *__restrict__ cand_idx) {
+#pragma unroll
+    for (int kk = 0; kk < KSEL; ++kk) {
+        float gv = row_max;                            // (round 0: the row maximum the caller already has)
+        if (kk > 0) {
+            const float lm = fmaxf(fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3])), fmaxf(fmaxf(v[4], v[5]), fmaxf(v[6], v[7])));
+            gv = row16_max(lm);
+        }
+        int lc = 1 << 20;                              // lowest local column holding gv (columns ascend with j: scan downwards)
+#pragma unroll
+        for (int j = 7; j >= 0; --j) lc = v[j] == gv ? sub + 16 * j : lc;
+        const int gc = row16_min_i(lc);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = (sub + 16 * j == gc) ? -INFINITY : v[j];     // retire the winner (one lane, one j)
+        if (write && sub == kk) {
+            cand_val[tbase * KSEL + kk] = gv;
+            cand_idx[tbase * KSEL + kk] = n0 + gc;
+        }
+    }
+}
+
 // lm_head epilogue: per (row, 128-col tile) max, sum exp(x - max) and top-k (value, column).  The
 // logits tile goes accumulators -> LDS (`Ct`, >= 64 x CT_LD floats -- 128 x CT_LD with FULL --, reusing the staging buffers;
 // the caller's main loop must have ended with a barrier) -> 16-lane groups, one row per group, 8
@@ -254,35 +290,7 @@ __device__ __forceinline__ void epilogue_topk(const f32x16 (&acc)[2][WaveGrid<WM
                 tile_max[tbase] = mx;
                 tile_sum[tbase] = se;
             }
-#pragma unroll
-            for (int kk = 0; kk < KSEL; ++kk) {
-                // lane-local best (lowest column wins ties: columns ascend with j)
-                float bv = v[0];
-                int bj = 0;
-#pragma unroll
-                for (int j = 1; j < 8; ++j)
-                    if (v[j] > bv) { bv = v[j]; bj = j; }
-                const int bc = sub + 16 * bj;   // local column
-                float gv = bv;
-                int gc = bc;
-#define TOPK_STEP(CTRL)                                                       \
-    {                                                                          \
-        const float ov = dpp_f<CTRL>(gv);                                      \
-        const int oc = dpp_i<CTRL>(gc);                                        \
-        if (ov > gv || (ov == gv && oc < gc)) { gv = ov; gc = oc; }            \
-    }
-                TOPK_STEP(DPP_XOR1) TOPK_STEP(DPP_XOR2) TOPK_STEP(DPP_HALF_MIRROR) TOPK_STEP(DPP_MIRROR)
-#undef TOPK_STEP
-                if (gc == bc) {           // this lane owned the winner: retire it
-#pragma unroll
-                    for (int j = 0; j < 8; ++j)
-                        if (j == bj) v[j] = -INFINITY;
-                }
-                if (row < M && sub == kk) {
-                    cand_val[tbase * KSEL + kk] = gv;
-                    cand_idx[tbase * KSEL + kk] = n0 + gc;
-                }
-            }
+            row_tile_topk<KSEL>(v, mx, sub, n0, row < M, tbase, cand_val, cand_idx);
         }
         if (!FULL) __syncthreads();
     }

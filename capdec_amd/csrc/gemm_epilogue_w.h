@@ -125,34 +125,7 @@ __device__ __forceinline__ void epilogue_topk_w(const f32x16 (&acc)[G::TI][G::TJ
                 tile_max[tbase] = mx;
                 tile_sum[tbase] = se;
             }
-#pragma unroll
-            for (int kk = 0; kk < KSEL; ++kk) {
-                float bv = v[0];
-                int bj = 0;
-#pragma unroll
-                for (int j = 1; j < 8; ++j)
-                    if (v[j] > bv) { bv = v[j]; bj = j; }
-                const int bc = sub + 16 * bj;
-                float gv = bv;
-                int gc = bc;
-#define TOPKW_STEP(CTRL)                                                      \
-    {                                                                          \
-        const float ov = dpp_f<CTRL>(gv);                                      \
-        const int oc = dpp_i<CTRL>(gc);                                        \
-        if (ov > gv || (ov == gv && oc < gc)) { gv = ov; gc = oc; }            \
-    }
-                TOPKW_STEP(DPP_XOR1) TOPKW_STEP(DPP_XOR2) TOPKW_STEP(DPP_HALF_MIRROR) TOPKW_STEP(DPP_MIRROR)
-#undef TOPKW_STEP
-                if (gc == bc) {
-#pragma unroll
-                    for (int j = 0; j < 8; ++j)
-                        if (j == bj) v[j] = -INFINITY;
-                }
-                if (row < M && sub == kk) {
-                    cand_val[tbase * KSEL + kk] = gv;
-                    cand_idx[tbase * KSEL + kk] = n0 + gc;
-                }
-            }
+            row_tile_topk<KSEL>(v, mx, sub, n0, row < M, tbase, cand_val, cand_idx);
         }
         __syncthreads();
     }

@@ -835,6 +835,58 @@ def test_activation_range_probe_reports_saturation():
     e.close()
 
 
+def test_outlier_shaped_checkpoint_decodes_like_the_oracle():
+    """weights shaped like a trained GPT-2 rather than like a fresh init: a few residual-stream channels carry values in
+    the hundreds (fed by large c_proj columns / biases, with tiny LayerNorm gains on those channels, as in the published
+    checkpoints), some LayerNorm gains are large, and mlp.c_fc holds entries beyond 16 (so that matrix leaves the
+    single-accumulator GEMM kernels: GemmEpilogue::wide_ok).  Whole greedy and beam decodes in the default f16x2 mode
+    must still equal the fp32 oracle token for token -- the fp16-plane operand format sees a 10^4 dynamic range per
+    row here -- and nothing may be clamped (saturated_quads == 0)"""
+    from capdec_amd import gpt2_prefix_eval as E
+    from oracle import capdec_oracle as O
+    dims = synth.GPT2_TINY
+    model, sd = _model(dims, "mlp", 512, seed=11)
+    g = torch.Generator().manual_seed(3)
+    hot = [7, 138, 378]
+    t = "gpt.transformer."
+    for i in range(dims.n_layer):
+        h = f"{t}h.{i}."
+        sd[h + "mlp.c_proj.weight"][:, hot] *= 40.0                   # these channels of the residual stream run into the hundreds
+        sd[h + "mlp.c_proj.bias"][hot] += torch.tensor([30.0, -25.0, 40.0])
+        sd[h + "attn.c_proj.weight"][:, hot] *= 10.0
+        for ln in ("ln_1", "ln_2"):
+            sd[h + ln + ".weight"][hot] = 0.02                           # ... and the LayerNorms that read them look away
+            big = torch.randint(0, dims.n_embd, (6,), generator=g)
+            sd[h + ln + ".weight"][big] *= 8.0
+        w = sd[h + "mlp.c_fc.weight"]
+        idx = torch.randint(0, w.numel(), (40,), generator=g)
+        w.view(-1)[idx] = torch.where(torch.rand(40, generator=g) > 0.5, 21.0, -19.0)      # max |w| >= 16
+    sd[t + "ln_f.weight"][hot] = 0.02
+    sd[t + "wpe.weight"][:, hot] *= 30.0
+    model.load_state_dict(sd)
+    eng = model.engine
+    n, T_ = 96, 16
+    x = synth.synthetic_clip_embeddings(n, 512, seed=77)
+    pe = O.clip_project(x, sd, "mlp", 10).reshape(n, 10, -1)
+    seen, orig = [], O.F.layer_norm                                    # what the LayerNorms of the oracle are fed
+    O.F.layer_norm = lambda x_, *a, **k: (seen.append(float(x_.abs().max())), orig(x_, *a, **k))[1]
+    try:
+        O.gpt2_hidden(pe[:4], sd, dims.n_head)
+    finally:
+        O.F.layer_norm = orig
+    assert max(seen) > 100.0, seen                                     # the residual stream really carries outliers
+    eng.decode_counters()
+    ids, lens = E.decode_greedy_ids(model, pe, 443, T_)
+    ok, ties = _greedy_rows_vs_oracle(ids.cpu().numpy(), lens.cpu().numpy(), sd, pe, list(range(n)), 443, T_, dims.n_head,
+                                      "outlier-shaped checkpoint: 96 greedy captions")
+    assert ok >= n - 2 and ok + ties == n, (ok, ties)
+    i, l, s_, o = E.decode_beam_ids(model, pe[:48], 614, 5, T_)
+    got = (i.cpu().numpy(), l.cpu().numpy(), s_.cpu().numpy(), o.cpu().numpy())
+    ok, ties = _beam_rows_vs_oracle(got, sd, pe[:48], list(range(48)), 614, T_, dims.n_head, "outlier-shaped checkpoint: 48 captions x beam 5")
+    assert ok >= 46 and ok + ties == 48, (ok, ties)
+    assert eng.decode_counters()["saturated_quads"] == 0
+
+
 def test_kv_slot_statistic_and_diverged_beams():
     """capdec_decode_counters: distinct K/V slots per (caption, position) of a beam decode -- between 1 (all beams share
     their history) and the beam width; with the debug switch of the MEASUREMENT build (the shipped library has no such

@@ -34,7 +34,7 @@ python tools/pmc_summary.py "$OUT" "$OUT/${TAG}_pmc_traffic.json" \
     "python bench.py --cpu-seconds 0 --no-checks --steps 1 --warmup 0 (default workload: 5000 captions, beam 5, T=67)" f16x2 5000 "${TAG}"
 find "$OUT" -name "*counter_collection.csv" -delete
 export CAPDEC_HOOK_PACKA=1 CAPDEC_HOOK_CACHE=1
-for h in 0 2; do for data in random zeros; do
+for h in 0 2 10 12; do for data in random zeros; do
     CAPDEC_H2W=$h timeout 200 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE \
        --output-format csv -d "$OUT/${TAG}_pmc_sq_${h}_${data}" -- python tools/gemm_one.py 16384 2048 768 6 $data > "$OUT/${TAG}_pmc_sq_${h}_${data}.log" 2>&1
 done; done
@@ -43,8 +43,9 @@ python - "$OUT" "$TAG" <<'PY' > "$OUT/${TAG}_pmc_sq_gemm.txt" 2>&1
 import csv, glob, collections, sys
 out, tag = sys.argv[1], sys.argv[2]
 print("SQ counters, GEMM 16384 x 2048 x 768 (a whole number of rounds for both tile shapes), 6 launches each;")
-print("h2w 0 = round-2 128x128 two-accumulator kernel, h2w 2 = 256x128 single-accumulator kernel; operands random / zero-filled")
-for h in ("0", "2"):
+print("h2w 0 = round-2 128x128 two-accumulator kernel, h2w 2 = 256x128 single-accumulator kernel, 10 / 12 = round-4 ping-pong kernels")
+print("(256x128 two accumulator sets / 256x256 one set: ONE 8-wavefront block per CU); operands random / zero-filled")
+for h in ("0", "2", "10", "12"):
     for data in ("random", "zeros"):
         acc = collections.defaultdict(lambda: collections.defaultdict(lambda: [0, 0.0]))
         for p in glob.glob(f"{out}/{tag}_pmc_sq_{h}_{data}/**/*counter_collection.csv", recursive=True):
@@ -54,6 +55,7 @@ for h in ("0", "2"):
                 k = k[:72]
                 a = acc[k][row["Counter_Name"]]; a[0] += 1; a[1] += float(row["Counter_Value"])
         for k, cs in acc.items():
+            if "pack_planes" in k: continue
             print(f"h2w={h} data={data} {k}")
             for c, (n, s) in sorted(cs.items()):
                 print(f"   {c:36s} n={n:4d} avg={s/n:16.1f}")
