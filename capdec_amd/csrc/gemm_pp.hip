@@ -332,6 +332,11 @@ using P128x256s = PGeo<2, 4, 2, 2, 5, false>;
 
 int pp_splitk_slices(int which, int M, int N, int K);
 
+// measurement builds: the main-loop ablations exist for geometry 10 (256 x 128), the direct epilogue (8) also for the
+// 256 x 256 tile; anything else runs the product kernel
+template <class G> constexpr int pp_abl_for(int a) {
+    return (G::BM == 256 && G::BN == 128 && G::TWOACC) ? a : (a == 8 && G::BN == 256) ? 8 : 0;
+}
 template <class G>
 static int launch_pp(hipStream_t st, const void *Apacked, const void *Bpacked, float *C, int ldc, int M, int N, int K,
                      const GemmEpilogue &epi, float scale, int S) {
@@ -350,7 +355,7 @@ static int launch_pp(hipStream_t st, const void *Apacked, const void *Bpacked, f
     const QkvScatter sc = epi.qkv_scatter ? *epi.qkv_scatter : QkvScatter();
     long long *stamps = nullptr;
 #define LAUNCH_PP(A)                                                                                                  \
-    hipLaunchKernelGGL((gemm_pp_kernel<G, (G::BM == 256 && G::BN == 128 && G::TWOACC) ? A : 0>), dim3(grid), dim3(G::THREADS), 0, st, (const _Float16 *)Apacked, \
+    hipLaunchKernelGGL((gemm_pp_kernel<G, pp_abl_for<G>(A)>), dim3(grid), dim3(G::THREADS), 0, st, (const _Float16 *)Apacked, \
                        (const _Float16 *)Bpacked, C, ldc, M, N, K, epi.bias, resid_arg, epi.ldr, epi.act, tiles_m, tiles_n, \
                        (char *)epi.packed_out, kscale, sc, stamps)
 #ifdef CAPDEC_MEASURE
@@ -364,8 +369,7 @@ static int launch_pp(hipStream_t st, const void *Apacked, const void *Bpacked, f
         if (!d_stamps) CAPDEC_HIP(hipMalloc(&d_stamps, 4096 * 4 * sizeof(long long)));
         if (grid <= 4096) { stamps = d_stamps; CAPDEC_HIP(hipMemsetAsync(d_stamps, 0, 4096 * 4 * sizeof(long long), st)); }
     }
-    constexpr bool kAbl = G::BM == 256 && G::BN == 128 && G::TWOACC;     // (ablation variants: geometry 10 only)
-    switch (kAbl ? abl : 0) {
+    switch (abl) {
         case 1: LAUNCH_PP(1); break;
         case 2: LAUNCH_PP(2); break;
         case 3: LAUNCH_PP(3); break;
