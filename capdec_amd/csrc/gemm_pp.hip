@@ -412,7 +412,9 @@ int pp_splitk_slices(int which, int M, int N, int K) {
     int bm, bn;
     pp_tile(which, bm, bn);
     const int tiles = ((M + bm - 1) / bm) * ((N + bn - 1) / bn), nk = K / X3_BK;
-    if (N % 4 != 0 || tiles * 3 > 256) return 1;
+    // (M <= 512 -- the small-batch regime whose results must not depend on the batch size -- is never cut here: the planner
+    //  does not use these kernels there, and a FORCED geometry, CAPDEC_H2W >= 10, then runs unsplit whatever M is)
+    if (N % 4 != 0 || tiles * 3 > 256 || M <= 512) return 1;
     int best = 1;
     for (int s = 2; tiles * s <= 256 && s <= nk / 8; ++s)
         if (nk % s == 0) best = s;
