@@ -94,6 +94,7 @@ SIGNATURES = {
     "capdec_set_batch_invariant": (C.c_int, [_VP, C.c_int]),
     "capdec_cross_entropy": (C.c_int, [_VP, _VP, C.c_int, _VP, C.c_int, C.c_int, C.c_int, _VP]),
     "capdec_decode_counters": (C.c_int, [_VP, C.POINTER(C.c_double), C.POINTER(C.c_longlong)]),
+    "capdec_decode_second_pass_rows": (C.c_int, [_VP, C.POINTER(C.c_longlong)]),
     "capdec_set_kv_budget": (C.c_int, [_VP, C.c_size_t]),
     "capdec_malloc": (C.c_int, [_VP, C.c_size_t, C.POINTER(_VP)]),
     "capdec_free": (C.c_int, [_VP, _VP]),

@@ -11,7 +11,7 @@ const char *const kFamilyNames[F_COUNT] = {"gemm_f32", "gemm_f32_lmhead_topk", "
                                            "layernorm", "embed", "select", "attn_mapper", "other", "gemm_bf16x3",
                                            "gemm_bf16x3_lmhead_topk", "gemm_bf16x3p", "gemm_x1",
                                            "gemm_x1_lmhead_topk", "gemm_f16x2p", "gemm_f16x2p_lmhead_topk",
-                                           "pack_activations"};
+                                           "pack_activations", "lmhead_second_pass"};
 
 int prof_collect(capdec_ctx *c) {
     if (c->prof.recs.empty()) return 0;
@@ -77,6 +77,7 @@ bool tuning_from_env(Tuning *t, std::string *err) {
     }
     env_int("CAPDEC_PP", &t->pp);
     env_flag("CAPDEC_LMHEAD_WIDE", &t->lmhead_wide);
+    env_flag("CAPDEC_LMHEAD_K3", &t->lmhead_k3);
     env_flag("CAPDEC_KV_DIRECT", &t->kv_direct);
     env_flag("CAPDEC_RN_PACKED", &t->rn_packed);
     env_flag("CAPDEC_RN_IMPLICIT", &t->rn_implicit);
@@ -254,6 +255,18 @@ int capdec_decode_stats(capdec_ctx *c, int *steps, int *compactions, long long *
     if (steps) *steps = c->stat_steps;
     if (compactions) *compactions = c->stat_compactions;
     if (row_steps) *row_steps = c->stat_row_steps;
+    return 0;
+}
+
+int capdec_decode_second_pass_rows(capdec_ctx *c, long long *rows) {
+    CAPDEC_CHECK(c && rows, "null argument");
+    *rows = 0;
+    if (!c->lmflag_live) return 0;
+    CAPDEC_HIP(hipSetDevice(c->device));
+    int total = 0;
+    CAPDEC_HIP(hipMemcpyAsync(&total, c->lmflag.as<int>() + 1, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    CAPDEC_HIP(hipStreamSynchronize(c->stream));
+    *rows = total;
     return 0;
 }
 

@@ -176,6 +176,9 @@ int launch_gemm_pp(hipStream_t st, int which, const void *Apacked, const void *B
 // planner: 0 = keep the kernels of rounds 2-3, else a ping-pong geometry (10 = 256x128, 14 = 256x192, 12 = 256x256)
 int pp_plan(int M, int N, int K, bool wide_ok, bool can_split, int mode = 2);
 size_t pp_splitk_ws_bytes(int which, int M, int N, int K);
+// exact second pass of the fused lm_head (decode.hip): k = 5 lists for the *m_dev rows of a compacted packed A operand
+int launch_gemm_h2w_topk_dev(hipStream_t st, const void *Apacked, const void *Bpacked, const int *m_dev, int N, int K,
+                             float inv_temp, float *tile_max, float *tile_sum, float *cand_val, int *cand_idx);
 // generic packer for any PackFmt (gemm_f16x2.hip); the one-plane formats use it
 int launch_pack_planes_fmt(hipStream_t st, const float *w, int ldw, int N, int K, void *out, int fmt);
 // round-2 one-plane kernels on the f16x2 main loop (gemm_f16x2.hip): 128x128 tile, two blocks per CU, 32-deep stages
@@ -269,6 +272,18 @@ int launch_attn_mapper(hipStream_t st, const float *q, int ldq, const float *k, 
 // select.hip
 int launch_topk_merge(hipStream_t st, const float *tile_max, const float *tile_sum, const float *cand_val,
                       const int *cand_idx, int rows, int ntiles, int k, float *lse, float *top_val, int *top_idx);
+// Three candidates per (row, tile) in, the row's top 5 + logsumexp out; a row one of whose tiles may hide a fourth
+// candidate that still matters (the tile's third kept candidate is strictly better than the row's fifth) is appended to
+// flag_rows[atomicAdd(flag_count)] -- its top 5 are provisional until the exact second pass has rewritten them
+int launch_topk_merge_k3(hipStream_t st, const float *tile_max, const float *tile_sum, const float *cand_val,
+                         const int *cand_idx, int rows, int ntiles, float *lse, float *top_val, int *top_idx,
+                         int *flag_rows, int *flag_count, int *flag_total);
+// the second pass's merge: *count_dev compact rows of k = 5 lists -> top_val / top_idx of rows out_rows[i]
+int launch_topk_merge_rows(hipStream_t st, const float *cand_val, const int *cand_idx, const int *count_dev,
+                           const int *out_rows, int rows_cap, int ntiles, float *top_val, int *top_idx);
+// rows src_rows[i], i < *count_dev, of a packed f16x2 operand [*, K] -> rows i of `out` (same format)
+int launch_gather_packed_rows(hipStream_t st, const void *packed, int K, const int *src_rows, const int *count_dev,
+                              int rows_cap, void *out);
 struct BeamState {
     int *tokens = nullptr;      // [ncap, beam, T]
     float *scores = nullptr;    // [ncap, beam]  running SUM of log-probs (reference `scores`)

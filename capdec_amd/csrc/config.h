@@ -30,6 +30,7 @@ struct Tuning {
                                   //             10 / 12 / 14 = force a round-4 ping-pong tile (tests)
     int pp = 2;                   // CAPDEC_PP: ping-pong planner: 0 never, 2 mid-size launches (default), 1 also large, 3 large only
     bool lmhead_wide = true;      // CAPDEC_LMHEAD_WIDE=0: 128-row lm_head tiles at every size
+    bool lmhead_k3 = true;        // CAPDEC_LMHEAD_K3=0: the wide lm_head keeps k candidates per tile (no exact second pass)
     bool kv_direct = true;        // CAPDEC_KV_DIRECT=0: the attention kernel appends K / V itself
     bool rn_packed = true;        // CAPDEC_RN_PACKED=0: fp32 im2col in the ResNet tower
     bool rn_implicit = true;      // CAPDEC_RN_IMPLICIT=0: fp32 activations in the ResNet tower

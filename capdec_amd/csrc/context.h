@@ -101,7 +101,7 @@ struct ResNet {
 };
 
 enum Family { F_GEMM = 0, F_LMHEAD, F_ATTN_DEC, F_ATTN_PRE, F_LN, F_EMBED, F_SELECT, F_MAP_ATTN, F_OTHER, F_GEMM_X3,
-              F_LMHEAD_X3, F_GEMM_X3P, F_GEMM_BF16P, F_LMHEAD_BF16, F_GEMM_H2P, F_LMHEAD_H2, F_PACK, F_COUNT };
+              F_LMHEAD_X3, F_GEMM_X3P, F_GEMM_BF16P, F_LMHEAD_BF16, F_GEMM_H2P, F_LMHEAD_H2, F_PACK, F_LMHEAD_2ND, F_COUNT };
 extern const char *const kFamilyNames[F_COUNT];
 constexpr int PROF_SLOTS = 24;   // capdec_profile_get fills at most this many families (engine.py sizes its arrays by it)
 static_assert(F_COUNT <= PROF_SLOTS, "profile arrays too small");
@@ -143,6 +143,7 @@ struct capdec_ctx {
     bool batch_invariant = false;   // capdec_set_batch_invariant: no launch-size dependent summation order (no split-K, pinned kernel variants)
     int diverge = 0;                // measurement: beams never share history (capdec_set_debug_diverge)
     double stat_kv_slots = 0.0, stat_kv_pos = 0.0;   // last beam decode: sums behind capdec_decode_counters (filled lazily)
+    bool lmflag_live = false;                        // `lmflag` holds the second-pass row count of the last decode call
     int kvstat_n = 0;                                // captions of the last beam decode whose counters sit in `kvstat`
     bool compact = true;       // decode: drop finished captions from the batch at the poll points (CAPDEC_COMPACT=0: off)
     bool pack_chain = true;    // ... and attention / the fc GEMM epilogue emit the packed A operand of the GEMM that follows
@@ -151,6 +152,8 @@ struct capdec_ctx {
     // workspaces
     DBuf h, x, qkv, att, ff, xl, tmax, tsum, cval, cidx, lse, topv, topi, kc, vc;
     DBuf tokens, scores, seq, stopped, done, anc, next_tok, alive, gids, glens, cmap, kvstat;
+    DBuf lmflag, xpk2;     // fused lm_head with 3 candidates per tile: [count, total, rows...] of the rows whose top 5 need
+                           // the exact second pass; their compacted packed A operand (decode.hip: lm_head_select)
     DBuf m_hid, m_lin, m_seq, m_x, m_qkv, m_att, m_ff;
     DBuf t_idx, t_patch, t_pout, p_desc, p_inter, splitk, absmax;
     int *alive_host = nullptr;   // pinned

@@ -115,6 +115,8 @@ static int lm_head_select(capdec_ctx *c, const float *h0, int ldh, int R, int k,
     CAPDEC_TRY(c->lse.ensure((size_t)R * 4));
     CAPDEC_TRY(c->topv.ensure((size_t)R * k * 4));
     CAPDEC_TRY(c->topi.ensure((size_t)R * k * 4));
+    bool k3 = false;                 // the fused kernel kept 3 candidates per tile of a k = 5 selection (below)
+    const void *wte_planes = nullptr;
     if (use_packed_a(c, d)) {
         CAPDEC_TRY(c->xpk.ensure(x3_packed_bytes_host(R, d)));
         { ProfScope ps(c, F_LN); CAPDEC_TRY(launch_layernorm_packed(c->stream, h0, ldh, g.lnfw, g.lnfb, g.eps, c->xpk.p, R, d, pack_fmt(c))); }
@@ -127,10 +129,16 @@ static int lm_head_select(capdec_ctx *c, const float *h0, int ldh, int R, int k,
             // by half as many row tiles); small row counts keep the 128-row tile (more blocks, the same partial lists)
             const bool lm_wide = c->tune.lmhead_wide;
             const int h2w = c->tune.h2w;
-            if (wide_ok && !c->batch_invariant && ((lm_wide && h2w >= 1 && R >= 2048) || h2w >= 2))   // (CAPDEC_H2W >= 2: forced, tests)
-                CAPDEC_TRY(launch_gemm_h2w_topk(c->stream, c->xpk.p, pl, R, g.vocab, d, k, inv_temp, c->tmax.as<float>(),
+            if (wide_ok && !c->batch_invariant && ((lm_wide && h2w >= 1 && R >= 2048) || h2w >= 2)) {   // (CAPDEC_H2W >= 2: forced, tests)
+                // Beam search (k = 5): keep THREE candidates per (row, 128-column tile) -- two selection rounds fewer in
+                // every tile's epilogue.  The merge then knows exactly which rows that can have been too few for (some
+                // tile's third candidate is still strictly better than the row's fifth: with 393 tiles a rare event) and
+                // those rows alone go through the k = 5 kernel again, compacted; the result is the k = 5 result.
+                k3 = c->tune.lmhead_k3 && k == 5;
+                CAPDEC_TRY(launch_gemm_h2w_topk(c->stream, c->xpk.p, pl, R, g.vocab, d, k3 ? 3 : k, inv_temp, c->tmax.as<float>(),
                                                 c->tsum.as<float>(), c->cval.as<float>(), c->cidx.as<int>(), &c->tune));
-            else
+                wte_planes = pl;
+            } else
             CAPDEC_TRY(launch_gemm_f16x2p_topk(c->stream, c->xpk.p, pl, R, g.vocab, d, k, inv_temp, c->tmax.as<float>(),
                                                c->tsum.as<float>(), c->cval.as<float>(), c->cidx.as<int>()));
         } else if (mode_single(c)) {
@@ -157,6 +165,28 @@ static int lm_head_select(capdec_ctx *c, const float *h0, int ldh, int R, int k,
         CAPDEC_TRY(launch_gemm_f32_topk(c->stream, c->xl.as<float>(), d, g.wte, d, R, g.vocab, d, k, inv_temp,
                                         c->tmax.as<float>(), c->tsum.as<float>(), c->cval.as<float>(),
                                         c->cidx.as<int>(), &c->tune));
+    }
+    if (k3) {
+        CAPDEC_TRY(c->lmflag.ensure(((size_t)R + 2) * 4));
+        CAPDEC_TRY(c->xpk2.ensure(x3_packed_bytes_host(R, d)));
+        int *cnt = c->lmflag.as<int>(), *total = cnt + 1, *rows = cnt + 2;
+        {
+            ProfScope ps(c, F_SELECT);
+            CAPDEC_HIP(hipMemsetAsync(cnt, 0, sizeof(int), c->stream));
+            CAPDEC_TRY(launch_topk_merge_k3(c->stream, c->tmax.as<float>(), c->tsum.as<float>(), c->cval.as<float>(),
+                                            c->cidx.as<int>(), R, nt, c->lse.as<float>(), c->topv.as<float>(),
+                                            c->topi.as<int>(), rows, cnt, total));
+        }
+        // the second pass: gather, k = 5 kernel over the device-side row count, merge (the partial lists of the first pass
+        // are dead once its merge has run: their buffers are reused)
+        ProfScope ps(c, F_LMHEAD_2ND);
+        CAPDEC_TRY(launch_gather_packed_rows(c->stream, c->xpk.p, d, rows, cnt, R, c->xpk2.p));
+        CAPDEC_TRY(launch_gemm_h2w_topk_dev(c->stream, c->xpk2.p, wte_planes, cnt, g.vocab, d, inv_temp, c->tmax.as<float>(),
+                                            c->tsum.as<float>(), c->cval.as<float>(), c->cidx.as<int>()));
+        CAPDEC_TRY(launch_topk_merge_rows(c->stream, c->cval.as<float>(), c->cidx.as<int>(), cnt, rows, R, nt,
+                                          c->topv.as<float>(), c->topi.as<int>()));
+        c->lmflag_live = true;
+        return 0;
     }
     {
         ProfScope ps(c, F_SELECT);
@@ -361,6 +391,10 @@ static int decode_common(capdec_ctx *c, const float *prefix, int n, int P, int b
     }
     const int ctx = P + T - 1;
     const int chunk = chunk_captions(c, n, beam, ctx);
+    // lm_head second-pass bookkeeping ([count, total, rows...], lm_head_select): sized once for the largest step, total zeroed
+    CAPDEC_TRY(c->lmflag.ensure(((size_t)std::min(chunk, n) * beam + 2) * 4));
+    CAPDEC_HIP(hipMemsetAsync(c->lmflag.p, 0, 2 * sizeof(int), c->stream));
+    c->lmflag_live = false;
     for (int c0 = 0; c0 < n; c0 += chunk) {
         const int nc = std::min(chunk, n - c0);
         CAPDEC_TRY(decode_chunk(c, prefix + (size_t)c0 * P * c->gpt.d, nc, P, beam, greedy, stop_id, alt_stop_id, T,

@@ -138,34 +138,8 @@ __device__ __forceinline__ void epilogue_store_t(const f32x16 (&acc)[2][2], floa
     }
 }
 
-// K / V third of the decode-step qkv projection: acc + bias straight into the KV cache (QkvScatter, common.h).  The tile's
-// 128 columns are two heads of ONE of K / V (d % 128 == 0); a lane's four consecutive columns are 16 contiguous bytes of
-// a cached key / value.
-__device__ __forceinline__ void epilogue_store_kv_t(const f32x16 (&acc)[2][2], int M, int m0, int n0,
-                                                    const float *__restrict__ bias, const QkvScatter &sc) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int wm = wave >> 1, wn = wave & 1, half = lane >> 5, l32 = lane & 31;
-    float *cache = n0 >= 2 * sc.d ? sc.vc : sc.kc;
-    const int c0 = n0 - (n0 >= 2 * sc.d ? 2 * sc.d : sc.d);          // first column of the tile inside K (or V)
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int row = m0 + wm * 64 + i * 32 + l32;
-        if (row >= M) continue;
-        const int cap = row / sc.beam, b = row - cap * sc.beam;
-        const size_t srow = (size_t)(sc.cmap ? sc.cmap[cap] : cap) * sc.beam + b;
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int lc = wn * 64 + j * 32 + 8 * g + 4 * half;       // column inside the tile
-                float4 v = acc_quad(acc[i][j], g);
-                const float4 bq = *reinterpret_cast<const float4 *>(bias + n0 + lc);
-                v.x += bq.x; v.y += bq.y; v.z += bq.z; v.w += bq.w;
-                const int hc = c0 + lc, head = hc >> 6;
-                *reinterpret_cast<float4 *>(cache + ((srow * sc.heads + head) * sc.ctx + sc.pos) * 64 + (hc & 63)) = v;
-            }
-    }
-}
+// (round 4: the K / V scatter of the decode-step qkv projection lives in gemm_epilogue_lds.h, MODE 2: whole 256-byte keys /
+//  values per instruction instead of 16-byte pieces of 64 different rows)
 
 // act(acc + bias) written as the packed split-bf16 A operand of the NEXT GEMM (its K = this GEMM's N, N % 16 == 0):
 // a lane's four consecutive columns are exactly one quad of that operand -- split3 and three 8-byte stores, the fp32

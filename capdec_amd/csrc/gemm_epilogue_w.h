@@ -1,5 +1,7 @@
 // Epilogues of the wide-tile GEMM kernels (gemm_h2w.hip, gemm_pp.hip): a wavefront owns TI x TJ blocks of 32 x 32 of
 // the block tile; G supplies WN (wavefronts along N), TI, TJ (and BM / BN / NW / SMEM_B for the top-k epilogue).
+// The two DIRECT store epilogues below (round 3: 16-byte / 8-byte pieces of 64 different rows per instruction) are what
+// gemm_epilogue_lds.h replaced; they remain for the A/B of the measurement build (gemm_pp.hip, CAPDEC_PP_ABL=8).
 #pragma once
 #include "gemm_epilogue.h"
 

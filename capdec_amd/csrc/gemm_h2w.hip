@@ -270,6 +270,28 @@ __global__ __launch_bounds__(G::THREADS, G::MINW) void gemm_h2w_topk_kernel(cons
                              tile_sum, cand_val, cand_idx);
 }
 
+// The same kernel over a row count only the DEVICE knows (*m_dev rows of a compacted A operand: the exact second pass of
+// the fused lm_head, decode.hip): a fixed grid of persistent blocks walks the tiles there are; with *m_dev == 0 every block
+// leaves at once.
+template <class G, int KSEL>
+__global__ __launch_bounds__(G::THREADS, G::MINW) void gemm_h2w_topk_dev_kernel(const _Float16 *__restrict__ Apk,
+                                                                               const _Float16 *__restrict__ Bpk,
+                                                                               const int *__restrict__ m_dev, int N, int K,
+                                                                               float scale, float *tile_max, float *tile_sum,
+                                                                               float *cand_val, int *cand_idx, int tiles_n) {
+    __shared__ __attribute__((aligned(16))) char smem[G::SMEM_B];
+    const int M = *m_dev;
+    const int tiles_m = (M + G::BM - 1) / G::BM, ntiles = tiles_m * tiles_n;
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        int tm, tn;
+        tile_coords(tiles_m, tiles_n, tm, tn, tile);
+        f32x16 acc[G::TI][G::TJ];
+        h2w_mainloop<G, false>(Apk, Bpk, K, tm, tn, ((M + 127) >> 7) * 4, ((N + 127) >> 7) * 4, smem, acc);   // ends with a barrier
+        epilogue_topk_w<G, KSEL>(acc, scale, reinterpret_cast<float *>(smem), M, N, tm * G::BM, tn * G::BN, tn, tiles_n,
+                                 tile_max, tile_sum, cand_val, cand_idx);      // (ends with a barrier: the ring is free again)
+    }
+}
+
 using W256x128 = WGeo<2, 2, 4, 2, 3, 2>;      // 4 waves, 72 KB, two blocks per CU
 #ifdef CAPDEC_MEASURE
 using W256x256 = WGeo<2, 4, 4, 2, 4, 2>;      // 8 waves, 128 KB, one block per CU (measured: -4 .. -27 %)
@@ -380,6 +402,19 @@ int launch_gemm_h2w_topk(hipStream_t st, const void *Apacked, const void *Bpacke
         default: CAPDEC_CHECK(false, "gemm_topk: k must be in 1..8");
     }
 #undef LAUNCH_TOPKW
+    CAPDEC_HIP(hipGetLastError());
+    return 0;
+}
+
+// k = 5 on *m_dev rows (m_cap = the capacity the output lists were sized for)
+int launch_gemm_h2w_topk_dev(hipStream_t st, const void *Apacked, const void *Bpacked, const int *m_dev, int N, int K,
+                             float inv_temp, float *tile_max, float *tile_sum, float *cand_val, int *cand_idx) {
+    CAPDEC_CHECK(m_dev && N > 0 && K > 0 && K % 64 == 0, "gemm_h2w_topk_dev: bad argument");
+    using G = W256x128;
+    const int tiles_n = (N + G::BN - 1) / G::BN;
+    hipLaunchKernelGGL((gemm_h2w_topk_dev_kernel<G, 5>), dim3(512), dim3(G::THREADS), 0, st, (const _Float16 *)Apacked,
+                       (const _Float16 *)Bpacked, m_dev, N, K, inv_temp / H2_LO_SCALE, tile_max, tile_sum, cand_val, cand_idx,
+                       tiles_n);
     CAPDEC_HIP(hipGetLastError());
     return 0;
 }

@@ -68,6 +68,142 @@ __global__ __launch_bounds__(256) void topk_merge_kernel(const float *__restrict
     }
 }
 
+// ---- k = 3 per tile in, top 5 out, with the "may hide a fourth" flag (common.h)
+__global__ __launch_bounds__(256) void topk_merge_k3_kernel(const float *__restrict__ tile_max, const float *__restrict__ tile_sum,
+                                                            const float *__restrict__ cand_val, const int *__restrict__ cand_idx,
+                                                            int rows, int ntiles, float *__restrict__ lse,
+                                                            float *__restrict__ top_val, int *__restrict__ top_idx,
+                                                            int *__restrict__ flag_rows, int *__restrict__ flag_count,
+                                                            int *__restrict__ flag_total) {
+    constexpr int KIN = 3, KOUT = 5;
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const size_t base = (size_t)row * ntiles;
+    float m = -INFINITY;
+    for (int t = lane; t < ntiles; t += 64) m = fmaxf(m, tile_max[base + t]);
+    m = wave_max(m);
+    float s = 0.f;
+    for (int t = lane; t < ntiles; t += 64) s += tile_sum[base + t] * expf(tile_max[base + t] - m);
+    s = wave_sum(s);
+    if (lane == 0) lse[row] = m + logf(s);
+
+    float bv[KOUT];
+    int bi[KOUT];
+#pragma unroll
+    for (int j = 0; j < KOUT; ++j) { bv[j] = -INFINITY; bi[j] = 0x7fffffff; }
+    float l3v = -INFINITY;                 // the best LAST-kept candidate among this lane's tiles: what bounds their hidden ones
+    int l3i = 0x7fffffff;
+    for (int t = lane; t < ntiles; t += 64) {
+#pragma unroll
+        for (int kk = 0; kk < KIN; ++kk) {
+            float v = cand_val[(base + t) * KIN + kk];
+            int i = cand_idx[(base + t) * KIN + kk];
+            if (kk == KIN - 1 && better(v, i, l3v, l3i)) { l3v = v; l3i = i; }
+#pragma unroll
+            for (int j = 0; j < KOUT; ++j) {
+                if (better(v, i, bv[j], bi[j])) {
+                    const float tv = bv[j]; const int ti = bi[j];
+                    bv[j] = v; bi[j] = i; v = tv; i = ti;
+                }
+            }
+        }
+    }
+    float gv = -INFINITY;
+    int gi = 0x7fffffff;
+#pragma unroll
+    for (int r = 0; r < KOUT; ++r) {
+        gv = bv[0];
+        gi = bi[0];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float ov = __shfl_xor(gv, o, 64);
+            const int oi = __shfl_xor(gi, o, 64);
+            if (better(ov, oi, gv, gi)) { gv = ov; gi = oi; }
+        }
+        if (gi == bi[0] && gv == bv[0]) {   // this lane held the winner: pop it
+#pragma unroll
+            for (int j = 0; j + 1 < KOUT; ++j) { bv[j] = bv[j + 1]; bi[j] = bi[j + 1]; }
+            bv[KOUT - 1] = -INFINITY; bi[KOUT - 1] = 0x7fffffff;
+        }
+        if (lane == 0) { top_val[(size_t)row * KOUT + r] = gv; top_idx[(size_t)row * KOUT + r] = gi; }
+    }
+    // (gv, gi) = the row's fifth.  A tile's hidden candidates are all worse than its third kept one, so they can only
+    // matter if that third one is STRICTLY better than the fifth (if it IS the fifth, or worse, nothing hidden can pass it)
+    const bool mine = better(l3v, l3i, gv, gi);
+    if (__ballot(mine) != 0ull && lane == 0) {
+        flag_rows[atomicAdd(flag_count, 1)] = row;
+        atomicAdd(flag_total, 1);
+    }
+}
+
+int launch_topk_merge_k3(hipStream_t st, const float *tile_max, const float *tile_sum, const float *cand_val,
+                         const int *cand_idx, int rows, int ntiles, float *lse, float *top_val, int *top_idx,
+                         int *flag_rows, int *flag_count, int *flag_total) {
+    if (rows <= 0) return 0;
+    hipLaunchKernelGGL(topk_merge_k3_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, tile_max, tile_sum, cand_val, cand_idx,
+                       rows, ntiles, lse, top_val, top_idx, flag_rows, flag_count, flag_total);
+    CAPDEC_HIP(hipGetLastError());
+    return 0;
+}
+
+// ---- the second pass's merge: compact row i (k = 5 lists) -> top 5 of row out_rows[i]; persistent over *count_dev rows
+__global__ __launch_bounds__(256) void topk_merge_rows_kernel(const float *__restrict__ cand_val, const int *__restrict__ cand_idx,
+                                                              const int *__restrict__ count_dev, const int *__restrict__ out_rows,
+                                                              int ntiles, float *__restrict__ top_val, int *__restrict__ top_idx) {
+    constexpr int KSEL = 5;
+    const int lane = threadIdx.x & 63;
+    const int n = *count_dev;
+    for (int row = blockIdx.x * 4 + (threadIdx.x >> 6); row < n; row += gridDim.x * 4) {
+        const size_t base = (size_t)row * ntiles;
+        float bv[KSEL];
+        int bi[KSEL];
+#pragma unroll
+        for (int j = 0; j < KSEL; ++j) { bv[j] = -INFINITY; bi[j] = 0x7fffffff; }
+        for (int t = lane; t < ntiles; t += 64) {
+#pragma unroll
+            for (int kk = 0; kk < KSEL; ++kk) {
+                float v = cand_val[(base + t) * KSEL + kk];
+                int i = cand_idx[(base + t) * KSEL + kk];
+#pragma unroll
+                for (int j = 0; j < KSEL; ++j) {
+                    if (better(v, i, bv[j], bi[j])) {
+                        const float tv = bv[j]; const int ti = bi[j];
+                        bv[j] = v; bi[j] = i; v = tv; i = ti;
+                    }
+                }
+            }
+        }
+        const size_t orow = (size_t)out_rows[row];
+#pragma unroll
+        for (int r = 0; r < KSEL; ++r) {
+            float gv = bv[0];
+            int gi = bi[0];
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                const float ov = __shfl_xor(gv, o, 64);
+                const int oi = __shfl_xor(gi, o, 64);
+                if (better(ov, oi, gv, gi)) { gv = ov; gi = oi; }
+            }
+            if (gi == bi[0] && gv == bv[0]) {
+#pragma unroll
+                for (int j = 0; j + 1 < KSEL; ++j) { bv[j] = bv[j + 1]; bi[j] = bi[j + 1]; }
+                bv[KSEL - 1] = -INFINITY; bi[KSEL - 1] = 0x7fffffff;
+            }
+            if (lane == 0) { top_val[orow * KSEL + r] = gv; top_idx[orow * KSEL + r] = gi; }
+        }
+    }
+}
+
+int launch_topk_merge_rows(hipStream_t st, const float *cand_val, const int *cand_idx, const int *count_dev,
+                           const int *out_rows, int rows_cap, int ntiles, float *top_val, int *top_idx) {
+    if (rows_cap <= 0) return 0;
+    hipLaunchKernelGGL(topk_merge_rows_kernel, dim3(std::min((rows_cap + 3) / 4, 1024)), dim3(256), 0, st, cand_val, cand_idx,
+                       count_dev, out_rows, ntiles, top_val, top_idx);
+    CAPDEC_HIP(hipGetLastError());
+    return 0;
+}
+
 int launch_topk_merge(hipStream_t st, const float *tile_max, const float *tile_sum, const float *cand_val,
                       const int *cand_idx, int rows, int ntiles, int k, float *lse, float *top_val, int *top_idx) {
     if (rows <= 0) return 0;

@@ -477,6 +477,12 @@ class Engine:
         self._chk(self.lib.capdec_decode_counters(self._h, C.byref(kv), C.byref(sat)), "decode_counters")
         return dict(kv_slots_per_position=kv.value, saturated_quads=sat.value)
 
+    def second_pass_rows(self) -> int:
+        """(row, step) pairs of the last decode call whose lm_head top 5 went through the exact second pass (capdec.h)"""
+        n = C.c_longlong(0)
+        self._chk(self.lib.capdec_decode_second_pass_rows(self._h, C.byref(n)), "decode_second_pass_rows")
+        return n.value
+
     def set_batch_invariant(self, on: bool = True):
         """results independent of batch size / chunking / sharding (no split-K, pinned kernel variants); see capdec.h"""
         self._chk(self.lib.capdec_set_batch_invariant(self._h, int(bool(on))), "set_batch_invariant")

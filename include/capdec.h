@@ -303,6 +303,13 @@ int capdec_decode_stats(capdec_ctx *ctx, int *steps, int *compactions, long long
  * the clamps of all of them.  Either pointer may be NULL; the K/V statistic is accumulated on the device and read back
  * (one small copy + a stream synchronisation) only by this call. */
 int capdec_decode_counters(capdec_ctx *ctx, double *kv_slots_per_position, long long *saturated_quads);
+/* rows: over the last decode call, how many (row, step) pairs of the fused lm_head went through its exact second pass.
+ * Beam search needs the 5 best logits of a row; above 2048 rows the fused kernel keeps only 3 per 128-column vocabulary
+ * tile, the merge detects every row for which that can have dropped a candidate that matters, and those rows alone are
+ * recomputed with 5 per tile (results are identical to keeping 5 everywhere; CAPDEC_LMHEAD_K3=0 does exactly that).  Compare
+ * with row_steps of capdec_decode_stats: a checkpoint whose vocabulary clusters its best candidates in one tile pays for
+ * the second pass, and this is the number that shows it. */
+int capdec_decode_second_pass_rows(capdec_ctx *ctx, long long *rows);
 #ifdef CAPDEC_MEASURE
 /* MEASUREMENT BUILDS ONLY (libcapdec_hip_measure.so, compiled with -DCAPDEC_MEASURE; the shipped library does not export
  * it): every beam continues ITSELF (candidates of other parents are ignored), so no two beams of a caption share history

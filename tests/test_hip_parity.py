@@ -955,6 +955,39 @@ def test_wide_single_accumulator_kernels_against_goldens(geometry):
     assert r.returncode == 0 and " passed" in tail and "failed" not in tail, tail
 
 
+def test_lm_head_three_candidates_with_exact_second_pass(monkeypatch):
+    """From 2048 rows the fused lm_head keeps 3 candidates per 128-column vocabulary tile of a k = 5 selection and
+    re-runs, with 5 per tile, exactly the rows for which that can have dropped a candidate (select.hip:
+    topk_merge_k3_kernel; decode.hip: lm_head_select).  The result must be the k = 5 result bit for bit: beam ids, lengths,
+    scores and order with CAPDEC_LMHEAD_K3=0 (5 per tile everywhere) and with the default are compared in full -- on a
+    12-tile vocabulary, where a few percent of the rows need the second pass (observed: 939 of 41 600), and on GPT-2's 393
+    tiles, where almost none does -- and a subset goes against the oracle"""
+    from capdec_amd.engine import Engine
+    from oracle import capdec_oracle as O
+    for dims, n, T_, stop, expect_many in ((synth.GPT2_TINY, 640, 14, 614, True), (synth.GPT2_SMALL, 440, 10, 13, False)):
+        sd = synth.hot_state_dict(7, "mlp", 512, 10, dims=dims)
+        x = synth.synthetic_clip_embeddings(n, 512, seed=77)
+        pe = O.clip_project(x, sd, "mlp", 10).reshape(n, 10, -1)
+        outs, second = {}, {}
+        for k3 in ("1", "0"):
+            monkeypatch.setenv("CAPDEC_LMHEAD_K3", k3)
+            e = Engine(0)
+            e.load_gpt2(sd)
+            i, l, s_, o = e.decode_beam(pe, stop, 5, T_)
+            outs[k3] = tuple(t.cpu().numpy() for t in (i, l, s_, o))
+            second[k3] = e.second_pass_rows()
+            rs = e.decode_stats()["row_steps"]
+            e.close()
+        _report(f"[lm_head second pass] V = {dims.vocab}: {second['1']} of {rs} (row, step) pairs recomputed with 5 per tile")
+        assert second["0"] == 0
+        assert (second["1"] >= 200) if expect_many else (second["1"] < 0.02 * rs), (second, rs)
+        for a, b in zip(outs["1"], outs["0"]):
+            np.testing.assert_array_equal(a, b)
+        rows = sorted(np.random.default_rng(3).choice(n, 10, replace=False).tolist())
+        ok, ties = _beam_rows_vs_oracle(outs["1"], sd, pe, rows, stop, T_, dims.n_head, f"3 per tile + second pass, V = {dims.vocab}")
+        assert ok + ties == len(rows) and ok >= len(rows) - 1, (ok, ties)
+
+
 def test_finished_caption_compaction(monkeypatch):
     """captions that stop early leave the batch at the poll points (activation rows are compacted, KV / beam state stay
     in place): with a stop id that fires at staggered steps the results still equal the oracle token for token, the

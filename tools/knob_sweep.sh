@@ -10,5 +10,5 @@ for kv in "X=0" $1; do
     env $kv $B 2>/dev/null | python -c "
 import sys,json
 r=json.loads(sys.stdin.read().strip().splitlines()[-1]); k=r['kernels']
-print(r['value'], 'gemm', k['gemm_f16x2p']['avg_ms'], k['gemm_f16x2p'].get('tflops'), 'lmhead', k['gemm_f16x2p_lmhead_topk']['avg_ms'], 'attn', k['attn_decode']['avg_ms'], 'W', r['power']['watts'], 'MHz', r['power']['sclk_mhz'])"
+print(r['value'], 'gemm', k['gemm_f16x2p']['avg_ms'], k['gemm_f16x2p'].get('tflops'), 'lmhead', k['gemm_f16x2p_lmhead_topk']['avg_ms'], 'attn', k['attn_decode']['avg_ms'], '2nd', (k.get('lmhead_second_pass') or {}).get('avg_ms'), 'select', k['select']['avg_ms'], 'W', r['power']['watts'], 'MHz', r['power']['sclk_mhz'])"
 done
