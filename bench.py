@@ -548,6 +548,7 @@ def main():
     prof = eng.profile_get()
     eng.profile_enable(False)
     counters = eng.decode_counters()
+    second_pass = (eng.second_pass_rows(), eng.decode_stats()["row_steps"]) if beam else None   # of the last timed step
     assert out[0].shape[0] == n_global and int(out[1].min()) >= 1
 
     # ---- untimed checks (rank 0, N = 1): (a) ids_check -- the whole batch decoded once more in BATCH-INVARIANT mode (one
@@ -787,6 +788,11 @@ def main():
             rec["kernels"]["attn_decode"]["kv_slots_per_position"] = round(counters["kv_slots_per_position"], 3)
             if diverged:
                 rec["kernels"]["attn_decode_diverged"] = diverged
+        if second_pass and "gemm_f16x2p_lmhead_topk" in rec["kernels"]:
+            # (row, step) pairs of one timed step whose lm_head top 5 needed the exact second pass (3 candidates kept per
+            # vocabulary tile, capdec.h: capdec_decode_second_pass_rows), of the row-steps the step ran
+            rec["kernels"]["gemm_f16x2p_lmhead_topk"]["second_pass_rows"] = second_pass[0]
+            rec["kernels"]["gemm_f16x2p_lmhead_topk"]["row_steps"] = second_pass[1]
         rec["oracle_check"] = oracle_check
         if power and power.get("sclk_mhz"):
             # the dominant kernel against the peak AT THE CLOCK THE CHIP ACTUALLY HELD (it runs at its package power cap)

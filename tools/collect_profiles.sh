@@ -1,6 +1,7 @@
 #!/bin/bash
 # Reproduce everything under profiles/ on an MI355X box (one gpurun call):
 #   gpurun --timeout 1500 -- 'bash tools/collect_profiles.sh r4'
+# (SHORT=1: only the two bench lines and the rocprofv3 --kernel-trace --stats pass of the bench command, ~8 minutes)
 # then copy gpurun_out/<tag>_* into profiles/.  Steps: the driver-style bench line (with the CPU baseline), the same
 # command under rocprofv3 --kernel-trace --stats (kernel averages must agree with the hipEvent averages of the bench
 # line), the FETCH_SIZE / WRITE_SIZE counters in their own passes (never combined with tracing), summarised per kernel,
@@ -18,14 +19,19 @@ cd "$R"
 timeout 400 python bench.py --steps 20 --warmup 5 > "$OUT/${TAG}_bench.json" 2> "$OUT/${TAG}_bench.err"
 timeout 300 python bench.py --captions 625 --steps 20 --warmup 5 --cpu-seconds 0 > "$OUT/${TAG}_bench_625.json" 2> "$OUT/${TAG}_bench_625.err"
 # what one decode step of the 625-caption shard is made of: per-(kernel, grid) table of a traced pass
-timeout 300 rocprofv3 --kernel-trace --output-format csv -d "$OUT/${TAG}_kt625" -- python bench.py --cpu-seconds 0 --no-checks --no-smi --captions 625 --steps 1 --warmup 1 \
+[ "${SHORT:-0}" = 1 ] || timeout 300 rocprofv3 --kernel-trace --output-format csv -d "$OUT/${TAG}_kt625" -- python bench.py --cpu-seconds 0 --no-checks --no-smi --captions 625 --steps 1 --warmup 1 \
     > "$OUT/${TAG}_kt625.json" 2> "$OUT/${TAG}_kt625.err"
-python tools/trace_summary.py "$OUT/${TAG}_kt625" "$OUT/${TAG}_625_kernels.txt" --title "bench.py --captions 625 --steps 1 --warmup 1 under rocprofv3 --kernel-trace (two passes of 67 steps + mapper + prefill)"
+[ "${SHORT:-0}" = 1 ] || python tools/trace_summary.py "$OUT/${TAG}_kt625" "$OUT/${TAG}_625_kernels.txt" --title "bench.py --captions 625 --steps 1 --warmup 1 under rocprofv3 --kernel-trace (two passes of 67 steps + mapper + prefill)"
 find "$OUT/${TAG}_kt625" -name "*.csv" -delete
 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/${TAG}_kt" -- python bench.py --cpu-seconds 0 --cpu-captions 0 --no-checks --no-smi \
     > "$OUT/${TAG}_bench_under_rocprof.json" 2> "$OUT/${TAG}_kt.err"
 find "$OUT/${TAG}_kt" -name "*kernel_stats.csv" -exec cp {} "$OUT/${TAG}_bench_kernel_stats.csv" \;
 find "$OUT/${TAG}_kt" -name "*kernel_trace.csv" -delete
+if [ "${SHORT:-0}" = 1 ]; then
+    tail -c 600 "$OUT/${TAG}_bench.json"; echo; tail -c 300 "$OUT/${TAG}_bench_625.json"; echo
+    head -8 "$OUT/${TAG}_bench_kernel_stats.csv" | cut -c1-170
+    exit 0
+fi
 for c in FETCH_SIZE WRITE_SIZE; do
     timeout 300 rocprofv3 --pmc $c --output-format csv -d "$OUT/${TAG}_pmc_$c" -- python bench.py --cpu-seconds 0 --cpu-captions 0 --no-checks --no-smi --steps 1 --warmup 0 \
         > "$OUT/${TAG}_pmc_$c.log" 2>&1
