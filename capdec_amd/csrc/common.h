@@ -179,6 +179,8 @@ size_t pp_splitk_ws_bytes(int which, int M, int N, int K);
 // exact second pass of the fused lm_head (decode.hip): k = 5 lists for the *m_dev rows of a compacted packed A operand
 int launch_gemm_h2w_topk_dev(hipStream_t st, const void *Apacked, const void *Bpacked, const int *m_dev, int N, int K,
                              float inv_temp, float *tile_max, float *tile_sum, float *cand_val, int *cand_idx);
+int launch_gemm_x1_topk_dev(hipStream_t st, const void *Apacked, const void *Bpacked, const int *m_dev, int N, int K,
+                            float inv_temp, float *tile_max, float *tile_sum, float *cand_val, int *cand_idx, int fmt);
 // generic packer for any PackFmt (gemm_f16x2.hip); the one-plane formats use it
 int launch_pack_planes_fmt(hipStream_t st, const float *w, int ldw, int N, int K, void *out, int fmt);
 // round-2 one-plane kernels on the f16x2 main loop (gemm_f16x2.hip): 128x128 tile, two blocks per CU, 32-deep stages
@@ -281,9 +283,9 @@ int launch_topk_merge_k3(hipStream_t st, const float *tile_max, const float *til
 // the second pass's merge: *count_dev compact rows of k = 5 lists -> top_val / top_idx of rows out_rows[i]
 int launch_topk_merge_rows(hipStream_t st, const float *cand_val, const int *cand_idx, const int *count_dev,
                            const int *out_rows, int rows_cap, int ntiles, float *top_val, int *top_idx);
-// rows src_rows[i], i < *count_dev, of a packed f16x2 operand [*, K] -> rows i of `out` (same format)
+// rows src_rows[i], i < *count_dev, of a packed operand [*, K] (PK_F16X2 or a one-plane format) -> rows i of `out`
 int launch_gather_packed_rows(hipStream_t st, const void *packed, int K, const int *src_rows, const int *count_dev,
-                              int rows_cap, void *out);
+                              int rows_cap, void *out, int fmt);
 struct BeamState {
     int *tokens = nullptr;      // [ncap, beam, T]
     float *scores = nullptr;    // [ncap, beam]  running SUM of log-probs (reference `scores`)

@@ -143,7 +143,9 @@ static int lm_head_select(capdec_ctx *c, const float *h0, int ldh, int R, int k,
                                                c->tsum.as<float>(), c->cval.as<float>(), c->cidx.as<int>()));
         } else if (mode_single(c)) {
             ProfScope ps(c, F_LMHEAD_BF16, 2.0 * R * (double)g.vocab * d);
-            CAPDEC_TRY(launch_gemm_x1_topk(c->stream, c->xpk.p, pl, R, g.vocab, d, k, inv_temp, c->tmax.as<float>(),
+            k3 = c->tune.lmhead_k3 && k == 5 && R >= 2048 && !c->batch_invariant;      // (as in the two-plane mode above)
+            wte_planes = pl;
+            CAPDEC_TRY(launch_gemm_x1_topk(c->stream, c->xpk.p, pl, R, g.vocab, d, k3 ? 3 : k, inv_temp, c->tmax.as<float>(),
                                            c->tsum.as<float>(), c->cval.as<float>(), c->cidx.as<int>(), pack_fmt(c)));
         } else {
             ProfScope ps(c, F_LMHEAD_X3, 2.0 * R * (double)g.vocab * d);
@@ -180,9 +182,13 @@ static int lm_head_select(capdec_ctx *c, const float *h0, int ldh, int R, int k,
         // the second pass: gather, k = 5 kernel over the device-side row count, merge (the partial lists of the first pass
         // are dead once its merge has run: their buffers are reused)
         ProfScope ps(c, F_LMHEAD_2ND);
-        CAPDEC_TRY(launch_gather_packed_rows(c->stream, c->xpk.p, d, rows, cnt, R, c->xpk2.p));
-        CAPDEC_TRY(launch_gemm_h2w_topk_dev(c->stream, c->xpk2.p, wte_planes, cnt, g.vocab, d, inv_temp, c->tmax.as<float>(),
-                                            c->tsum.as<float>(), c->cval.as<float>(), c->cidx.as<int>()));
+        CAPDEC_TRY(launch_gather_packed_rows(c->stream, c->xpk.p, d, rows, cnt, R, c->xpk2.p, pack_fmt(c)));
+        if (mode_single(c))
+            CAPDEC_TRY(launch_gemm_x1_topk_dev(c->stream, c->xpk2.p, wte_planes, cnt, g.vocab, d, inv_temp, c->tmax.as<float>(),
+                                               c->tsum.as<float>(), c->cval.as<float>(), c->cidx.as<int>(), pack_fmt(c)));
+        else
+            CAPDEC_TRY(launch_gemm_h2w_topk_dev(c->stream, c->xpk2.p, wte_planes, cnt, g.vocab, d, inv_temp, c->tmax.as<float>(),
+                                                c->tsum.as<float>(), c->cval.as<float>(), c->cidx.as<int>()));
         CAPDEC_TRY(launch_topk_merge_rows(c->stream, c->cval.as<float>(), c->cidx.as<int>(), cnt, rows, R, nt,
                                           c->topv.as<float>(), c->topi.as<int>()));
         c->lmflag_live = true;

@@ -469,27 +469,36 @@ int launch_vision_assemble(hipStream_t st, const float *patch_out, const float *
 
 // rows src_rows[i] (i < *count_dev) of a packed f16x2 operand -> rows i of `out`: one wavefront per row, a lane moves
 // (k-step, quad) pieces of 8 bytes per plane (the swizzle of a piece depends on its row: x3_group_offset)
+template <int PLANES>
 __global__ __launch_bounds__(256) void gather_packed_rows_kernel(const char *__restrict__ packed, int nk,
                                                                  const int *__restrict__ src_rows,
                                                                  const int *__restrict__ count_dev, char *__restrict__ out) {
+    constexpr int BLOCK_B = PLANES * X3_PLANE_B;
     const int lane = threadIdx.x & 63;
     const int n = *count_dev;
     for (int i = blockIdx.x * 4 + (threadIdx.x >> 6); i < n; i += gridDim.x * 4) {
         const int r = src_rows[i];
         for (int q = lane; q < nk * 4; q += 64) {
             const int ks = q >> 2, quad = q & 3;
-            const char *sp = packed + ((size_t)(r >> 7) * nk + ks) * H2_BLOCK_B + x3_group_offset(r & 127, quad);
-            char *dp = out + ((size_t)(i >> 7) * nk + ks) * H2_BLOCK_B + x3_group_offset(i & 127, quad);
-            *reinterpret_cast<uint2 *>(dp) = *reinterpret_cast<const uint2 *>(sp);
-            *reinterpret_cast<uint2 *>(dp + X3_PLANE_B) = *reinterpret_cast<const uint2 *>(sp + X3_PLANE_B);
+            const char *sp = packed + ((size_t)(r >> 7) * nk + ks) * BLOCK_B + x3_group_offset(r & 127, quad);
+            char *dp = out + ((size_t)(i >> 7) * nk + ks) * BLOCK_B + x3_group_offset(i & 127, quad);
+#pragma unroll
+            for (int pl = 0; pl < PLANES; ++pl)
+                *reinterpret_cast<uint2 *>(dp + pl * X3_PLANE_B) = *reinterpret_cast<const uint2 *>(sp + pl * X3_PLANE_B);
         }
     }
 }
 int launch_gather_packed_rows(hipStream_t st, const void *packed, int K, const int *src_rows, const int *count_dev,
-                              int rows_cap, void *out) {
+                              int rows_cap, void *out, int fmt) {
     CAPDEC_CHECK(K % 16 == 0 && rows_cap > 0, "gather_packed_rows: bad sizes");
-    hipLaunchKernelGGL(gather_packed_rows_kernel, dim3(std::min((rows_cap + 3) / 4, 1024)), dim3(256), 0, st,
-                       (const char *)packed, K / X3_BK, src_rows, count_dev, (char *)out);
+    CAPDEC_CHECK(fmt == PK_F16X2 || fmt == PK_F16X1 || fmt == PK_BF16X1, "gather_packed_rows: f16x2 or one-plane operands");
+    const dim3 grid(std::min((rows_cap + 3) / 4, 1024));
+    if (fmt == PK_F16X2)
+        hipLaunchKernelGGL(gather_packed_rows_kernel<2>, grid, dim3(256), 0, st, (const char *)packed, K / X3_BK, src_rows,
+                           count_dev, (char *)out);
+    else
+        hipLaunchKernelGGL(gather_packed_rows_kernel<1>, grid, dim3(256), 0, st, (const char *)packed, K / X3_BK, src_rows,
+                           count_dev, (char *)out);
     CAPDEC_HIP(hipGetLastError());
     return 0;
 }

@@ -510,6 +510,43 @@ __global__ __launch_bounds__(256, 2) void gemm_x1_topk_kernel(const _Float16 *__
                                  tile_max, tile_sum, cand_val, cand_idx);
 }
 
+// the same kernel (k = 5) over *m_dev rows of a compacted A operand: the exact second pass of the fused lm_head in the
+// one-plane modes (decode.hip: lm_head_select; two-plane form: gemm_h2w.hip: gemm_h2w_topk_dev_kernel)
+template <int KIND>
+__global__ __launch_bounds__(256, 2) void gemm_x1_topk_dev_kernel(const _Float16 *__restrict__ Apk,
+                                                                  const _Float16 *__restrict__ Bpk,
+                                                                  const int *__restrict__ m_dev, int N, int K, float inv_temp,
+                                                                  float *tile_max, float *tile_sum, float *cand_val,
+                                                                  int *cand_idx, int tiles_n) {
+    __shared__ __attribute__((aligned(16))) char smem[H2Geo<H2_NS>::SMEM_B];
+    const int M = *m_dev;
+    const int tiles_m = (M + GEMM_BM - 1) / GEMM_BM, ntiles = tiles_m * tiles_n;
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        int tm, tn;
+        tile_coords(tiles_m, tiles_n, tm, tn, tile);
+        f32x16 am[2][2], ac[2][2];
+        h2p_mainloop<false, H2_NS, 0, KIND>(Apk, Bpk, K, tm, tn, smem, am, ac);      // ends with a barrier
+        epilogue_topk<5, 2, true>(am, reinterpret_cast<float *>(smem), M, N, tm * GEMM_BM, tn * GEMM_BN, tn, tiles_n, inv_temp,
+                                  tile_max, tile_sum, cand_val, cand_idx);
+        __syncthreads();                                                             // the ring is free again
+    }
+}
+
+int launch_gemm_x1_topk_dev(hipStream_t st, const void *Apacked, const void *Bpacked, const int *m_dev, int N, int K,
+                            float inv_temp, float *tile_max, float *tile_sum, float *cand_val, int *cand_idx, int fmt) {
+    CAPDEC_CHECK(m_dev && N > 0 && K > 0 && K % 64 == 0, "gemm_x1_topk_dev: bad argument");
+    CAPDEC_CHECK(fmt == PK_F16X1 || fmt == PK_BF16X1, "gemm_x1_topk_dev: one-plane operand formats only");
+    const int tiles_n = (N + GEMM_BN - 1) / GEMM_BN;
+    if (fmt == PK_F16X1)
+        hipLaunchKernelGGL((gemm_x1_topk_dev_kernel<1>), dim3(512), dim3(256), 0, st, (const _Float16 *)Apacked,
+                           (const _Float16 *)Bpacked, m_dev, N, K, inv_temp, tile_max, tile_sum, cand_val, cand_idx, tiles_n);
+    else
+        hipLaunchKernelGGL((gemm_x1_topk_dev_kernel<2>), dim3(512), dim3(256), 0, st, (const _Float16 *)Apacked,
+                           (const _Float16 *)Bpacked, m_dev, N, K, inv_temp, tile_max, tile_sum, cand_val, cand_idx, tiles_n);
+    CAPDEC_HIP(hipGetLastError());
+    return 0;
+}
+
 // split-K of the one-plane kernels (same regimes and reduce pass as the two-plane kernel: gemm_splitk_slices)
 template <int KIND>
 __global__ __launch_bounds__(256, 2) void gemm_x1_splitk_kernel(const _Float16 *__restrict__ Apk,
