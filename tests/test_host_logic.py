@@ -113,6 +113,24 @@ def test_ctypes_structs_match_header_layout(tmp_path):
         assert n_decl == len(cls._fields_), (cname, n_decl, len(cls._fields_))
 
 
+def test_every_device_buffer_of_the_context_is_released_by_destroy():
+    """capdec_destroy frees the context's grow-only device buffers from an explicit list: a buffer added to capdec_ctx
+    (context.h) and forgotten there leaks once per context"""
+    import re
+    csrc = os.path.join(ROOT, "capdec_amd", "csrc")
+    ctx = open(os.path.join(csrc, "context.h")).read()
+    body = ctx[ctx.index("struct capdec_ctx {"):]
+    names = []
+    for decl in re.findall(r"^\s*DBuf\s+([^;]+);", body, flags=re.M):
+        names += [n.strip() for n in decl.split(",")]
+    assert len(names) > 60 and "lmflag" in names and "kc" in names
+    destroy = open(os.path.join(csrc, "capi_context.hip")).read()
+    destroy = destroy[destroy.index("void capdec_destroy("):]
+    destroy = destroy[:destroy.index("\n}\n")]
+    missing = [n for n in names if f"&c->{n}" not in destroy and f"c->{n}.release()" not in destroy]
+    assert not missing, missing
+
+
 def test_no_cpu_fallback_without_gpu():
     if torch.cuda.is_available():
         pytest.skip("GPU present")
