@@ -78,6 +78,7 @@ bool tuning_from_env(Tuning *t, std::string *err) {
     env_int("CAPDEC_PP", &t->pp);
     env_flag("CAPDEC_LMHEAD_WIDE", &t->lmhead_wide);
     env_flag("CAPDEC_LMHEAD_K3", &t->lmhead_k3);
+    env_int("CAPDEC_LMHEAD_K3_MAX", &t->lmhead_k3_max);
     env_flag("CAPDEC_KV_DIRECT", &t->kv_direct);
     env_flag("CAPDEC_RN_PACKED", &t->rn_packed);
     env_flag("CAPDEC_RN_IMPLICIT", &t->rn_implicit);
@@ -149,7 +150,7 @@ int capdec_create(int device_id, capdec_ctx **out) {
     c->stream = c->own_stream;
     CAPDEC_HIP(hipEventCreate(&c->t0));
     CAPDEC_HIP(hipEventCreate(&c->t1));
-    CAPDEC_HIP(hipHostMalloc((void **)&c->alive_host, sizeof(int), hipHostMallocDefault));
+    CAPDEC_HIP(hipHostMalloc((void **)&c->alive_host, 2 * sizeof(int), hipHostMallocDefault));
     *out = c.release();
     return 0;
 }

@@ -31,6 +31,8 @@ struct Tuning {
     int pp = 2;                   // CAPDEC_PP: ping-pong planner: 0 never, 2 mid-size launches (default), 1 also large, 3 large only
     bool lmhead_wide = true;      // CAPDEC_LMHEAD_WIDE=0: 128-row lm_head tiles at every size
     bool lmhead_k3 = true;        // CAPDEC_LMHEAD_K3=0: the wide lm_head keeps k candidates per tile (no exact second pass)
+    int lmhead_k3_max = 60;       // CAPDEC_LMHEAD_K3_MAX: per mille of the rows taking the second pass above which a decode
+                                  //   call goes back to k per tile (checked at the poll points; break-even is ~80)
     bool kv_direct = true;        // CAPDEC_KV_DIRECT=0: the attention kernel appends K / V itself
     bool rn_packed = true;        // CAPDEC_RN_PACKED=0: fp32 im2col in the ResNet tower
     bool rn_implicit = true;      // CAPDEC_RN_IMPLICIT=0: fp32 activations in the ResNet tower

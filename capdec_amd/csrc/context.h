@@ -143,6 +143,8 @@ struct capdec_ctx {
     bool batch_invariant = false;   // capdec_set_batch_invariant: no launch-size dependent summation order (no split-K, pinned kernel variants)
     int diverge = 0;                // measurement: beams never share history (capdec_set_debug_diverge)
     double stat_kv_slots = 0.0, stat_kv_pos = 0.0;   // last beam decode: sums behind capdec_decode_counters (filled lazily)
+    bool k3_off = false;                             // this decode call went back to k candidates per tile (poll_alive)
+    long long k3_rows = 0;                           // rows of this call's lm_head launches that kept 3 per tile
     bool lmflag_live = false;                        // `lmflag` holds the second-pass row count of the last decode call
     int kvstat_n = 0;                                // captions of the last beam decode whose counters sit in `kvstat`
     bool compact = true;       // decode: drop finished captions from the batch at the poll points (CAPDEC_COMPACT=0: off)
@@ -156,7 +158,7 @@ struct capdec_ctx {
                            // the exact second pass; their compacted packed A operand (decode.hip: lm_head_select)
     DBuf m_hid, m_lin, m_seq, m_x, m_qkv, m_att, m_ff;
     DBuf t_idx, t_patch, t_pout, p_desc, p_inter, splitk, absmax;
-    int *alive_host = nullptr;   // pinned
+    int *alive_host = nullptr;   // pinned: [captions still generating, second-pass rows so far]
     // caption-shard communicator (RCCL), see capdec_comm_init
     ncclComm_t comm = nullptr;
     int comm_rank = 0, comm_world = 1;

@@ -134,7 +134,7 @@ static int lm_head_select(capdec_ctx *c, const float *h0, int ldh, int R, int k,
                 // every tile's epilogue.  The merge then knows exactly which rows that can have been too few for (some
                 // tile's third candidate is still strictly better than the row's fifth: with 393 tiles a rare event) and
                 // those rows alone go through the k = 5 kernel again, compacted; the result is the k = 5 result.
-                k3 = c->tune.lmhead_k3 && k == 5;
+                k3 = c->tune.lmhead_k3 && k == 5 && !c->k3_off;
                 CAPDEC_TRY(launch_gemm_h2w_topk(c->stream, c->xpk.p, pl, R, g.vocab, d, k3 ? 3 : k, inv_temp, c->tmax.as<float>(),
                                                 c->tsum.as<float>(), c->cval.as<float>(), c->cidx.as<int>(), &c->tune));
                 wte_planes = pl;
@@ -143,7 +143,7 @@ static int lm_head_select(capdec_ctx *c, const float *h0, int ldh, int R, int k,
                                                c->tsum.as<float>(), c->cval.as<float>(), c->cidx.as<int>()));
         } else if (mode_single(c)) {
             ProfScope ps(c, F_LMHEAD_BF16, 2.0 * R * (double)g.vocab * d);
-            k3 = c->tune.lmhead_k3 && k == 5 && R >= 2048 && !c->batch_invariant;      // (as in the two-plane mode above)
+            k3 = c->tune.lmhead_k3 && k == 5 && R >= 2048 && !c->batch_invariant && !c->k3_off;   // (as in the two-plane mode above)
             wte_planes = pl;
             CAPDEC_TRY(launch_gemm_x1_topk(c->stream, c->xpk.p, pl, R, g.vocab, d, k3 ? 3 : k, inv_temp, c->tmax.as<float>(),
                                            c->tsum.as<float>(), c->cval.as<float>(), c->cidx.as<int>(), pack_fmt(c)));
@@ -192,6 +192,7 @@ static int lm_head_select(capdec_ctx *c, const float *h0, int ldh, int R, int k,
         CAPDEC_TRY(launch_topk_merge_rows(c->stream, c->cval.as<float>(), c->cidx.as<int>(), cnt, rows, R, nt,
                                           c->topv.as<float>(), c->topi.as<int>()));
         c->lmflag_live = true;
+        c->k3_rows += R;
         return 0;
     }
     {
@@ -228,8 +229,13 @@ static int ensure_kv(capdec_ctx *c, KvCache &kv, int rows, int ctx, int heads = 
 
 static int poll_alive(capdec_ctx *c, int *alive) {
     CAPDEC_HIP(hipMemcpyAsync(c->alive_host, c->alive.p, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    const bool watch = c->lmflag_live && !c->k3_off;
+    if (watch) CAPDEC_HIP(hipMemcpyAsync(c->alive_host + 1, c->lmflag.as<int>() + 1, sizeof(int), hipMemcpyDeviceToHost, c->stream));
     CAPDEC_HIP(hipStreamSynchronize(c->stream));
     *alive = *c->alive_host;
+    // a vocabulary that clusters a row's best candidates inside one 128-column tile sends many rows through the lm_head's
+    // second pass: past the break-even the rest of the call keeps k candidates per tile (same results either way)
+    if (watch && c->k3_rows > 0 && (double)c->alive_host[1] * 1000.0 > (double)c->tune.lmhead_k3_max * (double)c->k3_rows) c->k3_off = true;
     return 0;
 }
 
@@ -401,6 +407,8 @@ static int decode_common(capdec_ctx *c, const float *prefix, int n, int P, int b
     CAPDEC_TRY(c->lmflag.ensure(((size_t)std::min(chunk, n) * beam + 2) * 4));
     CAPDEC_HIP(hipMemsetAsync(c->lmflag.p, 0, 2 * sizeof(int), c->stream));
     c->lmflag_live = false;
+    c->k3_off = false;
+    c->k3_rows = 0;
     for (int c0 = 0; c0 < n; c0 += chunk) {
         const int nc = std::min(chunk, n - c0);
         CAPDEC_TRY(decode_chunk(c, prefix + (size_t)c0 * P * c->gpt.d, nc, P, beam, greedy, stop_id, alt_stop_id, T,

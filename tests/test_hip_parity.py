@@ -972,8 +972,11 @@ def test_lm_head_three_candidates_with_exact_second_pass(monkeypatch, mode):
         x = synth.synthetic_clip_embeddings(n, 512, seed=77)
         pe = O.clip_project(x, sd, "mlp", 10).reshape(n, 10, -1)
         outs, second = {}, {}
-        for k3 in ("1", "0"):
-            monkeypatch.setenv("CAPDEC_LMHEAD_K3", k3)
+        for k3 in ("1", "0", "fallback"):
+            # ("fallback": a call whose second pass takes more than CAPDEC_LMHEAD_K3_MAX per mille of the rows goes back to
+            #  5 per tile at the next poll point -- forced here with a threshold of 1 per mille)
+            monkeypatch.setenv("CAPDEC_LMHEAD_K3", "0" if k3 == "0" else "1")
+            monkeypatch.setenv("CAPDEC_LMHEAD_K3_MAX", "1" if k3 == "fallback" else "60")
             e = Engine(0)
             e.load_gpt2(sd)
             i, l, s_, o = e.decode_beam(pe, stop, 5, T_)
@@ -984,8 +987,11 @@ def test_lm_head_three_candidates_with_exact_second_pass(monkeypatch, mode):
         _report(f"[lm_head second pass] {mode}, V = {dims.vocab}: {second['1']} of {rs} (row, step) pairs recomputed with 5 per tile")
         assert second["0"] == 0
         assert (second["1"] >= 200) if expect_many else (second["1"] < 0.02 * rs), (second, rs)
-        for a, b in zip(outs["1"], outs["0"]):
+        for a, b, c_ in zip(outs["1"], outs["0"], outs["fallback"]):
             np.testing.assert_array_equal(a, b)
+            np.testing.assert_array_equal(a, c_)
+        if expect_many:
+            assert 0 < second["fallback"] < second["1"], second      # the call left the 3-per-tile path at its second poll
         if mode != "f16x2":
             continue
         rows = sorted(np.random.default_rng(3).choice(n, 10, replace=False).tolist())
