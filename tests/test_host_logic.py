@@ -131,6 +131,47 @@ def test_every_device_buffer_of_the_context_is_released_by_destroy():
     assert not missing, missing
 
 
+def test_three_candidates_per_tile_flag_criterion_is_exact():
+    """The rule behind the fused lm_head's second pass (select.hip: topk_merge_k3_kernel), restated in numpy and checked
+    against brute force: keep the 3 best (value desc, column asc) of every 128-column tile, take the top 5 of what was
+    kept, flag the row iff some tile's THIRD kept candidate is strictly better than that fifth.  Claim: an unflagged
+    row's top 5 of the kept candidates IS its true top 5 -- also with many exactly equal logits (the tie rule is part of
+    the order) and with a ragged last tile"""
+    rng = np.random.default_rng(0)
+    V, TILE, KEEP, K = 1531, 128, 3, 5
+    nt = (V + TILE - 1) // TILE
+    flagged = exact_unflagged = 0
+    for trial in range(400):
+        if trial % 2:      # few distinct values: ties everywhere
+            x = rng.integers(0, 6, V).astype(np.float32)
+        else:              # a cluster of large values inside one tile now and then
+            x = rng.standard_normal(V).astype(np.float32)
+            if trial % 4 == 0:
+                t0 = int(rng.integers(0, nt)) * TILE
+                x[t0 + rng.integers(0, min(TILE, V - t0), 4)] += 3.0
+        order = np.lexsort((np.arange(V), -x))                 # value descending, column ascending
+        truth = order[:K]
+        rank = np.empty(V, np.int64); rank[order] = np.arange(V)     # position in the total order: smaller = better
+        kept, thirds = [], []
+        for t in range(nt):
+            cols = np.arange(t * TILE, min(V, (t + 1) * TILE))
+            best = cols[np.argsort(rank[cols])][:KEEP]
+            kept += best.tolist()
+            if len(best) == KEEP:
+                thirds.append(best[-1])
+        kept = np.array(kept)
+        top = kept[np.argsort(rank[kept])][:K]
+        flag = any(rank[c] < rank[top[-1]] for c in thirds)
+        if flag:
+            flagged += 1
+        else:
+            exact_unflagged += 1
+            np.testing.assert_array_equal(top, truth)
+        if not np.array_equal(top, truth):
+            assert flag                                        # every row the 3-per-tile lists get wrong is flagged
+    assert flagged > 20 and exact_unflagged > 100, (flagged, exact_unflagged)
+
+
 def test_no_cpu_fallback_without_gpu():
     if torch.cuda.is_available():
         pytest.skip("GPU present")
