@@ -252,6 +252,172 @@ def train_forward(sd: SD, tokens: Tensor, prefix: Tensor, mapping_type: str, pre
 
 
 # ----------------------------------------------------------------------------------------
+# the train step with a frozen GPT-2 (reference train.py:344-354 run with --only_prefix: ClipCaptionPrefix,
+# :279-287 -- parameters() = the mapper's, GPT-2 in eval mode, so no dropout anywhere and the step is deterministic)
+# ----------------------------------------------------------------------------------------
+# Backward passes are written out by hand (no autograd): this is the algorithm the HIP train step implements, and
+# tests/test_oracle_vs_golden.py checks it against gradients the reference's own loss.backward() produced
+# (tools/gen_golden.py:gen_train_step -> tests/golden/train_step_*.npz).
+def _ln_fwd(x: Tensor, w: Tensor, b: Tensor, eps: float = 1e-5) -> Tensor:
+    return F.layer_norm(x, (x.shape[-1],), w, b, eps)
+
+
+def _ln_bwd(x: Tensor, w: Tensor, dy: Tensor, eps: float = 1e-5) -> Tuple[Tensor, Tensor, Tensor]:
+    """LayerNorm backward: (dx, dw, db) for y = xhat * w + b, xhat = (x - mean) * rstd (biased variance)"""
+    mu = x.mean(-1, keepdim=True)
+    rstd = torch.rsqrt(((x - mu) ** 2).mean(-1, keepdim=True) + eps)
+    xhat = (x - mu) * rstd
+    g = dy * w
+    dx = rstd * (g - g.mean(-1, keepdim=True) - xhat * (g * xhat).mean(-1, keepdim=True))
+    red = tuple(range(x.dim() - 1))
+    return dx, (dy * xhat).sum(red), dy.sum(red)
+
+
+def gelu_new_grad(x: Tensor) -> Tensor:
+    """d/dx of transformers activations.py:65-66"""
+    c = math.sqrt(2.0 / math.pi)
+    t = torch.tanh(c * (x + 0.044715 * x ** 3))
+    return 0.5 * (1.0 + t) + 0.5 * x * (1.0 - t * t) * c * (1.0 + 3.0 * 0.044715 * x * x)
+
+
+def gpt2_forward_saved(embeds: Tensor, sd: SD, n_head: int = 12, g: str = "gpt.") -> Tuple[Tensor, list]:
+    """gpt2_hidden (above) keeping what the backward pass needs per layer; returns (ln_f output, saved)"""
+    N, L, d = embeds.shape
+    hd = d // n_head
+    t = g + "transformer."
+    h = embeds + sd[t + "wpe.weight"][:L]
+    causal = torch.ones(L, L, dtype=torch.bool).tril()
+    saved = []
+    for i in range(_n_layer(sd, g)):
+        b = f"{t}h.{i}."
+        a1 = _ln_fwd(h, sd[b + "ln_1.weight"], sd[b + "ln_1.bias"])
+        qkv = torch.addmm(sd[b + "attn.c_attn.bias"], a1.reshape(-1, d), sd[b + "attn.c_attn.weight"]).view(N, L, 3 * d)
+        q, k, v = (x.view(N, L, n_head, hd).transpose(1, 2) for x in qkv.split(d, dim=2))
+        w = torch.matmul(q, k.transpose(-1, -2)) / math.sqrt(hd)
+        w = torch.where(causal, w, torch.full((), torch.finfo(w.dtype).min)).softmax(dim=-1)
+        att = torch.matmul(w, v).transpose(1, 2).reshape(N, L, d)
+        h_mid = h + torch.addmm(sd[b + "attn.c_proj.bias"], att.reshape(-1, d), sd[b + "attn.c_proj.weight"]).view(N, L, d)
+        a2 = _ln_fwd(h_mid, sd[b + "ln_2.weight"], sd[b + "ln_2.bias"])
+        fc = torch.addmm(sd[b + "mlp.c_fc.bias"], a2.reshape(-1, d), sd[b + "mlp.c_fc.weight"])
+        h_out = h_mid + torch.addmm(sd[b + "mlp.c_proj.bias"], gelu_new(fc), sd[b + "mlp.c_proj.weight"]).view(N, L, d)
+        saved.append(dict(h=h, q=q, k=k, v=v, w=w, h_mid=h_mid, fc=fc))
+        h = h_out
+    saved.append(dict(h=h))
+    return _ln_fwd(h, sd[t + "ln_f.weight"], sd[t + "ln_f.bias"]), saved
+
+
+def gpt2_backward_dx(dhf: Tensor, saved: list, sd: SD, n_head: int = 12, g: str = "gpt.") -> Tensor:
+    """d loss / d inputs_embeds given d loss / d (ln_f output); the GPT-2 weights are frozen: no weight gradients.
+    Conv1D y = x W + b with W [in, out]  =>  dx = dy W^T."""
+    t = g + "transformer."
+    N, L, d = dhf.shape
+    hd = d // n_head
+    dh = _ln_bwd(saved[-1]["h"], sd[t + "ln_f.weight"], dhf)[0]
+    for i in reversed(range(_n_layer(sd, g))):
+        b, s = f"{t}h.{i}.", saved[i]
+        dg = dh.reshape(-1, d) @ sd[b + "mlp.c_proj.weight"].t()
+        dfc = dg * gelu_new_grad(s["fc"])
+        da2 = (dfc @ sd[b + "mlp.c_fc.weight"].t()).view(N, L, d)
+        dh_mid = dh + _ln_bwd(s["h_mid"], sd[b + "ln_2.weight"], da2)[0]
+        datt = (dh_mid.reshape(-1, d) @ sd[b + "attn.c_proj.weight"].t()).view(N, L, n_head, hd).transpose(1, 2)
+        # softmax attention backward: dV = P^T dO; dP = dO V^T; dS = P (dP - rowsum(P dP)); dQ = dS K / sqrt(hd); dK = dS^T Q / sqrt(hd)
+        dv = torch.matmul(s["w"].transpose(-1, -2), datt)
+        dp = torch.matmul(datt, s["v"].transpose(-1, -2))
+        ds = s["w"] * (dp - (s["w"] * dp).sum(-1, keepdim=True))
+        dq = torch.matmul(ds, s["k"]) / math.sqrt(hd)
+        dk = torch.matmul(ds.transpose(-1, -2), s["q"]) / math.sqrt(hd)
+        dqkv = torch.cat([x.transpose(1, 2).reshape(N, L, d) for x in (dq, dk, dv)], dim=2)
+        da1 = (dqkv.reshape(-1, 3 * d) @ sd[b + "attn.c_attn.weight"].t()).view(N, L, d)
+        dh = dh_mid + _ln_bwd(s["h"], sd[b + "ln_1.weight"], da1)[0]
+    return dh                                          # (wpe is frozen: the position term only adds a constant)
+
+
+def mlp_mapper_backward(x: Tensor, dy: Tensor, sd: SD, pfx: str = "clip_project.") -> Dict[str, Tensor]:
+    """gradients of the MLP mapper's four tensors (reference gpt2_prefix.py:114-126: Linear -> Tanh -> Linear)"""
+    hmid = torch.tanh(F.linear(x, sd[pfx + "model.0.weight"], sd[pfx + "model.0.bias"]))
+    dh = dy @ sd[pfx + "model.2.weight"]
+    da = dh * (1.0 - hmid * hmid)
+    return {pfx + "model.0.weight": da.t() @ x, pfx + "model.0.bias": da.sum(0),
+            pfx + "model.2.weight": dy.t() @ hmid, pfx + "model.2.bias": dy.sum(0)}
+
+
+def train_step_loss_and_grads(sd: SD, tokens: Tensor, prefix: Tensor, mapping_type: str, prefix_length: int,
+                              n_head: int = 12) -> Tuple[Tensor, Dict[str, Tensor]]:
+    """loss of reference train.py:348-349 (cross_entropy(logits[:, P-1:-1], tokens, ignore_index=0), mean over the
+    labels != 0) and its gradients with respect to the mapper's parameters (what loss.backward() leaves in .grad of
+    ClipCaptionPrefix.parameters(), :350).  ``prefix`` is the embedding batch AFTER noise_injection (:347)."""
+    if mapping_type != "mlp":
+        raise NotImplementedError("train step: MLP mapper only (the TransformerMapper backward is not restated yet)")
+    P, (B, L) = prefix_length, tokens.shape
+    d = sd["gpt.transformer.wte.weight"].shape[1]
+    pe = mlp_mapper(prefix, sd).reshape(B, P, d)
+    embeds = torch.cat((pe, wte(tokens.long(), sd)), dim=1)
+    hf, saved = gpt2_forward_saved(embeds, sd, n_head)
+    W = sd["gpt.transformer.wte.weight"]
+    logits = hf[:, P - 1:-1] @ W.t()                                   # [B, L, V]: the rows the loss reads
+    labels = tokens.long()
+    valid = labels != 0
+    n = int(valid.sum())
+    lse = torch.logsumexp(logits, -1)
+    picked = logits.gather(-1, labels.unsqueeze(-1)).squeeze(-1)
+    loss = ((lse - picked) * valid).sum() / n
+    dlogits = torch.softmax(logits, -1)
+    dlogits.scatter_add_(-1, labels.unsqueeze(-1), -torch.ones_like(picked).unsqueeze(-1))
+    dlogits = dlogits * (valid.unsqueeze(-1) / n)
+    dhf = torch.zeros_like(hf)
+    dhf[:, P - 1:-1] = dlogits @ W
+    dembeds = gpt2_backward_dx(dhf, saved, sd, n_head)
+    return loss, mlp_mapper_backward(prefix, dembeds[:, :P].reshape(B, P * d), sd)
+
+
+def linear_schedule_with_warmup(step: int, num_warmup_steps: int, num_training_steps: int) -> float:
+    """the lr factor of transformers.get_linear_schedule_with_warmup (reference train.py:329-331) at scheduler step
+    ``step``.  The reference calls optimizer.step() BEFORE scheduler.step() (:351-352), so the k-th update (k = 0, 1, ...)
+    runs at factor(k): the very first update has lr 0."""
+    if step < num_warmup_steps:
+        return float(step) / float(max(1, num_warmup_steps))
+    return max(0.0, float(num_training_steps - step) / float(max(1, num_training_steps - num_warmup_steps)))
+
+
+def adamw_transformers(p: Tensor, grad: Tensor, exp_avg: Tensor, exp_avg_sq: Tensor, step: int, lr: float,
+                       betas: Tuple[float, float] = (0.9, 0.999), eps: float = 1e-6, weight_decay: float = 0.0,
+                       correct_bias: bool = True) -> None:
+    """One update of ``transformers.AdamW`` (the optimizer reference train.py:326 constructs: ``AdamW(model.parameters(),
+    lr=args.lr)``; transformers pinned 4.24.0 in reference requirments.txt:12 -- the class no longer exists in the 5.15
+    installed here, so this is a restatement of the published algorithm, transformers/optimization.py ``AdamW.step``;
+    PARITY UNPINNED against the class itself).  Differs from torch.optim.AdamW: eps defaults to 1e-6 and is added to
+    sqrt(v) BEFORE the bias correction is applied through the step size; weight decay (default 0) is applied after the
+    update with the uncorrected lr.  In place; ``step`` = 1 for the first update."""
+    b1, b2 = betas
+    exp_avg.mul_(b1).add_(grad, alpha=1.0 - b1)
+    exp_avg_sq.mul_(b2).addcmul_(grad, grad, value=1.0 - b2)
+    denom = exp_avg_sq.sqrt().add_(eps)
+    step_size = lr
+    if correct_bias:
+        step_size = step_size * math.sqrt(1.0 - b2 ** step) / (1.0 - b1 ** step)
+    p.addcdiv_(exp_avg, denom, value=-step_size)
+    if weight_decay > 0.0:
+        p.add_(p, alpha=-lr * weight_decay)
+
+
+def train_steps(sd: SD, batches: Sequence[Tuple[Tensor, Tensor]], mapping_type: str, prefix_length: int, lr: float,
+                num_warmup_steps: int, num_training_steps: int, n_head: int = 12) -> Tuple[List[float], SD]:
+    """``len(batches)`` iterations of reference train.py:344-354 (frozen GPT-2) from the weights ``sd`` (not modified):
+    each batch = (tokens [B, L] right-padded with 0, prefix [B, D] after noise injection).  Returns the per-step losses
+    and the final state dict."""
+    sd = {k: (v.clone() if k.startswith("clip_project.") else v) for k, v in sd.items()}
+    state = {k: (torch.zeros_like(v), torch.zeros_like(v)) for k, v in sd.items() if k.startswith("clip_project.")}
+    losses = []
+    for it, (tokens, prefix) in enumerate(batches):
+        loss, grads = train_step_loss_and_grads(sd, tokens, prefix, mapping_type, prefix_length, n_head)
+        losses.append(float(loss))
+        cur_lr = lr * linear_schedule_with_warmup(it, num_warmup_steps, num_training_steps)
+        for k, gk in grads.items():
+            adamw_transformers(sd[k], gk, state[k][0], state[k][1], it + 1, cur_lr)
+    return losses, sd
+
+
+# ----------------------------------------------------------------------------------------
 # reference-shaped decode (batch 1, no KV cache): what the reference executes
 # ----------------------------------------------------------------------------------------
 def generate2_ref(sd: SD, embed: Tensor, stop_id: int = 13, entry_length: int = 67, top_p: float = 0.8,

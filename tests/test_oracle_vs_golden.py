@@ -215,6 +215,91 @@ def test_train_forward_small(golden):
     _check_train_forward(golden("train_forward_small"), synth.GPT2_SMALL)
 
 
+# ------------------------------------------------------------------ the train step with a frozen GPT-2 (train.py:344-354)
+def _check_train_step(g, dims):
+    """the oracle's hand-written backward pass against the reference's own loss.backward(): every mapper gradient of four
+    consecutive iterations (each taken at the weights the previous updates left), the losses, the lr sequence of the
+    real transformers scheduler and the final weights"""
+    sd = synth.hot_state_dict(42, "mlp", 512, 10, dims=dims)
+    assert synth.state_dict_checksum(sd) == int(g["sd_crc"]), "RNG drift"
+    names = [str(n) for n in g["names"]]
+    lr, warm, total = float(g["lr"]), int(g["warmup"]), int(g["total"])
+    iters = len(g["losses"])
+    cur = {k: (v.clone() if k.startswith("clip_project.") else v) for k, v in sd.items()}
+    state = {k: (torch.zeros_like(cur[k]), torch.zeros_like(cur[k])) for k in names}
+    for it in range(iters):
+        tokens, prefix = T(g[f"tokens_{it}"]), T(g[f"prefix_{it}"])
+        loss, grads = O.train_step_loss_and_grads(cur, tokens, prefix, "mlp", 10, n_head=dims.n_head)
+        assert abs(float(loss) - float(g["losses"][it])) < 2e-4, (it, float(loss), float(g["losses"][it]))
+        cur_lr = lr * O.linear_schedule_with_warmup(it, warm, total)
+        assert abs(cur_lr - float(g["lrs"][it])) < 1e-12
+        assert sorted(grads) == sorted(names)
+        for k in names:
+            flat = grads[k].flatten()
+            sub = flat[::max(1, flat.numel() // 4096)].numpy()
+            ref = g[f"grad_{it}_{k}_sub"]
+            scale = float(np.abs(ref).max())
+            np.testing.assert_allclose(sub, ref, atol=2e-5 * scale + 1e-9, rtol=1e-3)
+            assert abs(float(grads[k].double().norm()) / float(g[f"grad_{it}_{k}_norm"]) - 1.0) < 1e-4
+            O.adamw_transformers(cur[k], grads[k], state[k][0], state[k][1], it + 1, cur_lr)
+    for k in names:
+        flat = cur[k].flatten()
+        np.testing.assert_allclose(flat[::max(1, flat.numel() // 4096)].numpy(), g[f"final_{k}_sub"], atol=2e-5)
+    # the packaged loop gives the same thing
+    losses, fin = O.train_steps(sd, [(T(g[f"tokens_{it}"]), T(g[f"prefix_{it}"])) for it in range(iters)], "mlp", 10, lr, warm, total,
+                                n_head=dims.n_head)
+    np.testing.assert_allclose(losses, g["losses"], atol=2e-4)
+    for k in names:
+        assert torch.equal(fin[k], cur[k])
+
+
+def test_train_step_tiny(golden):
+    _check_train_step(golden("train_step_tiny"), synth.GPT2_TINY)
+
+
+@pytest.mark.slow
+def test_train_step_small(golden):
+    _check_train_step(golden("train_step_small"), synth.GPT2_SMALL)
+
+
+def test_adamw_restatement_against_torch_where_they_coincide():
+    """transformers-4.24 AdamW (restated in the oracle; the class is not installed) and torch.optim.AdamW are the same
+    update when eps = 0 and weight_decay = 0 (they differ only in where eps enters and in the decay term): pins the
+    moment updates and the bias correction of the restatement against an independent implementation; with the default
+    eps = 1e-6 the two must differ by what the published formulas say"""
+    g = torch.Generator().manual_seed(3)
+    p0 = torch.randn(257, generator=g)
+    grads = [torch.randn(257, generator=g) * (0.1 + i) for i in range(5)]
+    q = torch.nn.Parameter(p0.clone())
+    opt = torch.optim.AdamW([q], lr=3e-3, betas=(0.9, 0.999), eps=0.0, weight_decay=0.0)
+    p, m, v = p0.clone(), torch.zeros(257), torch.zeros(257)
+    for i, gr in enumerate(grads):
+        q.grad = gr.clone()
+        opt.step()
+        O.adamw_transformers(p, gr, m, v, i + 1, 3e-3, eps=0.0)
+        np.testing.assert_allclose(p.numpy(), q.detach().numpy(), rtol=2e-6, atol=1e-7)
+    # default eps: transformers adds it to sqrt(v) BEFORE the bias correction: first step = lr * g / (|g| + eps / sqrt(1 - b2))
+    p, m, v = torch.zeros(1), torch.zeros(1), torch.zeros(1)
+    O.adamw_transformers(p, torch.tensor([1e-4]), m, v, 1, 1.0)
+    want = -1e-4 / (1e-4 + 1e-6 / np.sqrt(1 - 0.999))
+    assert abs(float(p) - want) < 1e-6 * abs(want)
+    # weight decay after the update, with the uncorrected lr
+    p, m, v = torch.ones(1), torch.zeros(1), torch.zeros(1)
+    O.adamw_transformers(p, torch.zeros(1), m, v, 1, 0.5, weight_decay=0.1)
+    assert abs(float(p) - (1.0 - 0.5 * 0.1)) < 1e-7
+
+
+def test_linear_schedule_against_transformers():
+    from transformers import get_linear_schedule_with_warmup
+    q = torch.nn.Parameter(torch.zeros(1))
+    opt = torch.optim.SGD([q], lr=1.0)
+    sched = get_linear_schedule_with_warmup(opt, num_warmup_steps=5, num_training_steps=17)
+    for step in range(20):
+        assert abs(opt.param_groups[0]["lr"] - O.linear_schedule_with_warmup(step, 5, 17)) < 1e-12
+        opt.step()
+        sched.step()
+
+
 # ------------------------------------------------------------------ CLIP ViT-B/32 (HF stand-in pin)
 def _check_clip(g, dims):
     sd = synth.hot_clip_state_dict(43, dims)

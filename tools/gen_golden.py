@@ -370,6 +370,75 @@ def gen_train_forward(refs, dims, tag):
     print(f"train_forward_{tag}.npz written; loss {float(loss):.5f}")
 
 
+def gen_train_step(refs, dims, tag):
+    """The train step with a frozen GPT-2 (train.py:344-354 with --only_prefix): train.ClipCaptionPrefix (:279-287) in
+    train() mode, the batch of gen_train_forward, loss as at :349, the reference's own loss.backward() (:350) -> the
+    gradients of ClipCaptionPrefix.parameters().  Three iterations follow with the lr of the real
+    transformers.get_linear_schedule_with_warmup; the optimizer update itself is the oracle's restatement of
+    transformers-4.24 AdamW (the class is gone from the installed 5.15: that part is NOT pinned by this file -- what is
+    pinned is every gradient, computed by autograd at the weights the previous updates produced, and the losses)."""
+    ref_train = refs[3]
+    from transformers import GPT2Config, GPT2LMHeadModel, get_linear_schedule_with_warmup
+    from oracle import capdec_oracle as O
+    cfg = GPT2Config(n_layer=dims.n_layer, n_head=dims.n_head, n_embd=dims.n_embd, vocab_size=dims.vocab,
+                     n_positions=dims.n_pos)
+    GPT2LMHeadModel.from_pretrained = staticmethod(lambda name, *a, **k: GPT2LMHeadModel(cfg))
+    P, D = 10, 512
+    model = ref_train.ClipCaptionPrefix(P, clip_length=10, prefix_size=D, num_layers=8, mapping_type=ref_train.MappingType.MLP)
+    model.train()
+    assert not model.gpt.training and model.clip_project.training
+    sd = synth.hot_state_dict(42, "mlp", D, P, dims=dims)
+    missing, unexpected = model.load_state_dict(sd, strict=False)
+    assert not unexpected and all(".attn.bias" in m or ".attn.masked_bias" in m for m in missing)
+    names = [k for k, _ in model.named_parameters() if k.startswith("clip_project.")]
+    params = list(model.parameters())
+    assert len(params) == len(names) == 4
+    g = torch.Generator().manual_seed(23)
+    lr, warm, total, iters = 2e-3, 2, 8, 4
+    dummy = torch.optim.SGD([torch.nn.Parameter(torch.zeros(1))], lr=lr)     # only carries the lr for the real scheduler
+    sched = get_linear_schedule_with_warmup(dummy, num_warmup_steps=warm, num_training_steps=total)
+    state = {k: (torch.zeros_like(q), torch.zeros_like(q)) for k, q in zip(names, params)}
+    res = {"sd_crc": np.uint32(synth.state_dict_checksum(sd)), "lr": np.float64(lr), "warmup": np.int32(warm),
+           "total": np.int32(total), "names": np.array(names)}
+    losses, lrs = [], []
+    for it in range(iters):
+        lens = [[9, 4, 7], [5, 8, 3], [6, 6, 9], [2, 7, 5]][it]
+        L = max(lens)
+        tokens = torch.zeros(len(lens), L, dtype=torch.int64)
+        mask = torch.zeros(len(lens), P + L)
+        mask[:, :P] = 1
+        for r, n in enumerate(lens):
+            tokens[r, :n] = torch.randint(1, dims.vocab, (n,), generator=g)
+            mask[r, P:P + n] = 1
+        if it == 1:
+            tokens[1, 2] = 0                 # a REAL token with id 0 is ignored by the loss as well (ignore_index=0)
+        prefix = synth.synthetic_clip_embeddings(len(lens), D, seed=50 + it)
+        model.zero_grad()
+        out = model(tokens, prefix, mask)
+        logits = out.logits[:, P - 1:-1]
+        loss = torch.nn.functional.cross_entropy(logits.reshape(-1, logits.shape[-1]), tokens.flatten(), ignore_index=0)
+        loss.backward()
+        cur_lr = dummy.param_groups[0]["lr"]
+        res[f"tokens_{it}"], res[f"mask_{it}"], res[f"prefix_{it}"] = tokens.numpy(), mask.numpy(), prefix.numpy()
+        for k, q in zip(names, params):
+            gk = q.grad.detach()
+            flat = gk.flatten()
+            res[f"grad_{it}_{k}_sub"] = flat[::max(1, flat.numel() // 4096)].numpy().copy()
+            res[f"grad_{it}_{k}_norm"] = np.float64(gk.double().norm())
+            with torch.no_grad():
+                O.adamw_transformers(q.data, gk, state[k][0], state[k][1], it + 1, cur_lr)
+        losses.append(float(loss.detach()))
+        lrs.append(cur_lr)
+        dummy.step()
+        sched.step()
+    res["losses"], res["lrs"] = np.array(losses, np.float32), np.array(lrs, np.float64)
+    for k, q in zip(names, params):
+        flat = q.detach().flatten()
+        res[f"final_{k}_sub"] = flat[::max(1, flat.numel() // 4096)].numpy().copy()
+    np.savez_compressed(os.path.join(OUT, f"train_step_{tag}.npz"), **res)
+    print(f"train_step_{tag}.npz written; losses {losses} lrs {lrs}")
+
+
 def openai_to_hf_clip(sd, dims):
     """Map an OpenAI-CLIP-named state dict onto transformers.CLIPModel names (the independent
     stand-in used to pin the CLIP kernels: the reference's own `clip` package is not installed)."""
@@ -581,6 +650,8 @@ def main():
         "decode_p40_tiny": lambda: gen_decode_p40(refs, synth.GPT2_TINY, "tiny"),
         "train_forward_tiny": lambda: gen_train_forward(refs, synth.GPT2_TINY, "tiny"),
         "train_forward_small": lambda: gen_train_forward(refs, synth.GPT2_SMALL, "small"),
+        "train_step_tiny": lambda: gen_train_step(refs, synth.GPT2_TINY, "tiny"),
+        "train_step_small": lambda: gen_train_step(refs, synth.GPT2_SMALL, "small"),
         "prompt_tiny": lambda: gen_prompt(refs, synth.GPT2_TINY, "tiny"),
         "prompt_small": lambda: gen_prompt(refs, synth.GPT2_SMALL, "small"),
         "clip_tiny": lambda: gen_clip(synth.CLIP_TINY, "tiny", 6, 3),
