@@ -95,6 +95,10 @@ SIGNATURES = {
     "capdec_cross_entropy": (C.c_int, [_VP, _VP, C.c_int, _VP, C.c_int, C.c_int, C.c_int, _VP]),
     "capdec_decode_counters": (C.c_int, [_VP, C.POINTER(C.c_double), C.POINTER(C.c_longlong)]),
     "capdec_decode_second_pass_rows": (C.c_int, [_VP, C.POINTER(C.c_longlong)]),
+    "capdec_train_step": (C.c_int, [_VP, _VP, _VP, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float,
+                                    C.c_int, C.POINTER(C.c_float)]),
+    "capdec_train_get": (C.c_int, [_VP, C.c_int, C.c_int, _VP, C.c_size_t]),
+    "capdec_train_reset": (C.c_int, [_VP]),
     "capdec_set_kv_budget": (C.c_int, [_VP, C.c_size_t]),
     "capdec_malloc": (C.c_int, [_VP, C.c_size_t, C.POINTER(_VP)]),
     "capdec_free": (C.c_int, [_VP, _VP]),

@@ -168,6 +168,7 @@ void capdec_destroy(capdec_ctx *c) {
     free_all(c->clip_vision.owned);
     free_all(c->clip_resnet.owned);
     drop_planes(c);
+    train_release(c);
     c->x3_tmp.release();
     DBuf *bufs[] = {&c->h, &c->x, &c->qkv, &c->att, &c->ff, &c->xl, &c->tmax, &c->tsum, &c->cval, &c->cidx,
                     &c->lse, &c->topv, &c->topi, &c->kc, &c->vc, &c->tokens, &c->scores, &c->seq, &c->stopped,

@@ -122,6 +122,7 @@ struct Prof {
 
 using namespace capdec;
 
+namespace capdec { struct TrainState; }      // train.hip: saved activations, gradients, AdamW moments of the train step
 struct capdec_ctx {
     capdec::Tuning tune;            // the environment knobs, parsed once by capdec_create (config.h)
     int device = 0;
@@ -154,6 +155,7 @@ struct capdec_ctx {
     // workspaces
     DBuf h, x, qkv, att, ff, xl, tmax, tsum, cval, cidx, lse, topv, topi, kc, vc;
     DBuf tokens, scores, seq, stopped, done, anc, next_tok, alive, gids, glens, cmap, kvstat;
+    capdec::TrainState *train = nullptr;     // created by the first capdec_train_step, freed by train_release
     DBuf lmflag, xpk2;     // fused lm_head with 3 candidates per tile: [count, total, rows...] of the rows whose top 5 need
                            // the exact second pass; their compacted packed A operand (decode.hip: lm_head_select)
     DBuf m_hid, m_lin, m_seq, m_x, m_qkv, m_att, m_ff;
@@ -197,6 +199,9 @@ struct ProfScope {
 };
 int prof_collect(capdec_ctx *c);
 
+// ---- train.hip
+void train_release(capdec_ctx *c);      // frees the train-step state (a mapper / GPT-2 reload invalidates it)
+
 // ---- comm.hip
 void comm_release(capdec_ctx *c);       // destroys the context's communicator, if any
 
@@ -209,6 +214,7 @@ void free_all(std::vector<void *> &owned);
 
 // ---- gemm_dispatch.hip: the planner
 void drop_planes(capdec_ctx *c);
+void drop_planes_of(capdec_ctx *c, const void *weight);      // one cached weight (its values changed: train.hip)
 int pack_fmt(const capdec_ctx *c);
 inline bool mode_single(const capdec_ctx *c) { return c->gemm_mode == GEMM_BF16 || c->gemm_mode == GEMM_F16; }
 int pack_any(capdec_ctx *c, const float *W, int N, int K, int fmt, void *out);

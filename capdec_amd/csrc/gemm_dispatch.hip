@@ -12,6 +12,12 @@ void drop_planes(capdec_ctx *c) {
     for (auto &kv : c->planes) (void)hipFree(kv.second.p);
     c->planes.clear();
 }
+void drop_planes_of(capdec_ctx *c, const void *weight) {
+    auto it = c->planes.find(weight);
+    if (it == c->planes.end()) return;
+    (void)hipFree(it->second.p);
+    c->planes.erase(it);
+}
 // packed operand format of the block-stack / lm_head GEMMs in the current mode (bf16x3.h): two fp16 planes (f16x2),
 // three bf16 planes (bf16x3), or ONE bf16 / fp16 plane (the reduced-precision modes)
 int pack_fmt(const capdec_ctx *c) {

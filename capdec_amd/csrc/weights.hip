@@ -111,6 +111,7 @@ int capdec_load_gpt2(capdec_ctx *c, const capdec_gpt2_weights *w) {
     Gpt2 &g = c->gpt;
     free_all(g.owned);
     drop_planes(c);
+    train_release(c);
     g = Gpt2();
     g.n_layer = w->n_layer; g.n_head = w->n_head; g.d = w->n_embd; g.vocab = w->vocab; g.n_pos = w->n_pos;
     g.eps = w->ln_eps > 0 ? w->ln_eps : 1e-5f;
@@ -148,6 +149,7 @@ int capdec_load_mapper_mlp(capdec_ctx *c, int D, int P, int hidden, const float 
     Mapper &m = c->map;
     free_all(m.owned);
     drop_planes(c);
+    train_release(c);
     m = Mapper();
     m.D = D; m.P = P; m.hidden = hidden;
     m.d = c->gpt.loaded ? c->gpt.d : 768;
@@ -168,6 +170,7 @@ int capdec_load_mapper_transformer(capdec_ctx *c, const capdec_tmapper_weights *
     Mapper &m = c->map;
     free_all(m.owned);
     drop_planes(c);
+    train_release(c);
     m = Mapper();
     m.D = w->prefix_dim; m.P = w->prefix_length; m.clip_len = w->clip_length; m.n_layers = w->num_layers;
     m.heads = w->num_heads; m.d = w->d; m.mlp_hidden = w->mlp_hidden;

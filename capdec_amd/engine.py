@@ -477,6 +477,43 @@ class Engine:
         self._chk(self.lib.capdec_decode_counters(self._h, C.byref(kv), C.byref(sat)), "decode_counters")
         return dict(kv_slots_per_position=kv.value, saturated_quads=sat.value)
 
+    # ---- the train step with a frozen GPT-2 (reference train.py:344-354 with --only_prefix)
+    _TRAIN_TENSORS = ("model.0.weight", "model.0.bias", "model.2.weight", "model.2.bias")
+
+    def train_step(self, prefix: torch.Tensor, tokens: torch.Tensor, lr: float, betas=(0.9, 0.999), eps: float = 1e-6,
+                   weight_decay: float = 0.0, apply_update: bool = True) -> float:
+        """one iteration on the device-resident MLP mapper (capdec_train_step): ``prefix`` [B, D] AFTER noise injection,
+        ``tokens`` [B, L] right-padded with 0; returns the loss of train.py:349"""
+        x = prefix.to(self.device, torch.float32).contiguous()
+        tok = tokens.to(self.device, torch.int32).contiguous()
+        if x.dim() != 2 or tok.dim() != 2 or x.shape[0] != tok.shape[0]:
+            raise CapdecError("train_step: prefix [B, D] and tokens [B, L] expected")
+        loss = C.c_float(0.0)
+        self._chk(self.lib.capdec_train_step(self._h, x.data_ptr(), tok.data_ptr(), tok.shape[0], tok.shape[1], float(lr),
+                                             float(betas[0]), float(betas[1]), float(eps), float(weight_decay),
+                                             int(bool(apply_update)), C.byref(loss)), "train_step")
+        return float(loss.value)
+
+    def _train_get(self, kind: int, shapes) -> Dict[str, torch.Tensor]:
+        out = {}
+        for i, name in enumerate(self._TRAIN_TENSORS):
+            t = torch.empty(shapes[name], device=self.device, dtype=torch.float32)
+            self._chk(self.lib.capdec_train_get(self._h, kind, i, t.data_ptr(), t.numel()), "train_get")
+            out[name] = t
+        return out
+
+    def mapper_parameters(self, shapes) -> Dict[str, torch.Tensor]:
+        """the mapper's current tensors on the device (after train steps: the updated values), keyed like MLP.state_dict"""
+        return self._train_get(0, shapes)
+
+    def mapper_gradients(self, shapes) -> Dict[str, torch.Tensor]:
+        """d loss / d tensor of the last train_step (what loss.backward() leaves in .grad, train.py:350)"""
+        return self._train_get(1, shapes)
+
+    def train_reset(self):
+        """a fresh optimizer: drops the AdamW moments and the step count"""
+        self._chk(self.lib.capdec_train_reset(self._h), "train_reset")
+
     def second_pass_rows(self) -> int:
         """(row, step) pairs of the last decode call whose lm_head top 5 went through the exact second pass (capdec.h)"""
         n = C.c_longlong(0)

@@ -59,9 +59,13 @@ class _HipModule:
         self.training = mode
         return self
 
+    def _before_engine_close(self):
+        """hook: values that only the device holds (weights updated by train steps) are pulled to the host first"""
+
     def to(self, device):
         idx = _device_index(device)
         if idx != self._device_index and self._engine is not None:
+            self._before_engine_close()
             self._engine.close()
             self._engine = None
             self._dirty = True
@@ -89,6 +93,7 @@ class _HipModule:
         cache, workspaces -- is released; the weights are uploaded again on the next use."""
         if bool(on) != self._measure:
             if self._engine is not None:
+                self._before_engine_close()
                 self._engine.close()
                 self._engine = None
             self._measure = bool(on)
@@ -173,6 +178,29 @@ class ClipCaptionModel(_HipModule):
     def get_dummy_token(self, batch_size: int, device) -> torch.Tensor:
         return torch.zeros(batch_size, self.prefix_length, dtype=torch.int64, device=device)
 
+    # ---- train steps update the mapper ON THE DEVICE (capdec_amd.train.train_step): the host copy follows lazily
+    _device_ahead = False
+
+    def _mapper_shapes(self):
+        return {k: tuple(v.shape) for k, v in self.clip_project._sd.items()}
+
+    def _pull_mapper(self):
+        if not self._device_ahead or self._engine is None:
+            return
+        for k, v in self._engine.mapper_parameters(self._mapper_shapes()).items():
+            self.clip_project._sd[k] = v.cpu()
+            self._sd["clip_project." + k] = self.clip_project._sd[k]
+        self._device_ahead = False
+
+    def _before_engine_close(self):
+        self._pull_mapper()
+
+    def state_dict(self):
+        """reference train.py:359-371 saves ``model.state_dict()``: after train steps the mapper's tensors are read back
+        from the device first"""
+        self._pull_mapper()
+        return OrderedDict(self._sd)
+
     def load_state_dict(self, sd: Dict[str, torch.Tensor], strict: bool = True):
         """Reference checkpoints (train.py:359-371).  Ignores the transformers-4.24 buffers
         ``gpt.transformer.h.{i}.attn.bias`` / ``.attn.masked_bias``; accepts fp16 tensors."""
@@ -180,6 +208,7 @@ class ClipCaptionModel(_HipModule):
         gpt_keys = [k for k in sd if k.startswith("gpt.") and not (k.endswith(".attn.bias") or k.endswith(".attn.masked_bias"))]
         if strict and (not mapper_keys or "gpt.transformer.wte.weight" not in sd):
             raise RuntimeError("Missing key(s) in state_dict: clip_project.* / gpt.transformer.wte.weight")
+        self._device_ahead = False
         self._sd = OrderedDict((k, sd[k].detach().float().cpu()) for k in mapper_keys + gpt_keys)
         self.clip_project.load_state_dict({k[len("clip_project."):]: self._sd[k] for k in mapper_keys}, strict=strict)
         self._dirty = True

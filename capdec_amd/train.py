@@ -1,7 +1,8 @@
-"""Drop-in surface of the inference-relevant part of reference ``train.py``: ``noise_injection``
-(:27-39), ``get_uniform_ball_noise`` (:18-24), ``MappingType`` (:42-44) and the
-``ClipCaptionModel`` ctor spelling with ``prefix_size`` (:262).  The optimiser / backward loop
-(:317-392) is out of scope."""
+"""Drop-in surface of reference ``train.py``: ``noise_injection`` (:27-39), ``get_uniform_ball_noise`` (:18-24),
+``MappingType`` (:42-44), the ``ClipCaptionModel`` ctor spelling with ``prefix_size`` (:262), and the train loop of
+:317-392 for the FROZEN-GPT-2 configuration (``--only_prefix``: ``ClipCaptionPrefix`` with an MLP mapper): ``AdamW``,
+``get_linear_schedule_with_warmup``, ``train_step`` (= :345-353 as one device call) and ``train``.  Training GPT-2 itself
+(the default ``ClipCaptionModel`` run, with dropout) and the TransformerMapper's backward are not implemented."""
 from __future__ import annotations
 
 import math
@@ -9,6 +10,7 @@ from typing import Optional
 
 import torch
 
+from ._capi import CapdecError
 from .engine import get_engine
 from .gpt2_prefix import ClipCaptionModel, ClipCaptionPrefix, MappingType  # noqa: F401  (re-exported names)
 
@@ -52,3 +54,123 @@ def noise_injection(x, variance=0.001, modality_offset=None, uniform_noise=False
     eng = get_engine(x.device.index or 0 if x.is_cuda else device.index or 0)
     return eng.noise_inject(x, variance, modality_offset, uniform=uniform_noise, dont_norm=dont_norm,
                             seed=_next_seed() if seed is None else seed, noise=noise, u=u)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# the train loop of reference train.py:317-392 for a frozen GPT-2 (--only_prefix)
+# ---------------------------------------------------------------------------------------------------------------------
+class AdamW:
+    """``transformers.AdamW(params, lr, betas, eps, weight_decay, correct_bias)`` as reference train.py:326 constructs it
+    (transformers 4.24 defaults: eps 1e-6, no weight decay, bias correction).  The moments live in the HIP context of the
+    model; this object carries the hyper-parameters and the current learning rate (``param_groups[0]["lr"]``, which the
+    scheduler rewrites).  ``step`` / ``zero_grad`` exist so the reference's loop reads the same, but the update itself is
+    applied by ``train_step`` (gradient and update are one device call)."""
+
+    def __init__(self, params=None, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-6, weight_decay: float = 0.0,
+                 correct_bias: bool = True):
+        if not correct_bias:
+            raise CapdecError("AdamW: correct_bias=False is not implemented")
+        if params is not None:
+            list(params)                       # (a generator of device handles: nothing to keep)
+        self.defaults = dict(lr=lr, betas=tuple(betas), eps=eps, weight_decay=weight_decay, correct_bias=True)
+        self.param_groups = [dict(self.defaults, initial_lr=lr)]
+
+    def step(self):
+        pass
+
+    def zero_grad(self):
+        pass
+
+
+class _LinearSchedule:
+    def __init__(self, optimizer: AdamW, num_warmup_steps: int, num_training_steps: int):
+        self.optimizer, self.warmup, self.total, self.last_epoch = optimizer, num_warmup_steps, num_training_steps, 0
+        self._apply()
+
+    def _factor(self) -> float:
+        k = self.last_epoch
+        if k < self.warmup:
+            return float(k) / float(max(1, self.warmup))
+        return max(0.0, float(self.total - k) / float(max(1, self.total - self.warmup)))
+
+    def _apply(self):
+        for g in self.optimizer.param_groups:
+            g["lr"] = g["initial_lr"] * self._factor()
+
+    def step(self):
+        self.last_epoch += 1
+        self._apply()
+
+    def get_last_lr(self):
+        return [g["lr"] for g in self.optimizer.param_groups]
+
+
+def get_linear_schedule_with_warmup(optimizer: AdamW, num_warmup_steps: int, num_training_steps: int) -> _LinearSchedule:
+    """``transformers.get_linear_schedule_with_warmup`` (reference train.py:329-331): like torch's LambdaLR it sets the lr of
+    step 0 at construction -- 0 when there is a warm-up, so the reference's first update moves nothing"""
+    return _LinearSchedule(optimizer, num_warmup_steps, num_training_steps)
+
+
+def train_step(model: ClipCaptionModel, optimizer: AdamW, tokens: torch.Tensor, mask: Optional[torch.Tensor],
+               prefix: torch.Tensor, *, apply_update: bool = True) -> float:
+    """reference train.py:345-351 and :353 for one batch -- ``model.zero_grad(); outputs = model(tokens, prefix, mask);
+    loss = cross_entropy(outputs.logits[:, P-1:-1], tokens, ignore_index=0); loss.backward(); optimizer.step();
+    optimizer.zero_grad()`` -- as ONE device call (capdec_train_step); returns ``loss.item()``.  ``prefix`` is the batch
+    after ``noise_injection`` (:347); the caller steps the scheduler afterwards (:352), as the reference does.
+    ``mask`` must be the dataset's right-padding mask (or None): see ClipCaptionModel.forward."""
+    if not isinstance(model, ClipCaptionPrefix) or model.mapping_type != MappingType.MLP:
+        raise CapdecError("train_step: implemented for ClipCaptionPrefix (frozen GPT-2, --only_prefix) with an MLP mapper")
+    tokens = tokens.to(torch.device("cuda", model._device_index))
+    if mask is not None:
+        m = mask.to(tokens.device) > 0
+        P = model.prefix_length
+        if m.shape != (tokens.shape[0], P + tokens.shape[1]) or bool((m[:, 1:] & ~m[:, :-1]).any()) or not bool(m[:, :P].all()):
+            raise CapdecError("train_step: only the reference dataset's right-padding mask is supported")
+        if bool(((tokens != 0) & ~m[:, P:]).any()):
+            raise CapdecError("train_step: a non-zero token under a zero mask (the loss would read it, the reference's "
+                              "attention would not)")
+    g = optimizer.param_groups[0]
+    loss = model.engine.train_step(prefix, tokens, g["lr"], g["betas"], g["eps"], g["weight_decay"], apply_update)
+    if apply_update:
+        model._device_ahead = True
+    return loss
+
+
+def mapper_gradients(model: ClipCaptionModel):
+    """``{name: p.grad}`` of the mapper after the last ``train_step`` (names as in ``clip_project.state_dict()``)"""
+    return model.engine.mapper_gradients(model._mapper_shapes())
+
+
+def train(dataset, model: ClipCaptionModel, args, warmup_steps: int = 5000, output_dir: str = ".", output_prefix: str = ""):
+    """reference train.py:317-392 (the loop; the validation pass of :373-390 is left to the caller): ``dataset`` yields
+    ``(tokens, mask, prefix)`` like train.ClipCocoDataset.__getitem__ (:66-75); ``args`` needs ``bs, epochs, lr,
+    noise_variance, uniform_noise, dont_norm, save_every`` (and optionally ``modality_offset``: the tensor the reference
+    reads from others/CLIP_embeddings_centers_info.pkl at :333-337)."""
+    import os
+    import sys
+    from torch.utils.data import DataLoader
+    os.makedirs(output_dir, exist_ok=True)
+    model.train()
+    optimizer = AdamW(model.parameters(), lr=args.lr)
+    loader = DataLoader(dataset, batch_size=args.bs, shuffle=True, drop_last=True)
+    scheduler = get_linear_schedule_with_warmup(optimizer, num_warmup_steps=warmup_steps,
+                                                num_training_steps=args.epochs * len(loader))
+    modality_offset = getattr(args, "modality_offset", None)
+    loss_per_epoch_train = []
+    for epoch in range(args.epochs):
+        print(f">>> Training epoch {epoch} / {args.epochs}")
+        sys.stdout.flush()
+        accumulated_loss = 0.0
+        for idx, (tokens, mask, prefix) in enumerate(loader):
+            prefix = prefix.to(device, dtype=torch.float32)
+            prefix = noise_injection(prefix, args.noise_variance, modality_offset=modality_offset,
+                                     uniform_noise=args.uniform_noise, dont_norm=args.dont_norm)
+            accumulated_loss += train_step(model, optimizer, tokens, mask, prefix)
+            scheduler.step()
+            if (idx + 1) % 10000 == 0:
+                torch.save(model.state_dict(), os.path.join(output_dir, f"{output_prefix}_latest.pt"))
+        loss_per_epoch_train.append(accumulated_loss / max(1, len(loader)))
+        print('loss_per_epoch_train: ', loss_per_epoch_train)
+        if epoch % args.save_every == 0 or epoch == args.epochs - 1:
+            torch.save(model.state_dict(), os.path.join(output_dir, f"{output_prefix}-{epoch:03d}.pt"))
+    return model

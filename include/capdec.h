@@ -239,6 +239,24 @@ int capdec_clip_encode_image(capdec_ctx *ctx, const float *d_pixels, int n, floa
  * materialises); 0 -> d_logits [n, vocab], last position only (what it uses). */
 int capdec_gpt2_logits(capdec_ctx *ctx, const float *d_embeds, int n, int L, int all_positions,
                        float *d_logits);
+/* ---- the train step with a frozen GPT-2 (reference train.py:344-354 run with --only_prefix: ClipCaptionPrefix,
+ * train.py:279-287 -- parameters() are the mapper's, GPT-2 stays in eval mode, so the step is deterministic) -------------
+ * One iteration for an MLP mapper (capdec_load_mapper_mlp): d_prefix [batch, D] is the embedding batch AFTER
+ * noise_injection (train.py:347; capdec_noise_inject), d_tokens [batch, length] int32 right-padded with 0 as
+ * train.ClipCocoDataset pads (:52-63; under the causal mask the padding mask of :348 changes nothing a real position
+ * sees).  Computes logits[:, P-1:-1], the loss of :349 (cross_entropy with ignore_index = 0: padding AND real tokens with
+ * id 0 are skipped; mean over the rest), its gradient with respect to the mapper's four tensors (:350), and -- with
+ * apply_update != 0 -- one update of transformers-4.24 AdamW (:351; betas / eps / weight_decay as passed: the reference's
+ * AdamW(params, lr) means 0.9, 0.999, 1e-6, 0.0; bias correction on; `lr` is the scheduler's current value, :352) on the
+ * device-resident mapper weights, which the inference entry points then use.  *loss (host) receives the loss.
+ * The optimizer state lives in the context; loading a mapper or GPT-2 again, or capdec_train_reset, drops it.
+ * capdec_train_get copies a tensor of the mapper (kind 0) or its gradient from the last step (kind 1) to d_out (device):
+ * which = 0 model.0.weight [hidden, D], 1 model.0.bias, 2 model.2.weight [P * d, hidden], 3 model.2.bias. */
+int capdec_train_step(capdec_ctx *ctx, const float *d_prefix, const int32_t *d_tokens, int batch, int length, float lr,
+                      float beta1, float beta2, float eps, float weight_decay, int apply_update, float *loss);
+int capdec_train_get(capdec_ctx *ctx, int kind, int which, float *d_out, size_t n);
+int capdec_train_reset(capdec_ctx *ctx);
+
 /* The loss of the train step's forward (reference train.py:349 `nnf.cross_entropy(logits, tokens, ignore_index=0)`,
  * and GPT2LMHeadModel's shifted `labels=` loss used by gpt2_prefix.py:154): mean over the rows whose label differs
  * from ignore_index of logsumexp(d_logits[row, 0..vocab)) - d_logits[row, label].  d_logits: device fp32 [rows, ld],

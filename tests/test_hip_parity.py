@@ -375,6 +375,58 @@ def test_train_step_forward_vs_reference_golden(golden, dims, tag):
         model(tokens, prefix, bad)
 
 
+@pytest.mark.parametrize("dims,tag", [(synth.GPT2_TINY, "tiny"), (synth.GPT2_SMALL, "small")], ids=["tiny", "small"])
+def test_train_step_frozen_gpt2_vs_reference_golden(golden, dims, tag):
+    """The train step with a frozen GPT-2 (reference train.py:344-354 with --only_prefix; capdec_train_step): four
+    consecutive iterations on the batches of tests/golden/train_step_*.npz -- the loss of every iteration, EVERY mapper
+    gradient of every iteration against what the reference's own loss.backward() left in .grad (each taken at the weights
+    the previous updates produced), the lr sequence, and the weights after the four AdamW updates (the update rule itself
+    is the restated transformers-4.24 AdamW: oracle/capdec_oracle.py adamw_transformers).  Then the trained mapper is
+    what inference uses.  Tolerances: loss 3e-4; gradients 3e-3 relative to the tensor's largest entry... (subsample of
+    4096 entries per tensor + the norm within 2e-3); final weights 5e-5 abs."""
+    from capdec_amd import train as Tr
+    from capdec_amd.gpt2_prefix import ClipCaptionPrefix, MappingType
+    from oracle import capdec_oracle as O
+    g = golden(f"train_step_{tag}")
+    sd = synth.hot_state_dict(42, "mlp", 512, 10, dims=dims)
+    assert synth.state_dict_checksum(sd) == int(g["sd_crc"]), "RNG drift"
+    model = ClipCaptionPrefix(10, clip_length=10, prefix_size=512, num_layers=8, mapping_type=MappingType.MLP,
+                              gpt2_dims=dims).to("cuda:0")
+    model.load_state_dict(sd)
+    model.train()
+    opt = Tr.AdamW(model.parameters(), lr=float(g["lr"]))
+    sched = Tr.get_linear_schedule_with_warmup(opt, int(g["warmup"]), int(g["total"]))
+    names = [str(n) for n in g["names"]]
+    for it in range(len(g["losses"])):
+        tokens, mask, prefix = T(g[f"tokens_{it}"]), T(g[f"mask_{it}"]), T(g[f"prefix_{it}"])
+        assert abs(opt.param_groups[0]["lr"] - float(g["lrs"][it])) < 1e-12
+        loss = Tr.train_step(model, opt, tokens, mask, prefix)
+        assert abs(loss - float(g["losses"][it])) < 3e-4, (it, loss, float(g["losses"][it]))
+        grads = Tr.mapper_gradients(model)
+        for k in names:
+            gk = grads[k[len("clip_project."):]].cpu()
+            flat = gk.flatten()
+            sub = flat[::max(1, flat.numel() // 4096)].numpy()
+            ref = g[f"grad_{it}_{k}_sub"]
+            scale = float(np.abs(ref).max())
+            np.testing.assert_allclose(sub, ref, atol=3e-3 * scale + 1e-9, rtol=0, err_msg=f"iteration {it}, {k}")
+            assert abs(float(gk.double().norm()) / float(g[f"grad_{it}_{k}_norm"]) - 1.0) < 2e-3, (it, k)
+        sched.step()
+    fin = model.state_dict()
+    for k in names:
+        flat = fin[k].flatten()
+        np.testing.assert_allclose(flat[::max(1, flat.numel() // 4096)].numpy(), g[f"final_{k}_sub"], atol=5e-5, err_msg=k)
+    # the trained mapper is the one inference runs
+    x = T(g["prefix_0"])
+    want = O.mlp_mapper(x, {k: fin[k] for k in names})
+    np.testing.assert_allclose(model.clip_project(x).cpu().numpy(), want.numpy(), atol=2e-4)
+    # a real token under a zero mask is refused (the reference's attention would hide what its loss reads)
+    bad = T(g["mask_0"]).clone()
+    bad[0, 10] = 0
+    with pytest.raises(Exception):
+        Tr.train_step(model, opt, T(g["tokens_0"]), bad, T(g["prefix_0"]))
+
+
 @pytest.mark.parametrize("mode", ["f16x2", "bf16x3", "f32"])
 def test_gemm_modes_vs_fp64(mode):
     """every fp32-accurate GEMM back-end stays in the fp32 round-off class (error relative to sum |a||b|)"""
