@@ -294,7 +294,7 @@ def gpt2_forward_saved(embeds: Tensor, sd: SD, n_head: int = 12, g: str = "gpt."
         qkv = torch.addmm(sd[b + "attn.c_attn.bias"], a1.reshape(-1, d), sd[b + "attn.c_attn.weight"]).view(N, L, 3 * d)
         q, k, v = (x.view(N, L, n_head, hd).transpose(1, 2) for x in qkv.split(d, dim=2))
         w = torch.matmul(q, k.transpose(-1, -2)) / math.sqrt(hd)
-        w = torch.where(causal, w, torch.full((), torch.finfo(w.dtype).min)).softmax(dim=-1)
+        w = torch.where(causal, w, torch.full((), torch.finfo(w.dtype).min, dtype=w.dtype)).softmax(dim=-1)
         att = torch.matmul(w, v).transpose(1, 2).reshape(N, L, d)
         h_mid = h + torch.addmm(sd[b + "attn.c_proj.bias"], att.reshape(-1, d), sd[b + "attn.c_proj.weight"]).view(N, L, d)
         a2 = _ln_fwd(h_mid, sd[b + "ln_2.weight"], sd[b + "ln_2.bias"])
@@ -341,16 +341,67 @@ def mlp_mapper_backward(x: Tensor, dy: Tensor, sd: SD, pfx: str = "clip_project.
             pfx + "model.2.weight": dy.t() @ hmid, pfx + "model.2.bias": dy.sum(0)}
 
 
+def transformer_mapper_backward(x: Tensor, dout: Tensor, sd: SD, clip_length: int, num_layers: int = 8,
+                                pfx: str = "clip_project.", num_heads: int = 8) -> Dict[str, Tensor]:
+    """gradients of every tensor of the TransformerMapper (reference transformer_mapper.py:113-127 -> :76-110 -> :54-73 ->
+    :22-51, :4-19) given d loss / d output [B, P, d]; forward as ``transformer_mapper`` above, kept per layer"""
+    d = sd[pfx + "prefix_const"].shape[1]
+    B, hd = x.shape[0], d // num_heads
+    h = torch.cat((F.linear(x, sd[pfx + "linear.weight"], sd[pfx + "linear.bias"]).view(B, clip_length, d),
+                   sd[pfx + "prefix_const"].unsqueeze(0).expand(B, -1, -1)), dim=1)
+    S = h.shape[1]
+    saved = []
+    for i in range(num_layers):
+        l = f"{pfx}transformer.layers.{i}."
+        a1 = _ln_fwd(h, sd[l + "norm1.weight"], sd[l + "norm1.bias"])
+        q = F.linear(a1, sd[l + "attn.to_queries.weight"]).reshape(B, S, num_heads, hd)
+        kv = F.linear(a1, sd[l + "attn.to_keys_values.weight"]).reshape(B, S, 2, num_heads, hd)
+        k, v = kv[:, :, 0], kv[:, :, 1]
+        w = (torch.einsum("bnhd,bmhd->bnmh", q, k) * (hd ** -0.5)).softmax(dim=2)
+        att = torch.einsum("bnmh,bmhd->bnhd", w, v).reshape(B, S, d)
+        h_mid = h + F.linear(att, sd[l + "attn.project.weight"], sd[l + "attn.project.bias"])
+        a2 = _ln_fwd(h_mid, sd[l + "norm2.weight"], sd[l + "norm2.bias"])
+        r = torch.relu(F.linear(a2, sd[l + "mlp.fc1.weight"], sd[l + "mlp.fc1.bias"]))
+        saved.append(dict(h=h, a1=a1, q=q, k=k, v=v, w=w, att=att, h_mid=h_mid, a2=a2, r=r))
+        h = h_mid + F.linear(r, sd[l + "mlp.fc2.weight"], sd[l + "mlp.fc2.bias"])
+    g: Dict[str, Tensor] = {}
+    dh = torch.zeros_like(h)
+    dh[:, clip_length:] = dout
+    f2 = lambda t: t.reshape(-1, t.shape[-1])                       # noqa: E731
+    for i in reversed(range(num_layers)):
+        l, s = f"{pfx}transformer.layers.{i}.", saved[i]
+        g[l + "mlp.fc2.weight"], g[l + "mlp.fc2.bias"] = f2(dh).t() @ f2(s["r"]), f2(dh).sum(0)
+        dr = (dh @ sd[l + "mlp.fc2.weight"]) * (s["r"] > 0)
+        g[l + "mlp.fc1.weight"], g[l + "mlp.fc1.bias"] = f2(dr).t() @ f2(s["a2"]), f2(dr).sum(0)
+        dx, g[l + "norm2.weight"], g[l + "norm2.bias"] = _ln_bwd(s["h_mid"], sd[l + "norm2.weight"], dr @ sd[l + "mlp.fc1.weight"])
+        dh_mid = dh + dx
+        g[l + "attn.project.weight"], g[l + "attn.project.bias"] = f2(dh_mid).t() @ f2(s["att"]), f2(dh_mid).sum(0)
+        datt = (dh_mid @ sd[l + "attn.project.weight"]).reshape(B, S, num_heads, hd)
+        dv = torch.einsum("bnmh,bnhd->bmhd", s["w"], datt)
+        dp = torch.einsum("bnhd,bmhd->bnmh", datt, s["v"])
+        ds = s["w"] * (dp - (s["w"] * dp).sum(2, keepdim=True))
+        dq = torch.einsum("bnmh,bmhd->bnhd", ds, s["k"]) * (hd ** -0.5)
+        dk = torch.einsum("bnmh,bnhd->bmhd", ds, s["q"]) * (hd ** -0.5)
+        dq2, dkv2 = dq.reshape(B * S, d), torch.stack((dk, dv), dim=2).reshape(B * S, 2 * d)
+        g[l + "attn.to_queries.weight"] = dq2.t() @ f2(s["a1"])
+        g[l + "attn.to_keys_values.weight"] = dkv2.t() @ f2(s["a1"])
+        da1 = (dq2 @ sd[l + "attn.to_queries.weight"] + dkv2 @ sd[l + "attn.to_keys_values.weight"]).view(B, S, d)
+        dx, g[l + "norm1.weight"], g[l + "norm1.bias"] = _ln_bwd(s["h"], sd[l + "norm1.weight"], da1)
+        dh = dh_mid + dx
+    g[pfx + "prefix_const"] = dh[:, clip_length:].sum(0)
+    dlin = dh[:, :clip_length].reshape(B, clip_length * d)
+    g[pfx + "linear.weight"], g[pfx + "linear.bias"] = dlin.t() @ x, dlin.sum(0)
+    return g
+
+
 def train_step_loss_and_grads(sd: SD, tokens: Tensor, prefix: Tensor, mapping_type: str, prefix_length: int,
-                              n_head: int = 12) -> Tuple[Tensor, Dict[str, Tensor]]:
+                              n_head: int = 12, clip_length: int = 10, num_layers: int = 8) -> Tuple[Tensor, Dict[str, Tensor]]:
     """loss of reference train.py:348-349 (cross_entropy(logits[:, P-1:-1], tokens, ignore_index=0), mean over the
     labels != 0) and its gradients with respect to the mapper's parameters (what loss.backward() leaves in .grad of
     ClipCaptionPrefix.parameters(), :350).  ``prefix`` is the embedding batch AFTER noise_injection (:347)."""
-    if mapping_type != "mlp":
-        raise NotImplementedError("train step: MLP mapper only (the TransformerMapper backward is not restated yet)")
     P, (B, L) = prefix_length, tokens.shape
     d = sd["gpt.transformer.wte.weight"].shape[1]
-    pe = mlp_mapper(prefix, sd).reshape(B, P, d)
+    pe = clip_project(prefix, sd, mapping_type, P, clip_length, num_layers)
     embeds = torch.cat((pe, wte(tokens.long(), sd)), dim=1)
     hf, saved = gpt2_forward_saved(embeds, sd, n_head)
     W = sd["gpt.transformer.wte.weight"]
@@ -367,7 +418,9 @@ def train_step_loss_and_grads(sd: SD, tokens: Tensor, prefix: Tensor, mapping_ty
     dhf = torch.zeros_like(hf)
     dhf[:, P - 1:-1] = dlogits @ W
     dembeds = gpt2_backward_dx(dhf, saved, sd, n_head)
-    return loss, mlp_mapper_backward(prefix, dembeds[:, :P].reshape(B, P * d), sd)
+    if mapping_type == "mlp":
+        return loss, mlp_mapper_backward(prefix, dembeds[:, :P].reshape(B, P * d), sd)
+    return loss, transformer_mapper_backward(prefix, dembeds[:, :P], sd, clip_length, num_layers)
 
 
 def linear_schedule_with_warmup(step: int, num_warmup_steps: int, num_training_steps: int) -> float:
@@ -401,7 +454,8 @@ def adamw_transformers(p: Tensor, grad: Tensor, exp_avg: Tensor, exp_avg_sq: Ten
 
 
 def train_steps(sd: SD, batches: Sequence[Tuple[Tensor, Tensor]], mapping_type: str, prefix_length: int, lr: float,
-                num_warmup_steps: int, num_training_steps: int, n_head: int = 12) -> Tuple[List[float], SD]:
+                num_warmup_steps: int, num_training_steps: int, n_head: int = 12, clip_length: int = 10,
+                num_layers: int = 8) -> Tuple[List[float], SD]:
     """``len(batches)`` iterations of reference train.py:344-354 (frozen GPT-2) from the weights ``sd`` (not modified):
     each batch = (tokens [B, L] right-padded with 0, prefix [B, D] after noise injection).  Returns the per-step losses
     and the final state dict."""
@@ -409,7 +463,7 @@ def train_steps(sd: SD, batches: Sequence[Tuple[Tensor, Tensor]], mapping_type: 
     state = {k: (torch.zeros_like(v), torch.zeros_like(v)) for k, v in sd.items() if k.startswith("clip_project.")}
     losses = []
     for it, (tokens, prefix) in enumerate(batches):
-        loss, grads = train_step_loss_and_grads(sd, tokens, prefix, mapping_type, prefix_length, n_head)
+        loss, grads = train_step_loss_and_grads(sd, tokens, prefix, mapping_type, prefix_length, n_head, clip_length, num_layers)
         losses.append(float(loss))
         cur_lr = lr * linear_schedule_with_warmup(it, num_warmup_steps, num_training_steps)
         for k, gk in grads.items():

@@ -370,7 +370,7 @@ def gen_train_forward(refs, dims, tag):
     print(f"train_forward_{tag}.npz written; loss {float(loss):.5f}")
 
 
-def gen_train_step(refs, dims, tag):
+def gen_train_step(refs, dims, tag, mapping="mlp"):
     """The train step with a frozen GPT-2 (train.py:344-354 with --only_prefix): train.ClipCaptionPrefix (:279-287) in
     train() mode, the batch of gen_train_forward, loss as at :349, the reference's own loss.backward() (:350) -> the
     gradients of ClipCaptionPrefix.parameters().  Three iterations follow with the lr of the real
@@ -384,15 +384,17 @@ def gen_train_step(refs, dims, tag):
                      n_positions=dims.n_pos)
     GPT2LMHeadModel.from_pretrained = staticmethod(lambda name, *a, **k: GPT2LMHeadModel(cfg))
     P, D = 10, 512
-    model = ref_train.ClipCaptionPrefix(P, clip_length=10, prefix_size=D, num_layers=8, mapping_type=ref_train.MappingType.MLP)
+    mt = ref_train.MappingType.MLP if mapping == "mlp" else ref_train.MappingType.Transformer
+    nlay = 8 if mapping == "mlp" else 3                      # (three mapper layers keep the fixture small)
+    model = ref_train.ClipCaptionPrefix(P, clip_length=10, prefix_size=D, num_layers=nlay, mapping_type=mt)
     model.train()
     assert not model.gpt.training and model.clip_project.training
-    sd = synth.hot_state_dict(42, "mlp", D, P, dims=dims)
+    sd = synth.hot_state_dict(42, mapping, D, P, 10, nlay, dims)
     missing, unexpected = model.load_state_dict(sd, strict=False)
     assert not unexpected and all(".attn.bias" in m or ".attn.masked_bias" in m for m in missing)
     names = [k for k, _ in model.named_parameters() if k.startswith("clip_project.")]
     params = list(model.parameters())
-    assert len(params) == len(names) == 4
+    assert len(params) == len(names) == (4 if mapping == "mlp" else 3 + 12 * nlay)
     g = torch.Generator().manual_seed(23)
     lr, warm, total, iters = 2e-3, 2, 8, 4
     dummy = torch.optim.SGD([torch.nn.Parameter(torch.zeros(1))], lr=lr)     # only carries the lr for the real scheduler
@@ -652,6 +654,7 @@ def main():
         "train_forward_small": lambda: gen_train_forward(refs, synth.GPT2_SMALL, "small"),
         "train_step_tiny": lambda: gen_train_step(refs, synth.GPT2_TINY, "tiny"),
         "train_step_small": lambda: gen_train_step(refs, synth.GPT2_SMALL, "small"),
+        "train_step_tm_tiny": lambda: gen_train_step(refs, synth.GPT2_TINY, "tm_tiny", "transformer_encoder"),
         "prompt_tiny": lambda: gen_prompt(refs, synth.GPT2_TINY, "tiny"),
         "prompt_small": lambda: gen_prompt(refs, synth.GPT2_SMALL, "small"),
         "clip_tiny": lambda: gen_clip(synth.CLIP_TINY, "tiny", 6, 3),
