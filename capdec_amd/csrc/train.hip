@@ -4,7 +4,8 @@
 //     prefix -> MLP mapper -> cat(prefix rows, wte(tokens)) -> GPT-2 -> logits[:, P-1:-1] -> cross_entropy(ignore_index=0)
 //     -> backward down to the mapper's four tensors -> transformers-4.24 AdamW
 //
-// Scope: the MLP mapper (gpt2_prefix.py:114-126).  Structure: the forward keeps every activation the backward needs
+// Both mapping networks: the MLP (gpt2_prefix.py:114-126) and the TransformerMapper (transformer_mapper.py:113-127: every
+// one of its 3 + 12 n_layers tensors).  Structure: the forward keeps every activation the backward needs
 // (fp32, per layer: block input, qkv, attention output, mid-block residual, c_fc pre-activation: 30 KB per token and
 // layer -- 1.2 GB for the reference's default batch of 34 captions x (40 + ~20) positions x 12 layers); the backward is
 // dX-only through GPT-2 (its weights are frozen: no weight gradients, no optimizer state for 124 M parameters) on the
@@ -45,6 +46,36 @@ __global__ void gelu_new_bwd_kernel(const float *__restrict__ x, const float *dy
 __global__ void tanh_bwd_kernel(const float *__restrict__ y, const float *dy, float *dx, size_t n) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) dx[i] = dy[i] * (1.0f - y[i] * y[i]);
+}
+// dx = dy where y > 0 (y = relu(.)), else 0
+__global__ void relu_bwd_kernel(const float *__restrict__ y, const float *dy, float *dx, size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dx[i] = y[i] > 0.f ? dy[i] : 0.f;
+}
+// TransformerMapper output = rows clip_len.. of the sequence: dseq[b, s] = s >= clip_len ? dout[b, s - clip_len] : 0
+__global__ void tmapper_put_kernel(const float *__restrict__ dout, float *__restrict__ dseq, int n, int clip_len, int P, int d) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int S = clip_len + P;
+    if (i >= (size_t)n * S * d) return;
+    const int c = (int)(i % d), s_ = (int)((i / d) % S), b = (int)(i / ((size_t)d * S));
+    dseq[i] = s_ >= clip_len ? dout[((size_t)b * P + (s_ - clip_len)) * d + c] : 0.f;
+}
+// the sequence's first layer input = cat(linear(x).view(B, clip_len, d), prefix_const): dlin[b, s, :] = dseq[b, s < clip_len],
+// g_prefix_const[p, :] = sum_b dseq[b, clip_len + p, :]
+__global__ void tmapper_split_grad_kernel(const float *__restrict__ dseq, float *__restrict__ dlin, float *__restrict__ gpc,
+                                          int n, int clip_len, int P, int d) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int S = clip_len + P;
+    if (i < (size_t)n * clip_len * d) {
+        const int c = (int)(i % d), s_ = (int)((i / d) % clip_len), b = (int)(i / ((size_t)d * clip_len));
+        dlin[i] = dseq[((size_t)b * S + s_) * d + c];
+    }
+    if (i < (size_t)P * d) {
+        const int c = (int)(i % d), pp = (int)(i / d);
+        float a = 0.f;
+        for (int b = 0; b < n; ++b) a += dseq[((size_t)b * S + clip_len + pp) * d + c];
+        gpc[i] = a;
+    }
 }
 // x[i] *= 1 / *count   (count > 0)
 __global__ void scale_by_count_kernel(float *x, size_t n, const int *__restrict__ count) {
@@ -100,10 +131,12 @@ __global__ void adamw_kernel(float *__restrict__ p, const float *__restrict__ g,
 
 // ---------------------------------------------------------------------------------------------- LayerNorm backward
 // dx = add + rstd (g - mean(g) - xhat mean(g xhat)), g = dy w; one wavefront per row, d = 64 * NPL
+// (gw / gb != nullptr: the LayerNorm's own weight / bias gradients are accumulated too -- sum over rows of dy xhat and of
+//  dy, by atomic adds into buffers the caller zeroed)
 template <int NPL>
 __global__ __launch_bounds__(256) void ln_bwd_dx_kernel(const float *__restrict__ x, const float *__restrict__ w,
                                                         const float *__restrict__ dy, const float *add, float *dx,
-                                                        int rows, float eps) {
+                                                        int rows, float eps, float *gw = nullptr, float *gb = nullptr) {
     constexpr int d = 64 * NPL;
     const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -121,7 +154,12 @@ __global__ __launch_bounds__(256) void ln_bwd_dx_kernel(const float *__restrict_
 #pragma unroll
     for (int k = 0; k < NPL; ++k) {
         xv[k] *= rstd;                                       // xhat
-        gv[k] = dyr[lane + 64 * k] * w[lane + 64 * k];
+        const float dyk = dyr[lane + 64 * k];
+        if (gw) {
+            atomicAdd(gw + lane + 64 * k, dyk * xv[k]);
+            atomicAdd(gb + lane + 64 * k, dyk);
+        }
+        gv[k] = dyk * w[lane + 64 * k];
         sg += gv[k];
         sgx += gv[k] * xv[k];
     }
@@ -134,72 +172,119 @@ __global__ __launch_bounds__(256) void ln_bwd_dx_kernel(const float *__restrict_
 }
 
 // ---------------------------------------------------------------------------------------------- attention backward
-// Causal softmax attention, head_dim 64, rows = (sample, position) with S positions per sample, qkv rows [q | k | v] of
-// 3 d floats.  One wavefront per (sample, head, query i): lane = head dimension.
-//   s_j = q_i . k_j / 8, p = softmax_j<=i(s), dP_j = dO_i . v_j, D = sum_j p_j dP_j, dS_j = p_j (dP_j - D)
-//   dq_i = sum_j dS_j k_j / 8;  lse_i and D_i are kept for the key-side kernel
+// Softmax attention, rows = (sample, position) with S positions per sample, qkv rows [q | k | v] of 3 d floats, head h at
+// columns h HD; CAUSAL (GPT-2, HD = 64, scale 1/8) or over all S keys (TransformerMapper, HD = 96, scale HD^-0.5).
+// One wavefront per (sample, head, query i); a lane owns the head dimensions lane and lane + 64 (< HD).
+//   s_j = q_i . k_j scale, p = softmax_j(s), dP_j = dO_i . v_j, D = sum_j p_j dP_j, dS_j = p_j (dP_j - D)
+//   dq_i = sum_j dS_j k_j scale;  lse_i and D_i are kept for the key-side kernel
+template <int HD, bool CAUSAL>
 __global__ __launch_bounds__(256) void attn_bwd_q_kernel(const float *__restrict__ qkv, const float *__restrict__ dout,
                                                          float *__restrict__ dqkv, float *__restrict__ lse_out,
-                                                         float *__restrict__ dsum_out, int total, int S, int heads) {
+                                                         float *__restrict__ dsum_out, int total, int S, int heads,
+                                                         float scale) {
+    constexpr int NE = (HD + 63) / 64;
     extern __shared__ float sh[];                     // [4 waves][2][S]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int gw = blockIdx.x * 4 + wave;
     if (gw >= total) return;
     const int i = gw % S, bh = gw / S, h = bh % heads, b = bh / heads;
-    const int d = heads * 64;
+    const int d = heads * HD;
     float *sc = sh + (size_t)wave * 2 * S, *dp = sc + S;
     const size_t row = (size_t)b * S + i;
-    const float q = qkv[row * 3 * d + h * 64 + lane], go = dout[row * d + h * 64 + lane];
-    for (int j = 0; j <= i; ++j) {
-        const float *kr = qkv + ((size_t)b * S + j) * 3 * d + d + h * 64;
-        const float s = wave_sum(q * kr[lane]) * 0.125f, t = wave_sum(go * kr[d + lane]);
-        if (lane == 0) { sc[j] = s; dp[j] = t; }
+    const int nk = CAUSAL ? i + 1 : S;
+    float q[NE], go[NE];
+#pragma unroll
+    for (int e = 0; e < NE; ++e) {
+        const bool ok = lane + 64 * e < HD;
+        q[e] = ok ? qkv[row * 3 * d + h * HD + lane + 64 * e] : 0.f;
+        go[e] = ok ? dout[row * d + h * HD + lane + 64 * e] : 0.f;
+    }
+    for (int j = 0; j < nk; ++j) {
+        const float *kr = qkv + ((size_t)b * S + j) * 3 * d + d + h * HD;
+        float a = 0.f, t = 0.f;
+#pragma unroll
+        for (int e = 0; e < NE; ++e)
+            if (lane + 64 * e < HD) { a += q[e] * kr[lane + 64 * e]; t += go[e] * kr[d + lane + 64 * e]; }
+        a = wave_sum(a) * scale;
+        t = wave_sum(t);
+        if (lane == 0) { sc[j] = a; dp[j] = t; }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     float mx = -INFINITY;
-    for (int j = lane; j <= i; j += 64) mx = fmaxf(mx, sc[j]);
+    for (int j = lane; j < nk; j += 64) mx = fmaxf(mx, sc[j]);
     mx = wave_max(mx);
     float l = 0.f;
-    for (int j = lane; j <= i; j += 64) l += expf(sc[j] - mx);
+    for (int j = lane; j < nk; j += 64) l += expf(sc[j] - mx);
     l = wave_sum(l);
     const float lse = mx + logf(l);
     float D = 0.f;
-    for (int j = lane; j <= i; j += 64) D += expf(sc[j] - lse) * dp[j];
+    for (int j = lane; j < nk; j += 64) D += expf(sc[j] - lse) * dp[j];
     D = wave_sum(D);
-    for (int j = lane; j <= i; j += 64) sc[j] = expf(sc[j] - lse) * (dp[j] - D);       // dS_j
+    for (int j = lane; j < nk; j += 64) sc[j] = expf(sc[j] - lse) * (dp[j] - D);       // dS_j
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    float dq = 0.f;
-    for (int j = 0; j <= i; ++j) dq += sc[j] * qkv[((size_t)b * S + j) * 3 * d + d + h * 64 + lane];
-    dqkv[row * 3 * d + h * 64 + lane] = dq * 0.125f;
+    float dq[NE];
+#pragma unroll
+    for (int e = 0; e < NE; ++e) dq[e] = 0.f;
+    for (int j = 0; j < nk; ++j) {
+        const float *kr = qkv + ((size_t)b * S + j) * 3 * d + d + h * HD;
+#pragma unroll
+        for (int e = 0; e < NE; ++e)
+            if (lane + 64 * e < HD) dq[e] += sc[j] * kr[lane + 64 * e];
+    }
+#pragma unroll
+    for (int e = 0; e < NE; ++e)
+        if (lane + 64 * e < HD) dqkv[row * 3 * d + h * HD + lane + 64 * e] = dq[e] * scale;
     if (lane == 0) { lse_out[gw] = lse; dsum_out[gw] = D; }
 }
-// one wavefront per (sample, head, key j): dk_j = sum_{i>=j} dS_ij q_i / 8, dv_j = sum_{i>=j} p_ij dO_i
+// one wavefront per (sample, head, key j): dk_j = sum_i dS_ij q_i scale, dv_j = sum_i p_ij dO_i  (i >= j when CAUSAL)
+template <int HD, bool CAUSAL>
 __global__ __launch_bounds__(256) void attn_bwd_kv_kernel(const float *__restrict__ qkv, const float *__restrict__ dout,
                                                           float *__restrict__ dqkv, const float *__restrict__ lse_in,
-                                                          const float *__restrict__ dsum_in, int total, int S, int heads) {
+                                                          const float *__restrict__ dsum_in, int total, int S, int heads,
+                                                          float scale) {
+    constexpr int NE = (HD + 63) / 64;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int gw = blockIdx.x * 4 + wave;
     if (gw >= total) return;
     const int j = gw % S, bh = gw / S, h = bh % heads, b = bh / heads;
-    const int d = heads * 64;
+    const int d = heads * HD;
     const size_t rowj = (size_t)b * S + j;
-    const float k = qkv[rowj * 3 * d + d + h * 64 + lane], v = qkv[rowj * 3 * d + 2 * d + h * 64 + lane];
-    float dk = 0.f, dv = 0.f;
-    for (int i = j; i < S; ++i) {
-        const size_t rowi = (size_t)b * S + i;
-        const float q = qkv[rowi * 3 * d + h * 64 + lane], go = dout[rowi * d + h * 64 + lane];
-        const int gi = (bh * S) + i;
-        const float p = expf(wave_sum(q * k) * 0.125f - lse_in[gi]);
-        const float ds = p * (wave_sum(go * v) - dsum_in[gi]);
-        dk += ds * q;
-        dv += p * go;
+    float k[NE], v[NE], dk[NE], dv[NE];
+#pragma unroll
+    for (int e = 0; e < NE; ++e) {
+        const bool ok = lane + 64 * e < HD;
+        k[e] = ok ? qkv[rowj * 3 * d + d + h * HD + lane + 64 * e] : 0.f;
+        v[e] = ok ? qkv[rowj * 3 * d + 2 * d + h * HD + lane + 64 * e] : 0.f;
+        dk[e] = dv[e] = 0.f;
     }
-    dqkv[rowj * 3 * d + d + h * 64 + lane] = dk * 0.125f;
-    dqkv[rowj * 3 * d + 2 * d + h * 64 + lane] = dv;
+    for (int i = CAUSAL ? j : 0; i < S; ++i) {
+        const size_t rowi = (size_t)b * S + i;
+        float q[NE], go[NE];
+        float a = 0.f, t = 0.f;
+#pragma unroll
+        for (int e = 0; e < NE; ++e) {
+            const bool ok = lane + 64 * e < HD;
+            q[e] = ok ? qkv[rowi * 3 * d + h * HD + lane + 64 * e] : 0.f;
+            go[e] = ok ? dout[rowi * d + h * HD + lane + 64 * e] : 0.f;
+            a += q[e] * k[e];
+            t += go[e] * v[e];
+        }
+        const int gi = bh * S + i;
+        const float p = expf(wave_sum(a) * scale - lse_in[gi]);
+        const float ds = p * (wave_sum(t) - dsum_in[gi]);
+#pragma unroll
+        for (int e = 0; e < NE; ++e) { dk[e] += ds * q[e]; dv[e] += p * go[e]; }
+    }
+#pragma unroll
+    for (int e = 0; e < NE; ++e)
+        if (lane + 64 * e < HD) {
+            dqkv[rowj * 3 * d + d + h * HD + lane + 64 * e] = dk[e] * scale;
+            dqkv[rowj * 3 * d + 2 * d + h * HD + lane + 64 * e] = dv[e];
+        }
 }
 
 // ---------------------------------------------------------------------------------------------- cross-entropy
@@ -259,6 +344,11 @@ __global__ __launch_bounds__(256) void ce_finish_kernel(const float *__restrict_
 }
 
 // ---------------------------------------------------------------------------------------------- workspace
+// One trainable tensor: where it lives and where its gradient / AdamW moments sit in the three arenas (same offset in each)
+struct Slot {
+    float *p;
+    size_t n, off;
+};
 struct TrainState {
     // transposed copies of the frozen GPT-2 weights: the "[N, K]" operand of dX = dY W^T (= the checkpoint's own Conv1D
     // layout [in, out]); wte_t [d][Vp] zero-padded to a multiple of 64 columns
@@ -268,27 +358,34 @@ struct TrainState {
     int Vp = 0;
     std::vector<void *> owned;
     bool weights_ready = false;
-    // saved activations + gradients (grow-only)
-    DBuf pe, emb, hs, a, qkv, att, hmid, fc, gl, hf, hfl, logits, ids, labels, rloss, cnt, loss_dev;
-    DBuf dh, dh2, da, dqkv, datt, dfc, dhfl, lse, dsum, dy, dhid, tmp_t, tmp_t2, w2_t;
-    DBuf hid;                                // mapper hidden (tanh output) [Bp, hidden]
-    DBuf g_w1, g_b1, g_w2, g_b2;             // gradients of the last step
-    DBuf m_w1, m_b1, m_w2, m_b2, v_w1, v_b1, v_w2, v_b2;   // AdamW moments
+    // the mapper's trainable tensors (build_slots) + gradient and moment arenas
+    std::vector<Slot> slots;
+    size_t n_params = 0;
+    DBuf G, Mo, Vo;
+    // saved activations + gradient scratch (grow-only)
+    DBuf pe, emb, hs, a, qkv, att, hmid, fc, gl, hf, hfl, logits, ids, rloss, cnt;
+    DBuf dh, dh2, da, dqkv, datt, dfc, dhfl, lse, dsum, dy, tA, tB, wT;
+    DBuf hid, dhid;                          // MLP mapper: tanh output, its gradient
+    DBuf t_lin, t_seq, t_a1, t_qkv, t_att, t_mid, t_a2, t_r;      // TransformerMapper: per-layer saved activations
+    DBuf t_ds, t_ds2, t_da, t_dr, t_dqkv, t_datt, t_dlin;         // ... gradient scratch
     long long step = 0;                      // updates applied (bias correction uses step + 1)
     bool have_grads = false;
     void release() {
         for (void *p : owned) (void)hipFree(p);
         owned.clear();
         lt.clear();
+        slots.clear();
         wte_t = nullptr;
         weights_ready = false;
-        DBuf *bufs[] = {&pe, &emb, &hs, &a, &qkv, &att, &hmid, &fc, &gl, &hf, &hfl, &logits, &ids, &labels, &rloss, &cnt,
-                        &loss_dev, &dh, &dh2, &da, &dqkv, &datt, &dfc, &dhfl, &lse, &dsum, &dy, &dhid, &tmp_t, &tmp_t2, &w2_t,
-                        &hid, &g_w1, &g_b1, &g_w2, &g_b2, &m_w1, &m_b1, &m_w2, &m_b2, &v_w1, &v_b1, &v_w2, &v_b2};
+        DBuf *bufs[] = {&G, &Mo, &Vo, &pe, &emb, &hs, &a, &qkv, &att, &hmid, &fc, &gl, &hf, &hfl, &logits, &ids, &rloss, &cnt,
+                        &dh, &dh2, &da, &dqkv, &datt, &dfc, &dhfl, &lse, &dsum, &dy, &tA, &tB, &wT, &hid, &dhid,
+                        &t_lin, &t_seq, &t_a1, &t_qkv, &t_att, &t_mid, &t_a2, &t_r, &t_ds, &t_ds2, &t_da, &t_dr, &t_dqkv,
+                        &t_datt, &t_dlin};
         for (DBuf *b : bufs) b->release();
         step = 0;
         have_grads = false;
     }
+    float *grad(int slot) { return G.as<float>() + slots[slot].off; }
 };
 
 void train_release(capdec_ctx *c) {
@@ -296,6 +393,38 @@ void train_release(capdec_ctx *c) {
     c->train->release();
     delete c->train;
     c->train = nullptr;
+}
+
+// Slot order (capdec.h: capdec_train_get).  MLP: model.0.weight, model.0.bias, model.2.weight, model.2.bias.
+// TransformerMapper: linear.weight, linear.bias, prefix_const, then per layer norm1.weight, norm1.bias,
+// attn.to_queries.weight, attn.to_keys_values.weight (adjacent halves of the fused [3d, d] projection on the device),
+// attn.project.weight, attn.project.bias, norm2.weight, norm2.bias, mlp.fc1.weight, mlp.fc1.bias, mlp.fc2.weight, mlp.fc2.bias
+static int build_slots(capdec_ctx *c, TrainState &t) {
+    if (!t.slots.empty()) return 0;
+    Mapper &m = c->map;
+    const size_t d = m.d;
+    auto add = [&](float *p, size_t n) { t.slots.push_back(Slot{p, n, t.n_params}); t.n_params += n; };
+    t.n_params = 0;
+    if (m.kind == 1) {
+        const size_t O = (size_t)m.P * d;
+        add(m.w1, (size_t)m.hidden * m.D); add(m.b1, m.hidden); add(m.w2, O * m.hidden); add(m.b2, O);
+    } else {
+        add(m.lin_w, (size_t)m.clip_len * d * m.D); add(m.lin_b, (size_t)m.clip_len * d); add(m.prefix_const, (size_t)m.P * d);
+        for (TMapLayer &l : m.layers) {
+            add(l.n1w, d); add(l.n1b, d);
+            add(l.wqkv, d * d); add(l.wqkv + d * d, 2 * d * d);
+            add(l.wproj, d * d); add(l.bproj, d);
+            add(l.n2w, d); add(l.n2b, d);
+            add(l.wfc1, (size_t)m.mlp_hidden * d); add(l.bfc1, m.mlp_hidden);
+            add(l.wfc2, d * m.mlp_hidden); add(l.bfc2, d);
+        }
+    }
+    CAPDEC_TRY(t.G.ensure(t.n_params * 4));
+    CAPDEC_TRY(t.Mo.ensure(t.n_params * 4));
+    CAPDEC_TRY(t.Vo.ensure(t.n_params * 4));
+    CAPDEC_HIP(hipMemsetAsync(t.Mo.p, 0, t.n_params * 4, c->stream));
+    CAPDEC_HIP(hipMemsetAsync(t.Vo.p, 0, t.n_params * 4, c->stream));
+    return 0;
 }
 
 static int dev_alloc(std::vector<void *> &owned, size_t bytes, float **out) {
@@ -336,24 +465,146 @@ static int prepare_backward_weights(capdec_ctx *c, TrainState &t) {
     return 0;
 }
 
-// C[M, N] = A[M, K] . Bt[N, K]^T (+ resid) on the native fp32 MFMA GEMM
-static int gemm_fp32(capdec_ctx *c, const float *A, int lda, const float *Bt, int ldb, float *C, int ldc, int M, int N, int K,
-                     const float *resid = nullptr, int ldr = 0) {
+// C[M, N] = A[M, K] . Bt[N, K]^T on the native fp32 MFMA GEMM
+static int gemm_fp32(capdec_ctx *c, const float *A, int lda, const float *Bt, int ldb, float *C, int ldc, int M, int N, int K) {
     GemmEpilogue e;
     e.tune = &c->tune;
-    e.resid = resid;
-    e.ldr = ldr;
     ProfScope ps(c, F_GEMM, 2.0 * M * (double)N * K);
     return launch_gemm_f32(c->stream, A, lda, Bt, ldb, C, ldc, M, N, K, e);
 }
 static inline dim3 grid1(size_t n) { return dim3((unsigned)((n + 255) / 256)); }
+static inline int pad32(int n) { return (n + 31) / 32 * 32; }
 
 static int ln_bwd(capdec_ctx *c, const float *x, const float *w, const float *dy, const float *add, float *dx, int rows,
-                  int d, float eps) {
+                  int d, float eps, float *gw = nullptr, float *gb = nullptr) {
     CAPDEC_CHECK(d == 768, "train: LayerNorm backward is instantiated for d = 768");
-    hipLaunchKernelGGL(ln_bwd_dx_kernel<12>, dim3((rows + 3) / 4), dim3(256), 0, c->stream, x, w, dy, add, dx, rows, eps);
+    hipLaunchKernelGGL(ln_bwd_dx_kernel<12>, dim3((rows + 3) / 4), dim3(256), 0, c->stream, x, w, dy, add, dx, rows, eps, gw, gb);
     CAPDEC_HIP(hipGetLastError());
     return 0;
+}
+// dX = dY W for an nn.Linear weight W [out, in] that CHANGES every step: transposed into the scratch `wT` first
+static int linear_dx(capdec_ctx *c, TrainState &t, const float *dy, const float *W, float *dx, int M, int out, int in) {
+    CAPDEC_TRY(t.wT.ensure((size_t)out * in * 4));
+    CAPDEC_TRY(transpose_pad(c, W, out, in, t.wT.as<float>(), out));               // [in][out]
+    return gemm_fp32(c, dy, out, t.wT.as<float>(), out, dx, in, M, in, out);
+}
+// dW = dY^T X ([out, in]; dY [rows, out], X [rows, in]; the GEMM's K = rows, zero-padded to a multiple of 32), db = colsum(dY)
+static int linear_dw(capdec_ctx *c, TrainState &t, const float *dy, const float *x, int rows, int out, int in, float *gW,
+                     float *gb) {
+    const int Kp = pad32(rows);
+    CAPDEC_TRY(t.tA.ensure((size_t)out * Kp * 4));
+    CAPDEC_TRY(t.tB.ensure((size_t)in * Kp * 4));
+    CAPDEC_TRY(transpose_pad(c, dy, rows, out, t.tA.as<float>(), Kp));
+    CAPDEC_TRY(transpose_pad(c, x, rows, in, t.tB.as<float>(), Kp));
+    CAPDEC_TRY(gemm_fp32(c, t.tA.as<float>(), Kp, t.tB.as<float>(), Kp, gW, in, out, in, Kp));
+    if (gb) hipLaunchKernelGGL(colsum_kernel, grid1(out), dim3(256), 0, c->stream, dy, rows, out, gb);
+    CAPDEC_HIP(hipGetLastError());
+    return 0;
+}
+
+// ---- the mapper's forward with everything its backward needs; out = pe [B, P d]
+static int mapper_forward_saved(capdec_ctx *c, TrainState &t, const float *x, int B, float *pe) {
+    Mapper &m = c->map;
+    const int d = m.d, D = m.D, O = m.P * d;
+    hipStream_t st = c->stream;
+    if (m.kind == 1) {
+        const int H = m.hidden;
+        CAPDEC_TRY(t.hid.ensure((size_t)B * H * 4));
+        // (current weights: never the cached planes of an earlier step)
+        CAPDEC_TRY(gemm(c, x, D, m.w1, D, t.hid.as<float>(), H, B, H, D, m.b1, CAPDEC_ACT_TANH, nullptr, 0, false));
+        return gemm(c, t.hid.as<float>(), H, m.w2, H, pe, O, B, O, H, m.b2, CAPDEC_ACT_NONE, nullptr, 0, false);
+    }
+    const int S = m.clip_len + m.P, M = B * S, hd = d / m.heads, hid = m.mlp_hidden, nl = m.n_layers;
+    const size_t Md = (size_t)M * d;
+    CAPDEC_TRY(t.t_lin.ensure((size_t)B * m.clip_len * d * 4));
+    CAPDEC_TRY(t.t_seq.ensure(Md * 4 * (nl + 1)));
+    CAPDEC_TRY(t.t_a1.ensure(Md * 4 * nl));
+    CAPDEC_TRY(t.t_qkv.ensure(Md * 3 * 4 * nl));
+    CAPDEC_TRY(t.t_att.ensure(Md * 4 * nl));
+    CAPDEC_TRY(t.t_mid.ensure(Md * 4 * nl));
+    CAPDEC_TRY(t.t_a2.ensure(Md * 4 * nl));
+    CAPDEC_TRY(t.t_r.ensure((size_t)M * hid * 4 * nl));
+    float *seq = t.t_seq.as<float>();
+    CAPDEC_TRY(gemm(c, x, D, m.lin_w, D, t.t_lin.as<float>(), m.clip_len * d, B, m.clip_len * d, D, m.lin_b, CAPDEC_ACT_NONE,
+                    nullptr, 0, false));
+    { ProfScope ps(c, F_OTHER); CAPDEC_TRY(launch_tmapper_concat(st, t.t_lin.as<float>(), m.prefix_const, seq, B, m.clip_len, m.P, d)); }
+    for (int l = 0; l < nl; ++l) {
+        const TMapLayer &w = m.layers[l];
+        float *h = seq + Md * l, *hn = seq + Md * (l + 1), *a1 = t.t_a1.as<float>() + Md * l, *qkv = t.t_qkv.as<float>() + Md * 3 * l,
+              *att = t.t_att.as<float>() + Md * l, *mid = t.t_mid.as<float>() + Md * l, *a2 = t.t_a2.as<float>() + Md * l,
+              *r = t.t_r.as<float>() + (size_t)M * hid * l;
+        { ProfScope ps(c, F_LN); CAPDEC_TRY(launch_layernorm(st, h, d, w.n1w, w.n1b, 1e-5f, a1, d, M, d)); }
+        CAPDEC_TRY(gemm(c, a1, d, w.wqkv, d, qkv, 3 * d, M, 3 * d, d, nullptr, CAPDEC_ACT_NONE, nullptr, 0, false));
+        { ProfScope ps(c, F_MAP_ATTN); CAPDEC_TRY(launch_attn_mapper(st, qkv, 3 * d, qkv + d, qkv + 2 * d, 3 * d, att, B, S, m.heads, hd)); }
+        CAPDEC_TRY(gemm(c, att, d, w.wproj, d, mid, d, M, d, d, w.bproj, CAPDEC_ACT_NONE, h, d, false));
+        { ProfScope ps(c, F_LN); CAPDEC_TRY(launch_layernorm(st, mid, d, w.n2w, w.n2b, 1e-5f, a2, d, M, d)); }
+        CAPDEC_TRY(gemm(c, a2, d, w.wfc1, d, r, hid, M, hid, d, w.bfc1, CAPDEC_ACT_RELU, nullptr, 0, false));
+        CAPDEC_TRY(gemm(c, r, hid, w.wfc2, hid, hn, d, M, d, hid, w.bfc2, CAPDEC_ACT_NONE, mid, d, false));
+    }
+    ProfScope ps(c, F_OTHER);
+    return launch_tmapper_take(st, seq + Md * nl, pe, B, m.clip_len, m.P, d);
+}
+
+// ---- the mapper's backward: dy [B, P d] = d loss / d pe  ->  every slot's gradient in the arena G
+static int mapper_backward(capdec_ctx *c, TrainState &t, const float *x, const float *dy, int B) {
+    Mapper &m = c->map;
+    const int d = m.d, D = m.D, O = m.P * d;
+    hipStream_t st = c->stream;
+    if (m.kind == 1) {
+        const int H = m.hidden;
+        CAPDEC_TRY(t.dhid.ensure((size_t)B * H * 4));
+        float *hid = t.hid.as<float>(), *dhid = t.dhid.as<float>();
+        CAPDEC_TRY(linear_dw(c, t, dy, hid, B, O, H, t.grad(2), t.grad(3)));
+        CAPDEC_TRY(linear_dx(c, t, dy, m.w2, dhid, B, O, H));
+        hipLaunchKernelGGL(tanh_bwd_kernel, grid1((size_t)B * H), dim3(256), 0, st, hid, dhid, dhid, (size_t)B * H);
+        return linear_dw(c, t, dhid, x, B, H, D, t.grad(0), t.grad(1));
+    }
+    const int S = m.clip_len + m.P, M = B * S, hid = m.mlp_hidden, nl = m.n_layers, HD = d / m.heads;
+    CAPDEC_CHECK(HD == 96 && d == 768, "train: the TransformerMapper backward is instantiated for d = 768, 8 heads of 96");
+    const size_t Md = (size_t)M * d;
+    CAPDEC_TRY(t.t_ds.ensure(Md * 4));
+    CAPDEC_TRY(t.t_ds2.ensure(Md * 4));
+    CAPDEC_TRY(t.t_da.ensure(Md * 4));
+    CAPDEC_TRY(t.t_dr.ensure((size_t)M * hid * 4));
+    CAPDEC_TRY(t.t_dqkv.ensure(Md * 3 * 4));
+    CAPDEC_TRY(t.t_datt.ensure(Md * 4));
+    CAPDEC_TRY(t.t_dlin.ensure((size_t)B * m.clip_len * d * 4));
+    CAPDEC_TRY(t.lse.ensure((size_t)B * m.heads * S * 4));
+    CAPDEC_TRY(t.dsum.ensure((size_t)B * m.heads * S * 4));
+    float *ds = t.t_ds.as<float>(), *ds2 = t.t_ds2.as<float>(), *da = t.t_da.as<float>(), *dr = t.t_dr.as<float>(),
+          *dqkv = t.t_dqkv.as<float>(), *datt = t.t_datt.as<float>(), *dlin = t.t_dlin.as<float>();
+    const float *seq = t.t_seq.as<float>();
+    const float scale = (float)pow((double)HD, -0.5);
+    const int nbh = B * m.heads * S;
+    hipLaunchKernelGGL(tmapper_put_kernel, grid1(Md), dim3(256), 0, st, dy, ds, B, m.clip_len, m.P, d);
+    for (int l = nl - 1; l >= 0; --l) {
+        const TMapLayer &w = m.layers[l];
+        const int s0 = 3 + 12 * l;
+        const float *h = seq + Md * l, *a1 = t.t_a1.as<float>() + Md * l, *qkv = t.t_qkv.as<float>() + Md * 3 * l,
+                    *att = t.t_att.as<float>() + Md * l, *mid = t.t_mid.as<float>() + Md * l, *a2 = t.t_a2.as<float>() + Md * l,
+                    *r = t.t_r.as<float>() + (size_t)M * hid * l;
+        // mlp: out = mid + fc2(relu(fc1(a2)))
+        CAPDEC_TRY(linear_dw(c, t, ds, r, M, d, hid, t.grad(s0 + 10), t.grad(s0 + 11)));
+        CAPDEC_TRY(linear_dx(c, t, ds, w.wfc2, dr, M, d, hid));
+        hipLaunchKernelGGL(relu_bwd_kernel, grid1((size_t)M * hid), dim3(256), 0, st, r, dr, dr, (size_t)M * hid);
+        CAPDEC_TRY(linear_dw(c, t, dr, a2, M, hid, d, t.grad(s0 + 8), t.grad(s0 + 9)));
+        CAPDEC_TRY(linear_dx(c, t, dr, w.wfc1, da, M, hid, d));
+        CAPDEC_TRY(ln_bwd(c, mid, w.n2w, da, ds, ds2, M, d, 1e-5f, t.grad(s0 + 6), t.grad(s0 + 7)));        // ds2 = d mid
+        // attention: mid = h + project(att)
+        CAPDEC_TRY(linear_dw(c, t, ds2, att, M, d, d, t.grad(s0 + 4), t.grad(s0 + 5)));
+        CAPDEC_TRY(linear_dx(c, t, ds2, w.wproj, datt, M, d, d));
+        hipLaunchKernelGGL((attn_bwd_q_kernel<96, false>), dim3((nbh + 3) / 4), dim3(256), (size_t)4 * 2 * S * sizeof(float), st,
+                           qkv, datt, dqkv, t.lse.as<float>(), t.dsum.as<float>(), nbh, S, m.heads, scale);
+        hipLaunchKernelGGL((attn_bwd_kv_kernel<96, false>), dim3((nbh + 3) / 4), dim3(256), 0, st, qkv, datt, dqkv,
+                           t.lse.as<float>(), t.dsum.as<float>(), nbh, S, m.heads, scale);
+        CAPDEC_TRY(linear_dw(c, t, dqkv, a1, M, 3 * d, d, t.grad(s0 + 2), nullptr));      // [to_queries ; to_keys_values]: no bias
+        CAPDEC_TRY(linear_dx(c, t, dqkv, w.wqkv, da, M, 3 * d, d));
+        CAPDEC_TRY(ln_bwd(c, h, w.n1w, da, ds2, ds, M, d, 1e-5f, t.grad(s0 + 0), t.grad(s0 + 1)));          // ds = d h
+    }
+    hipLaunchKernelGGL(tmapper_split_grad_kernel, grid1(std::max((size_t)B * m.clip_len * d, (size_t)m.P * d)), dim3(256), 0, st,
+                       ds, dlin, t.grad(2), B, m.clip_len, m.P, d);
+    CAPDEC_HIP(hipGetLastError());
+    return linear_dw(c, t, dlin, x, B, m.clip_len * d, D, t.grad(0), t.grad(1));
 }
 
 // the whole step; see capdec.h: capdec_train_step
@@ -361,20 +612,20 @@ static int train_step(capdec_ctx *c, const float *prefix, const int *tokens, int
                       float eps, float weight_decay, int apply_update, float *loss_host) {
     const Gpt2 &g = c->gpt;
     Mapper &m = c->map;
-    CAPDEC_CHECK(g.loaded && m.kind == 1, "train_step: needs GPT-2 weights and an MLP mapper (capdec_load_mapper_mlp)");
-    CAPDEC_CHECK(g.d == 768 && g.d / g.n_head == 64, "train_step: d = 768, head_dim = 64");
-    const int d = g.d, P = m.P, S = P + L, R = B * S, Rl = B * L, H = m.hidden, O = P * d, D = m.D;
+    CAPDEC_CHECK(g.loaded && (m.kind == 1 || m.kind == 2), "train_step: needs GPT-2 weights and a mapper");
+    CAPDEC_CHECK(g.d == 768 && g.d / g.n_head == 64 && m.d == g.d, "train_step: d = 768, head_dim = 64");
+    const int d = g.d, P = m.P, S = P + L, R = B * S, Rl = B * L, O = P * d, D = m.D;
     CAPDEC_CHECK(B >= 1 && L >= 1 && S <= 256 && S <= g.n_pos, "train_step: bad batch geometry (prefix_length + L <= 256)");
-    CAPDEC_CHECK(D % 32 == 0 && H % 32 == 0 && O % 32 == 0, "train_step: mapper dims must be multiples of 32");
+    CAPDEC_CHECK(D % 32 == 0 && O % 32 == 0, "train_step: mapper dims must be multiples of 32");
     if (!c->train) c->train = new TrainState();
     TrainState &t = *c->train;
     CAPDEC_TRY(prepare_backward_weights(c, t));
+    CAPDEC_TRY(build_slots(c, t));
     hipStream_t st = c->stream;
-    const int nl = g.n_layer, Vp = t.Vp, Bp = (B + 31) / 32 * 32;
+    const int nl = g.n_layer, Vp = t.Vp;
     const size_t Rd = (size_t)R * d;
     // ---- buffers
-    CAPDEC_TRY(t.hid.ensure((size_t)Bp * H * 4));
-    CAPDEC_TRY(t.pe.ensure((size_t)Bp * O * 4));
+    CAPDEC_TRY(t.pe.ensure((size_t)B * O * 4));
     CAPDEC_TRY(t.emb.ensure(Rd * 4));
     CAPDEC_TRY(t.hs.ensure(Rd * 4 * (nl + 1)));              // block inputs h_0 .. h_nl
     CAPDEC_TRY(t.a.ensure(Rd * 4));
@@ -386,7 +637,7 @@ static int train_step(capdec_ctx *c, const float *prefix, const int *tokens, int
     CAPDEC_TRY(t.hf.ensure(Rd * 4));
     CAPDEC_TRY(t.hfl.ensure((size_t)Rl * d * 4));
     CAPDEC_TRY(t.logits.ensure((size_t)Rl * Vp * 4));
-    CAPDEC_TRY(t.ids.ensure((size_t)(Rl + R) * 4));
+    CAPDEC_TRY(t.ids.ensure((size_t)Rl * 4));
     CAPDEC_TRY(t.rloss.ensure((size_t)Rl * 4));
     CAPDEC_TRY(t.cnt.ensure(16));
     CAPDEC_TRY(t.dh.ensure(Rd * 4));
@@ -398,34 +649,19 @@ static int train_step(capdec_ctx *c, const float *prefix, const int *tokens, int
     CAPDEC_TRY(t.dhfl.ensure((size_t)Rl * d * 4));
     CAPDEC_TRY(t.lse.ensure((size_t)B * g.n_head * S * 4));
     CAPDEC_TRY(t.dsum.ensure((size_t)B * g.n_head * S * 4));
-    CAPDEC_TRY(t.dy.ensure((size_t)Bp * O * 4));
-    CAPDEC_TRY(t.dhid.ensure((size_t)Bp * H * 4));
-    CAPDEC_TRY(t.tmp_t.ensure((size_t)std::max(O, H) * Bp * 4));
-    CAPDEC_TRY(t.tmp_t2.ensure((size_t)std::max(H, D) * Bp * 4));
-    CAPDEC_TRY(t.w2_t.ensure((size_t)O * H * 4));
-    const size_t n_w1 = (size_t)H * D, n_w2 = (size_t)O * H;
-    CAPDEC_TRY(t.g_w1.ensure(n_w1 * 4));
-    CAPDEC_TRY(t.g_b1.ensure((size_t)H * 4));
-    CAPDEC_TRY(t.g_w2.ensure(n_w2 * 4));
-    CAPDEC_TRY(t.g_b2.ensure((size_t)O * 4));
-    float *hid = t.hid.as<float>(), *pe = t.pe.as<float>(), *emb = t.emb.as<float>(), *hs = t.hs.as<float>(),
-          *a = t.a.as<float>(), *gl = t.gl.as<float>(), *hf = t.hf.as<float>(), *hfl = t.hfl.as<float>(),
-          *logits = t.logits.as<float>();
+    CAPDEC_TRY(t.dy.ensure((size_t)B * O * 4));
+    float *pe = t.pe.as<float>(), *emb = t.emb.as<float>(), *hs = t.hs.as<float>(), *a = t.a.as<float>(), *gl = t.gl.as<float>(),
+          *hf = t.hf.as<float>(), *hfl = t.hfl.as<float>(), *logits = t.logits.as<float>();
     int *row_ids = t.ids.as<int>();
     int *cnt = t.cnt.as<int>();
     float *loss_dev = reinterpret_cast<float *>(cnt + 1);
 
-    // ---- forward: mapper (current weights: never the cached planes of an earlier step)
-    CAPDEC_TRY(gemm(c, prefix, D, m.w1, D, hid, H, B, H, D, m.b1, CAPDEC_ACT_TANH, nullptr, 0, false));
-    CAPDEC_TRY(gemm(c, hid, H, m.w2, H, pe, O, B, O, H, m.b2, CAPDEC_ACT_NONE, nullptr, 0, false));
-    // embeds = cat(pe.view(B, P, d), wte(tokens)): built on the host side of this function from two row maps
-    {
-        // rows of `emb`: (b, p < P) <- pe[b, p]; (b, P + t) <- wte[tokens[b, t]]
-        for (int b = 0; b < B; ++b) {
-            CAPDEC_HIP(hipMemcpyAsync(emb + (size_t)(b * S) * d, pe + (size_t)b * O, (size_t)O * 4, hipMemcpyDeviceToDevice, st));
-            ProfScope ps(c, F_EMBED);
-            CAPDEC_TRY(launch_gather_rows(st, g.wte, tokens + (size_t)b * L, emb + (size_t)(b * S + P) * d, L, d));
-        }
+    // ---- forward: mapper, then embeds = cat(pe.view(B, P, d), wte(tokens))
+    CAPDEC_TRY(mapper_forward_saved(c, t, prefix, B, pe));
+    for (int b = 0; b < B; ++b) {
+        CAPDEC_HIP(hipMemcpyAsync(emb + (size_t)(b * S) * d, pe + (size_t)b * O, (size_t)O * 4, hipMemcpyDeviceToDevice, st));
+        ProfScope ps(c, F_EMBED);
+        CAPDEC_TRY(launch_gather_rows(st, g.wte, tokens + (size_t)b * L, emb + (size_t)(b * S + P) * d, L, d));
     }
     { ProfScope ps(c, F_EMBED); CAPDEC_TRY(launch_embed_prefix(st, emb, g.wpe, hs, B, S, 0, d)); }
     KvCache kv;
@@ -482,63 +718,35 @@ static int train_step(capdec_ctx *c, const float *prefix, const int *tokens, int
         CAPDEC_TRY(gemm_fp32(c, dfc, 4 * d, wt.wfc_t, 4 * d, da, d, R, d, 4 * d));                // d a2
         CAPDEC_TRY(ln_bwd(c, hmid, w.ln2w, da, dh, dh2, R, d, g.eps));                            // dh_mid = dh + LN'(..)
         CAPDEC_TRY(gemm_fp32(c, dh2, d, wt.wproj_t, d, datt, d, R, d, d));                        // d att
-        hipLaunchKernelGGL(attn_bwd_q_kernel, dim3((nbh + 3) / 4), dim3(256), (size_t)4 * 2 * S * sizeof(float), st, qkv, datt,
-                           dqkv, t.lse.as<float>(), t.dsum.as<float>(), nbh, S, g.n_head);
-        hipLaunchKernelGGL(attn_bwd_kv_kernel, dim3((nbh + 3) / 4), dim3(256), 0, st, qkv, datt, dqkv, t.lse.as<float>(),
-                           t.dsum.as<float>(), nbh, S, g.n_head);
+        hipLaunchKernelGGL((attn_bwd_q_kernel<64, true>), dim3((nbh + 3) / 4), dim3(256), (size_t)4 * 2 * S * sizeof(float), st, qkv,
+                           datt, dqkv, t.lse.as<float>(), t.dsum.as<float>(), nbh, S, g.n_head, 0.125f);
+        hipLaunchKernelGGL((attn_bwd_kv_kernel<64, true>), dim3((nbh + 3) / 4), dim3(256), 0, st, qkv, datt, dqkv,
+                           t.lse.as<float>(), t.dsum.as<float>(), nbh, S, g.n_head, 0.125f);
         CAPDEC_TRY(gemm_fp32(c, dqkv, 3 * d, wt.wqkv_t, 3 * d, da, d, R, d, 3 * d));              // d a1
         CAPDEC_TRY(ln_bwd(c, h, w.ln1w, da, dh2, dh, R, d, g.eps));                               // dh = dh_mid + LN'(..)
     }
     CAPDEC_HIP(hipGetLastError());
-    // ---- the mapper: dY = d embeds[:, :P] / count  (rows b of [Bp, O]; the padding rows stay zero)
-    float *dy = t.dy.as<float>(), *dhid = t.dhid.as<float>(), *tA = t.tmp_t.as<float>(), *tB = t.tmp_t2.as<float>();
-    CAPDEC_HIP(hipMemsetAsync(dy, 0, (size_t)Bp * O * 4, st));
+    // ---- the mapper: dY = d embeds[:, :P] / count
+    float *dy = t.dy.as<float>();
     for (int b = 0; b < B; ++b)
         CAPDEC_HIP(hipMemcpyAsync(dy + (size_t)b * O, dh + (size_t)(b * S) * d, (size_t)O * 4, hipMemcpyDeviceToDevice, st));
     hipLaunchKernelGGL(scale_by_count_kernel, grid1((size_t)B * O), dim3(256), 0, st, dy, (size_t)B * O, cnt);
-    // d W2 = dY^T hid  ([O, H], K = batch), d b2 = colsum(dY)
-    if (Bp > B) CAPDEC_HIP(hipMemsetAsync(hid + (size_t)B * H, 0, (size_t)(Bp - B) * H * 4, st));
-    CAPDEC_TRY(transpose_pad(c, dy, Bp, O, tA, Bp));                                             // [O, Bp]
-    CAPDEC_TRY(transpose_pad(c, hid, Bp, H, tB, Bp));                                            // [H, Bp]
-    CAPDEC_TRY(gemm_fp32(c, tA, Bp, tB, Bp, t.g_w2.as<float>(), H, O, H, Bp));
-    hipLaunchKernelGGL(colsum_kernel, grid1(O), dim3(256), 0, st, dy, B, O, t.g_b2.as<float>());
-    // d hid = dY W2 (W2 [O, H]: the "[N, K]" operand is W2^T [H, O]); d pre-tanh = d hid (1 - hid^2)
-    CAPDEC_TRY(transpose_pad(c, m.w2, O, H, t.w2_t.as<float>(), O));                              // [H, O]
-    CAPDEC_TRY(gemm_fp32(c, dy, O, t.w2_t.as<float>(), O, dhid, H, Bp, H, O));
-    hipLaunchKernelGGL(tanh_bwd_kernel, grid1((size_t)Bp * H), dim3(256), 0, st, hid, dhid, dhid, (size_t)Bp * H);
-    // d W1 = d pre^T x  ([H, D]), d b1 = colsum
-    CAPDEC_TRY(transpose_pad(c, dhid, Bp, H, tA, Bp));                                           // [H, Bp]
-    CAPDEC_TRY(transpose_pad(c, prefix, B, D, tB, Bp));                                          // [D, Bp] (zero padded)
-    CAPDEC_TRY(gemm_fp32(c, tA, Bp, tB, Bp, t.g_w1.as<float>(), D, H, D, Bp));
-    hipLaunchKernelGGL(colsum_kernel, grid1(H), dim3(256), 0, st, dhid, B, H, t.g_b1.as<float>());
+    CAPDEC_HIP(hipMemsetAsync(t.G.p, 0, t.n_params * 4, st));       // (the LayerNorm weight gradients are accumulated)
+    CAPDEC_TRY(mapper_backward(c, t, prefix, dy, B));
     CAPDEC_HIP(hipGetLastError());
     t.have_grads = true;
     // ---- AdamW (transformers 4.24 semantics)
     if (apply_update) {
-        const size_t sizes[4] = {n_w1, (size_t)H, n_w2, (size_t)O};
-        DBuf *ms[4] = {&t.m_w1, &t.m_b1, &t.m_w2, &t.m_b2}, *vs[4] = {&t.v_w1, &t.v_b1, &t.v_w2, &t.v_b2};
-        DBuf *gs[4] = {&t.g_w1, &t.g_b1, &t.g_w2, &t.g_b2};
-        float *ps[4] = {m.w1, m.b1, m.w2, m.b2};
         const double tt = (double)(t.step + 1);
         const float step_size = (float)((double)lr * std::sqrt(1.0 - std::pow((double)b2, tt)) / (1.0 - std::pow((double)b1, tt)));
-        for (int k = 0; k < 4; ++k) {
-            if (ms[k]->cap < sizes[k] * 4) {                       // first update: zero moments
-                CAPDEC_TRY(ms[k]->ensure(sizes[k] * 4));
-                CAPDEC_TRY(vs[k]->ensure(sizes[k] * 4));
-                CAPDEC_HIP(hipMemsetAsync(ms[k]->p, 0, sizes[k] * 4, st));
-                CAPDEC_HIP(hipMemsetAsync(vs[k]->p, 0, sizes[k] * 4, st));
-            }
-            hipLaunchKernelGGL(adamw_kernel, grid1(sizes[k]), dim3(256), 0, st, ps[k], gs[k]->as<float>(), ms[k]->as<float>(),
-                               vs[k]->as<float>(), sizes[k], step_size, b1, b2, eps, lr * weight_decay);
-        }
+        for (const Slot &sl : t.slots)
+            hipLaunchKernelGGL(adamw_kernel, grid1(sl.n), dim3(256), 0, st, sl.p, t.G.as<float>() + sl.off, t.Mo.as<float>() + sl.off,
+                               t.Vo.as<float>() + sl.off, sl.n, step_size, b1, b2, eps, lr * weight_decay);
         CAPDEC_HIP(hipGetLastError());
         t.step += 1;
-        drop_planes_of(c, m.w1);              // inference must never see planes packed from the old weights
-        drop_planes_of(c, m.w2);
+        for (const Slot &sl : t.slots) drop_planes_of(c, sl.p);      // inference must never see planes packed from old values
     }
-    if (loss_host) {
-        CAPDEC_HIP(hipMemcpyAsync(loss_host, loss_dev, sizeof(float), hipMemcpyDeviceToHost, st));
-    }
+    if (loss_host) CAPDEC_HIP(hipMemcpyAsync(loss_host, loss_dev, sizeof(float), hipMemcpyDeviceToHost, st));
     CAPDEC_HIP(hipStreamSynchronize(st));
     return 0;
 }
@@ -556,35 +764,18 @@ int capdec_train_step(capdec_ctx *c, const float *d_prefix, const int32_t *d_tok
     return train_step(c, d_prefix, d_tokens, batch, length, lr, beta1, beta2, eps, weight_decay, apply_update, loss);
 }
 
-// which: 0 model.0.weight [hidden, D], 1 model.0.bias, 2 model.2.weight [P d, hidden], 3 model.2.bias
-static int mapper_tensor(capdec_ctx *c, int which, float **p, size_t *n) {
-    Mapper &m = c->map;
-    CAPDEC_CHECK(m.kind == 1, "train: MLP mapper not loaded");
-    const size_t O = (size_t)m.P * m.d;
-    switch (which) {
-        case 0: *p = m.w1; *n = (size_t)m.hidden * m.D; return 0;
-        case 1: *p = m.b1; *n = (size_t)m.hidden; return 0;
-        case 2: *p = m.w2; *n = O * m.hidden; return 0;
-        case 3: *p = m.b2; *n = O; return 0;
-        default: CAPDEC_CHECK(false, "train: tensor index must be 0..3");
-    }
-}
-
 int capdec_train_get(capdec_ctx *c, int kind, int which, float *d_out, size_t n) {
     CAPDEC_CHECK(c && d_out, "train_get: null argument");
+    CAPDEC_CHECK(c->gpt.loaded && (c->map.kind == 1 || c->map.kind == 2), "train_get: needs GPT-2 weights and a mapper");
+    CAPDEC_CHECK(kind == 0 || kind == 1, "train_get: kind must be 0 (parameter) or 1 (gradient)");
     CAPDEC_HIP(hipSetDevice(c->device));
-    float *p = nullptr;
-    size_t cnt = 0;
-    CAPDEC_TRY(mapper_tensor(c, which, &p, &cnt));
-    CAPDEC_CHECK(n == cnt, "train_get: wrong element count");
-    const void *src = p;
-    if (kind == 1) {
-        CAPDEC_CHECK(c->train && c->train->have_grads, "train_get: no gradients yet (run capdec_train_step)");
-        DBuf *gs[4] = {&c->train->g_w1, &c->train->g_b1, &c->train->g_w2, &c->train->g_b2};
-        src = gs[which]->p;
-    } else {
-        CAPDEC_CHECK(kind == 0, "train_get: kind must be 0 (parameter) or 1 (gradient)");
-    }
+    if (!c->train) c->train = new TrainState();
+    TrainState &t = *c->train;
+    CAPDEC_TRY(build_slots(c, t));
+    CAPDEC_CHECK(which >= 0 && which < (int)t.slots.size(), "train_get: tensor index out of range");
+    CAPDEC_CHECK(n == t.slots[which].n, "train_get: wrong element count");
+    CAPDEC_CHECK(kind == 0 || t.have_grads, "train_get: no gradients yet (run capdec_train_step)");
+    const void *src = kind == 0 ? (const void *)t.slots[which].p : (const void *)t.grad(which);
     CAPDEC_HIP(hipMemcpyAsync(d_out, src, n * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
     CAPDEC_HIP(hipStreamSynchronize(c->stream));
     return 0;

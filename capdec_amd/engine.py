@@ -478,11 +478,22 @@ class Engine:
         return dict(kv_slots_per_position=kv.value, saturated_quads=sat.value)
 
     # ---- the train step with a frozen GPT-2 (reference train.py:344-354 with --only_prefix)
-    _TRAIN_TENSORS = ("model.0.weight", "model.0.bias", "model.2.weight", "model.2.bias")
+    @staticmethod
+    def train_tensor_names(mapping: str, num_layers: int = 8):
+        """the mapper's trainable tensors in the order capdec_train_get indexes them (names as in ``clip_project.state_dict()``)"""
+        if mapping == "mlp":
+            return ["model.0.weight", "model.0.bias", "model.2.weight", "model.2.bias"]
+        names = ["linear.weight", "linear.bias", "prefix_const"]
+        for i in range(num_layers):
+            names += [f"transformer.layers.{i}.{n}" for n in (
+                "norm1.weight", "norm1.bias", "attn.to_queries.weight", "attn.to_keys_values.weight", "attn.project.weight",
+                "attn.project.bias", "norm2.weight", "norm2.bias", "mlp.fc1.weight", "mlp.fc1.bias", "mlp.fc2.weight",
+                "mlp.fc2.bias")]
+        return names
 
     def train_step(self, prefix: torch.Tensor, tokens: torch.Tensor, lr: float, betas=(0.9, 0.999), eps: float = 1e-6,
                    weight_decay: float = 0.0, apply_update: bool = True) -> float:
-        """one iteration on the device-resident MLP mapper (capdec_train_step): ``prefix`` [B, D] AFTER noise injection,
+        """one iteration on the device-resident mapper (capdec_train_step): ``prefix`` [B, D] AFTER noise injection,
         ``tokens`` [B, L] right-padded with 0; returns the loss of train.py:349"""
         x = prefix.to(self.device, torch.float32).contiguous()
         tok = tokens.to(self.device, torch.int32).contiguous()
@@ -495,8 +506,9 @@ class Engine:
         return float(loss.value)
 
     def _train_get(self, kind: int, shapes) -> Dict[str, torch.Tensor]:
+        """``shapes``: ordered {name: shape} in the order of train_tensor_names"""
         out = {}
-        for i, name in enumerate(self._TRAIN_TENSORS):
+        for i, name in enumerate(shapes):
             t = torch.empty(shapes[name], device=self.device, dtype=torch.float32)
             self._chk(self.lib.capdec_train_get(self._h, kind, i, t.data_ptr(), t.numel()), "train_get")
             out[name] = t

@@ -182,7 +182,14 @@ class ClipCaptionModel(_HipModule):
     _device_ahead = False
 
     def _mapper_shapes(self):
-        return {k: tuple(v.shape) for k, v in self.clip_project._sd.items()}
+        """ordered {name: shape} of the mapper's trainable tensors, in the device's slot order"""
+        mlp = self.mapping_type == MappingType.MLP
+        names = Engine.train_tensor_names("mlp" if mlp else "transformer", self.num_layers)
+        sd = self.clip_project._sd
+        missing = [n for n in names if n not in sd]
+        if missing or len(names) != len(sd):
+            raise CapdecError(f"mapper state dict does not match its trainable tensors: {missing or sorted(set(sd) - set(names))}")
+        return OrderedDict((n, tuple(sd[n].shape)) for n in names)
 
     def _pull_mapper(self):
         if not self._device_ahead or self._engine is None:

@@ -1,8 +1,8 @@
 """Drop-in surface of reference ``train.py``: ``noise_injection`` (:27-39), ``get_uniform_ball_noise`` (:18-24),
 ``MappingType`` (:42-44), the ``ClipCaptionModel`` ctor spelling with ``prefix_size`` (:262), and the train loop of
-:317-392 for the FROZEN-GPT-2 configuration (``--only_prefix``: ``ClipCaptionPrefix`` with an MLP mapper): ``AdamW``,
+:317-392 for the FROZEN-GPT-2 configuration (``--only_prefix``: ``ClipCaptionPrefix`` with either mapper): ``AdamW``,
 ``get_linear_schedule_with_warmup``, ``train_step`` (= :345-353 as one device call) and ``train``.  Training GPT-2 itself
-(the default ``ClipCaptionModel`` run, with dropout) and the TransformerMapper's backward are not implemented."""
+(the default ``ClipCaptionModel`` run, with dropout) is not implemented."""
 from __future__ import annotations
 
 import math
@@ -118,8 +118,8 @@ def train_step(model: ClipCaptionModel, optimizer: AdamW, tokens: torch.Tensor, 
     optimizer.zero_grad()`` -- as ONE device call (capdec_train_step); returns ``loss.item()``.  ``prefix`` is the batch
     after ``noise_injection`` (:347); the caller steps the scheduler afterwards (:352), as the reference does.
     ``mask`` must be the dataset's right-padding mask (or None): see ClipCaptionModel.forward."""
-    if not isinstance(model, ClipCaptionPrefix) or model.mapping_type != MappingType.MLP:
-        raise CapdecError("train_step: implemented for ClipCaptionPrefix (frozen GPT-2, --only_prefix) with an MLP mapper")
+    if not isinstance(model, ClipCaptionPrefix):
+        raise CapdecError("train_step: implemented for ClipCaptionPrefix (frozen GPT-2: the reference's --only_prefix)")
     tokens = tokens.to(torch.device("cuda", model._device_index))
     if mask is not None:
         m = mask.to(tokens.device) > 0

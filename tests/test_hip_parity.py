@@ -375,23 +375,27 @@ def test_train_step_forward_vs_reference_golden(golden, dims, tag):
         model(tokens, prefix, bad)
 
 
-@pytest.mark.parametrize("dims,tag", [(synth.GPT2_TINY, "tiny"), (synth.GPT2_SMALL, "small")], ids=["tiny", "small"])
-def test_train_step_frozen_gpt2_vs_reference_golden(golden, dims, tag):
+@pytest.mark.parametrize("dims,tag,mapping,nlay", [(synth.GPT2_TINY, "tiny", "mlp", 8), (synth.GPT2_SMALL, "small", "mlp", 8),
+                                                   (synth.GPT2_TINY, "tm_tiny", "transformer_encoder", 3)],
+                         ids=["mlp_tiny", "mlp_small", "transformer_mapper_tiny"])
+def test_train_step_frozen_gpt2_vs_reference_golden(golden, dims, tag, mapping, nlay):
     """The train step with a frozen GPT-2 (reference train.py:344-354 with --only_prefix; capdec_train_step): four
     consecutive iterations on the batches of tests/golden/train_step_*.npz -- the loss of every iteration, EVERY mapper
-    gradient of every iteration against what the reference's own loss.backward() left in .grad (each taken at the weights
-    the previous updates produced), the lr sequence, and the weights after the four AdamW updates (the update rule itself
-    is the restated transformers-4.24 AdamW: oracle/capdec_oracle.py adamw_transformers).  Then the trained mapper is
-    what inference uses.  Tolerances: loss 3e-4; gradients 3e-3 relative to the tensor's largest entry... (subsample of
-    4096 entries per tensor + the norm within 2e-3); final weights 5e-5 abs."""
+    gradient of every iteration (MLP: 4 tensors; TransformerMapper with three layers: 39) against what the reference's own
+    loss.backward() left in .grad (each taken at the weights the previous updates produced), the lr sequence, and the
+    weights after the four AdamW updates (the update rule itself is the restated transformers-4.24 AdamW:
+    oracle/capdec_oracle.py adamw_transformers).  Then the trained mapper is what inference uses.  Tolerances: loss 3e-4;
+    gradients 3e-3 of the tensor's largest entry on a 4096-entry subsample (TransformerMapper, last iteration: 5e-2 --
+    fp32 round-off amplified by two Adam updates, see tests/test_oracle_vs_golden.py) + the norm within 2e-3; final
+    weights 5e-5 abs."""
     from capdec_amd import train as Tr
     from capdec_amd.gpt2_prefix import ClipCaptionPrefix, MappingType
     from oracle import capdec_oracle as O
     g = golden(f"train_step_{tag}")
-    sd = synth.hot_state_dict(42, "mlp", 512, 10, dims=dims)
+    sd = synth.hot_state_dict(42, mapping, 512, 10, 10, nlay, dims)
     assert synth.state_dict_checksum(sd) == int(g["sd_crc"]), "RNG drift"
-    model = ClipCaptionPrefix(10, clip_length=10, prefix_size=512, num_layers=8, mapping_type=MappingType.MLP,
-                              gpt2_dims=dims).to("cuda:0")
+    mt = MappingType.MLP if mapping == "mlp" else MappingType.TransformerEncoder
+    model = ClipCaptionPrefix(10, clip_length=10, prefix_size=512, num_layers=nlay, mapping_type=mt, gpt2_dims=dims).to("cuda:0")
     model.load_state_dict(sd)
     model.train()
     opt = Tr.AdamW(model.parameters(), lr=float(g["lr"]))
@@ -403,13 +407,15 @@ def test_train_step_frozen_gpt2_vs_reference_golden(golden, dims, tag):
         loss = Tr.train_step(model, opt, tokens, mask, prefix)
         assert abs(loss - float(g["losses"][it])) < 3e-4, (it, loss, float(g["losses"][it]))
         grads = Tr.mapper_gradients(model)
+        assert len(grads) == len(names)
+        loose = mapping != "mlp" and it >= 3
         for k in names:
             gk = grads[k[len("clip_project."):]].cpu()
             flat = gk.flatten()
             sub = flat[::max(1, flat.numel() // 4096)].numpy()
             ref = g[f"grad_{it}_{k}_sub"]
             scale = float(np.abs(ref).max())
-            np.testing.assert_allclose(sub, ref, atol=3e-3 * scale + 1e-9, rtol=0, err_msg=f"iteration {it}, {k}")
+            np.testing.assert_allclose(sub, ref, atol=(5e-2 if loose else 3e-3) * scale + 1e-9, rtol=0, err_msg=f"iteration {it}, {k}")
             assert abs(float(gk.double().norm()) / float(g[f"grad_{it}_{k}_norm"]) - 1.0) < 2e-3, (it, k)
         sched.step()
     fin = model.state_dict()
@@ -418,8 +424,8 @@ def test_train_step_frozen_gpt2_vs_reference_golden(golden, dims, tag):
         np.testing.assert_allclose(flat[::max(1, flat.numel() // 4096)].numpy(), g[f"final_{k}_sub"], atol=5e-5, err_msg=k)
     # the trained mapper is the one inference runs
     x = T(g["prefix_0"])
-    want = O.mlp_mapper(x, {k: fin[k] for k in names})
-    np.testing.assert_allclose(model.clip_project(x).cpu().numpy(), want.numpy(), atol=2e-4)
+    want = O.clip_project(x, {k: fin[k] for k in names}, mapping, 10, 10, nlay)
+    np.testing.assert_allclose(model.clip_project(x).cpu().numpy().reshape(want.shape), want.numpy(), atol=2e-4)
     # a real token under a zero mask is refused (the reference's attention would hide what its loss reads)
     bad = T(g["mask_0"]).clone()
     bad[0, 10] = 0
