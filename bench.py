@@ -282,6 +282,74 @@ def side_workload(args, world, rank, dev, emit=print):
                                      "gemm_mode": model.engine.gemm_mode()}}))
 
 
+def train_workload(args, world, rank, dev, emit=print):
+    """Side workload: the train step with a frozen GPT-2 (reference train.py:344-354 with --only_prefix) at the
+    reference's default geometry -- batch 34 (train.py:411), prefix_length = prefix_length_clip = 40, TransformerMapper with
+    8 layers on 640-d (RN50x4) embeddings, 20 caption tokens per sample.  A "step" = noise injection + forward + loss +
+    backward + AdamW + scheduler for one batch.  Data parallelism over ranks would need a gradient all-reduce that this
+    path does not have: N = 1 only.  The CPU leg times the oracle's hand-written step (torch CPU ops) on the same batch."""
+    from capdec_amd import train as Tr
+    from capdec_amd.gpt2_prefix import ClipCaptionPrefix, MappingType
+    if world != 1:
+        raise SystemExit("bench.py --workload train_step: one GPU only (no gradient all-reduce on this path)")
+    P, D, B, L, nlay = 40, 640, args.train_batch, 20, 8
+    sd = synth.hot_state_dict(42, "transformer_encoder", D, P, P, nlay)
+    model = ClipCaptionPrefix(P, clip_length=P, prefix_size=D, num_layers=nlay, mapping_type=MappingType.TransformerEncoder).to(dev)
+    model.load_state_dict(sd)
+    model.train()
+    g = torch.Generator().manual_seed(9)
+    tokens = torch.randint(1, synth.GPT2_SMALL.vocab, (B, L), generator=g)
+    lens = torch.randint(8, L + 1, (B,), generator=g)
+    lens[0] = L
+    tokens[torch.arange(L)[None, :] >= lens[:, None]] = 0           # right padding, as train.ClipCocoDataset pads
+    mask = torch.cat((torch.ones(B, P), (tokens != 0).float()), dim=1)
+    prefix = synth.synthetic_clip_embeddings(B, D, seed=6).to(dev)
+    opt = Tr.AdamW(model.parameters(), lr=2e-5)
+    sched = Tr.get_linear_schedule_with_warmup(opt, 5000, 10 * 16000)
+    eng = model.engine
+
+    def step():
+        x = Tr.noise_injection(prefix, 0.016, seed=11)
+        loss = Tr.train_step(model, opt, tokens, mask, x)
+        sched.step()
+        return loss
+
+    for _ in range(args.warmup):
+        step()
+    eng.profile_enable(1)
+    eng.profile_reset()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    losses = [step() for _ in range(args.steps)]
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    prof = eng.profile_get()
+    eng.profile_enable(False)
+    cpu = None
+    if args.cpu_seconds > 0:
+        from oracle import capdec_oracle as O
+        torch.set_num_threads(min(16, os.cpu_count() or 1))
+        x_cpu = prefix.cpu()
+        t1 = time.perf_counter()
+        n_cpu = 0
+        while n_cpu < 1 or (time.perf_counter() - t1 < args.cpu_seconds and n_cpu < 3):
+            O.train_step_loss_and_grads(sd, tokens, x_cpu, "transformer_encoder", P, clip_length=P, num_layers=nlay)
+            n_cpu += 1
+        cdt = time.perf_counter() - t1
+        cpu = {"value": round(n_cpu / cdt, 4), "unit": "steps/s", "cores": torch.get_num_threads(), "kind": "port",
+               "sample": f"{n_cpu} step(s) of the oracle's hand-written forward + backward (no optimizer update) on the same batch, "
+                         f"{cdt:.1f} s wall"}
+    emit(json.dumps({"metric": "train steps/sec, side workload train_step (frozen GPT-2, reference train.py:344-354 --only_prefix)",
+                     "value": round(args.steps / dt, 3), "unit": "steps/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+                     "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True, "dtype": "f32", "data": "synthetic",
+                     "samples_per_s": round(B * args.steps / dt, 1), "loss_first_last": [round(losses[0], 4), round(losses[-1], 4)],
+                     "kernels": {k: {"ms_per_step": round(v["ms"] / args.steps, 3), "launches_per_step": round(v["calls"] / args.steps, 1)}
+                                 for k, v in prof.items() if v["launches"]},
+                     "config": {"workload": "train_step", "batch": B, "prefix_length": P, "caption_tokens": L, "mapper": "transformer, 8 layers, 640-d",
+                                "gpt2": "small, frozen", "optimizer": "AdamW (transformers 4.24 semantics), linear warm-up"},
+                     "cpu_baseline": cpu}))
+
+
 class Watchdog:
     """Every rank of a multi-GPU run carries one: if the run is still going after `limit_s` seconds the rank says WHERE it
     is stuck on stderr and exits with status 3 (torchrun then takes the other ranks down) -- an unattended 8-GPU run must
@@ -394,7 +462,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", choices=["beam_transformer", "greedy_mlp", "text_embed", "image_beam"],
+    ap.add_argument("--train-batch", type=int, default=34, help="--workload train_step: samples per batch (reference train.py:411)")
+    ap.add_argument("--workload", choices=["beam_transformer", "greedy_mlp", "text_embed", "image_beam", "train_step"],
                     default="beam_transformer",
                     help="beam_transformer = BASELINE metric config (default); greedy_mlp = configs[1] shape; "
                          "text_embed = configs[3] (CLIP ViT-B/32 encode_text + noise + mapper); "
@@ -474,6 +543,8 @@ def main():
 
     if args.workload in ("text_embed", "image_beam"):
         return side_workload(args, world, rank, dev, emit)
+    if args.workload == "train_step":
+        return train_workload(args, world, rank, dev, emit)
     beam = args.workload == "beam_transformer"
     mapper = "transformer_encoder" if beam else "mlp"
     P, T, B = args.prefix_length, args.entry_length, (5 if beam else 1)
