@@ -77,18 +77,42 @@ __global__ void tmapper_split_grad_kernel(const float *__restrict__ dseq, float 
         gpc[i] = a;
     }
 }
-// x[i] *= 1 / *count   (count > 0)
-__global__ void scale_by_count_kernel(float *x, size_t n, const int *__restrict__ count) {
+// Row maps of the step's sequences (S = P + L positions per sample, d4 = d / 4 float4 per row):
+// embeds[(b, s)] = s < P ? pe[b, s] : wte[tokens[b, s - P]]
+__global__ void build_embeds_kernel(const float *__restrict__ pe, const float *__restrict__ wte, const int *__restrict__ tokens,
+                                    float *__restrict__ emb, int B, int P, int L, int d4) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) x[i] = x[i] / (float)max(*count, 1);
+    const int S = P + L;
+    if (i >= (size_t)B * S * d4) return;
+    const int c = (int)(i % d4), s_ = (int)((i / d4) % S), b = (int)(i / ((size_t)d4 * S));
+    const float4 *src = s_ < P ? reinterpret_cast<const float4 *>(pe) + ((size_t)b * P + s_) * d4
+                               : reinterpret_cast<const float4 *>(wte) + (size_t)tokens[(size_t)b * L + (s_ - P)] * d4;
+    reinterpret_cast<float4 *>(emb)[i] = src[c];
 }
-// out[ids[r]] = in[r]   (rows of d floats, d % 4 == 0)
-__global__ void scatter_rows_kernel(const float *__restrict__ in, const int *__restrict__ ids, float *__restrict__ out,
-                                    int rows, int d4) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= rows * d4) return;
-    const int r = i / d4, c = i - r * d4;
-    reinterpret_cast<float4 *>(out)[(size_t)ids[r] * d4 + c] = reinterpret_cast<const float4 *>(in)[i];
+// the rows the loss reads, logits[:, P-1:-1]: out[(b, t)] = in[(b, P - 1 + t)]
+__global__ void take_loss_rows_kernel(const float *__restrict__ in, float *__restrict__ out, int B, int P, int L, int d4) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)B * L * d4) return;
+    const int c = (int)(i % d4), t_ = (int)((i / d4) % L), b = (int)(i / ((size_t)d4 * L));
+    reinterpret_cast<float4 *>(out)[i] = reinterpret_cast<const float4 *>(in)[((size_t)b * (P + L) + P - 1 + t_) * d4 + c];
+}
+// its transpose: out[(b, s)] = (P - 1 <= s < P - 1 + L) ? in[(b, s - P + 1)] : 0
+__global__ void put_loss_rows_kernel(const float *__restrict__ in, float *__restrict__ out, int B, int P, int L, int d4) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int S = P + L;
+    if (i >= (size_t)B * S * d4) return;
+    const int c = (int)(i % d4), s_ = (int)((i / d4) % S), b = (int)(i / ((size_t)d4 * S));
+    const int t_ = s_ - (P - 1);
+    reinterpret_cast<float4 *>(out)[i] = (t_ >= 0 && t_ < L) ? reinterpret_cast<const float4 *>(in)[((size_t)b * L + t_) * d4 + c]
+                                                             : make_float4(0.f, 0.f, 0.f, 0.f);
+}
+// d pe[b, p] = d embeds[(b, p)] / *count   (the mapper's output gradient, normalised by the number of scored labels)
+__global__ void take_prefix_grad_kernel(const float *__restrict__ dh, float *__restrict__ dy, int B, int P, int L, int d,
+                                        const int *__restrict__ count) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)B * P * d) return;
+    const int c = (int)(i % d), p_ = (int)((i / d) % P), b = (int)(i / ((size_t)d * P));
+    dy[i] = dh[((size_t)b * (P + L) + p_) * d + c] / (float)max(*count, 1);
 }
 // dst[c][r] = src[r][c] for r < rows, 0 for rows <= r < ld   (dst [cols][ld])
 __global__ void transpose_pad_kernel(const float *__restrict__ src, int rows, int cols, float *__restrict__ dst, int ld) {
@@ -105,13 +129,23 @@ __global__ void transpose_pad_kernel(const float *__restrict__ src, int rows, in
         if (c < cols && r < ld) dst[(size_t)c * ld + r] = tile[tx][k];
     }
 }
-// out[j] = sum over rows of x[r][j]
+// out[j] += sum over rows of x[r][j]: block (x, y) sums rows [64 y, 64 y + 64) of 256 columns and adds its partial sum
+// atomically (`out` is zeroed by the caller: the gradient arena is cleared once per step)
+constexpr int COLSUM_ROWS = 64;
 __global__ void colsum_kernel(const float *__restrict__ x, int rows, int n, float *__restrict__ out) {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= n) return;
-    float s = 0.f;
-    for (int r = 0; r < rows; ++r) s += x[(size_t)r * n + j];
-    out[j] = s;
+    const int r0 = blockIdx.y * COLSUM_ROWS, r1 = min(rows, r0 + COLSUM_ROWS);
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int r = r0;
+    for (; r + 3 < r1; r += 4) {
+        s0 += x[(size_t)r * n + j];
+        s1 += x[(size_t)(r + 1) * n + j];
+        s2 += x[(size_t)(r + 2) * n + j];
+        s3 += x[(size_t)(r + 3) * n + j];
+    }
+    for (; r < r1; ++r) s0 += x[(size_t)r * n + j];
+    atomicAdd(out + j, (s0 + s1) + (s2 + s3));
 }
 // transformers-4.24 AdamW (optimization.py AdamW.step): m, v updated in place; p -= step_size * m / (sqrt(v) + eps);
 // then p -= decay * p (decay = lr * weight_decay, 0 by default).  step_size = lr * sqrt(1 - b2^t) / (1 - b1^t) (host)
@@ -131,12 +165,11 @@ __global__ void adamw_kernel(float *__restrict__ p, const float *__restrict__ g,
 
 // ---------------------------------------------------------------------------------------------- LayerNorm backward
 // dx = add + rstd (g - mean(g) - xhat mean(g xhat)), g = dy w; one wavefront per row, d = 64 * NPL
-// (gw / gb != nullptr: the LayerNorm's own weight / bias gradients are accumulated too -- sum over rows of dy xhat and of
-//  dy, by atomic adds into buffers the caller zeroed)
+// (stats != nullptr: the row's (mean, rstd) are kept for ln_param_grad_kernel)
 template <int NPL>
 __global__ __launch_bounds__(256) void ln_bwd_dx_kernel(const float *__restrict__ x, const float *__restrict__ w,
                                                         const float *__restrict__ dy, const float *add, float *dx,
-                                                        int rows, float eps, float *gw = nullptr, float *gb = nullptr) {
+                                                        int rows, float eps, float2 *stats = nullptr) {
     constexpr int d = 64 * NPL;
     const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -154,12 +187,7 @@ __global__ __launch_bounds__(256) void ln_bwd_dx_kernel(const float *__restrict_
 #pragma unroll
     for (int k = 0; k < NPL; ++k) {
         xv[k] *= rstd;                                       // xhat
-        const float dyk = dyr[lane + 64 * k];
-        if (gw) {
-            atomicAdd(gw + lane + 64 * k, dyk * xv[k]);
-            atomicAdd(gb + lane + 64 * k, dyk);
-        }
-        gv[k] = dyk * w[lane + 64 * k];
+        gv[k] = dyr[lane + 64 * k] * w[lane + 64 * k];
         sg += gv[k];
         sgx += gv[k] * xv[k];
     }
@@ -168,6 +196,31 @@ __global__ __launch_bounds__(256) void ln_bwd_dx_kernel(const float *__restrict_
     for (int k = 0; k < NPL; ++k) {
         const float r = rstd * (gv[k] - mg - xv[k] * mgx);
         dx[(size_t)row * d + lane + 64 * k] = add ? add[(size_t)row * d + lane + 64 * k] + r : r;
+    }
+    if (stats && lane == 0) stats[row] = make_float2(mu, rstd);
+}
+// the LayerNorm's own gradients: gw[c] += sum_r dy[r, c] (x[r, c] - mean_r) rstd_r, gb[c] += sum_r dy[r, c].  Block (x, y):
+// 64 columns x rows [128 y, 128 y + 128), four row lanes per column reduced through LDS, one atomic add per column
+__global__ __launch_bounds__(256) void ln_param_grad_kernel(const float *__restrict__ x, const float *__restrict__ dy,
+                                                            const float2 *__restrict__ stats, int rows, int d,
+                                                            float *__restrict__ gw, float *__restrict__ gb) {
+    __shared__ float sw[4][64], sb[4][64];
+    const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6, c = blockIdx.x * 64 + cl;
+    const int r0 = blockIdx.y * 128, r1 = min(rows, r0 + 128);
+    float a = 0.f, b = 0.f;
+    if (c < d)
+        for (int r = r0 + rl; r < r1; r += 4) {
+            const float2 st = stats[r];
+            const float g = dy[(size_t)r * d + c];
+            a += g * (x[(size_t)r * d + c] - st.x) * st.y;
+            b += g;
+        }
+    sw[rl][cl] = a;
+    sb[rl][cl] = b;
+    __syncthreads();
+    if (rl == 0 && c < d) {
+        atomicAdd(gw + c, (sw[0][cl] + sw[1][cl]) + (sw[2][cl] + sw[3][cl]));
+        atomicAdd(gb + c, (sb[0][cl] + sb[1][cl]) + (sb[2][cl] + sb[3][cl]));
     }
 }
 
@@ -363,8 +416,8 @@ struct TrainState {
     size_t n_params = 0;
     DBuf G, Mo, Vo;
     // saved activations + gradient scratch (grow-only)
-    DBuf pe, emb, hs, a, qkv, att, hmid, fc, gl, hf, hfl, logits, ids, rloss, cnt;
-    DBuf dh, dh2, da, dqkv, datt, dfc, dhfl, lse, dsum, dy, tA, tB, wT;
+    DBuf pe, emb, hs, a, qkv, att, hmid, fc, gl, hf, hfl, logits, rloss, cnt;
+    DBuf dh, dh2, da, dqkv, datt, dfc, dhfl, lse, dsum, dy, tA, tB, wT, lnstat;
     DBuf hid, dhid;                          // MLP mapper: tanh output, its gradient
     DBuf t_lin, t_seq, t_a1, t_qkv, t_att, t_mid, t_a2, t_r;      // TransformerMapper: per-layer saved activations
     DBuf t_ds, t_ds2, t_da, t_dr, t_dqkv, t_datt, t_dlin;         // ... gradient scratch
@@ -377,8 +430,8 @@ struct TrainState {
         slots.clear();
         wte_t = nullptr;
         weights_ready = false;
-        DBuf *bufs[] = {&G, &Mo, &Vo, &pe, &emb, &hs, &a, &qkv, &att, &hmid, &fc, &gl, &hf, &hfl, &logits, &ids, &rloss, &cnt,
-                        &dh, &dh2, &da, &dqkv, &datt, &dfc, &dhfl, &lse, &dsum, &dy, &tA, &tB, &wT, &hid, &dhid,
+        DBuf *bufs[] = {&G, &Mo, &Vo, &pe, &emb, &hs, &a, &qkv, &att, &hmid, &fc, &gl, &hf, &hfl, &logits, &rloss, &cnt,
+                        &dh, &dh2, &da, &dqkv, &datt, &dfc, &dhfl, &lse, &dsum, &dy, &tA, &tB, &wT, &lnstat, &hid, &dhid,
                         &t_lin, &t_seq, &t_a1, &t_qkv, &t_att, &t_mid, &t_a2, &t_r, &t_ds, &t_ds2, &t_da, &t_dr, &t_dqkv,
                         &t_datt, &t_dlin};
         for (DBuf *b : bufs) b->release();
@@ -478,7 +531,15 @@ static inline int pad32(int n) { return (n + 31) / 32 * 32; }
 static int ln_bwd(capdec_ctx *c, const float *x, const float *w, const float *dy, const float *add, float *dx, int rows,
                   int d, float eps, float *gw = nullptr, float *gb = nullptr) {
     CAPDEC_CHECK(d == 768, "train: LayerNorm backward is instantiated for d = 768");
-    hipLaunchKernelGGL(ln_bwd_dx_kernel<12>, dim3((rows + 3) / 4), dim3(256), 0, c->stream, x, w, dy, add, dx, rows, eps, gw, gb);
+    float2 *stats = nullptr;
+    if (gw) {
+        CAPDEC_TRY(c->train->lnstat.ensure((size_t)rows * sizeof(float2)));
+        stats = c->train->lnstat.as<float2>();
+    }
+    hipLaunchKernelGGL(ln_bwd_dx_kernel<12>, dim3((rows + 3) / 4), dim3(256), 0, c->stream, x, w, dy, add, dx, rows, eps, stats);
+    if (gw)
+        hipLaunchKernelGGL(ln_param_grad_kernel, dim3((d + 63) / 64, (rows + 127) / 128), dim3(256), 0, c->stream, x, dy, stats, rows,
+                           d, gw, gb);
     CAPDEC_HIP(hipGetLastError());
     return 0;
 }
@@ -497,7 +558,9 @@ static int linear_dw(capdec_ctx *c, TrainState &t, const float *dy, const float 
     CAPDEC_TRY(transpose_pad(c, dy, rows, out, t.tA.as<float>(), Kp));
     CAPDEC_TRY(transpose_pad(c, x, rows, in, t.tB.as<float>(), Kp));
     CAPDEC_TRY(gemm_fp32(c, t.tA.as<float>(), Kp, t.tB.as<float>(), Kp, gW, in, out, in, Kp));
-    if (gb) hipLaunchKernelGGL(colsum_kernel, grid1(out), dim3(256), 0, c->stream, dy, rows, out, gb);
+    if (gb)
+        hipLaunchKernelGGL(colsum_kernel, dim3((out + 255) / 256, (rows + COLSUM_ROWS - 1) / COLSUM_ROWS), dim3(256), 0, c->stream,
+                           dy, rows, out, gb);
     CAPDEC_HIP(hipGetLastError());
     return 0;
 }
@@ -637,7 +700,6 @@ static int train_step(capdec_ctx *c, const float *prefix, const int *tokens, int
     CAPDEC_TRY(t.hf.ensure(Rd * 4));
     CAPDEC_TRY(t.hfl.ensure((size_t)Rl * d * 4));
     CAPDEC_TRY(t.logits.ensure((size_t)Rl * Vp * 4));
-    CAPDEC_TRY(t.ids.ensure((size_t)Rl * 4));
     CAPDEC_TRY(t.rloss.ensure((size_t)Rl * 4));
     CAPDEC_TRY(t.cnt.ensure(16));
     CAPDEC_TRY(t.dh.ensure(Rd * 4));
@@ -652,18 +714,16 @@ static int train_step(capdec_ctx *c, const float *prefix, const int *tokens, int
     CAPDEC_TRY(t.dy.ensure((size_t)B * O * 4));
     float *pe = t.pe.as<float>(), *emb = t.emb.as<float>(), *hs = t.hs.as<float>(), *a = t.a.as<float>(), *gl = t.gl.as<float>(),
           *hf = t.hf.as<float>(), *hfl = t.hfl.as<float>(), *logits = t.logits.as<float>();
-    int *row_ids = t.ids.as<int>();
     int *cnt = t.cnt.as<int>();
     float *loss_dev = reinterpret_cast<float *>(cnt + 1);
 
     // ---- forward: mapper, then embeds = cat(pe.view(B, P, d), wte(tokens))
     CAPDEC_TRY(mapper_forward_saved(c, t, prefix, B, pe));
-    for (int b = 0; b < B; ++b) {
-        CAPDEC_HIP(hipMemcpyAsync(emb + (size_t)(b * S) * d, pe + (size_t)b * O, (size_t)O * 4, hipMemcpyDeviceToDevice, st));
+    {
         ProfScope ps(c, F_EMBED);
-        CAPDEC_TRY(launch_gather_rows(st, g.wte, tokens + (size_t)b * L, emb + (size_t)(b * S + P) * d, L, d));
+        hipLaunchKernelGGL(build_embeds_kernel, grid1(Rd / 4), dim3(256), 0, st, pe, g.wte, tokens, emb, B, P, L, d / 4);
+        CAPDEC_TRY(launch_embed_prefix(st, emb, g.wpe, hs, B, S, 0, d));
     }
-    { ProfScope ps(c, F_EMBED); CAPDEC_TRY(launch_embed_prefix(st, emb, g.wpe, hs, B, S, 0, d)); }
     KvCache kv;
     kv_geometry(kv, B, S, g.n_head, 64);
     kv.tune = &c->tune;
@@ -684,14 +744,7 @@ static int train_step(capdec_ctx *c, const float *prefix, const int *tokens, int
     float *hL = hs + Rd * nl;
     { ProfScope ps(c, F_LN); CAPDEC_TRY(launch_layernorm(st, hL, d, g.lnfw, g.lnfb, g.eps, hf, d, R, d)); }
     // the rows the loss reads: logits[:, P-1:-1]  ->  row (b, P - 1 + t) predicts tokens[b, t]
-    {
-        std::vector<int> ids((size_t)Rl);
-        for (int b = 0; b < B; ++b)
-            for (int tt = 0; tt < L; ++tt) ids[(size_t)b * L + tt] = b * S + P - 1 + tt;
-        CAPDEC_HIP(hipMemcpyAsync(row_ids, ids.data(), ids.size() * 4, hipMemcpyHostToDevice, st));
-        CAPDEC_HIP(hipStreamSynchronize(st));                       // (`ids` leaves scope)
-    }
-    { ProfScope ps(c, F_EMBED); CAPDEC_TRY(launch_gather_rows(st, hf, row_ids, hfl, Rl, d)); }
+    hipLaunchKernelGGL(take_loss_rows_kernel, grid1((size_t)Rl * (d / 4)), dim3(256), 0, st, hf, hfl, B, P, L, d / 4);
     CAPDEC_HIP(hipMemsetAsync(logits, 0, (size_t)Rl * Vp * 4, st));
     CAPDEC_TRY(gemm(c, hfl, d, g.wte, d, logits, Vp, Rl, g.vocab, d, nullptr, CAPDEC_ACT_NONE, nullptr, 0, true));
     // ---- loss + d logits (unnormalised: softmax - onehot; the 1 / count factor is applied where the mapper's gradient
@@ -703,8 +756,7 @@ static int train_step(capdec_ctx *c, const float *prefix, const int *tokens, int
     float *dh = t.dh.as<float>(), *dh2 = t.dh2.as<float>(), *da = t.da.as<float>(), *dqkv = t.dqkv.as<float>(),
           *datt = t.datt.as<float>(), *dfc = t.dfc.as<float>(), *dhfl = t.dhfl.as<float>();
     CAPDEC_TRY(gemm_fp32(c, logits, Vp, t.wte_t, Vp, dhfl, d, Rl, d, Vp));
-    CAPDEC_HIP(hipMemsetAsync(da, 0, Rd * 4, st));
-    hipLaunchKernelGGL(scatter_rows_kernel, grid1((size_t)Rl * (d / 4)), dim3(256), 0, st, dhfl, row_ids, da, Rl, d / 4);
+    hipLaunchKernelGGL(put_loss_rows_kernel, grid1(Rd / 4), dim3(256), 0, st, dhfl, da, B, P, L, d / 4);
     CAPDEC_TRY(ln_bwd(c, hL, g.lnfw, da, nullptr, dh, R, d, g.eps));
     // ---- backward through the blocks (dX only: the GPT-2 weights are frozen)
     const int nbh = B * g.n_head * S;
@@ -728,9 +780,7 @@ static int train_step(capdec_ctx *c, const float *prefix, const int *tokens, int
     CAPDEC_HIP(hipGetLastError());
     // ---- the mapper: dY = d embeds[:, :P] / count
     float *dy = t.dy.as<float>();
-    for (int b = 0; b < B; ++b)
-        CAPDEC_HIP(hipMemcpyAsync(dy + (size_t)b * O, dh + (size_t)(b * S) * d, (size_t)O * 4, hipMemcpyDeviceToDevice, st));
-    hipLaunchKernelGGL(scale_by_count_kernel, grid1((size_t)B * O), dim3(256), 0, st, dy, (size_t)B * O, cnt);
+    hipLaunchKernelGGL(take_prefix_grad_kernel, grid1((size_t)B * O), dim3(256), 0, st, dh, dy, B, P, L, d, cnt);
     CAPDEC_HIP(hipMemsetAsync(t.G.p, 0, t.n_params * 4, st));       // (the LayerNorm weight gradients are accumulated)
     CAPDEC_TRY(mapper_backward(c, t, prefix, dy, B));
     CAPDEC_HIP(hipGetLastError());
