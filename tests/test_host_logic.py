@@ -172,6 +172,28 @@ def test_three_candidates_per_tile_flag_criterion_is_exact():
     assert flagged > 20 and exact_unflagged > 100, (flagged, exact_unflagged)
 
 
+def test_train_facade_schedule_and_tensor_names(golden):
+    """host side of the train step (capdec_amd/train.py): the scheduler object walks the lr sequence the real transformers
+    scheduler produced for the fixture (set at construction like LambdaLR, advanced by step()), AdamW carries the
+    transformers-4.24 defaults, and the device's tensor order names exactly the reference model's parameters"""
+    from capdec_amd import train as Tr
+    from capdec_amd.engine import Engine
+    g = golden("train_step_tm_tiny")
+    opt = Tr.AdamW(None, lr=float(g["lr"]))
+    assert opt.param_groups[0]["eps"] == 1e-6 and opt.param_groups[0]["weight_decay"] == 0.0 and opt.param_groups[0]["betas"] == (0.9, 0.999)
+    sched = Tr.get_linear_schedule_with_warmup(opt, int(g["warmup"]), int(g["total"]))
+    for want in g["lrs"]:
+        assert abs(opt.param_groups[0]["lr"] - float(want)) < 1e-12
+        opt.step()
+        sched.step()
+    assert sched.get_last_lr() == [opt.param_groups[0]["lr"]]
+    ref_names = sorted(str(n)[len("clip_project."):] for n in g["names"])
+    assert sorted(Engine.train_tensor_names("transformer", 3)) == ref_names and len(ref_names) == 3 + 12 * 3
+    assert sorted("clip_project." + n for n in Engine.train_tensor_names("mlp")) == sorted(str(n) for n in golden("train_step_tiny")["names"])
+    with pytest.raises(Exception):
+        Tr.AdamW(None, lr=1e-3, correct_bias=False)
+
+
 def test_no_cpu_fallback_without_gpu():
     if torch.cuda.is_available():
         pytest.skip("GPU present")
