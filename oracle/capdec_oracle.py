@@ -306,20 +306,28 @@ def gpt2_forward_saved(embeds: Tensor, sd: SD, n_head: int = 12, g: str = "gpt."
     return _ln_fwd(h, sd[t + "ln_f.weight"], sd[t + "ln_f.bias"]), saved
 
 
-def gpt2_backward_dx(dhf: Tensor, saved: list, sd: SD, n_head: int = 12, g: str = "gpt.") -> Tensor:
-    """d loss / d inputs_embeds given d loss / d (ln_f output); the GPT-2 weights are frozen: no weight gradients.
-    Conv1D y = x W + b with W [in, out]  =>  dx = dy W^T."""
+def gpt2_backward_dx(dhf: Tensor, saved: list, sd: SD, n_head: int = 12, g: str = "gpt.",
+                     wgrads: Optional[Dict[str, Tensor]] = None) -> Tensor:
+    """d loss / d inputs_embeds given d loss / d (ln_f output).  With a frozen GPT-2 (``wgrads`` None) no weight gradient
+    is formed; with ``wgrads`` (a dict) the gradients of every tensor of the block stack, ln_f and wpe are stored there
+    under their state-dict names (the reference's default run trains them too, train.py:326).
+    Conv1D y = x W + b with W [in, out]  =>  dx = dy W^T, dW = x^T dy, db = sum dy."""
     t = g + "transformer."
     N, L, d = dhf.shape
     hd = d // n_head
-    dh = _ln_bwd(saved[-1]["h"], sd[t + "ln_f.weight"], dhf)[0]
+    f2 = lambda x: x.reshape(-1, x.shape[-1])                       # noqa: E731
+    dh, gw, gb = _ln_bwd(saved[-1]["h"], sd[t + "ln_f.weight"], dhf)
+    if wgrads is not None:
+        wgrads[t + "ln_f.weight"], wgrads[t + "ln_f.bias"] = gw, gb
     for i in reversed(range(_n_layer(sd, g))):
         b, s = f"{t}h.{i}.", saved[i]
         dg = dh.reshape(-1, d) @ sd[b + "mlp.c_proj.weight"].t()
         dfc = dg * gelu_new_grad(s["fc"])
         da2 = (dfc @ sd[b + "mlp.c_fc.weight"].t()).view(N, L, d)
-        dh_mid = dh + _ln_bwd(s["h_mid"], sd[b + "ln_2.weight"], da2)[0]
-        datt = (dh_mid.reshape(-1, d) @ sd[b + "attn.c_proj.weight"].t()).view(N, L, n_head, hd).transpose(1, 2)
+        dx2, g2w, g2b = _ln_bwd(s["h_mid"], sd[b + "ln_2.weight"], da2)
+        dh_mid = dh + dx2
+        datt_m = dh_mid.reshape(-1, d) @ sd[b + "attn.c_proj.weight"].t()
+        datt = datt_m.view(N, L, n_head, hd).transpose(1, 2)
         # softmax attention backward: dV = P^T dO; dP = dO V^T; dS = P (dP - rowsum(P dP)); dQ = dS K / sqrt(hd); dK = dS^T Q / sqrt(hd)
         dv = torch.matmul(s["w"].transpose(-1, -2), datt)
         dp = torch.matmul(datt, s["v"].transpose(-1, -2))
@@ -328,8 +336,22 @@ def gpt2_backward_dx(dhf: Tensor, saved: list, sd: SD, n_head: int = 12, g: str 
         dk = torch.matmul(ds.transpose(-1, -2), s["q"]) / math.sqrt(hd)
         dqkv = torch.cat([x.transpose(1, 2).reshape(N, L, d) for x in (dq, dk, dv)], dim=2)
         da1 = (dqkv.reshape(-1, 3 * d) @ sd[b + "attn.c_attn.weight"].t()).view(N, L, d)
-        dh = dh_mid + _ln_bwd(s["h"], sd[b + "ln_1.weight"], da1)[0]
-    return dh                                          # (wpe is frozen: the position term only adds a constant)
+        dx1, g1w, g1b = _ln_bwd(s["h"], sd[b + "ln_1.weight"], da1)
+        if wgrads is not None:
+            a1 = _ln_fwd(s["h"], sd[b + "ln_1.weight"], sd[b + "ln_1.bias"])
+            a2 = _ln_fwd(s["h_mid"], sd[b + "ln_2.weight"], sd[b + "ln_2.bias"])
+            att = torch.matmul(s["w"], s["v"]).transpose(1, 2).reshape(N * L, d)
+            wgrads[b + "mlp.c_proj.weight"], wgrads[b + "mlp.c_proj.bias"] = gelu_new(s["fc"]).t() @ f2(dh), f2(dh).sum(0)
+            wgrads[b + "mlp.c_fc.weight"], wgrads[b + "mlp.c_fc.bias"] = f2(a2).t() @ dfc, dfc.sum(0)
+            wgrads[b + "ln_2.weight"], wgrads[b + "ln_2.bias"] = g2w, g2b
+            wgrads[b + "attn.c_proj.weight"], wgrads[b + "attn.c_proj.bias"] = att.t() @ f2(dh_mid), f2(dh_mid).sum(0)
+            wgrads[b + "attn.c_attn.weight"], wgrads[b + "attn.c_attn.bias"] = f2(a1).t() @ f2(dqkv), f2(dqkv).sum(0)
+            wgrads[b + "ln_1.weight"], wgrads[b + "ln_1.bias"] = g1w, g1b
+        dh = dh_mid + dx1
+    if wgrads is not None:
+        wgrads[t + "wpe.weight"] = torch.zeros_like(sd[t + "wpe.weight"])
+        wgrads[t + "wpe.weight"][:L] = dh.sum(0)
+    return dh                                          # (frozen wpe: the position term only adds a constant)
 
 
 def mlp_mapper_backward(x: Tensor, dy: Tensor, sd: SD, pfx: str = "clip_project.") -> Dict[str, Tensor]:
@@ -395,10 +417,14 @@ def transformer_mapper_backward(x: Tensor, dout: Tensor, sd: SD, clip_length: in
 
 
 def train_step_loss_and_grads(sd: SD, tokens: Tensor, prefix: Tensor, mapping_type: str, prefix_length: int,
-                              n_head: int = 12, clip_length: int = 10, num_layers: int = 8) -> Tuple[Tensor, Dict[str, Tensor]]:
+                              n_head: int = 12, clip_length: int = 10, num_layers: int = 8,
+                              train_gpt: bool = False) -> Tuple[Tensor, Dict[str, Tensor]]:
     """loss of reference train.py:348-349 (cross_entropy(logits[:, P-1:-1], tokens, ignore_index=0), mean over the
     labels != 0) and its gradients with respect to the mapper's parameters (what loss.backward() leaves in .grad of
-    ClipCaptionPrefix.parameters(), :350).  ``prefix`` is the embedding batch AFTER noise_injection (:347)."""
+    ClipCaptionPrefix.parameters(), :350).  ``prefix`` is the embedding batch AFTER noise_injection (:347).
+    ``train_gpt``: the reference's DEFAULT run (ClipCaptionModel: ``model.parameters()`` includes GPT-2) -- the
+    gradients of every GPT-2 tensor are returned too (the tied wte collects the lm_head's and the token lookup's);
+    deterministic only with GPT-2's dropouts at 0 (the reference trains with transformers' default 0.1)."""
     P, (B, L) = prefix_length, tokens.shape
     d = sd["gpt.transformer.wte.weight"].shape[1]
     pe = clip_project(prefix, sd, mapping_type, P, clip_length, num_layers)
@@ -417,10 +443,17 @@ def train_step_loss_and_grads(sd: SD, tokens: Tensor, prefix: Tensor, mapping_ty
     dlogits = dlogits * (valid.unsqueeze(-1) / n)
     dhf = torch.zeros_like(hf)
     dhf[:, P - 1:-1] = dlogits @ W
-    dembeds = gpt2_backward_dx(dhf, saved, sd, n_head)
+    grads: Dict[str, Tensor] = {}
+    dembeds = gpt2_backward_dx(dhf, saved, sd, n_head, wgrads=grads if train_gpt else None)
+    if train_gpt:
+        gw = dlogits.reshape(-1, dlogits.shape[-1]).t() @ hf[:, P - 1:-1].reshape(-1, d)          # lm_head (tied)
+        gw.index_add_(0, labels.reshape(-1), dembeds[:, P:].reshape(-1, d))                        # token lookup
+        grads["gpt.transformer.wte.weight"] = gw
     if mapping_type == "mlp":
-        return loss, mlp_mapper_backward(prefix, dembeds[:, :P].reshape(B, P * d), sd)
-    return loss, transformer_mapper_backward(prefix, dembeds[:, :P], sd, clip_length, num_layers)
+        grads.update(mlp_mapper_backward(prefix, dembeds[:, :P].reshape(B, P * d), sd))
+    else:
+        grads.update(transformer_mapper_backward(prefix, dembeds[:, :P], sd, clip_length, num_layers))
+    return loss, grads
 
 
 def linear_schedule_with_warmup(step: int, num_warmup_steps: int, num_training_steps: int) -> float:

@@ -272,6 +272,27 @@ def test_train_step_small(golden):
     _check_train_step(golden("train_step_small"), synth.GPT2_SMALL)
 
 
+def test_train_full_model_gradients_tiny(golden):
+    """the reference's DEFAULT train step (ClipCaptionModel: GPT-2 is trained too; dropouts at 0 in the fixture): the
+    oracle's hand-written backward gives every tensor's gradient -- mapper, each block's LayerNorms / Conv1Ds, ln_f, wpe and
+    the tied wte (lm_head + token lookup, one id occurring twice) -- as the reference's loss.backward() does.  Oracle only:
+    the HIP train step covers the frozen-GPT-2 configuration."""
+    g = golden("train_full_tiny")
+    dims = synth.GPT2_TINY
+    sd = synth.hot_state_dict(42, "mlp", 512, 10, dims=dims)
+    assert synth.state_dict_checksum(sd) == int(g["sd_crc"]), "RNG drift"
+    loss, grads = O.train_step_loss_and_grads(sd, T(g["tokens"]), T(g["prefix"]), "mlp", 10, n_head=dims.n_head, train_gpt=True)
+    assert abs(float(loss) - float(g["loss"])) < 2e-4
+    names = [str(n) for n in g["names"]]
+    assert sorted(grads) == sorted(names) and len(names) == 4 + 12 * dims.n_layer + 4
+    for k in names:
+        flat = grads[k].flatten()
+        ref = g[f"grad_{k}_sub"]
+        scale = float(np.abs(ref).max())
+        np.testing.assert_allclose(flat[::max(1, flat.numel() // 1024)].numpy(), ref, atol=2e-5 * scale + 1e-9, rtol=1e-3, err_msg=k)
+        assert abs(float(grads[k].double().norm()) / float(g[f"grad_{k}_norm"]) - 1.0) < 1e-4, k
+
+
 def test_adamw_restatement_against_torch_where_they_coincide():
     """transformers-4.24 AdamW (restated in the oracle; the class is not installed) and torch.optim.AdamW are the same
     update when eps = 0 and weight_decay = 0 (they differ only in where eps enters and in the decay term): pins the

@@ -441,6 +441,52 @@ def gen_train_step(refs, dims, tag, mapping="mlp"):
     print(f"train_step_{tag}.npz written; losses {losses} lrs {lrs}")
 
 
+def gen_train_full(refs, dims, tag):
+    """The reference's DEFAULT train step (train.py:344-350 with train.ClipCaptionModel: model.parameters() includes
+    GPT-2): gradients of EVERY tensor -- mapper, all GPT-2 blocks, ln_f, wpe and the tied wte -- from the reference's own
+    loss.backward(), with GPT-2's dropouts set to 0 (the reference trains with transformers' default 0.1, which no fixture
+    can pin).  One iteration; pins oracle/capdec_oracle.py train_step_loss_and_grads(train_gpt=True)."""
+    ref_train = refs[3]
+    from transformers import GPT2Config, GPT2LMHeadModel
+    cfg = GPT2Config(n_layer=dims.n_layer, n_head=dims.n_head, n_embd=dims.n_embd, vocab_size=dims.vocab,
+                     n_positions=dims.n_pos, resid_pdrop=0.0, embd_pdrop=0.0, attn_pdrop=0.0)
+    GPT2LMHeadModel.from_pretrained = staticmethod(lambda name, *a, **k: GPT2LMHeadModel(cfg))
+    P, D = 10, 512
+    model = ref_train.ClipCaptionModel(P, clip_length=10, prefix_size=D, num_layers=8, mapping_type=ref_train.MappingType.MLP)
+    model.train()
+    assert model.gpt.training
+    sd = synth.hot_state_dict(42, "mlp", D, P, dims=dims)
+    missing, unexpected = model.load_state_dict(sd, strict=False)
+    assert not unexpected and all(".attn.bias" in m or ".attn.masked_bias" in m for m in missing)
+    g = torch.Generator().manual_seed(29)
+    lens = [7, 9, 3, 6]
+    L = max(lens)
+    tokens = torch.zeros(len(lens), L, dtype=torch.int64)
+    mask = torch.zeros(len(lens), P + L)
+    mask[:, :P] = 1
+    for r, n in enumerate(lens):
+        tokens[r, :n] = torch.randint(1, dims.vocab, (n,), generator=g)
+        mask[r, P:P + n] = 1
+    tokens[2, 1] = tokens[0, 3]                                  # a token id that occurs twice: the lookup gradient adds up
+    prefix = synth.synthetic_clip_embeddings(len(lens), D, seed=61)
+    model.zero_grad()
+    out = model(tokens, prefix, mask)
+    logits = out.logits[:, P - 1:-1]
+    loss = torch.nn.functional.cross_entropy(logits.reshape(-1, logits.shape[-1]), tokens.flatten(), ignore_index=0)
+    loss.backward()
+    names = [k for k, q in model.named_parameters() if q.grad is not None]
+    res = {"sd_crc": np.uint32(synth.state_dict_checksum(sd)), "tokens": tokens.numpy(), "mask": mask.numpy(),
+           "prefix": prefix.numpy(), "loss": np.float32(loss.detach()), "names": np.array(names)}
+    for k, q in model.named_parameters():
+        if q.grad is None:
+            continue
+        flat = q.grad.detach().flatten()
+        res[f"grad_{k}_sub"] = flat[::max(1, flat.numel() // 1024)].numpy().copy()
+        res[f"grad_{k}_norm"] = np.float64(q.grad.detach().double().norm())
+    np.savez_compressed(os.path.join(OUT, f"train_full_{tag}.npz"), **res)
+    print(f"train_full_{tag}.npz written; loss {float(loss):.5f}; {len(names)} tensors")
+
+
 def openai_to_hf_clip(sd, dims):
     """Map an OpenAI-CLIP-named state dict onto transformers.CLIPModel names (the independent
     stand-in used to pin the CLIP kernels: the reference's own `clip` package is not installed)."""
@@ -654,6 +700,7 @@ def main():
         "train_forward_small": lambda: gen_train_forward(refs, synth.GPT2_SMALL, "small"),
         "train_step_tiny": lambda: gen_train_step(refs, synth.GPT2_TINY, "tiny"),
         "train_step_small": lambda: gen_train_step(refs, synth.GPT2_SMALL, "small"),
+        "train_full_tiny": lambda: gen_train_full(refs, synth.GPT2_TINY, "tiny"),
         "train_step_tm_tiny": lambda: gen_train_step(refs, synth.GPT2_TINY, "tm_tiny", "transformer_encoder"),
         "prompt_tiny": lambda: gen_prompt(refs, synth.GPT2_TINY, "tiny"),
         "prompt_small": lambda: gen_prompt(refs, synth.GPT2_SMALL, "small"),
