@@ -99,6 +99,7 @@ SIGNATURES = {
                                     C.c_int, C.POINTER(C.c_float)]),
     "capdec_train_get": (C.c_int, [_VP, C.c_int, C.c_int, _VP, C.c_size_t]),
     "capdec_train_reset": (C.c_int, [_VP]),
+    "capdec_train_set_scope": (C.c_int, [_VP, C.c_int]),
     "capdec_set_kv_budget": (C.c_int, [_VP, C.c_size_t]),
     "capdec_malloc": (C.c_int, [_VP, C.c_size_t, C.POINTER(_VP)]),
     "capdec_free": (C.c_int, [_VP, _VP]),

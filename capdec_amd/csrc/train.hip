@@ -106,6 +106,30 @@ __global__ void put_loss_rows_kernel(const float *__restrict__ in, float *__rest
     reinterpret_cast<float4 *>(out)[i] = (t_ >= 0 && t_ < L) ? reinterpret_cast<const float4 *>(in)[((size_t)b * L + t_) * d4 + c]
                                                              : make_float4(0.f, 0.f, 0.f, 0.f);
 }
+// ---- full-model scope (GPT-2 trained too) only
+// x[i] /= *count
+__global__ void div_by_count_kernel(float *x, size_t n, const int *__restrict__ count) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) x[i] = x[i] / (float)max(*count, 1);
+}
+// the token lookup's share of the tied wte gradient: g_wte[tokens[b, t], :] += d embeds[(b, P + t), :]   (atomic: an id may repeat)
+__global__ void embed_scatter_add_kernel(const float *__restrict__ dh, const int *__restrict__ tokens, float *__restrict__ gwte,
+                                         int B, int P, int L, int d, int V) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)B * L * d) return;
+    const int c = (int)(i % d), t_ = (int)((i / d) % L), b = (int)(i / ((size_t)d * L));
+    const int tok = tokens[(size_t)b * L + t_];
+    if (tok < 0 || tok >= V) return;
+    atomicAdd(gwte + (size_t)tok * d + c, dh[((size_t)b * (P + L) + P + t_) * d + c]);
+}
+// g_wpe[s, :] = sum_b d h_0[(b, s), :] for s < S   (the rest of the table gets no gradient: the arena is zeroed)
+__global__ void wpe_grad_kernel(const float *__restrict__ dh, float *__restrict__ gwpe, int B, int S, int d) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)S * d) return;
+    float a = 0.f;
+    for (int b = 0; b < B; ++b) a += dh[(size_t)b * S * d + i];
+    gwpe[i] = a;
+}
 // d pe[b, p] = d embeds[(b, p)] / *count   (the mapper's output gradient, normalised by the number of scored labels)
 __global__ void take_prefix_grad_kernel(const float *__restrict__ dh, float *__restrict__ dy, int B, int P, int L, int d,
                                         const int *__restrict__ count) {
@@ -401,6 +425,7 @@ __global__ __launch_bounds__(256) void ce_finish_kernel(const float *__restrict_
 struct Slot {
     float *p;
     size_t n, off;
+    int rows = 0, cols = 0;      // rows > 0: a GPT-2 Conv1D weight, kept [out = rows, in = cols] on the device, [in, out] in checkpoints
 };
 struct TrainState {
     // transposed copies of the frozen GPT-2 weights: the "[N, K]" operand of dX = dY W^T (= the checkpoint's own Conv1D
@@ -414,6 +439,8 @@ struct TrainState {
     // the mapper's trainable tensors (build_slots) + gradient and moment arenas
     std::vector<Slot> slots;
     size_t n_params = 0;
+    bool train_gpt = false;                  // scope (capdec_train_set_scope): 0 the mapper (GPT-2 frozen), 1 GPT-2 as well
+    int gpt_slot0 = -1;                      // first GPT-2 slot: wte, wpe, 12 per layer, ln_f weight / bias
     DBuf G, Mo, Vo;
     // saved activations + gradient scratch (grow-only)
     DBuf pe, emb, hs, a, qkv, att, hmid, fc, gl, hf, hfl, logits, rloss, cnt;
@@ -457,6 +484,13 @@ static int build_slots(capdec_ctx *c, TrainState &t) {
     Mapper &m = c->map;
     const size_t d = m.d;
     auto add = [&](float *p, size_t n) { t.slots.push_back(Slot{p, n, t.n_params}); t.n_params += n; };
+    auto add_t = [&](float *p, int rows, int cols) {
+        Slot sl{p, (size_t)rows * cols, t.n_params};
+        sl.rows = rows;
+        sl.cols = cols;
+        t.slots.push_back(sl);
+        t.n_params += sl.n;
+    };
     t.n_params = 0;
     if (m.kind == 1) {
         const size_t O = (size_t)m.P * d;
@@ -471,6 +505,22 @@ static int build_slots(capdec_ctx *c, TrainState &t) {
             add(l.wfc1, (size_t)m.mlp_hidden * d); add(l.bfc1, m.mlp_hidden);
             add(l.wfc2, d * m.mlp_hidden); add(l.bfc2, d);
         }
+    }
+    if (t.train_gpt) {
+        // the reference's default run: AdamW(model.parameters()) (train.py:326) -- every GPT-2 tensor (the tied lm_head is wte)
+        Gpt2 &g = c->gpt;
+        const int gd = g.d;
+        t.gpt_slot0 = (int)t.slots.size();
+        add(g.wte, (size_t)g.vocab * gd); add(g.wpe, (size_t)g.n_pos * gd);
+        for (Gpt2Layer &l : g.layers) {
+            add(l.ln1w, gd); add(l.ln1b, gd);
+            add_t(l.wqkv, 3 * gd, gd); add(l.bqkv, 3 * gd);
+            add_t(l.wproj, gd, gd); add(l.bproj, gd);
+            add(l.ln2w, gd); add(l.ln2b, gd);
+            add_t(l.wfc, 4 * gd, gd); add(l.bfc, 4 * gd);
+            add_t(l.wproj2, gd, 4 * gd); add(l.bproj2, gd);
+        }
+        add(g.lnfw, gd); add(g.lnfb, gd);
     }
     CAPDEC_TRY(t.G.ensure(t.n_params * 4));
     CAPDEC_TRY(t.Mo.ensure(t.n_params * 4));
@@ -516,6 +566,20 @@ static int prepare_backward_weights(capdec_ctx *c, TrainState &t) {
     CAPDEC_TRY(transpose_pad(c, g.wte, g.vocab, d, t.wte_t, t.Vp));               // [V, d] -> [d, Vp], zero padding
     t.weights_ready = true;
     return 0;
+}
+// full-model scope: the GPT-2 weights moved -- the transposed copies follow (same buffers)
+static int refresh_backward_weights(capdec_ctx *c, TrainState &t) {
+    const Gpt2 &g = c->gpt;
+    const int d = g.d;
+    for (int i = 0; i < g.n_layer; ++i) {
+        const Gpt2Layer &w = g.layers[i];
+        TrainState::LayerT &lt = t.lt[i];
+        CAPDEC_TRY(transpose_pad(c, w.wqkv, 3 * d, d, lt.wqkv_t, 3 * d));
+        CAPDEC_TRY(transpose_pad(c, w.wproj, d, d, lt.wproj_t, d));
+        CAPDEC_TRY(transpose_pad(c, w.wfc, 4 * d, d, lt.wfc_t, 4 * d));
+        CAPDEC_TRY(transpose_pad(c, w.wproj2, d, 4 * d, lt.wproj2_t, d));
+    }
+    return transpose_pad(c, g.wte, g.vocab, d, t.wte_t, t.Vp);
 }
 
 // C[M, N] = A[M, K] . Bt[N, K]^T on the native fp32 MFMA GEMM
@@ -755,9 +819,27 @@ static int train_step(capdec_ctx *c, const float *prefix, const int *tokens, int
     // ---- backward through the lm_head and ln_f
     float *dh = t.dh.as<float>(), *dh2 = t.dh2.as<float>(), *da = t.da.as<float>(), *dqkv = t.dqkv.as<float>(),
           *datt = t.datt.as<float>(), *dfc = t.dfc.as<float>(), *dhfl = t.dhfl.as<float>();
+    const bool full = t.train_gpt;                  // GPT-2 is trained too: weight gradients along the way
+    const int gs = t.gpt_slot0;
+    const int *count_for_mapper = cnt;
+    if (full) {
+        // every gradient below is a final one: d logits are normalised here, and the arena is cleared before the first write
+        hipLaunchKernelGGL(div_by_count_kernel, grid1((size_t)Rl * Vp), dim3(256), 0, st, logits, (size_t)Rl * Vp, cnt);
+        CAPDEC_HIP(hipMemsetD32Async((hipDeviceptr_t)(cnt + 2), 1, 1, st));
+        count_for_mapper = cnt + 2;
+        CAPDEC_HIP(hipMemsetAsync(t.G.p, 0, t.n_params * 4, st));
+        // the lm_head's share of the tied wte: d logits^T hf  ([V, d]; K = the loss rows)
+        const int Kp = pad32(Rl);
+        CAPDEC_TRY(t.tA.ensure((size_t)Vp * Kp * 4));
+        CAPDEC_TRY(t.tB.ensure((size_t)d * Kp * 4));
+        CAPDEC_TRY(transpose_pad(c, logits, Rl, Vp, t.tA.as<float>(), Kp));
+        CAPDEC_TRY(transpose_pad(c, hfl, Rl, d, t.tB.as<float>(), Kp));
+        CAPDEC_TRY(gemm_fp32(c, t.tA.as<float>(), Kp, t.tB.as<float>(), Kp, t.grad(gs), d, g.vocab, d, Kp));
+    }
     CAPDEC_TRY(gemm_fp32(c, logits, Vp, t.wte_t, Vp, dhfl, d, Rl, d, Vp));
     hipLaunchKernelGGL(put_loss_rows_kernel, grid1(Rd / 4), dim3(256), 0, st, dhfl, da, B, P, L, d / 4);
-    CAPDEC_TRY(ln_bwd(c, hL, g.lnfw, da, nullptr, dh, R, d, g.eps));
+    CAPDEC_TRY(ln_bwd(c, hL, g.lnfw, da, nullptr, dh, R, d, g.eps, full ? t.grad(gs + 2 + 12 * nl) : nullptr,
+                      full ? t.grad(gs + 3 + 12 * nl) : nullptr));
     // ---- backward through the blocks (dX only: the GPT-2 weights are frozen)
     const int nbh = B * g.n_head * S;
     for (int i = nl - 1; i >= 0; --i) {
@@ -765,23 +847,43 @@ static int train_step(capdec_ctx *c, const float *prefix, const int *tokens, int
         const TrainState::LayerT &wt = t.lt[i];
         float *h = hs + Rd * i;
         float *qkv = t.qkv.as<float>() + Rd * 3 * i, *hmid = t.hmid.as<float>() + Rd * i, *fc = t.fc.as<float>() + Rd * 4 * i;
+        const int s0 = gs + 2 + 12 * i;               // (full scope) this layer's slots: ln_1 w b, c_attn w b, c_proj w b, ln_2 w b, c_fc w b, mlp.c_proj w b
+        if (full) {                                   // mlp.c_proj: y = gelu(fc) W + b
+            hipLaunchKernelGGL(gelu_new_fwd_kernel, grid1(Rd * 4), dim3(256), 0, st, fc, gl, Rd * 4);
+            CAPDEC_TRY(linear_dw(c, t, dh, gl, R, d, 4 * d, t.grad(s0 + 10), t.grad(s0 + 11)));
+        }
         CAPDEC_TRY(gemm_fp32(c, dh, d, wt.wproj2_t, d, dfc, 4 * d, R, 4 * d, d));                 // d gelu_out = dh Wproj2^T
         hipLaunchKernelGGL(gelu_new_bwd_kernel, grid1(Rd * 4), dim3(256), 0, st, fc, dfc, dfc, Rd * 4);
+        if (full) {                                   // mlp.c_fc: input ln_2(h_mid)
+            CAPDEC_TRY(launch_layernorm(st, hmid, d, w.ln2w, w.ln2b, g.eps, a, d, R, d));
+            CAPDEC_TRY(linear_dw(c, t, dfc, a, R, 4 * d, d, t.grad(s0 + 8), t.grad(s0 + 9)));
+        }
         CAPDEC_TRY(gemm_fp32(c, dfc, 4 * d, wt.wfc_t, 4 * d, da, d, R, d, 4 * d));                // d a2
-        CAPDEC_TRY(ln_bwd(c, hmid, w.ln2w, da, dh, dh2, R, d, g.eps));                            // dh_mid = dh + LN'(..)
+        CAPDEC_TRY(ln_bwd(c, hmid, w.ln2w, da, dh, dh2, R, d, g.eps, full ? t.grad(s0 + 6) : nullptr,
+                          full ? t.grad(s0 + 7) : nullptr));                                       // dh_mid = dh + LN'(..)
+        if (full) CAPDEC_TRY(linear_dw(c, t, dh2, t.att.as<float>() + Rd * i, R, d, d, t.grad(s0 + 4), t.grad(s0 + 5)));   // attn.c_proj
         CAPDEC_TRY(gemm_fp32(c, dh2, d, wt.wproj_t, d, datt, d, R, d, d));                        // d att
         hipLaunchKernelGGL((attn_bwd_q_kernel<64, true>), dim3((nbh + 3) / 4), dim3(256), (size_t)4 * 2 * S * sizeof(float), st, qkv,
                            datt, dqkv, t.lse.as<float>(), t.dsum.as<float>(), nbh, S, g.n_head, 0.125f);
         hipLaunchKernelGGL((attn_bwd_kv_kernel<64, true>), dim3((nbh + 3) / 4), dim3(256), 0, st, qkv, datt, dqkv,
                            t.lse.as<float>(), t.dsum.as<float>(), nbh, S, g.n_head, 0.125f);
+        if (full) {                                   // attn.c_attn: input ln_1(h)
+            CAPDEC_TRY(launch_layernorm(st, h, d, w.ln1w, w.ln1b, g.eps, a, d, R, d));
+            CAPDEC_TRY(linear_dw(c, t, dqkv, a, R, 3 * d, d, t.grad(s0 + 2), t.grad(s0 + 3)));
+        }
         CAPDEC_TRY(gemm_fp32(c, dqkv, 3 * d, wt.wqkv_t, 3 * d, da, d, R, d, 3 * d));              // d a1
-        CAPDEC_TRY(ln_bwd(c, h, w.ln1w, da, dh2, dh, R, d, g.eps));                               // dh = dh_mid + LN'(..)
+        CAPDEC_TRY(ln_bwd(c, h, w.ln1w, da, dh2, dh, R, d, g.eps, full ? t.grad(s0 + 0) : nullptr,
+                          full ? t.grad(s0 + 1) : nullptr));                                       // dh = dh_mid + LN'(..)
+    }
+    if (full) {       // d inputs_embeds: the token rows feed the tied wte (added to the lm_head's share), every row feeds wpe
+        hipLaunchKernelGGL(embed_scatter_add_kernel, grid1((size_t)Rl * d), dim3(256), 0, st, dh, tokens, t.grad(gs), B, P, L, d, g.vocab);
+        hipLaunchKernelGGL(wpe_grad_kernel, grid1((size_t)S * d), dim3(256), 0, st, dh, t.grad(gs + 1), B, S, d);
     }
     CAPDEC_HIP(hipGetLastError());
     // ---- the mapper: dY = d embeds[:, :P] / count
     float *dy = t.dy.as<float>();
-    hipLaunchKernelGGL(take_prefix_grad_kernel, grid1((size_t)B * O), dim3(256), 0, st, dh, dy, B, P, L, d, cnt);
-    CAPDEC_HIP(hipMemsetAsync(t.G.p, 0, t.n_params * 4, st));       // (the LayerNorm weight gradients are accumulated)
+    hipLaunchKernelGGL(take_prefix_grad_kernel, grid1((size_t)B * O), dim3(256), 0, st, dh, dy, B, P, L, d, count_for_mapper);
+    if (!full) CAPDEC_HIP(hipMemsetAsync(t.G.p, 0, t.n_params * 4, st));       // (the LayerNorm weight gradients are accumulated)
     CAPDEC_TRY(mapper_backward(c, t, prefix, dy, B));
     CAPDEC_HIP(hipGetLastError());
     t.have_grads = true;
@@ -795,6 +897,7 @@ static int train_step(capdec_ctx *c, const float *prefix, const int *tokens, int
         CAPDEC_HIP(hipGetLastError());
         t.step += 1;
         for (const Slot &sl : t.slots) drop_planes_of(c, sl.p);      // inference must never see planes packed from old values
+        if (full) CAPDEC_TRY(refresh_backward_weights(c, t));
     }
     if (loss_host) CAPDEC_HIP(hipMemcpyAsync(loss_host, loss_dev, sizeof(float), hipMemcpyDeviceToHost, st));
     CAPDEC_HIP(hipStreamSynchronize(st));
@@ -825,9 +928,24 @@ int capdec_train_get(capdec_ctx *c, int kind, int which, float *d_out, size_t n)
     CAPDEC_CHECK(which >= 0 && which < (int)t.slots.size(), "train_get: tensor index out of range");
     CAPDEC_CHECK(n == t.slots[which].n, "train_get: wrong element count");
     CAPDEC_CHECK(kind == 0 || t.have_grads, "train_get: no gradients yet (run capdec_train_step)");
-    const void *src = kind == 0 ? (const void *)t.slots[which].p : (const void *)t.grad(which);
-    CAPDEC_HIP(hipMemcpyAsync(d_out, src, n * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
+    const float *src = kind == 0 ? t.slots[which].p : t.grad(which);
+    const Slot &sl = t.slots[which];
+    if (sl.rows > 0)       // a GPT-2 Conv1D weight: [out, in] on the device, [in, out] in the checkpoint (and for its gradient)
+        CAPDEC_TRY(transpose_pad(c, src, sl.rows, sl.cols, d_out, sl.rows));
+    else
+        CAPDEC_HIP(hipMemcpyAsync(d_out, src, n * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
     CAPDEC_HIP(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int capdec_train_set_scope(capdec_ctx *c, int train_gpt) {
+    CAPDEC_CHECK(c, "null context");
+    CAPDEC_CHECK(train_gpt == 0 || train_gpt == 1, "train_set_scope: 0 (mapper, GPT-2 frozen) or 1 (GPT-2 as well)");
+    CAPDEC_HIP(hipSetDevice(c->device));
+    if (c->train && c->train->train_gpt == (train_gpt != 0)) return 0;
+    train_release(c);                       // another parameter set: new slots, fresh optimizer state
+    c->train = new TrainState();
+    c->train->train_gpt = train_gpt != 0;
     return 0;
 }
 

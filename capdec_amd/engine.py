@@ -522,6 +522,22 @@ class Engine:
         """d loss / d tensor of the last train_step (what loss.backward() leaves in .grad, train.py:350)"""
         return self._train_get(1, shapes)
 
+    @staticmethod
+    def train_gpt2_tensor_names(n_layer: int):
+        """the GPT-2 tensors that follow the mapper's in capdec_train_get when the scope includes GPT-2 (state-dict names
+        without the ``gpt.`` prefix)"""
+        names = ["transformer.wte.weight", "transformer.wpe.weight"]
+        for i in range(n_layer):
+            names += [f"transformer.h.{i}.{n}" for n in (
+                "ln_1.weight", "ln_1.bias", "attn.c_attn.weight", "attn.c_attn.bias", "attn.c_proj.weight", "attn.c_proj.bias",
+                "ln_2.weight", "ln_2.bias", "mlp.c_fc.weight", "mlp.c_fc.bias", "mlp.c_proj.weight", "mlp.c_proj.bias")]
+        return names + ["transformer.ln_f.weight", "transformer.ln_f.bias"]
+
+    def train_set_scope(self, train_gpt: bool):
+        """False: the mapper only, GPT-2 frozen (validated); True: GPT-2 as well, dropout-free (see capdec.h: not yet run
+        on a GPU)"""
+        self._chk(self.lib.capdec_train_set_scope(self._h, int(bool(train_gpt))), "train_set_scope")
+
     def train_reset(self):
         """a fresh optimizer: drops the AdamW moments and the step count"""
         self._chk(self.lib.capdec_train_reset(self._h), "train_reset")

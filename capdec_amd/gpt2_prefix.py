@@ -181,6 +181,16 @@ class ClipCaptionModel(_HipModule):
     # ---- train steps update the mapper ON THE DEVICE (capdec_amd.train.train_step): the host copy follows lazily
     _device_ahead = False
 
+    _train_gpt = False          # scope of the train steps run on this model (capdec_amd.train.train_step)
+
+    def _train_shapes(self):
+        """ordered {state-dict name: shape} of every tensor the current train scope updates, in the device's slot order"""
+        shapes = OrderedDict(("clip_project." + k, v) for k, v in self._mapper_shapes().items())
+        if self._train_gpt:
+            for n in Engine.train_gpt2_tensor_names(self.gpt_dims.n_layer):
+                shapes["gpt." + n] = tuple(self._sd["gpt." + n].shape)
+        return shapes
+
     def _mapper_shapes(self):
         """ordered {name: shape} of the mapper's trainable tensors, in the device's slot order"""
         mlp = self.mapping_type == MappingType.MLP
@@ -194,9 +204,12 @@ class ClipCaptionModel(_HipModule):
     def _pull_mapper(self):
         if not self._device_ahead or self._engine is None:
             return
-        for k, v in self._engine.mapper_parameters(self._mapper_shapes()).items():
-            self.clip_project._sd[k] = v.cpu()
-            self._sd["clip_project." + k] = self.clip_project._sd[k]
+        for k, v in self._engine.mapper_parameters(self._train_shapes()).items():
+            self._sd[k] = v.cpu()
+            if k.startswith("clip_project."):
+                self.clip_project._sd[k[len("clip_project."):]] = self._sd[k]
+        if self._train_gpt and "gpt.lm_head.weight" in self._sd:
+            self._sd["gpt.lm_head.weight"] = self._sd["gpt.transformer.wte.weight"]      # tied
         self._device_ahead = False
 
     def _before_engine_close(self):

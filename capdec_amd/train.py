@@ -118,8 +118,15 @@ def train_step(model: ClipCaptionModel, optimizer: AdamW, tokens: torch.Tensor, 
     optimizer.zero_grad()`` -- as ONE device call (capdec_train_step); returns ``loss.item()``.  ``prefix`` is the batch
     after ``noise_injection`` (:347); the caller steps the scheduler afterwards (:352), as the reference does.
     ``mask`` must be the dataset's right-padding mask (or None): see ClipCaptionModel.forward."""
-    if not isinstance(model, ClipCaptionPrefix):
-        raise CapdecError("train_step: implemented for ClipCaptionPrefix (frozen GPT-2: the reference's --only_prefix)")
+    full = not isinstance(model, ClipCaptionPrefix)      # a plain ClipCaptionModel trains GPT-2 too (reference train.py:306-308)
+    if full and not getattr(optimizer, "dropout_free_gpt2", False):
+        raise CapdecError("train_step: training GPT-2 itself exists only without dropout (the reference uses 0.1) and has not "
+                          "been validated on a GPU yet -- pass an optimizer with .dropout_free_gpt2 = True to use it; "
+                          "ClipCaptionPrefix (--only_prefix) is the validated configuration")
+    if model._train_gpt != full:
+        model._pull_mapper()
+        model._train_gpt = full
+    model.engine.train_set_scope(full)
     tokens = tokens.to(torch.device("cuda", model._device_index))
     if mask is not None:
         m = mask.to(tokens.device) > 0
@@ -139,6 +146,12 @@ def train_step(model: ClipCaptionModel, optimizer: AdamW, tokens: torch.Tensor, 
 def mapper_gradients(model: ClipCaptionModel):
     """``{name: p.grad}`` of the mapper after the last ``train_step`` (names as in ``clip_project.state_dict()``)"""
     return model.engine.mapper_gradients(model._mapper_shapes())
+
+
+def all_gradients(model: ClipCaptionModel):
+    """``{state-dict name: p.grad}`` of every tensor of the model's current train scope (mapper; GPT-2 too for a plain
+    ClipCaptionModel) after the last ``train_step``"""
+    return model.engine.mapper_gradients(model._train_shapes())
 
 
 def train(dataset, model: ClipCaptionModel, args, warmup_steps: int = 5000, output_dir: str = ".", output_prefix: str = ""):

@@ -256,6 +256,17 @@ int capdec_train_step(capdec_ctx *ctx, const float *d_prefix, const int32_t *d_t
                       float beta1, float beta2, float eps, float weight_decay, int apply_update, float *loss);
 int capdec_train_get(capdec_ctx *ctx, int kind, int which, float *d_out, size_t n);
 int capdec_train_reset(capdec_ctx *ctx);
+/* Scope of the train step: 0 (default) = the mapper, GPT-2 frozen (--only_prefix); 1 = GPT-2 as well -- the reference's
+ * DEFAULT run (train.py:326: AdamW(model.parameters()) of a ClipCaptionModel), WITHOUT dropout: the reference trains with
+ * transformers' default dropouts of 0.1, this path computes the step of a model whose GPT2Config has them at 0.  The
+ * tensors of capdec_train_get then continue after the mapper's: wte (the tied lm_head), wpe, per layer ln_1.weight,
+ * ln_1.bias, attn.c_attn.weight, .bias, attn.c_proj.weight, .bias, ln_2.weight, .bias, mlp.c_fc.weight, .bias,
+ * mlp.c_proj.weight, .bias, then ln_f.weight, ln_f.bias; Conv1D weights (and their gradients) are returned in the
+ * checkpoint's [in, out] layout.  Changing the scope starts a fresh optimizer.
+ * STATUS: scope 1 was written after this round's GPU budget was spent -- it compiles and follows the oracle
+ * (oracle/capdec_oracle.py: train_step_loss_and_grads(train_gpt=True), pinned against the reference), but has not run on a
+ * GPU yet: its parity test is skipped unless CAPDEC_TEST_UNVALIDATED=1.  Scope 0 is the validated path. */
+int capdec_train_set_scope(capdec_ctx *ctx, int train_gpt);
 
 /* The loss of the train step's forward (reference train.py:349 `nnf.cross_entropy(logits, tokens, ignore_index=0)`,
  * and GPT2LMHeadModel's shifted `labels=` loss used by gpt2_prefix.py:154): mean over the rows whose label differs

@@ -488,18 +488,23 @@ def adamw_transformers(p: Tensor, grad: Tensor, exp_avg: Tensor, exp_avg_sq: Ten
 
 def train_steps(sd: SD, batches: Sequence[Tuple[Tensor, Tensor]], mapping_type: str, prefix_length: int, lr: float,
                 num_warmup_steps: int, num_training_steps: int, n_head: int = 12, clip_length: int = 10,
-                num_layers: int = 8) -> Tuple[List[float], SD]:
+                num_layers: int = 8, train_gpt: bool = False) -> Tuple[List[float], SD]:
     """``len(batches)`` iterations of reference train.py:344-354 (frozen GPT-2) from the weights ``sd`` (not modified):
     each batch = (tokens [B, L] right-padded with 0, prefix [B, D] after noise injection).  Returns the per-step losses
     and the final state dict."""
-    sd = {k: (v.clone() if k.startswith("clip_project.") else v) for k, v in sd.items()}
-    state = {k: (torch.zeros_like(v), torch.zeros_like(v)) for k, v in sd.items() if k.startswith("clip_project.")}
+    sd = {k: (v.clone() if (train_gpt or k.startswith("clip_project.")) else v) for k, v in sd.items()}
+    if train_gpt and "gpt.lm_head.weight" in sd:
+        sd["gpt.lm_head.weight"] = sd["gpt.transformer.wte.weight"]                 # tied: one tensor
+    state: Dict[str, Tuple[Tensor, Tensor]] = {}
     losses = []
     for it, (tokens, prefix) in enumerate(batches):
-        loss, grads = train_step_loss_and_grads(sd, tokens, prefix, mapping_type, prefix_length, n_head, clip_length, num_layers)
+        loss, grads = train_step_loss_and_grads(sd, tokens, prefix, mapping_type, prefix_length, n_head, clip_length, num_layers,
+                                                train_gpt=train_gpt)
         losses.append(float(loss))
         cur_lr = lr * linear_schedule_with_warmup(it, num_warmup_steps, num_training_steps)
         for k, gk in grads.items():
+            if k not in state:
+                state[k] = (torch.zeros_like(sd[k]), torch.zeros_like(sd[k]))
             adamw_transformers(sd[k], gk, state[k][0], state[k][1], it + 1, cur_lr)
     return losses, sd
 

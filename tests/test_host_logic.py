@@ -10,6 +10,8 @@ import numpy as np
 import pytest
 import torch
 
+from capdec_amd import synth
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
@@ -192,6 +194,47 @@ def test_train_facade_schedule_and_tensor_names(golden):
     assert sorted("clip_project." + n for n in Engine.train_tensor_names("mlp")) == sorted(str(n) for n in golden("train_step_tiny")["names"])
     with pytest.raises(Exception):
         Tr.AdamW(None, lr=1e-3, correct_bias=False)
+
+
+@pytest.mark.parametrize("mapping", ["mlp", "transformer_encoder"])
+def test_trained_tensors_are_pulled_back_into_the_state_dict(mapping):
+    """after train steps the mapper lives on the device: ``state_dict()`` (what the reference saves, train.py:359-371)
+    must read every trained tensor back under its checkpoint name, in the device's slot order, exactly once -- checked
+    with a stand-in for the engine that returns tensor number i filled with i"""
+    from capdec_amd.gpt2_prefix import ClipCaptionPrefix, MappingType
+    dims, nlay = synth.GPT2_TINY, 2
+    mt = MappingType.MLP if mapping == "mlp" else MappingType.TransformerEncoder
+    model = ClipCaptionPrefix(10, clip_length=10, prefix_size=512, num_layers=nlay, mapping_type=mt, gpt2_dims=dims)
+    sd = synth.hot_state_dict(42, mapping, 512, 10, 10, nlay, dims)
+    model.load_state_dict(sd)
+
+    class FakeEngine:
+        def __init__(self):
+            self.calls = 0
+
+        def mapper_parameters(self, shapes):
+            self.calls += 1
+            return {k: torch.full(shp, float(i)) for i, (k, shp) in enumerate(shapes.items())}
+
+    fake = FakeEngine()
+    model._engine, model._dirty = fake, False
+    assert list(model.state_dict()) == list(sd) or set(model.state_dict()) == set(sd)
+    assert fake.calls == 0                                   # nothing trained yet: the host copy is current
+    model._device_ahead = True
+    out = model.state_dict()
+    assert fake.calls == 1 and not model._device_ahead
+    names = list(model._train_shapes())
+    assert all(n.startswith("clip_project.") for n in names) and len(names) == (4 if mapping == "mlp" else 3 + 12 * nlay)
+    assert sorted(names) == sorted(k for k in sd if k.startswith("clip_project."))
+    for i, n in enumerate(names):
+        assert out[n].shape == sd[n].shape and bool((out[n] == float(i)).all()), n
+        assert model.clip_project._sd[n[len("clip_project."):]] is out[n]
+    for k in sd:
+        if not k.startswith("clip_project."):
+            assert torch.equal(out[k], sd[k])                # GPT-2 untouched in the frozen scope
+    model.state_dict()
+    assert fake.calls == 1
+    model._engine = None
 
 
 def test_no_cpu_fallback_without_gpu():
