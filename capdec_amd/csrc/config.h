@@ -36,6 +36,8 @@ struct Tuning {
     bool kv_direct = true;        // CAPDEC_KV_DIRECT=0: the attention kernel appends K / V itself
     bool rn_packed = true;        // CAPDEC_RN_PACKED=0: fp32 im2col in the ResNet tower
     bool rn_implicit = true;      // CAPDEC_RN_IMPLICIT=0: fp32 activations in the ResNet tower
+    bool train_f16x2 = false;     // CAPDEC_TRAIN_F16X2=1: the train step's backward GEMMs on the two-fp16-plane kernels instead of the
+                                  //   native fp32 MFMA GEMM (candidate default: to be A/B-ed and parity-tested on a GPU first)
     bool hook_packa = false;      // CAPDEC_HOOK_PACKA: capdec_gemm_f32 (test hook) packs A first (the LayerNorm -> GEMM path)
     bool hook_cache = false;      // CAPDEC_HOOK_CACHE: ... and treats both operands as resident (micro-benchmarks)
     std::string rccl_lib;         // CAPDEC_RCCL_LIB: path of librccl for the C-ABI communicator

@@ -583,7 +583,13 @@ static int refresh_backward_weights(capdec_ctx *c, TrainState &t) {
 }
 
 // C[M, N] = A[M, K] . Bt[N, K]^T on the native fp32 MFMA GEMM
-static int gemm_fp32(capdec_ctx *c, const float *A, int lda, const float *Bt, int ldb, float *C, int ldc, int M, int N, int K) {
+// (CAPDEC_TRAIN_F16X2=1, not the default: on the fp32-accurate two-fp16-plane kernels of the inference path instead -- the
+//  GPT-2 backward runs on un-normalised gradients of order one for exactly that; static_weight: Bt never changes, its
+//  packed planes may be cached)
+static int gemm_fp32(capdec_ctx *c, const float *A, int lda, const float *Bt, int ldb, float *C, int ldc, int M, int N, int K,
+                     bool static_weight = false) {
+    if (c->tune.train_f16x2 && K % 64 == 0 && ldb == K && lda % 4 == 0)
+        return gemm(c, A, lda, Bt, ldb, C, ldc, M, N, K, nullptr, CAPDEC_ACT_NONE, nullptr, 0, static_weight);
     GemmEpilogue e;
     e.tune = &c->tune;
     ProfScope ps(c, F_GEMM, 2.0 * M * (double)N * K);
@@ -591,6 +597,8 @@ static int gemm_fp32(capdec_ctx *c, const float *A, int lda, const float *Bt, in
 }
 static inline dim3 grid1(size_t n) { return dim3((unsigned)((n + 255) / 256)); }
 static inline int pad32(int n) { return (n + 31) / 32 * 32; }
+// K of a weight-gradient product = its row count, zero-padded to what the GEMM in use wants (32; 64 for the f16x2 kernels)
+static inline int pad_rows(const capdec_ctx *c, int n) { return c->tune.train_f16x2 ? (n + 63) / 64 * 64 : pad32(n); }
 
 static int ln_bwd(capdec_ctx *c, const float *x, const float *w, const float *dy, const float *add, float *dx, int rows,
                   int d, float eps, float *gw = nullptr, float *gb = nullptr) {
@@ -616,7 +624,7 @@ static int linear_dx(capdec_ctx *c, TrainState &t, const float *dy, const float 
 // dW = dY^T X ([out, in]; dY [rows, out], X [rows, in]; the GEMM's K = rows, zero-padded to a multiple of 32), db = colsum(dY)
 static int linear_dw(capdec_ctx *c, TrainState &t, const float *dy, const float *x, int rows, int out, int in, float *gW,
                      float *gb) {
-    const int Kp = pad32(rows);
+    const int Kp = pad_rows(c, rows);
     CAPDEC_TRY(t.tA.ensure((size_t)out * Kp * 4));
     CAPDEC_TRY(t.tB.ensure((size_t)in * Kp * 4));
     CAPDEC_TRY(transpose_pad(c, dy, rows, out, t.tA.as<float>(), Kp));
@@ -829,14 +837,14 @@ static int train_step(capdec_ctx *c, const float *prefix, const int *tokens, int
         count_for_mapper = cnt + 2;
         CAPDEC_HIP(hipMemsetAsync(t.G.p, 0, t.n_params * 4, st));
         // the lm_head's share of the tied wte: d logits^T hf  ([V, d]; K = the loss rows)
-        const int Kp = pad32(Rl);
+        const int Kp = pad_rows(c, Rl);
         CAPDEC_TRY(t.tA.ensure((size_t)Vp * Kp * 4));
         CAPDEC_TRY(t.tB.ensure((size_t)d * Kp * 4));
         CAPDEC_TRY(transpose_pad(c, logits, Rl, Vp, t.tA.as<float>(), Kp));
         CAPDEC_TRY(transpose_pad(c, hfl, Rl, d, t.tB.as<float>(), Kp));
         CAPDEC_TRY(gemm_fp32(c, t.tA.as<float>(), Kp, t.tB.as<float>(), Kp, t.grad(gs), d, g.vocab, d, Kp));
     }
-    CAPDEC_TRY(gemm_fp32(c, logits, Vp, t.wte_t, Vp, dhfl, d, Rl, d, Vp));
+    CAPDEC_TRY(gemm_fp32(c, logits, Vp, t.wte_t, Vp, dhfl, d, Rl, d, Vp, !full));
     hipLaunchKernelGGL(put_loss_rows_kernel, grid1(Rd / 4), dim3(256), 0, st, dhfl, da, B, P, L, d / 4);
     CAPDEC_TRY(ln_bwd(c, hL, g.lnfw, da, nullptr, dh, R, d, g.eps, full ? t.grad(gs + 2 + 12 * nl) : nullptr,
                       full ? t.grad(gs + 3 + 12 * nl) : nullptr));
@@ -852,17 +860,17 @@ static int train_step(capdec_ctx *c, const float *prefix, const int *tokens, int
             hipLaunchKernelGGL(gelu_new_fwd_kernel, grid1(Rd * 4), dim3(256), 0, st, fc, gl, Rd * 4);
             CAPDEC_TRY(linear_dw(c, t, dh, gl, R, d, 4 * d, t.grad(s0 + 10), t.grad(s0 + 11)));
         }
-        CAPDEC_TRY(gemm_fp32(c, dh, d, wt.wproj2_t, d, dfc, 4 * d, R, 4 * d, d));                 // d gelu_out = dh Wproj2^T
+        CAPDEC_TRY(gemm_fp32(c, dh, d, wt.wproj2_t, d, dfc, 4 * d, R, 4 * d, d, !full));          // d gelu_out = dh Wproj2^T
         hipLaunchKernelGGL(gelu_new_bwd_kernel, grid1(Rd * 4), dim3(256), 0, st, fc, dfc, dfc, Rd * 4);
         if (full) {                                   // mlp.c_fc: input ln_2(h_mid)
             CAPDEC_TRY(launch_layernorm(st, hmid, d, w.ln2w, w.ln2b, g.eps, a, d, R, d));
             CAPDEC_TRY(linear_dw(c, t, dfc, a, R, 4 * d, d, t.grad(s0 + 8), t.grad(s0 + 9)));
         }
-        CAPDEC_TRY(gemm_fp32(c, dfc, 4 * d, wt.wfc_t, 4 * d, da, d, R, d, 4 * d));                // d a2
+        CAPDEC_TRY(gemm_fp32(c, dfc, 4 * d, wt.wfc_t, 4 * d, da, d, R, d, 4 * d, !full));         // d a2
         CAPDEC_TRY(ln_bwd(c, hmid, w.ln2w, da, dh, dh2, R, d, g.eps, full ? t.grad(s0 + 6) : nullptr,
                           full ? t.grad(s0 + 7) : nullptr));                                       // dh_mid = dh + LN'(..)
         if (full) CAPDEC_TRY(linear_dw(c, t, dh2, t.att.as<float>() + Rd * i, R, d, d, t.grad(s0 + 4), t.grad(s0 + 5)));   // attn.c_proj
-        CAPDEC_TRY(gemm_fp32(c, dh2, d, wt.wproj_t, d, datt, d, R, d, d));                        // d att
+        CAPDEC_TRY(gemm_fp32(c, dh2, d, wt.wproj_t, d, datt, d, R, d, d, !full));                 // d att
         hipLaunchKernelGGL((attn_bwd_q_kernel<64, true>), dim3((nbh + 3) / 4), dim3(256), (size_t)4 * 2 * S * sizeof(float), st, qkv,
                            datt, dqkv, t.lse.as<float>(), t.dsum.as<float>(), nbh, S, g.n_head, 0.125f);
         hipLaunchKernelGGL((attn_bwd_kv_kernel<64, true>), dim3((nbh + 3) / 4), dim3(256), 0, st, qkv, datt, dqkv,
@@ -871,7 +879,7 @@ static int train_step(capdec_ctx *c, const float *prefix, const int *tokens, int
             CAPDEC_TRY(launch_layernorm(st, h, d, w.ln1w, w.ln1b, g.eps, a, d, R, d));
             CAPDEC_TRY(linear_dw(c, t, dqkv, a, R, 3 * d, d, t.grad(s0 + 2), t.grad(s0 + 3)));
         }
-        CAPDEC_TRY(gemm_fp32(c, dqkv, 3 * d, wt.wqkv_t, 3 * d, da, d, R, d, 3 * d));              // d a1
+        CAPDEC_TRY(gemm_fp32(c, dqkv, 3 * d, wt.wqkv_t, 3 * d, da, d, R, d, 3 * d, !full));       // d a1
         CAPDEC_TRY(ln_bwd(c, h, w.ln1w, da, dh2, dh, R, d, g.eps, full ? t.grad(s0 + 0) : nullptr,
                           full ? t.grad(s0 + 1) : nullptr));                                       // dh = dh_mid + LN'(..)
     }
