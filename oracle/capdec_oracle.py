@@ -280,12 +280,30 @@ def gelu_new_grad(x: Tensor) -> Tensor:
     return 0.5 * (1.0 + t) + 0.5 * x * (1.0 - t * t) * c * (1.0 + 3.0 * 0.044715 * x * x)
 
 
-def gpt2_forward_saved(embeds: Tensor, sd: SD, n_head: int = 12, g: str = "gpt.") -> Tuple[Tensor, list]:
-    """gpt2_hidden (above) keeping what the backward pass needs per layer; returns (ln_f output, saved)"""
+def dropout_sites(n_layer: int, N: int, L: int, d: int, n_head: int) -> List[Tuple[str, Tuple[int, ...]]]:
+    """The dropout calls of one GPT-2 forward in train() mode, in call order (transformers GPT2Model: ``drop`` after
+    inputs_embeds + position_embeds; per block ``attn_dropout`` on the softmax weights, ``resid_dropout`` after attn.c_proj,
+    the MLP's ``dropout`` after mlp.c_proj): (name, mask shape).  The mask stream of capdec_train_set_dropout_masks is
+    these masks flattened and concatenated in this order, one byte per element (1 = keep)."""
+    sites = [("embd", (N, L, d))]
+    for i in range(n_layer):
+        sites += [(f"h.{i}.attn", (N, n_head, L, L)), (f"h.{i}.resid", (N, L, d)), (f"h.{i}.mlp", (N, L, d))]
+    return sites
+
+
+def gpt2_forward_saved(embeds: Tensor, sd: SD, n_head: int = 12, g: str = "gpt.",
+                       drop: Optional[Tuple[float, Sequence[Tensor]]] = None) -> Tuple[Tensor, list]:
+    """gpt2_hidden (above) keeping what the backward pass needs per layer; returns (ln_f output, saved).
+    ``drop`` = (p, masks): GPT-2 in train() mode (the reference's default run, train.py:306-308 + model.train() at :321) --
+    every nn.Dropout / F.dropout of the stack multiplies by ``mask / (1 - p)`` with the keep-masks of ``dropout_sites``
+    in call order (torch's dropout: Bernoulli(1 - p) keep mask, survivors scaled by 1 / (1 - p))."""
     N, L, d = embeds.shape
     hd = d // n_head
     t = g + "transformer."
-    h = embeds + sd[t + "wpe.weight"][:L]
+    mi = iter(drop[1]) if drop is not None else None
+    keep = 1.0 - drop[0] if drop is not None else 1.0
+    dm = (lambda x: x * (next(mi).to(x.dtype) / keep)) if drop is not None else (lambda x: x)      # noqa: E731
+    h = dm(embeds + sd[t + "wpe.weight"][:L])
     causal = torch.ones(L, L, dtype=torch.bool).tril()
     saved = []
     for i in range(_n_layer(sd, g)):
@@ -295,14 +313,20 @@ def gpt2_forward_saved(embeds: Tensor, sd: SD, n_head: int = 12, g: str = "gpt."
         q, k, v = (x.view(N, L, n_head, hd).transpose(1, 2) for x in qkv.split(d, dim=2))
         w = torch.matmul(q, k.transpose(-1, -2)) / math.sqrt(hd)
         w = torch.where(causal, w, torch.full((), torch.finfo(w.dtype).min, dtype=w.dtype)).softmax(dim=-1)
-        att = torch.matmul(w, v).transpose(1, 2).reshape(N, L, d)
-        h_mid = h + torch.addmm(sd[b + "attn.c_proj.bias"], att.reshape(-1, d), sd[b + "attn.c_proj.weight"]).view(N, L, d)
+        m_att = (next(mi).to(w.dtype) / keep) if drop is not None else None
+        wd = w * m_att if drop is not None else w                   # the weights that multiply V
+        att = torch.matmul(wd, v).transpose(1, 2).reshape(N, L, d)
+        m_res = (next(mi).to(w.dtype) / keep) if drop is not None else None
+        y = torch.addmm(sd[b + "attn.c_proj.bias"], att.reshape(-1, d), sd[b + "attn.c_proj.weight"]).view(N, L, d)
+        h_mid = h + (y * m_res if drop is not None else y)
         a2 = _ln_fwd(h_mid, sd[b + "ln_2.weight"], sd[b + "ln_2.bias"])
         fc = torch.addmm(sd[b + "mlp.c_fc.bias"], a2.reshape(-1, d), sd[b + "mlp.c_fc.weight"])
-        h_out = h_mid + torch.addmm(sd[b + "mlp.c_proj.bias"], gelu_new(fc), sd[b + "mlp.c_proj.weight"]).view(N, L, d)
-        saved.append(dict(h=h, q=q, k=k, v=v, w=w, h_mid=h_mid, fc=fc))
+        m_mlp = (next(mi).to(w.dtype) / keep) if drop is not None else None
+        y2 = torch.addmm(sd[b + "mlp.c_proj.bias"], gelu_new(fc), sd[b + "mlp.c_proj.weight"]).view(N, L, d)
+        h_out = h_mid + (y2 * m_mlp if drop is not None else y2)
+        saved.append(dict(h=h, q=q, k=k, v=v, w=w, wd=wd, h_mid=h_mid, fc=fc, m_att=m_att, m_res=m_res, m_mlp=m_mlp))
         h = h_out
-    saved.append(dict(h=h))
+    saved.append(dict(h=h, m_embd=(drop[1][0].to(embeds.dtype) / keep) if drop is not None else None))
     return _ln_fwd(h, sd[t + "ln_f.weight"], sd[t + "ln_f.bias"]), saved
 
 
@@ -321,16 +345,21 @@ def gpt2_backward_dx(dhf: Tensor, saved: list, sd: SD, n_head: int = 12, g: str 
         wgrads[t + "ln_f.weight"], wgrads[t + "ln_f.bias"] = gw, gb
     for i in reversed(range(_n_layer(sd, g))):
         b, s = f"{t}h.{i}.", saved[i]
-        dg = dh.reshape(-1, d) @ sd[b + "mlp.c_proj.weight"].t()
+        dy2 = dh * s["m_mlp"] if s.get("m_mlp") is not None else dh          # through the MLP's dropout
+        dg = dy2.reshape(-1, d) @ sd[b + "mlp.c_proj.weight"].t()
         dfc = dg * gelu_new_grad(s["fc"])
         da2 = (dfc @ sd[b + "mlp.c_fc.weight"].t()).view(N, L, d)
         dx2, g2w, g2b = _ln_bwd(s["h_mid"], sd[b + "ln_2.weight"], da2)
         dh_mid = dh + dx2
-        datt_m = dh_mid.reshape(-1, d) @ sd[b + "attn.c_proj.weight"].t()
+        dy1 = dh_mid * s["m_res"] if s.get("m_res") is not None else dh_mid  # through resid_dropout
+        datt_m = dy1.reshape(-1, d) @ sd[b + "attn.c_proj.weight"].t()
         datt = datt_m.view(N, L, n_head, hd).transpose(1, 2)
-        # softmax attention backward: dV = P^T dO; dP = dO V^T; dS = P (dP - rowsum(P dP)); dQ = dS K / sqrt(hd); dK = dS^T Q / sqrt(hd)
-        dv = torch.matmul(s["w"].transpose(-1, -2), datt)
+        # softmax attention backward: dV = Pd^T dO (Pd = the dropped weights); dPd = dO V^T; dP = dPd mask / keep;
+        # dS = P (dP - rowsum(P dP)); dQ = dS K / sqrt(hd); dK = dS^T Q / sqrt(hd)
+        dv = torch.matmul(s.get("wd", s["w"]).transpose(-1, -2), datt)
         dp = torch.matmul(datt, s["v"].transpose(-1, -2))
+        if s.get("m_att") is not None:
+            dp = dp * s["m_att"]
         ds = s["w"] * (dp - (s["w"] * dp).sum(-1, keepdim=True))
         dq = torch.matmul(ds, s["k"]) / math.sqrt(hd)
         dk = torch.matmul(ds.transpose(-1, -2), s["q"]) / math.sqrt(hd)
@@ -340,14 +369,16 @@ def gpt2_backward_dx(dhf: Tensor, saved: list, sd: SD, n_head: int = 12, g: str 
         if wgrads is not None:
             a1 = _ln_fwd(s["h"], sd[b + "ln_1.weight"], sd[b + "ln_1.bias"])
             a2 = _ln_fwd(s["h_mid"], sd[b + "ln_2.weight"], sd[b + "ln_2.bias"])
-            att = torch.matmul(s["w"], s["v"]).transpose(1, 2).reshape(N * L, d)
-            wgrads[b + "mlp.c_proj.weight"], wgrads[b + "mlp.c_proj.bias"] = gelu_new(s["fc"]).t() @ f2(dh), f2(dh).sum(0)
+            att = torch.matmul(s.get("wd", s["w"]), s["v"]).transpose(1, 2).reshape(N * L, d)
+            wgrads[b + "mlp.c_proj.weight"], wgrads[b + "mlp.c_proj.bias"] = gelu_new(s["fc"]).t() @ f2(dy2), f2(dy2).sum(0)
             wgrads[b + "mlp.c_fc.weight"], wgrads[b + "mlp.c_fc.bias"] = f2(a2).t() @ dfc, dfc.sum(0)
             wgrads[b + "ln_2.weight"], wgrads[b + "ln_2.bias"] = g2w, g2b
-            wgrads[b + "attn.c_proj.weight"], wgrads[b + "attn.c_proj.bias"] = att.t() @ f2(dh_mid), f2(dh_mid).sum(0)
+            wgrads[b + "attn.c_proj.weight"], wgrads[b + "attn.c_proj.bias"] = att.t() @ f2(dy1), f2(dy1).sum(0)
             wgrads[b + "attn.c_attn.weight"], wgrads[b + "attn.c_attn.bias"] = f2(a1).t() @ f2(dqkv), f2(dqkv).sum(0)
             wgrads[b + "ln_1.weight"], wgrads[b + "ln_1.bias"] = g1w, g1b
         dh = dh_mid + dx1
+    if saved[-1].get("m_embd") is not None:
+        dh = dh * saved[-1]["m_embd"]                                  # through the embedding dropout
     if wgrads is not None:
         wgrads[t + "wpe.weight"] = torch.zeros_like(sd[t + "wpe.weight"])
         wgrads[t + "wpe.weight"][:L] = dh.sum(0)
@@ -418,18 +449,21 @@ def transformer_mapper_backward(x: Tensor, dout: Tensor, sd: SD, clip_length: in
 
 def train_step_loss_and_grads(sd: SD, tokens: Tensor, prefix: Tensor, mapping_type: str, prefix_length: int,
                               n_head: int = 12, clip_length: int = 10, num_layers: int = 8,
-                              train_gpt: bool = False) -> Tuple[Tensor, Dict[str, Tensor]]:
+                              train_gpt: bool = False,
+                              drop: Optional[Tuple[float, Sequence[Tensor]]] = None) -> Tuple[Tensor, Dict[str, Tensor]]:
     """loss of reference train.py:348-349 (cross_entropy(logits[:, P-1:-1], tokens, ignore_index=0), mean over the
     labels != 0) and its gradients with respect to the mapper's parameters (what loss.backward() leaves in .grad of
     ClipCaptionPrefix.parameters(), :350).  ``prefix`` is the embedding batch AFTER noise_injection (:347).
     ``train_gpt``: the reference's DEFAULT run (ClipCaptionModel: ``model.parameters()`` includes GPT-2) -- the
-    gradients of every GPT-2 tensor are returned too (the tied wte collects the lm_head's and the token lookup's);
-    deterministic only with GPT-2's dropouts at 0 (the reference trains with transformers' default 0.1)."""
+    gradients of every GPT-2 tensor are returned too (the tied wte collects the lm_head's and the token lookup's).
+    ``drop`` = (p, keep-masks in the order of ``dropout_sites``): GPT-2's dropouts (the reference trains with transformers'
+    default 0.1: embd_pdrop = attn_pdrop = resid_pdrop) with the masks supplied -- how the fixture
+    tests/golden/train_full_dropout_tiny.npz pins it against the reference's own loss.backward()."""
     P, (B, L) = prefix_length, tokens.shape
     d = sd["gpt.transformer.wte.weight"].shape[1]
     pe = clip_project(prefix, sd, mapping_type, P, clip_length, num_layers)
     embeds = torch.cat((pe, wte(tokens.long(), sd)), dim=1)
-    hf, saved = gpt2_forward_saved(embeds, sd, n_head)
+    hf, saved = gpt2_forward_saved(embeds, sd, n_head, drop=drop)
     W = sd["gpt.transformer.wte.weight"]
     logits = hf[:, P - 1:-1] @ W.t()                                   # [B, L, V]: the rows the loss reads
     labels = tokens.long()
@@ -488,7 +522,8 @@ def adamw_transformers(p: Tensor, grad: Tensor, exp_avg: Tensor, exp_avg_sq: Ten
 
 def train_steps(sd: SD, batches: Sequence[Tuple[Tensor, Tensor]], mapping_type: str, prefix_length: int, lr: float,
                 num_warmup_steps: int, num_training_steps: int, n_head: int = 12, clip_length: int = 10,
-                num_layers: int = 8, train_gpt: bool = False) -> Tuple[List[float], SD]:
+                num_layers: int = 8, train_gpt: bool = False,
+                drops: Optional[Sequence[Tuple[float, Sequence[Tensor]]]] = None) -> Tuple[List[float], SD]:
     """``len(batches)`` iterations of reference train.py:344-354 (frozen GPT-2) from the weights ``sd`` (not modified):
     each batch = (tokens [B, L] right-padded with 0, prefix [B, D] after noise injection).  Returns the per-step losses
     and the final state dict."""
@@ -499,7 +534,7 @@ def train_steps(sd: SD, batches: Sequence[Tuple[Tensor, Tensor]], mapping_type: 
     losses = []
     for it, (tokens, prefix) in enumerate(batches):
         loss, grads = train_step_loss_and_grads(sd, tokens, prefix, mapping_type, prefix_length, n_head, clip_length, num_layers,
-                                                train_gpt=train_gpt)
+                                                train_gpt=train_gpt, drop=drops[it] if drops is not None else None)
         losses.append(float(loss))
         cur_lr = lr * linear_schedule_with_warmup(it, num_warmup_steps, num_training_steps)
         for k, gk in grads.items():

@@ -293,6 +293,47 @@ def test_train_full_model_gradients_tiny(golden):
         assert abs(float(grads[k].double().norm()) / float(g[f"grad_{k}_norm"]) - 1.0) < 1e-4, k
 
 
+def unpack_dropout_masks(g, it, dims, B, S):
+    """the recorded keep-masks of iteration ``it`` of train_full_dropout_*.npz, split per call site (oracle.dropout_sites)"""
+    n = int(g[f"drop_n_{it}"])
+    flat = torch.from_numpy(np.unpackbits(g[f"drop_bits_{it}"])[:n].astype(np.uint8))
+    masks, o = [], 0
+    for _, shape in O.dropout_sites(dims.n_layer, B, S, dims.n_embd, dims.n_head):
+        k = int(np.prod(shape))
+        masks.append(flat[o:o + k].reshape(shape))
+        o += k
+    assert o == n
+    return flat, masks
+
+
+def test_train_full_model_with_dropout_tiny(golden):
+    """the reference's default train step AS IT RUNS -- ClipCaptionModel in train() mode, transformers' dropouts 0.1 -- with
+    the keep-masks the fixture generator recorded inside the reference's own F.dropout calls: loss and the gradient of all
+    32 tensors from the reference's loss.backward(), two independent batches"""
+    g = golden("train_full_dropout_tiny")
+    dims = synth.GPT2_TINY
+    sd = synth.hot_state_dict(42, "mlp", 512, 10, dims=dims)
+    assert synth.state_dict_checksum(sd) == int(g["sd_crc"]), "RNG drift"
+    names = [str(n) for n in g["names"]]
+    for it in range(2):
+        tokens, prefix = T(g[f"tokens_{it}"]), T(g[f"prefix_{it}"])
+        _, masks = unpack_dropout_masks(g, it, dims, tokens.shape[0], 10 + tokens.shape[1])
+        loss, grads = O.train_step_loss_and_grads(sd, tokens, prefix, "mlp", 10, n_head=dims.n_head, train_gpt=True,
+                                                  drop=(float(g["p"]), masks))
+        assert abs(float(loss) - float(g[f"loss_{it}"])) < 2e-4
+        assert sorted(grads) == sorted(names)
+        for k in names:
+            flat = grads[k].flatten()
+            ref = g[f"grad_{it}_{k}_sub"]
+            scale = float(np.abs(ref).max())
+            np.testing.assert_allclose(flat[::max(1, flat.numel() // 1024)].numpy(), ref, atol=2e-5 * scale + 1e-9, rtol=1e-3,
+                                       err_msg=f"{it} {k}")
+            assert abs(float(grads[k].double().norm()) / float(g[f"grad_{it}_{k}_norm"]) - 1.0) < 1e-4, (it, k)
+    # and the masks matter: without them the loss is a different number
+    loss0, _ = O.train_step_loss_and_grads(sd, T(g["tokens_0"]), T(g["prefix_0"]), "mlp", 10, n_head=dims.n_head, train_gpt=True)
+    assert abs(float(loss0) - float(g["loss_0"])) > 1e-2
+
+
 def test_adamw_restatement_against_torch_where_they_coincide():
     """transformers-4.24 AdamW (restated in the oracle; the class is not installed) and torch.optim.AdamW are the same
     update when eps = 0 and weight_decay = 0 (they differ only in where eps enters and in the decay term): pins the

@@ -487,6 +487,80 @@ def gen_train_full(refs, dims, tag):
     print(f"train_full_{tag}.npz written; loss {float(loss):.5f}; {len(names)} tensors")
 
 
+def gen_train_full_dropout(refs, dims, tag):
+    """The reference's DEFAULT train step as it really runs: train.ClipCaptionModel in train() mode with transformers'
+    default dropouts (embd_pdrop = attn_pdrop = resid_pdrop = 0.1).  torch.nn.functional.dropout is patched for the
+    duration of the forward so that every call draws its keep-mask from a seeded generator and the mask is RECORDED
+    (same arithmetic as torch's: x * mask / (1 - p)); the eager attention path is forced so the attention dropout is a
+    visible F.dropout call too.  Written: the masks (bit-packed, in call order), the loss and a subsample + norm of the
+    gradient of every tensor from the reference's own loss.backward() -- two iterations' worth of independent batches
+    (no update in between: the update rule is pinned elsewhere)."""
+    ref_train = refs[3]
+    from transformers import GPT2Config, GPT2LMHeadModel
+    from oracle import capdec_oracle as O
+    cfg = GPT2Config(n_layer=dims.n_layer, n_head=dims.n_head, n_embd=dims.n_embd, vocab_size=dims.vocab,
+                     n_positions=dims.n_pos)
+    assert cfg.resid_pdrop == cfg.embd_pdrop == cfg.attn_pdrop == 0.1
+    cfg._attn_implementation = "eager"
+    GPT2LMHeadModel.from_pretrained = staticmethod(lambda name, *a, **k: GPT2LMHeadModel(cfg))
+    P, D = 10, 512
+    model = ref_train.ClipCaptionModel(P, clip_length=10, prefix_size=D, num_layers=8, mapping_type=ref_train.MappingType.MLP)
+    model.train()
+    assert model.gpt.training
+    sd = synth.hot_state_dict(42, "mlp", D, P, dims=dims)
+    missing, unexpected = model.load_state_dict(sd, strict=False)
+    assert not unexpected and all(".attn.bias" in m or ".attn.masked_bias" in m for m in missing)
+    res = {"sd_crc": np.uint32(synth.state_dict_checksum(sd)), "p": np.float64(0.1)}
+    g = torch.Generator().manual_seed(31)
+    real_dropout = torch.nn.functional.dropout
+    for it, lens in enumerate([[7, 9, 3, 6], [5, 2, 8]]):
+        L = max(lens)
+        tokens = torch.zeros(len(lens), L, dtype=torch.int64)
+        mask = torch.zeros(len(lens), P + L)
+        mask[:, :P] = 1
+        for r, n in enumerate(lens):
+            tokens[r, :n] = torch.randint(1, dims.vocab, (n,), generator=g)
+            mask[r, P:P + n] = 1
+        prefix = synth.synthetic_clip_embeddings(len(lens), D, seed=71 + it)
+        recorded = []
+        mg = torch.Generator().manual_seed(900 + it)
+
+        def recording_dropout(x, p=0.5, training=True, inplace=False):
+            if not training or p == 0.0:
+                return x
+            keep = torch.rand(x.shape, generator=mg) >= p
+            recorded.append(keep)
+            return x * (keep.to(x.dtype) / (1.0 - p))
+
+        model.zero_grad()
+        torch.nn.functional.dropout = recording_dropout
+        try:
+            out = model(tokens, prefix, mask)
+        finally:
+            torch.nn.functional.dropout = real_dropout
+        want_sites = O.dropout_sites(dims.n_layer, len(lens), P + L, dims.n_embd, dims.n_head)
+        assert [tuple(m.shape) for m in recorded] == [s for _, s in want_sites], \
+            ([tuple(m.shape) for m in recorded], want_sites)
+        logits = out.logits[:, P - 1:-1]
+        loss = torch.nn.functional.cross_entropy(logits.reshape(-1, logits.shape[-1]), tokens.flatten(), ignore_index=0)
+        loss.backward()
+        names = [k for k, q in model.named_parameters() if q.grad is not None]
+        flatmask = torch.cat([m.flatten() for m in recorded]).numpy()
+        res[f"tokens_{it}"], res[f"mask_{it}"], res[f"prefix_{it}"] = tokens.numpy(), mask.numpy(), prefix.numpy()
+        res[f"drop_bits_{it}"], res[f"drop_n_{it}"] = np.packbits(flatmask), np.int64(flatmask.size)
+        res[f"loss_{it}"] = np.float32(loss.detach())
+        res["names"] = np.array(names)
+        for k, q in model.named_parameters():
+            if q.grad is None:
+                continue
+            flat = q.grad.detach().flatten()
+            res[f"grad_{it}_{k}_sub"] = flat[::max(1, flat.numel() // 1024)].numpy().copy()
+            res[f"grad_{it}_{k}_norm"] = np.float64(q.grad.detach().double().norm())
+        print(f"  iteration {it}: loss {float(loss):.5f}, {len(recorded)} dropout calls, keep rate {flatmask.mean():.4f}")
+    np.savez_compressed(os.path.join(OUT, f"train_full_dropout_{tag}.npz"), **res)
+    print(f"train_full_dropout_{tag}.npz written; {len(names)} tensors")
+
+
 def openai_to_hf_clip(sd, dims):
     """Map an OpenAI-CLIP-named state dict onto transformers.CLIPModel names (the independent
     stand-in used to pin the CLIP kernels: the reference's own `clip` package is not installed)."""
@@ -701,6 +775,7 @@ def main():
         "train_step_tiny": lambda: gen_train_step(refs, synth.GPT2_TINY, "tiny"),
         "train_step_small": lambda: gen_train_step(refs, synth.GPT2_SMALL, "small"),
         "train_full_tiny": lambda: gen_train_full(refs, synth.GPT2_TINY, "tiny"),
+        "train_full_dropout_tiny": lambda: gen_train_full_dropout(refs, synth.GPT2_TINY, "tiny"),
         "train_step_tm_tiny": lambda: gen_train_step(refs, synth.GPT2_TINY, "tm_tiny", "transformer_encoder"),
         "prompt_tiny": lambda: gen_prompt(refs, synth.GPT2_TINY, "tiny"),
         "prompt_small": lambda: gen_prompt(refs, synth.GPT2_SMALL, "small"),
