@@ -79,7 +79,7 @@ class ClipResNetWeights(C.Structure):
 
 #: every symbol include/capdec.h declares: name -> (restype, argtypes)
 _VP = C.c_void_p
-ABI_VERSION = 3          # include/capdec.h: CAPDEC_ABI_VERSION
+ABI_VERSION = 4          # include/capdec.h: CAPDEC_ABI_VERSION
 SIGNATURES = {
     "capdec_abi_version": (C.c_int, []),
     "capdec_build_id": (C.c_char_p, []),
@@ -100,6 +100,10 @@ SIGNATURES = {
     "capdec_train_get": (C.c_int, [_VP, C.c_int, C.c_int, _VP, C.c_size_t]),
     "capdec_train_reset": (C.c_int, [_VP]),
     "capdec_train_set_scope": (C.c_int, [_VP, C.c_int]),
+    "capdec_train_loss": (C.c_int, [_VP, C.POINTER(C.c_float), C.POINTER(C.c_double), C.POINTER(C.c_longlong), C.c_int]),
+    "capdec_train_set_dropout": (C.c_int, [_VP, C.c_float, C.c_uint64]),
+    "capdec_train_set_dropout_masks": (C.c_int, [_VP, _VP, C.c_size_t]),
+    "capdec_train_get_dropout_masks": (C.c_int, [_VP, _VP, C.c_size_t]),
     "capdec_set_kv_budget": (C.c_int, [_VP, C.c_size_t]),
     "capdec_malloc": (C.c_int, [_VP, C.c_size_t, C.POINTER(_VP)]),
     "capdec_free": (C.c_int, [_VP, _VP]),

@@ -81,6 +81,20 @@ __device__ __forceinline__ float wave_max(float v) {
     return fmaxf(fmaxf(lane_bcast(v, 0), lane_bcast(v, 16)), fmaxf(lane_bcast(v, 32), lane_bcast(v, 48)));
 }
 
+// Philox4x32-10 counter RNG (Salmon et al.): key = seed, counter = (element index, stream).
+__device__ __forceinline__ void philox4x32(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
+                                           uint32_t k1, uint32_t (&o)[4]) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1;
+        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    o[0] = c0; o[1] = c1; o[2] = c2; o[3] = c3;
+}
+
 // ---- launch geometry of the f32 MFMA GEMM ----------------------------------------------
 constexpr int GEMM_BM = 128, GEMM_BN = 128, GEMM_BK = 32;
 constexpr int TOPK_MAX = 8;
@@ -176,6 +190,11 @@ int launch_gemm_pp(hipStream_t st, int which, const void *Apacked, const void *B
 // planner: 0 = keep the kernels of rounds 2-3, else a ping-pong geometry (10 = 256x128, 14 = 256x192, 12 = 256x256)
 int pp_plan(int M, int N, int K, bool wide_ok, bool can_split, int mode = 2);
 size_t pp_splitk_ws_bytes(int which, int M, int N, int K);
+// ... and for the one-plane (bf16 / fp16) operand formats (gemm_pp.hip; mode = CAPDEC_PP_X1)
+int launch_gemm_pp_x1(hipStream_t st, int which, const void *Apacked, const void *Bpacked, float *C, int ldc, int M, int N,
+                      int K, const GemmEpilogue &epi, int fmt);
+int pp_plan_x1(int M, int N, int K, bool can_split, int mode);
+size_t pp_x1_splitk_ws_bytes(int M, int N, int K);
 // exact second pass of the fused lm_head (decode.hip): k = 5 lists for the *m_dev rows of a compacted packed A operand
 int launch_gemm_h2w_topk_dev(hipStream_t st, const void *Apacked, const void *Bpacked, const int *m_dev, int N, int K,
                              float inv_temp, float *tile_max, float *tile_sum, float *cand_val, int *cand_idx);

@@ -29,6 +29,8 @@ struct Tuning {
     int h2w = 1;                  // CAPDEC_H2W: 0 = round-2 kernels only, 1 = planners, 2 / 8 = force a round-3 wide tile,
                                   //             10 / 12 / 14 = force a round-4 ping-pong tile (tests)
     int pp = 2;                   // CAPDEC_PP: ping-pong planner: 0 never, 2 mid-size launches (default), 1 also large, 3 large only
+    int pp_x1 = 2;                // CAPDEC_PP_X1: ping-pong tiles for the one-plane (bf16 / f16) GEMMs: 0 never, 1 mid-size launches,
+                                  //   2 (default) mid-size and large, 3 large only
     bool lmhead_wide = true;      // CAPDEC_LMHEAD_WIDE=0: 128-row lm_head tiles at every size
     bool lmhead_k3 = true;        // CAPDEC_LMHEAD_K3=0: the wide lm_head keeps k candidates per tile (no exact second pass)
     int lmhead_k3_max = 60;       // CAPDEC_LMHEAD_K3_MAX: per mille of the rows taking the second pass above which a decode
@@ -36,8 +38,8 @@ struct Tuning {
     bool kv_direct = true;        // CAPDEC_KV_DIRECT=0: the attention kernel appends K / V itself
     bool rn_packed = true;        // CAPDEC_RN_PACKED=0: fp32 im2col in the ResNet tower
     bool rn_implicit = true;      // CAPDEC_RN_IMPLICIT=0: fp32 activations in the ResNet tower
-    bool train_f16x2 = false;     // CAPDEC_TRAIN_F16X2=1: the train step's backward GEMMs on the two-fp16-plane kernels instead of the
-                                  //   native fp32 MFMA GEMM (candidate default: to be A/B-ed and parity-tested on a GPU first)
+    bool train_f16x2 = true;      // CAPDEC_TRAIN_F16X2=0: the train step's backward GEMMs on the native fp32 MFMA GEMM instead of the
+                                  //   two-fp16-plane kernels (A/B: 39.4 vs 23.6 ms per step; both parity-tested)
     bool hook_packa = false;      // CAPDEC_HOOK_PACKA: capdec_gemm_f32 (test hook) packs A first (the LayerNorm -> GEMM path)
     bool hook_cache = false;      // CAPDEC_HOOK_CACHE: ... and treats both operands as resident (micro-benchmarks)
     std::string rccl_lib;         // CAPDEC_RCCL_LIB: path of librccl for the C-ABI communicator

@@ -12,8 +12,9 @@
 #include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <map>
 #include <memory>
-#include <unordered_map>
+#include <utility>
 
 #include "bf16x3.h"
 #include "common.h"
@@ -137,7 +138,8 @@ struct capdec_ctx {
     Prof prof;
     int gemm_mode = GEMM_F16X2;
     struct Planes { void *p; size_t n; int fmt; bool wide_ok; };   // wide_ok: max |w| < 16 (see GemmEpilogue::wide_ok)
-    std::unordered_map<const void *, Planes> planes;   // fp32 weight -> (packed planes, elements, PackFmt)
+    std::map<std::pair<const void *, int>, Planes> planes;   // (fp32 weight, PackFmt) -> packed planes: a weight used in two
+                                                             // formats (train forward f16x2, decode in a one-plane mode) keeps both
     DBuf x3_tmp, xpk, apk, fpk, a_tmp;   // scratch planes for un-cached matrices; packed LayerNorm output; packed fp32-A
     int stat_steps = 0, stat_compactions = 0;      // last decode call: steps run, compactions done,
     long long stat_row_steps = 0;                  // activation rows pushed through the GPT-2 body (prefill excluded)
@@ -156,6 +158,9 @@ struct capdec_ctx {
     DBuf h, x, qkv, att, ff, xl, tmax, tsum, cval, cidx, lse, topv, topi, kc, vc;
     DBuf tokens, scores, seq, stopped, done, anc, next_tok, alive, gids, glens, cmap, kvstat;
     capdec::TrainState *train = nullptr;     // created by the first capdec_train_step, freed by train_release
+    int train_scope = 0;                     // capdec_train_set_scope: survives capdec_train_reset and weight reloads
+    float train_drop_p = 0.f;                // capdec_train_set_dropout: GPT-2's dropout probability in scope 1 (0 = off)
+    unsigned long long train_drop_seed = 0;  // ... key of the Philox keep-mask stream (counter = element, train step)
     DBuf lmflag, xpk2;     // fused lm_head with 3 candidates per tile: [count, total, rows...] of the rows whose top 5 need
                            // the exact second pass; their compacted packed A operand (decode.hip: lm_head_select)
     DBuf m_hid, m_lin, m_seq, m_x, m_qkv, m_att, m_ff;

@@ -233,19 +233,7 @@ int launch_normalize_prefix(hipStream_t st, const float *x, int n, int dim, int 
     return 0;
 }
 
-// Philox4x32-10 counter RNG (Salmon et al.): key = seed, counter = (element index, stream).
-__device__ __forceinline__ void philox4x32(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
-                                           uint32_t k1, uint32_t (&o)[4]) {
-#pragma unroll
-    for (int r = 0; r < 10; ++r) {
-        const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
-        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1;
-        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
-        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
-        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
-    }
-    o[0] = c0; o[1] = c1; o[2] = c2; o[3] = c3;
-}
+// (philox4x32: common.h)
 __device__ __forceinline__ float u01(uint32_t x) { return ((float)(x >> 8) + 0.5f) * (1.0f / 16777216.0f); }
 __device__ __forceinline__ float philox_normal(uint64_t seed, uint64_t idx, uint32_t stream) {
     uint32_t o[4];

@@ -12,11 +12,11 @@ void drop_planes(capdec_ctx *c) {
     for (auto &kv : c->planes) (void)hipFree(kv.second.p);
     c->planes.clear();
 }
-void drop_planes_of(capdec_ctx *c, const void *weight) {
-    auto it = c->planes.find(weight);
-    if (it == c->planes.end()) return;
-    (void)hipFree(it->second.p);
-    c->planes.erase(it);
+void drop_planes_of(capdec_ctx *c, const void *weight) {       // every format cached for this weight
+    for (auto it = c->planes.lower_bound({weight, -1}); it != c->planes.end() && it->first.first == weight;) {
+        (void)hipFree(it->second.p);
+        it = c->planes.erase(it);
+    }
 }
 // packed operand format of the block-stack / lm_head GEMMs in the current mode (bf16x3.h): two fp16 planes (f16x2),
 // three bf16 planes (bf16x3), or ONE bf16 / fp16 plane (the reduced-precision modes)
@@ -55,14 +55,14 @@ int planes_of(capdec_ctx *c, const float *W, int N, int K, bool cache, const voi
     const size_t n = (size_t)N * K, bytes = x3_packed_bytes(N, K, fmt);
     if (wide_ok) *wide_ok = false;
     if (cache) {
-        auto it = c->planes.find(W);
+        auto it = c->planes.find({W, fmt});
         if (it != c->planes.end()) {
-            if (it->second.n == n && it->second.fmt == fmt) {
+            if (it->second.n == n) {
                 *out = it->second.p;
                 if (wide_ok) *wide_ok = it->second.wide_ok;
                 return 0;
             }
-            (void)hipFree(it->second.p);      // same address, different matrix (or the GEMM mode changed)
+            (void)hipFree(it->second.p);      // same address, different matrix
             c->planes.erase(it);
         }
         bool ok = false;
@@ -73,7 +73,7 @@ int planes_of(capdec_ctx *c, const float *W, int N, int K, bool cache, const voi
             (void)hipFree(p);
             return 1;
         }
-        c->planes[W] = capdec_ctx::Planes{p, n, fmt, ok};
+        c->planes[{W, fmt}] = capdec_ctx::Planes{p, n, fmt, ok};
         *out = p;
         if (wide_ok) *wide_ok = ok;
         return 0;

@@ -1,8 +1,14 @@
-// The train step with a frozen GPT-2 -- reference train.py:344-354 run with --only_prefix (ClipCaptionPrefix,
-// train.py:279-287: parameters() = the mapper's, GPT-2 in eval mode => no dropout, a deterministic step):
+// The train step -- reference train.py:344-354.  Scope 0: run with --only_prefix (ClipCaptionPrefix, train.py:279-287:
+// parameters() = the mapper's, GPT-2 in eval mode => no dropout, a deterministic step).  Scope 1: the reference's DEFAULT
+// run (ClipCaptionModel, :306-308: GPT-2 is trained too and, being in train() mode, applies transformers' dropouts --
+// embd / attention weights / both residual branches, p = 0.1 -- from a Philox keep-mask stream or from injected masks):
 //
 //     prefix -> MLP mapper -> cat(prefix rows, wte(tokens)) -> GPT-2 -> logits[:, P-1:-1] -> cross_entropy(ignore_index=0)
 //     -> backward down to the mapper's four tensors -> transformers-4.24 AdamW
+//
+// Gradients travel UN-NORMALISED (d logits = (softmax - onehot) x LS, LS a power of two) through every backward GEMM and
+// the factor 1 / (count LS) is applied where a gradient is consumed (AdamW, capdec_train_get): the GEMM operands then sit
+// in the range where the two-fp16-plane format is fp32-accurate, whatever the number of scored labels.
 //
 // Both mapping networks: the MLP (gpt2_prefix.py:114-126) and the TransformerMapper (transformer_mapper.py:113-127: every
 // one of its 3 + 12 n_layers tensors).  Structure: the forward keeps every activation the backward needs
@@ -52,6 +58,73 @@ __global__ void relu_bwd_kernel(const float *__restrict__ y, const float *dy, fl
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) dx[i] = y[i] > 0.f ? dy[i] : 0.f;
 }
+// ---- GPT-2's dropouts (scope 1).  Keep-masks: one byte per element (1 = keep), all sites of one step in one buffer in
+// the call order of transformers' GPT2Model: embd [B, S, d], then per block attn [B, H, S, S],
+// resid [B, S, d], mlp [B, S, d].  Survivors are scaled by 1 / (1 - p), like torch's dropout.
+// Philox4x32-10, key = seed, counter = (4-element group, train step): 4 mask bytes per thread
+__global__ void dropout_mask_kernel(uint32_t *__restrict__ mask4, size_t n4, float p, unsigned long long seed,
+                                    unsigned long long step) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n4) return;
+    uint32_t o[4];
+    philox4x32((uint32_t)i, (uint32_t)(i >> 32), (uint32_t)step, (uint32_t)(step >> 32), (uint32_t)seed, (uint32_t)(seed >> 32), o);
+    uint32_t m = 0;
+#pragma unroll
+    for (int e = 0; e < 4; ++e)      // torch: keep = rand >= p, rand = 24 random bits / 2^24
+        m |= ((float)(o[e] >> 8) * (1.0f / 16777216.0f) >= p ? 1u : 0u) << (8 * e);
+    mask4[i] = m;
+}
+__device__ __forceinline__ float4 mask4f(uint32_t m, float inv_keep) {
+    return make_float4((m & 0xffu) ? inv_keep : 0.f, (m & 0xff00u) ? inv_keep : 0.f, (m & 0xff0000u) ? inv_keep : 0.f,
+                       (m & 0xff000000u) ? inv_keep : 0.f);
+}
+// out = (resid ? resid : 0) + y * mask / keep   (y == out allowed: the embedding dropout; resid: the block's residual
+// branch h + dropout(conv1d(...)); backward through a dropout: resid = nullptr)
+__global__ void dropout_apply_kernel(const float4 *y, const uint32_t *__restrict__ mask4, const float4 *__restrict__ resid,
+                                     float4 *out, size_t n4, float inv_keep) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n4) return;
+    const float4 v = y[i], k = mask4f(mask4[i], inv_keep);
+    float4 r = make_float4(v.x * k.x, v.y * k.y, v.z * k.z, v.w * k.w);
+    if (resid) { const float4 a = resid[i]; r.x += a.x; r.y += a.y; r.z += a.z; r.w += a.w; }
+    out[i] = r;
+}
+// causal attention with dropout on the softmax weights (GPT-2 in train() mode: attn_dropout): one wavefront per
+// (sample, head, query i), HD = 64: lane = head dimension; out_i = sum_j softmax_j(q_i . k_j / 8) mask_ij / keep v_j
+__global__ __launch_bounds__(256) void attn_fwd_drop_kernel(const float *__restrict__ qkv, const uint8_t *__restrict__ mask,
+                                                            float *__restrict__ out, int total, int S, int heads,
+                                                            float scale, float inv_keep) {
+    extern __shared__ float sh[];                     // [4 waves][S]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int gw = blockIdx.x * 4 + wave;
+    if (gw >= total) return;
+    const int i = gw % S, bh = gw / S, h = bh % heads, b = bh / heads;
+    const int d = heads * 64;
+    float *sc = sh + (size_t)wave * S;
+    const size_t row = (size_t)b * S + i;
+    const float q = qkv[row * 3 * d + h * 64 + lane];
+    for (int j = 0; j <= i; ++j) {
+        const float a = wave_sum(q * qkv[((size_t)b * S + j) * 3 * d + d + h * 64 + lane]) * scale;
+        if (lane == 0) sc[j] = a;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    float mx = -INFINITY;
+    for (int j = lane; j <= i; j += 64) mx = fmaxf(mx, sc[j]);
+    mx = wave_max(mx);
+    float l = 0.f;
+    for (int j = lane; j <= i; j += 64) l += expf(sc[j] - mx);
+    l = wave_sum(l);
+    const float inv = 1.0f / l;
+    const uint8_t *mr = mask + ((size_t)bh * S + i) * S;
+    float o = 0.f;
+    for (int j = 0; j <= i; ++j) {
+        const float pj = expf(sc[j] - mx) * inv * (mr[j] ? inv_keep : 0.f);
+        o += pj * qkv[((size_t)b * S + j) * 3 * d + 2 * d + h * 64 + lane];
+    }
+    out[row * d + h * 64 + lane] = o;
+}
 // TransformerMapper output = rows clip_len.. of the sequence: dseq[b, s] = s >= clip_len ? dout[b, s - clip_len] : 0
 __global__ void tmapper_put_kernel(const float *__restrict__ dout, float *__restrict__ dseq, int n, int clip_len, int P, int d) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -80,13 +153,15 @@ __global__ void tmapper_split_grad_kernel(const float *__restrict__ dseq, float 
 // Row maps of the step's sequences (S = P + L positions per sample, d4 = d / 4 float4 per row):
 // embeds[(b, s)] = s < P ? pe[b, s] : wte[tokens[b, s - P]]
 __global__ void build_embeds_kernel(const float *__restrict__ pe, const float *__restrict__ wte, const int *__restrict__ tokens,
-                                    float *__restrict__ emb, int B, int P, int L, int d4) {
+                                    float *__restrict__ emb, int B, int P, int L, int d4, int V) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int S = P + L;
     if (i >= (size_t)B * S * d4) return;
     const int c = (int)(i % d4), s_ = (int)((i / d4) % S), b = (int)(i / ((size_t)d4 * S));
+    int tok = s_ < P ? 0 : tokens[(size_t)b * L + (s_ - P)];
+    if (tok < 0 || tok >= V) tok = 0;            // (an id outside the table: the step is flagged bad by ce_finish_kernel)
     const float4 *src = s_ < P ? reinterpret_cast<const float4 *>(pe) + ((size_t)b * P + s_) * d4
-                               : reinterpret_cast<const float4 *>(wte) + (size_t)tokens[(size_t)b * L + (s_ - P)] * d4;
+                               : reinterpret_cast<const float4 *>(wte) + (size_t)tok * d4;
     reinterpret_cast<float4 *>(emb)[i] = src[c];
 }
 // the rows the loss reads, logits[:, P-1:-1]: out[(b, t)] = in[(b, P - 1 + t)]
@@ -107,10 +182,10 @@ __global__ void put_loss_rows_kernel(const float *__restrict__ in, float *__rest
                                                              : make_float4(0.f, 0.f, 0.f, 0.f);
 }
 // ---- full-model scope (GPT-2 trained too) only
-// x[i] /= *count
-__global__ void div_by_count_kernel(float *x, size_t n, const int *__restrict__ count) {
+// x[i] *= *scale   (capdec_train_get: a gradient leaves the arena normalised)
+__global__ void scale_by_kernel(float *x, size_t n, const float *__restrict__ scale) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) x[i] = x[i] / (float)max(*count, 1);
+    if (i < n) x[i] *= *scale;
 }
 // the token lookup's share of the tied wte gradient: g_wte[tokens[b, t], :] += d embeds[(b, P + t), :]   (atomic: an id may repeat)
 __global__ void embed_scatter_add_kernel(const float *__restrict__ dh, const int *__restrict__ tokens, float *__restrict__ gwte,
@@ -130,13 +205,12 @@ __global__ void wpe_grad_kernel(const float *__restrict__ dh, float *__restrict_
     for (int b = 0; b < B; ++b) a += dh[(size_t)b * S * d + i];
     gwpe[i] = a;
 }
-// d pe[b, p] = d embeds[(b, p)] / *count   (the mapper's output gradient, normalised by the number of scored labels)
-__global__ void take_prefix_grad_kernel(const float *__restrict__ dh, float *__restrict__ dy, int B, int P, int L, int d,
-                                        const int *__restrict__ count) {
+// d pe[b, p] = d embeds[(b, p)]   (the mapper's output gradient, un-normalised like everything in the backward pass)
+__global__ void take_prefix_grad_kernel(const float *__restrict__ dh, float *__restrict__ dy, int B, int P, int L, int d) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (size_t)B * P * d) return;
     const int c = (int)(i % d), p_ = (int)((i / d) % P), b = (int)(i / ((size_t)d * P));
-    dy[i] = dh[((size_t)b * (P + L) + p_) * d + c] / (float)max(*count, 1);
+    dy[i] = dh[((size_t)b * (P + L) + p_) * d + c];
 }
 // dst[c][r] = src[r][c] for r < rows, 0 for rows <= r < ld   (dst [cols][ld])
 __global__ void transpose_pad_kernel(const float *__restrict__ src, int rows, int cols, float *__restrict__ dst, int ld) {
@@ -171,13 +245,33 @@ __global__ void colsum_kernel(const float *__restrict__ x, int rows, int n, floa
     for (; r < r1; ++r) s0 += x[(size_t)r * n + j];
     atomicAdd(out + j, (s0 + s1) + (s2 + s3));
 }
+// The step's device-side scalars (one 64-byte record; TrainState::cnt)
+struct StepScalars {
+    int count;              // labels scored by the loss (!= ignore_index)
+    float loss;             // mean over them (NaN when an id lies outside the vocabulary)
+    float gscale;           // 1 / (max(count, 1) LS): what turns an arena entry into d loss / d tensor
+    int bad;                // an id outside [0, vocab): the forward looked row 0 up instead; the update is skipped
+    long long updates;      // AdamW updates applied (bias correction uses updates + 1)
+    float step_size;        // lr sqrt(1 - b2^t) / (1 - b1^t) of the update being applied
+    float loss_sum;         // sum of the losses since the last capdec_train_loss(reset) ...
+    int loss_steps;         // ... and how many
+};
+// one thread: the update's step size from the device's own update counter (a bad step neither counts nor updates)
+__global__ void adam_prepare_kernel(StepScalars *s, float lr, float b1, float b2) {
+    if (s->bad) return;
+    const double t = (double)(s->updates + 1);
+    s->step_size = (float)((double)lr * sqrt(1.0 - pow((double)b2, t)) / (1.0 - pow((double)b1, t)));
+    s->updates += 1;
+}
 // transformers-4.24 AdamW (optimization.py AdamW.step): m, v updated in place; p -= step_size * m / (sqrt(v) + eps);
-// then p -= decay * p (decay = lr * weight_decay, 0 by default).  step_size = lr * sqrt(1 - b2^t) / (1 - b1^t) (host)
+// then p -= decay * p (decay = lr * weight_decay, 0 by default).  g = arena entry x gscale
 __global__ void adamw_kernel(float *__restrict__ p, const float *__restrict__ g, float *__restrict__ m,
-                             float *__restrict__ v, size_t n, float step_size, float b1, float b2, float eps, float decay) {
+                             float *__restrict__ v, size_t n, const StepScalars *__restrict__ sc, float b1, float b2, float eps,
+                             float decay) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const float gi = g[i];
+    if (i >= n || sc->bad) return;
+    const float step_size = sc->step_size;
+    const float gi = g[i] * sc->gscale;
     const float mi = m[i] * b1 + gi * (1.0f - b1);
     const float vi = v[i] * b2 + gi * gi * (1.0f - b2);
     m[i] = mi;
@@ -254,11 +348,14 @@ __global__ __launch_bounds__(256) void ln_param_grad_kernel(const float *__restr
 // One wavefront per (sample, head, query i); a lane owns the head dimensions lane and lane + 64 (< HD).
 //   s_j = q_i . k_j scale, p = softmax_j(s), dP_j = dO_i . v_j, D = sum_j p_j dP_j, dS_j = p_j (dP_j - D)
 //   dq_i = sum_j dS_j k_j scale;  lse_i and D_i are kept for the key-side kernel
+// mask != nullptr (GPT-2's attn_dropout, [B, H, S, S] keep bytes): the weights that multiplied V were p_j m_ij / keep,
+// so dP_j = (dO_i . v_j) m_ij / keep -- everything else as above
 template <int HD, bool CAUSAL>
 __global__ __launch_bounds__(256) void attn_bwd_q_kernel(const float *__restrict__ qkv, const float *__restrict__ dout,
                                                          float *__restrict__ dqkv, float *__restrict__ lse_out,
                                                          float *__restrict__ dsum_out, int total, int S, int heads,
-                                                         float scale) {
+                                                         float scale, const uint8_t *__restrict__ mask = nullptr,
+                                                         float inv_keep = 1.f) {
     constexpr int NE = (HD + 63) / 64;
     extern __shared__ float sh[];                     // [4 waves][2][S]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -284,6 +381,7 @@ __global__ __launch_bounds__(256) void attn_bwd_q_kernel(const float *__restrict
             if (lane + 64 * e < HD) { a += q[e] * kr[lane + 64 * e]; t += go[e] * kr[d + lane + 64 * e]; }
         a = wave_sum(a) * scale;
         t = wave_sum(t);
+        if (mask) t *= mask[((size_t)bh * S + i) * S + j] ? inv_keep : 0.f;
         if (lane == 0) { sc[j] = a; dp[j] = t; }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -322,7 +420,8 @@ template <int HD, bool CAUSAL>
 __global__ __launch_bounds__(256) void attn_bwd_kv_kernel(const float *__restrict__ qkv, const float *__restrict__ dout,
                                                           float *__restrict__ dqkv, const float *__restrict__ lse_in,
                                                           const float *__restrict__ dsum_in, int total, int S, int heads,
-                                                          float scale) {
+                                                          float scale, const uint8_t *__restrict__ mask = nullptr,
+                                                          float inv_keep = 1.f) {
     constexpr int NE = (HD + 63) / 64;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int gw = blockIdx.x * 4 + wave;
@@ -351,10 +450,11 @@ __global__ __launch_bounds__(256) void attn_bwd_kv_kernel(const float *__restric
             t += go[e] * v[e];
         }
         const int gi = bh * S + i;
+        const float mk = mask ? (mask[(size_t)gi * S + j] ? inv_keep : 0.f) : 1.f;
         const float p = expf(wave_sum(a) * scale - lse_in[gi]);
-        const float ds = p * (wave_sum(t) - dsum_in[gi]);
+        const float ds = p * (wave_sum(t) * mk - dsum_in[gi]);
 #pragma unroll
-        for (int e = 0; e < NE; ++e) { dk[e] += ds * q[e]; dv[e] += p * go[e]; }
+        for (int e = 0; e < NE; ++e) { dk[e] += ds * q[e]; dv[e] += p * mk * go[e]; }
     }
 #pragma unroll
     for (int e = 0; e < NE; ++e)
@@ -365,10 +465,10 @@ __global__ __launch_bounds__(256) void attn_bwd_kv_kernel(const float *__restric
 }
 
 // ---------------------------------------------------------------------------------------------- cross-entropy
-// logits [rows, ld] (columns >= V are padding) -> in place: (softmax - onehot) for rows whose label != ignore, 0 for the
-// others and for the padding; row_loss[r] = lse - logit[label] (0 for ignored rows).  One block per row.
+// logits [rows, ld] (columns >= V are padding) -> in place: (softmax - onehot) x ls for rows whose label != ignore, 0 for
+// the others and for the padding; row_loss[r] = lse - logit[label] (0 for ignored rows).  One block per row.
 __global__ __launch_bounds__(256) void ce_bwd_kernel(float *__restrict__ logits, int ld, const int *__restrict__ labels,
-                                                     int V, int ignore_index, float *__restrict__ row_loss) {
+                                                     int V, int ignore_index, float *__restrict__ row_loss, float ls) {
     __shared__ float red[4];
     const int row = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
     float *lr = logits + (size_t)row * ld;
@@ -394,29 +494,37 @@ __global__ __launch_bounds__(256) void ce_bwd_kernel(float *__restrict__ logits,
     const float lse = mx + logf((red[0] + red[1]) + (red[2] + red[3]));
     if (t == 0) row_loss[row] = lse - lr[lab];
     __syncthreads();                                                       // (lr[lab] is read before anyone rewrites it)
-    for (int c = t; c < ld; c += 256) lr[c] = c < V ? expf(lr[c] - lse) - (c == lab ? 1.f : 0.f) : 0.f;
+    for (int c = t; c < ld; c += 256) lr[c] = c < V ? (expf(lr[c] - lse) - (c == lab ? 1.f : 0.f)) * ls : 0.f;
 }
-// *count = number of labels != ignore (and in range); *loss = sum(row_loss) / count   (one block)
+// the step's scalars: count = labels != ignore (and in range), loss = sum(row_loss) / count, gscale = 1 / (count ls);
+// an id outside [0, V) (torch raises on it: the embedding lookup and the loss both index with it) flags the step bad --
+// loss NaN, no update   (one block)
 __global__ __launch_bounds__(256) void ce_finish_kernel(const float *__restrict__ row_loss, const int *__restrict__ labels,
-                                                        int rows, int V, int ignore_index, int *__restrict__ count,
-                                                        float *__restrict__ loss) {
+                                                        int rows, int V, int ignore_index, StepScalars *__restrict__ sc, float ls) {
     __shared__ float rs[4];
-    __shared__ int rc[4];
+    __shared__ int rc[4], rb[4];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     float s = 0.f;
-    int n = 0;
+    int n = 0, bad = 0;
     for (int r = t; r < rows; r += 256) {
         const int lab = labels[r];
-        if (lab != ignore_index && lab >= 0 && lab < V) { s += row_loss[r]; ++n; }
+        if (lab < 0 || lab >= V) bad = 1;
+        else if (lab != ignore_index) { s += row_loss[r]; ++n; }
     }
     s = wave_sum(s);
-    const float nf = wave_sum((float)n);
-    if (lane == 0) { rs[wave] = s; rc[wave] = (int)nf; }
+    const float nf = wave_sum((float)n), bf = wave_sum((float)bad);
+    if (lane == 0) { rs[wave] = s; rc[wave] = (int)nf; rb[wave] = bf > 0.f; }
     __syncthreads();
     if (t == 0) {
         const int c = rc[0] + rc[1] + rc[2] + rc[3];
-        *count = c;
-        *loss = ((rs[0] + rs[1]) + (rs[2] + rs[3])) / (float)max(c, 1);
+        const bool b = rb[0] | rb[1] | rb[2] | rb[3];
+        const float loss = b ? __builtin_nanf("") : ((rs[0] + rs[1]) + (rs[2] + rs[3])) / (float)max(c, 1);
+        sc->count = c;
+        sc->loss = loss;
+        sc->gscale = 1.0f / ((float)max(c, 1) * ls);
+        sc->bad = b;
+        sc->loss_sum += loss;
+        sc->loss_steps += 1;
     }
 }
 
@@ -439,17 +547,24 @@ struct TrainState {
     // the mapper's trainable tensors (build_slots) + gradient and moment arenas
     std::vector<Slot> slots;
     size_t n_params = 0;
-    bool train_gpt = false;                  // scope (capdec_train_set_scope): 0 the mapper (GPT-2 frozen), 1 GPT-2 as well
+    bool train_gpt = false;                  // scope (capdec_ctx::train_scope at creation): 0 the mapper (GPT-2 frozen), 1 GPT-2 as well
     int gpt_slot0 = -1;                      // first GPT-2 slot: wte, wpe, 12 per layer, ln_f weight / bias
     DBuf G, Mo, Vo;
     // saved activations + gradient scratch (grow-only)
     DBuf pe, emb, hs, a, qkv, att, hmid, fc, gl, hf, hfl, logits, rloss, cnt;
     DBuf dh, dh2, da, dqkv, datt, dfc, dhfl, lse, dsum, dy, tA, tB, wT, lnstat;
+    DBuf dmask, dinj, ytmp, dtmp;            // scope 1 with dropout: this step's keep-masks, masks injected for the next
+                                             // step, a Conv1D output before its dropout, a gradient after one
+    size_t dinj_n = 0;                       // bytes waiting in dinj (0: the next step draws its masks from Philox)
+    size_t dmask_n = 0;                      // bytes of the last step's mask stream (capdec_train_get_dropout_masks)
+    unsigned long long draws = 0;            // mask streams drawn from Philox so far (the counter's high half)
     DBuf hid, dhid;                          // MLP mapper: tanh output, its gradient
     DBuf t_lin, t_seq, t_a1, t_qkv, t_att, t_mid, t_a2, t_r;      // TransformerMapper: per-layer saved activations
     DBuf t_ds, t_ds2, t_da, t_dr, t_dqkv, t_datt, t_dlin;         // ... gradient scratch
-    long long step = 0;                      // updates applied (bias correction uses step + 1)
+    long long step = 0;                      // train steps run with apply_update (the mask stream's counter; the AdamW
+                                             // update counter lives on the device: StepScalars::updates)
     bool have_grads = false;
+    bool scalars_ready = false;
     void release() {
         for (void *p : owned) (void)hipFree(p);
         owned.clear();
@@ -459,17 +574,22 @@ struct TrainState {
         weights_ready = false;
         DBuf *bufs[] = {&G, &Mo, &Vo, &pe, &emb, &hs, &a, &qkv, &att, &hmid, &fc, &gl, &hf, &hfl, &logits, &rloss, &cnt,
                         &dh, &dh2, &da, &dqkv, &datt, &dfc, &dhfl, &lse, &dsum, &dy, &tA, &tB, &wT, &lnstat, &hid, &dhid,
+                        &dmask, &dinj, &ytmp, &dtmp,
                         &t_lin, &t_seq, &t_a1, &t_qkv, &t_att, &t_mid, &t_a2, &t_r, &t_ds, &t_ds2, &t_da, &t_dr, &t_dqkv,
                         &t_datt, &t_dlin};
         for (DBuf *b : bufs) b->release();
         step = 0;
         have_grads = false;
+        scalars_ready = false;
+        dinj_n = dmask_n = 0;
+        draws = 0;
     }
     float *grad(int slot) { return G.as<float>() + slots[slot].off; }
 };
 
 void train_release(capdec_ctx *c) {
     if (!c->train) return;
+    for (void *p : c->train->owned) drop_planes_of(c, p);      // planes packed from the transposed copies die with them
     c->train->release();
     delete c->train;
     c->train = nullptr;
@@ -582,10 +702,10 @@ static int refresh_backward_weights(capdec_ctx *c, TrainState &t) {
     return transpose_pad(c, g.wte, g.vocab, d, t.wte_t, t.Vp);
 }
 
-// C[M, N] = A[M, K] . Bt[N, K]^T on the native fp32 MFMA GEMM
-// (CAPDEC_TRAIN_F16X2=1, not the default: on the fp32-accurate two-fp16-plane kernels of the inference path instead -- the
-//  GPT-2 backward runs on un-normalised gradients of order one for exactly that; static_weight: Bt never changes, its
-//  packed planes may be cached)
+// C[M, N] = A[M, K] . Bt[N, K]^T on the fp32-accurate two-fp16-plane kernels of the inference path (the backward pass runs
+// on un-normalised, loss-scaled gradients for exactly that: see the header); CAPDEC_TRAIN_F16X2=0: the native fp32 MFMA
+// GEMM instead (39.4 vs 23.6 ms per step at the reference's default geometry, profiles/r5_first_call.txt).
+// static_weight: Bt never changes, its packed planes may be cached
 static int gemm_fp32(capdec_ctx *c, const float *A, int lda, const float *Bt, int ldb, float *C, int ldc, int M, int N, int K,
                      bool static_weight = false) {
     if (c->tune.train_f16x2 && K % 64 == 0 && ldb == K && lda % 4 == 0)
@@ -742,6 +862,31 @@ static int mapper_backward(capdec_ctx *c, TrainState &t, const float *x, const f
     return linear_dw(c, t, dlin, x, B, m.clip_len * d, D, t.grad(0), t.grad(1));
 }
 
+// the keep-masks of this step: injected ones (consumed once) or the Philox stream of (seed, step)
+static int prepare_dropout_masks(capdec_ctx *c, TrainState &t, size_t n) {
+    const size_t n4 = (n + 3) / 4;
+    CAPDEC_TRY(t.dmask.ensure(n4 * 4));
+    if (t.dinj_n) {
+        CAPDEC_CHECK(t.dinj_n == n, "train_step: the injected dropout masks do not have this batch's size "
+                                     "(B S d + n_layer (B H S S + 2 B S d) bytes, S = prefix_length + length)");
+        CAPDEC_HIP(hipMemcpyAsync(t.dmask.p, t.dinj.p, n, hipMemcpyDeviceToDevice, c->stream));
+        t.dinj_n = 0;
+    } else {
+        hipLaunchKernelGGL(dropout_mask_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, c->stream, t.dmask.as<uint32_t>(), n4,
+                           c->train_drop_p, c->train_drop_seed, t.draws);
+        CAPDEC_HIP(hipGetLastError());
+        t.draws += 1;
+    }
+    t.dmask_n = n;
+    return 0;
+}
+static inline void dropout_apply(hipStream_t st, const float *y, const uint8_t *mask, const float *resid, float *out, size_t n,
+                                 float inv_keep) {
+    hipLaunchKernelGGL(dropout_apply_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, st, reinterpret_cast<const float4 *>(y),
+                       reinterpret_cast<const uint32_t *>(mask), reinterpret_cast<const float4 *>(resid),
+                       reinterpret_cast<float4 *>(out), n / 4, inv_keep);
+}
+
 // the whole step; see capdec.h: capdec_train_step
 static int train_step(capdec_ctx *c, const float *prefix, const int *tokens, int B, int L, float lr, float b1, float b2,
                       float eps, float weight_decay, int apply_update, float *loss_host) {
@@ -752,13 +897,23 @@ static int train_step(capdec_ctx *c, const float *prefix, const int *tokens, int
     const int d = g.d, P = m.P, S = P + L, R = B * S, Rl = B * L, O = P * d, D = m.D;
     CAPDEC_CHECK(B >= 1 && L >= 1 && S <= 256 && S <= g.n_pos, "train_step: bad batch geometry (prefix_length + L <= 256)");
     CAPDEC_CHECK(D % 32 == 0 && O % 32 == 0, "train_step: mapper dims must be multiples of 32");
-    if (!c->train) c->train = new TrainState();
+    if (!c->train) { c->train = new TrainState(); c->train->train_gpt = c->train_scope != 0; }
     TrainState &t = *c->train;
     CAPDEC_TRY(prepare_backward_weights(c, t));
     CAPDEC_TRY(build_slots(c, t));
     hipStream_t st = c->stream;
     const int nl = g.n_layer, Vp = t.Vp;
     const size_t Rd = (size_t)R * d;
+    const bool full = t.train_gpt;                  // GPT-2 is trained too: weight gradients along the way
+    // GPT-2's dropouts exist only when GPT-2 is in train() mode: the frozen scope keeps it in eval mode (train.py:283-287)
+    const bool drop = full && (c->train_drop_p > 0.f || t.dinj_n);
+    const float keep = 1.0f - c->train_drop_p, inv_keep = 1.0f / keep;
+    const size_t mA = (size_t)B * g.n_head * S * S, mLayer = mA + 2 * Rd;       // mask stream: embd, then per layer attn, resid, mlp
+    CAPDEC_CHECK(!t.dinj_n || full, "train_step: dropout masks were injected but GPT-2 is frozen (scope 0: eval mode, no dropout)");
+    CAPDEC_CHECK(!t.dinj_n || c->train_drop_p > 0.f, "train_step: dropout masks were injected but the dropout probability is 0");
+    // loss scale of the backward pass: a power of two that lifts softmax probabilities of a 50 257-entry vocabulary into
+    // the two-fp16-plane format's full-precision range (>= 2^-14); exact, undone by StepScalars::gscale
+    const float LS = c->tune.train_f16x2 ? 64.f : 1.f;
     // ---- buffers
     CAPDEC_TRY(t.pe.ensure((size_t)B * O * 4));
     CAPDEC_TRY(t.emb.ensure(Rd * 4));
@@ -773,7 +928,7 @@ static int train_step(capdec_ctx *c, const float *prefix, const int *tokens, int
     CAPDEC_TRY(t.hfl.ensure((size_t)Rl * d * 4));
     CAPDEC_TRY(t.logits.ensure((size_t)Rl * Vp * 4));
     CAPDEC_TRY(t.rloss.ensure((size_t)Rl * 4));
-    CAPDEC_TRY(t.cnt.ensure(16));
+    CAPDEC_TRY(t.cnt.ensure(sizeof(StepScalars)));
     CAPDEC_TRY(t.dh.ensure(Rd * 4));
     CAPDEC_TRY(t.dh2.ensure(Rd * 4));
     CAPDEC_TRY(t.da.ensure(Rd * 4));
@@ -784,58 +939,77 @@ static int train_step(capdec_ctx *c, const float *prefix, const int *tokens, int
     CAPDEC_TRY(t.lse.ensure((size_t)B * g.n_head * S * 4));
     CAPDEC_TRY(t.dsum.ensure((size_t)B * g.n_head * S * 4));
     CAPDEC_TRY(t.dy.ensure((size_t)B * O * 4));
+    if (drop) {
+        CAPDEC_TRY(t.ytmp.ensure(Rd * 4));
+        CAPDEC_TRY(t.dtmp.ensure(Rd * 4));
+        CAPDEC_TRY(prepare_dropout_masks(c, t, Rd + (size_t)nl * mLayer));
+    }
+    if (!t.scalars_ready) {
+        CAPDEC_HIP(hipMemsetAsync(t.cnt.p, 0, sizeof(StepScalars), st));
+        t.scalars_ready = true;
+    }
     float *pe = t.pe.as<float>(), *emb = t.emb.as<float>(), *hs = t.hs.as<float>(), *a = t.a.as<float>(), *gl = t.gl.as<float>(),
           *hf = t.hf.as<float>(), *hfl = t.hfl.as<float>(), *logits = t.logits.as<float>();
-    int *cnt = t.cnt.as<int>();
-    float *loss_dev = reinterpret_cast<float *>(cnt + 1);
+    StepScalars *sc = t.cnt.as<StepScalars>();
+    const uint8_t *mk = t.dmask.as<uint8_t>();
+    float *ytmp = t.ytmp.as<float>(), *dtmp = t.dtmp.as<float>();
 
     // ---- forward: mapper, then embeds = cat(pe.view(B, P, d), wte(tokens))
     CAPDEC_TRY(mapper_forward_saved(c, t, prefix, B, pe));
     {
         ProfScope ps(c, F_EMBED);
-        hipLaunchKernelGGL(build_embeds_kernel, grid1(Rd / 4), dim3(256), 0, st, pe, g.wte, tokens, emb, B, P, L, d / 4);
+        hipLaunchKernelGGL(build_embeds_kernel, grid1(Rd / 4), dim3(256), 0, st, pe, g.wte, tokens, emb, B, P, L, d / 4, g.vocab);
         CAPDEC_TRY(launch_embed_prefix(st, emb, g.wpe, hs, B, S, 0, d));
+        if (drop) dropout_apply(st, hs, mk, nullptr, hs, Rd, inv_keep);                 // self.drop(inputs_embeds + position_embeds)
     }
     KvCache kv;
     kv_geometry(kv, B, S, g.n_head, 64);
     kv.tune = &c->tune;
+    const int nbh = B * g.n_head * S;
     for (int i = 0; i < nl; ++i) {
         const Gpt2Layer &w = g.layers[i];
         float *h = hs + Rd * i, *hn = hs + Rd * (i + 1);
         float *qkv = t.qkv.as<float>() + Rd * 3 * i, *att = t.att.as<float>() + Rd * i, *hmid = t.hmid.as<float>() + Rd * i,
               *fc = t.fc.as<float>() + Rd * 4 * i;
+        const uint8_t *m_att = mk + Rd + (size_t)i * mLayer, *m_res = m_att + mA, *m_mlp = m_res + Rd;
         { ProfScope ps(c, F_LN); CAPDEC_TRY(launch_layernorm(st, h, d, w.ln1w, w.ln1b, g.eps, a, d, R, d)); }
-        CAPDEC_TRY(gemm(c, a, d, w.wqkv, d, qkv, 3 * d, R, 3 * d, d, w.bqkv, CAPDEC_ACT_NONE, nullptr, 0, true));
-        { ProfScope ps(c, F_ATTN_PRE); CAPDEC_TRY(launch_attn_prefill(st, qkv, kv, i, B, S, 1, att, true)); }
-        CAPDEC_TRY(gemm(c, att, d, w.wproj, d, hmid, d, R, d, d, w.bproj, CAPDEC_ACT_NONE, h, d, true));
+        CAPDEC_TRY(gemm(c, a, d, w.wqkv, d, qkv, 3 * d, R, 3 * d, d, w.bqkv, CAPDEC_ACT_NONE, nullptr, 0, !full));
+        if (drop) {
+            ProfScope ps(c, F_ATTN_PRE);
+            hipLaunchKernelGGL(attn_fwd_drop_kernel, dim3((nbh + 3) / 4), dim3(256), (size_t)4 * S * sizeof(float), st, qkv, m_att, att,
+                               nbh, S, g.n_head, 0.125f, inv_keep);
+            CAPDEC_TRY(gemm(c, att, d, w.wproj, d, ytmp, d, R, d, d, w.bproj, CAPDEC_ACT_NONE, nullptr, 0, false));
+            dropout_apply(st, ytmp, m_res, h, hmid, Rd, inv_keep);                      // h + resid_dropout(c_proj(att))
+        } else {
+            { ProfScope ps(c, F_ATTN_PRE); CAPDEC_TRY(launch_attn_prefill(st, qkv, kv, i, B, S, 1, att, true)); }
+            CAPDEC_TRY(gemm(c, att, d, w.wproj, d, hmid, d, R, d, d, w.bproj, CAPDEC_ACT_NONE, h, d, !full));
+        }
         { ProfScope ps(c, F_LN); CAPDEC_TRY(launch_layernorm(st, hmid, d, w.ln2w, w.ln2b, g.eps, a, d, R, d)); }
-        CAPDEC_TRY(gemm(c, a, d, w.wfc, d, fc, 4 * d, R, 4 * d, d, w.bfc, CAPDEC_ACT_NONE, nullptr, 0, true));
+        CAPDEC_TRY(gemm(c, a, d, w.wfc, d, fc, 4 * d, R, 4 * d, d, w.bfc, CAPDEC_ACT_NONE, nullptr, 0, !full));
         hipLaunchKernelGGL(gelu_new_fwd_kernel, grid1(Rd * 4), dim3(256), 0, st, fc, gl, Rd * 4);
-        CAPDEC_TRY(gemm(c, gl, 4 * d, w.wproj2, 4 * d, hn, d, R, d, 4 * d, w.bproj2, CAPDEC_ACT_NONE, hmid, d, true));
+        if (drop) {
+            CAPDEC_TRY(gemm(c, gl, 4 * d, w.wproj2, 4 * d, ytmp, d, R, d, 4 * d, w.bproj2, CAPDEC_ACT_NONE, nullptr, 0, false));
+            dropout_apply(st, ytmp, m_mlp, hmid, hn, Rd, inv_keep);                     // h_mid + dropout(mlp.c_proj(...))
+        } else
+            CAPDEC_TRY(gemm(c, gl, 4 * d, w.wproj2, 4 * d, hn, d, R, d, 4 * d, w.bproj2, CAPDEC_ACT_NONE, hmid, d, !full));
     }
     float *hL = hs + Rd * nl;
     { ProfScope ps(c, F_LN); CAPDEC_TRY(launch_layernorm(st, hL, d, g.lnfw, g.lnfb, g.eps, hf, d, R, d)); }
     // the rows the loss reads: logits[:, P-1:-1]  ->  row (b, P - 1 + t) predicts tokens[b, t]
     hipLaunchKernelGGL(take_loss_rows_kernel, grid1((size_t)Rl * (d / 4)), dim3(256), 0, st, hf, hfl, B, P, L, d / 4);
     CAPDEC_HIP(hipMemsetAsync(logits, 0, (size_t)Rl * Vp * 4, st));
-    CAPDEC_TRY(gemm(c, hfl, d, g.wte, d, logits, Vp, Rl, g.vocab, d, nullptr, CAPDEC_ACT_NONE, nullptr, 0, true));
-    // ---- loss + d logits (unnormalised: softmax - onehot; the 1 / count factor is applied where the mapper's gradient
-    // starts, so every GPT-2 backward GEMM sees values of order one)
-    hipLaunchKernelGGL(ce_bwd_kernel, dim3(Rl), dim3(256), 0, st, logits, Vp, tokens, g.vocab, 0, t.rloss.as<float>());
-    hipLaunchKernelGGL(ce_finish_kernel, dim3(1), dim3(256), 0, st, t.rloss.as<float>(), tokens, Rl, g.vocab, 0, cnt, loss_dev);
+    CAPDEC_TRY(gemm(c, hfl, d, g.wte, d, logits, Vp, Rl, g.vocab, d, nullptr, CAPDEC_ACT_NONE, nullptr, 0, !full));
+    // ---- loss + d logits (un-normalised: (softmax - onehot) LS; the factor 1 / (count LS) is applied where gradients are
+    // consumed, so every backward GEMM sees operands of order one)
+    hipLaunchKernelGGL(ce_bwd_kernel, dim3(Rl), dim3(256), 0, st, logits, Vp, tokens, g.vocab, 0, t.rloss.as<float>(), LS);
+    hipLaunchKernelGGL(ce_finish_kernel, dim3(1), dim3(256), 0, st, t.rloss.as<float>(), tokens, Rl, g.vocab, 0, sc, LS);
     CAPDEC_HIP(hipGetLastError());
     // ---- backward through the lm_head and ln_f
     float *dh = t.dh.as<float>(), *dh2 = t.dh2.as<float>(), *da = t.da.as<float>(), *dqkv = t.dqkv.as<float>(),
           *datt = t.datt.as<float>(), *dfc = t.dfc.as<float>(), *dhfl = t.dhfl.as<float>();
-    const bool full = t.train_gpt;                  // GPT-2 is trained too: weight gradients along the way
     const int gs = t.gpt_slot0;
-    const int *count_for_mapper = cnt;
+    CAPDEC_HIP(hipMemsetAsync(t.G.p, 0, t.n_params * 4, st));        // (bias / LayerNorm / wte gradients are accumulated)
     if (full) {
-        // every gradient below is a final one: d logits are normalised here, and the arena is cleared before the first write
-        hipLaunchKernelGGL(div_by_count_kernel, grid1((size_t)Rl * Vp), dim3(256), 0, st, logits, (size_t)Rl * Vp, cnt);
-        CAPDEC_HIP(hipMemsetD32Async((hipDeviceptr_t)(cnt + 2), 1, 1, st));
-        count_for_mapper = cnt + 2;
-        CAPDEC_HIP(hipMemsetAsync(t.G.p, 0, t.n_params * 4, st));
         // the lm_head's share of the tied wte: d logits^T hf  ([V, d]; K = the loss rows)
         const int Kp = pad_rows(c, Rl);
         CAPDEC_TRY(t.tA.ensure((size_t)Vp * Kp * 4));
@@ -848,19 +1022,21 @@ static int train_step(capdec_ctx *c, const float *prefix, const int *tokens, int
     hipLaunchKernelGGL(put_loss_rows_kernel, grid1(Rd / 4), dim3(256), 0, st, dhfl, da, B, P, L, d / 4);
     CAPDEC_TRY(ln_bwd(c, hL, g.lnfw, da, nullptr, dh, R, d, g.eps, full ? t.grad(gs + 2 + 12 * nl) : nullptr,
                       full ? t.grad(gs + 3 + 12 * nl) : nullptr));
-    // ---- backward through the blocks (dX only: the GPT-2 weights are frozen)
-    const int nbh = B * g.n_head * S;
+    // ---- backward through the blocks (frozen scope: dX only)
     for (int i = nl - 1; i >= 0; --i) {
         const Gpt2Layer &w = g.layers[i];
         const TrainState::LayerT &wt = t.lt[i];
         float *h = hs + Rd * i;
         float *qkv = t.qkv.as<float>() + Rd * 3 * i, *hmid = t.hmid.as<float>() + Rd * i, *fc = t.fc.as<float>() + Rd * 4 * i;
+        const uint8_t *m_att = mk + Rd + (size_t)i * mLayer, *m_res = m_att + mA, *m_mlp = m_res + Rd;
         const int s0 = gs + 2 + 12 * i;               // (full scope) this layer's slots: ln_1 w b, c_attn w b, c_proj w b, ln_2 w b, c_fc w b, mlp.c_proj w b
+        const float *dy2 = dh;                        // d (mlp.c_proj output): dh through the MLP's dropout
+        if (drop) { dropout_apply(st, dh, m_mlp, nullptr, dtmp, Rd, inv_keep); dy2 = dtmp; }
         if (full) {                                   // mlp.c_proj: y = gelu(fc) W + b
             hipLaunchKernelGGL(gelu_new_fwd_kernel, grid1(Rd * 4), dim3(256), 0, st, fc, gl, Rd * 4);
-            CAPDEC_TRY(linear_dw(c, t, dh, gl, R, d, 4 * d, t.grad(s0 + 10), t.grad(s0 + 11)));
+            CAPDEC_TRY(linear_dw(c, t, dy2, gl, R, d, 4 * d, t.grad(s0 + 10), t.grad(s0 + 11)));
         }
-        CAPDEC_TRY(gemm_fp32(c, dh, d, wt.wproj2_t, d, dfc, 4 * d, R, 4 * d, d, !full));          // d gelu_out = dh Wproj2^T
+        CAPDEC_TRY(gemm_fp32(c, dy2, d, wt.wproj2_t, d, dfc, 4 * d, R, 4 * d, d, !full));         // d gelu_out = dy2 Wproj2^T
         hipLaunchKernelGGL(gelu_new_bwd_kernel, grid1(Rd * 4), dim3(256), 0, st, fc, dfc, dfc, Rd * 4);
         if (full) {                                   // mlp.c_fc: input ln_2(h_mid)
             CAPDEC_TRY(launch_layernorm(st, hmid, d, w.ln2w, w.ln2b, g.eps, a, d, R, d));
@@ -869,12 +1045,14 @@ static int train_step(capdec_ctx *c, const float *prefix, const int *tokens, int
         CAPDEC_TRY(gemm_fp32(c, dfc, 4 * d, wt.wfc_t, 4 * d, da, d, R, d, 4 * d, !full));         // d a2
         CAPDEC_TRY(ln_bwd(c, hmid, w.ln2w, da, dh, dh2, R, d, g.eps, full ? t.grad(s0 + 6) : nullptr,
                           full ? t.grad(s0 + 7) : nullptr));                                       // dh_mid = dh + LN'(..)
-        if (full) CAPDEC_TRY(linear_dw(c, t, dh2, t.att.as<float>() + Rd * i, R, d, d, t.grad(s0 + 4), t.grad(s0 + 5)));   // attn.c_proj
-        CAPDEC_TRY(gemm_fp32(c, dh2, d, wt.wproj_t, d, datt, d, R, d, d, !full));                 // d att
+        const float *dy1 = dh2;                       // d (attn.c_proj output): dh_mid through resid_dropout
+        if (drop) { dropout_apply(st, dh2, m_res, nullptr, dtmp, Rd, inv_keep); dy1 = dtmp; }
+        if (full) CAPDEC_TRY(linear_dw(c, t, dy1, t.att.as<float>() + Rd * i, R, d, d, t.grad(s0 + 4), t.grad(s0 + 5)));   // attn.c_proj
+        CAPDEC_TRY(gemm_fp32(c, dy1, d, wt.wproj_t, d, datt, d, R, d, d, !full));                 // d att
         hipLaunchKernelGGL((attn_bwd_q_kernel<64, true>), dim3((nbh + 3) / 4), dim3(256), (size_t)4 * 2 * S * sizeof(float), st, qkv,
-                           datt, dqkv, t.lse.as<float>(), t.dsum.as<float>(), nbh, S, g.n_head, 0.125f);
+                           datt, dqkv, t.lse.as<float>(), t.dsum.as<float>(), nbh, S, g.n_head, 0.125f, drop ? m_att : nullptr, inv_keep);
         hipLaunchKernelGGL((attn_bwd_kv_kernel<64, true>), dim3((nbh + 3) / 4), dim3(256), 0, st, qkv, datt, dqkv,
-                           t.lse.as<float>(), t.dsum.as<float>(), nbh, S, g.n_head, 0.125f);
+                           t.lse.as<float>(), t.dsum.as<float>(), nbh, S, g.n_head, 0.125f, drop ? m_att : nullptr, inv_keep);
         if (full) {                                   // attn.c_attn: input ln_1(h)
             CAPDEC_TRY(launch_layernorm(st, h, d, w.ln1w, w.ln1b, g.eps, a, d, R, d));
             CAPDEC_TRY(linear_dw(c, t, dqkv, a, R, 3 * d, d, t.grad(s0 + 2), t.grad(s0 + 3)));
@@ -883,32 +1061,34 @@ static int train_step(capdec_ctx *c, const float *prefix, const int *tokens, int
         CAPDEC_TRY(ln_bwd(c, h, w.ln1w, da, dh2, dh, R, d, g.eps, full ? t.grad(s0 + 0) : nullptr,
                           full ? t.grad(s0 + 1) : nullptr));                                       // dh = dh_mid + LN'(..)
     }
+    if (drop) dropout_apply(st, dh, mk, nullptr, dh, Rd, inv_keep);                                // through the embedding dropout
     if (full) {       // d inputs_embeds: the token rows feed the tied wte (added to the lm_head's share), every row feeds wpe
         hipLaunchKernelGGL(embed_scatter_add_kernel, grid1((size_t)Rl * d), dim3(256), 0, st, dh, tokens, t.grad(gs), B, P, L, d, g.vocab);
         hipLaunchKernelGGL(wpe_grad_kernel, grid1((size_t)S * d), dim3(256), 0, st, dh, t.grad(gs + 1), B, S, d);
     }
     CAPDEC_HIP(hipGetLastError());
-    // ---- the mapper: dY = d embeds[:, :P] / count
+    // ---- the mapper: dY = d embeds[:, :P]
     float *dy = t.dy.as<float>();
-    hipLaunchKernelGGL(take_prefix_grad_kernel, grid1((size_t)B * O), dim3(256), 0, st, dh, dy, B, P, L, d, count_for_mapper);
-    if (!full) CAPDEC_HIP(hipMemsetAsync(t.G.p, 0, t.n_params * 4, st));       // (the LayerNorm weight gradients are accumulated)
+    hipLaunchKernelGGL(take_prefix_grad_kernel, grid1((size_t)B * O), dim3(256), 0, st, dh, dy, B, P, L, d);
     CAPDEC_TRY(mapper_backward(c, t, prefix, dy, B));
     CAPDEC_HIP(hipGetLastError());
     t.have_grads = true;
-    // ---- AdamW (transformers 4.24 semantics)
+    // ---- AdamW (transformers 4.24 semantics) on arena x gscale
     if (apply_update) {
-        const double tt = (double)(t.step + 1);
-        const float step_size = (float)((double)lr * std::sqrt(1.0 - std::pow((double)b2, tt)) / (1.0 - std::pow((double)b1, tt)));
+        hipLaunchKernelGGL(adam_prepare_kernel, dim3(1), dim3(1), 0, st, sc, lr, b1, b2);
         for (const Slot &sl : t.slots)
             hipLaunchKernelGGL(adamw_kernel, grid1(sl.n), dim3(256), 0, st, sl.p, t.G.as<float>() + sl.off, t.Mo.as<float>() + sl.off,
-                               t.Vo.as<float>() + sl.off, sl.n, step_size, b1, b2, eps, lr * weight_decay);
+                               t.Vo.as<float>() + sl.off, sl.n, sc, b1, b2, eps, lr * weight_decay);
         CAPDEC_HIP(hipGetLastError());
         t.step += 1;
         for (const Slot &sl : t.slots) drop_planes_of(c, sl.p);      // inference must never see planes packed from old values
         if (full) CAPDEC_TRY(refresh_backward_weights(c, t));
     }
-    if (loss_host) CAPDEC_HIP(hipMemcpyAsync(loss_host, loss_dev, sizeof(float), hipMemcpyDeviceToHost, st));
-    CAPDEC_HIP(hipStreamSynchronize(st));
+    // loss == nullptr: nothing waits for the device (capdec_train_loss reads the step's loss, and their running sum, later)
+    if (loss_host) {
+        CAPDEC_HIP(hipMemcpyAsync(loss_host, &sc->loss, sizeof(float), hipMemcpyDeviceToHost, st));
+        CAPDEC_HIP(hipStreamSynchronize(st));
+    }
     return 0;
 }
 
@@ -925,13 +1105,21 @@ int capdec_train_step(capdec_ctx *c, const float *d_prefix, const int32_t *d_tok
     return train_step(c, d_prefix, d_tokens, batch, length, lr, beta1, beta2, eps, weight_decay, apply_update, loss);
 }
 
+}  // extern "C"
+
+static TrainState &train_state(capdec_ctx *c) {
+    if (!c->train) { c->train = new TrainState(); c->train->train_gpt = c->train_scope != 0; }
+    return *c->train;
+}
+
+extern "C" {
+
 int capdec_train_get(capdec_ctx *c, int kind, int which, float *d_out, size_t n) {
     CAPDEC_CHECK(c && d_out, "train_get: null argument");
     CAPDEC_CHECK(c->gpt.loaded && (c->map.kind == 1 || c->map.kind == 2), "train_get: needs GPT-2 weights and a mapper");
     CAPDEC_CHECK(kind == 0 || kind == 1, "train_get: kind must be 0 (parameter) or 1 (gradient)");
     CAPDEC_HIP(hipSetDevice(c->device));
-    if (!c->train) c->train = new TrainState();
-    TrainState &t = *c->train;
+    TrainState &t = train_state(c);
     CAPDEC_TRY(build_slots(c, t));
     CAPDEC_CHECK(which >= 0 && which < (int)t.slots.size(), "train_get: tensor index out of range");
     CAPDEC_CHECK(n == t.slots[which].n, "train_get: wrong element count");
@@ -942,6 +1130,10 @@ int capdec_train_get(capdec_ctx *c, int kind, int which, float *d_out, size_t n)
         CAPDEC_TRY(transpose_pad(c, src, sl.rows, sl.cols, d_out, sl.rows));
     else
         CAPDEC_HIP(hipMemcpyAsync(d_out, src, n * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
+    if (kind == 1) {       // the arena holds d loss / d tensor x count x LS (train_step)
+        hipLaunchKernelGGL(scale_by_kernel, grid1(n), dim3(256), 0, c->stream, d_out, n, &t.cnt.as<StepScalars>()->gscale);
+        CAPDEC_HIP(hipGetLastError());
+    }
     CAPDEC_HIP(hipStreamSynchronize(c->stream));
     return 0;
 }
@@ -950,17 +1142,69 @@ int capdec_train_set_scope(capdec_ctx *c, int train_gpt) {
     CAPDEC_CHECK(c, "null context");
     CAPDEC_CHECK(train_gpt == 0 || train_gpt == 1, "train_set_scope: 0 (mapper, GPT-2 frozen) or 1 (GPT-2 as well)");
     CAPDEC_HIP(hipSetDevice(c->device));
-    if (c->train && c->train->train_gpt == (train_gpt != 0)) return 0;
+    if (c->train_scope == train_gpt && (!c->train || c->train->train_gpt == (train_gpt != 0))) return 0;
+    c->train_scope = train_gpt;             // (kept by capdec_train_reset and by weight reloads)
     train_release(c);                       // another parameter set: new slots, fresh optimizer state
-    c->train = new TrainState();
-    c->train->train_gpt = train_gpt != 0;
+    return 0;
+}
+
+int capdec_train_set_dropout(capdec_ctx *c, float p, uint64_t seed) {
+    CAPDEC_CHECK(c, "null context");
+    CAPDEC_CHECK(p >= 0.f && p < 1.f, "train_set_dropout: p must lie in [0, 1)");
+    c->train_drop_p = p;
+    c->train_drop_seed = seed;
+    if (c->train) { c->train->draws = 0; c->train->dinj_n = 0; }
+    return 0;
+}
+
+int capdec_train_set_dropout_masks(capdec_ctx *c, const uint8_t *d_masks, size_t n) {
+    CAPDEC_CHECK(c && d_masks && n > 0, "train_set_dropout_masks: null argument");
+    CAPDEC_CHECK(c->train_scope == 1 && c->train_drop_p > 0.f, "train_set_dropout_masks: needs scope 1 (GPT-2 in train mode) and a "
+                                                                 "dropout probability > 0 (capdec_train_set_dropout)");
+    CAPDEC_HIP(hipSetDevice(c->device));
+    TrainState &t = train_state(c);
+    CAPDEC_TRY(t.dinj.ensure((n + 3) / 4 * 4));
+    CAPDEC_HIP(hipMemcpyAsync(t.dinj.p, d_masks, n, hipMemcpyDeviceToDevice, c->stream));
+    t.dinj_n = n;
+    return 0;
+}
+
+int capdec_train_get_dropout_masks(capdec_ctx *c, uint8_t *d_out, size_t n) {
+    CAPDEC_CHECK(c && d_out, "train_get_dropout_masks: null argument");
+    CAPDEC_CHECK(c->train && c->train->dmask_n > 0, "train_get_dropout_masks: the last train step used no dropout");
+    CAPDEC_CHECK(n == c->train->dmask_n, "train_get_dropout_masks: wrong byte count");
+    CAPDEC_HIP(hipSetDevice(c->device));
+    CAPDEC_HIP(hipMemcpyAsync(d_out, c->train->dmask.p, n, hipMemcpyDeviceToDevice, c->stream));
+    CAPDEC_HIP(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int capdec_train_loss(capdec_ctx *c, float *last, double *sum, long long *steps, int reset) {
+    CAPDEC_CHECK(c, "null context");
+    if (!c->train || !c->train->scalars_ready) {       // no step since the last reset: nothing accumulated
+        if (last) *last = 0.f;
+        if (sum) *sum = 0.0;
+        if (steps) *steps = 0;
+        return 0;
+    }
+    CAPDEC_HIP(hipSetDevice(c->device));
+    StepScalars h;
+    CAPDEC_HIP(hipMemcpyAsync(&h, c->train->cnt.p, sizeof(h), hipMemcpyDeviceToHost, c->stream));
+    CAPDEC_HIP(hipStreamSynchronize(c->stream));
+    if (last) *last = h.loss;
+    if (sum) *sum = (double)h.loss_sum;
+    if (steps) *steps = h.loss_steps;
+    if (reset) {
+        StepScalars *d = c->train->cnt.as<StepScalars>();
+        CAPDEC_HIP(hipMemsetAsync(&d->loss_sum, 0, sizeof(float) + sizeof(int), c->stream));
+    }
     return 0;
 }
 
 int capdec_train_reset(capdec_ctx *c) {
     CAPDEC_CHECK(c, "null context");
     CAPDEC_HIP(hipSetDevice(c->device));
-    train_release(c);
+    train_release(c);                       // (the scope and the dropout setting live in the context: they stay)
     return 0;
 }
 

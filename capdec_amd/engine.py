@@ -477,7 +477,7 @@ class Engine:
         self._chk(self.lib.capdec_decode_counters(self._h, C.byref(kv), C.byref(sat)), "decode_counters")
         return dict(kv_slots_per_position=kv.value, saturated_quads=sat.value)
 
-    # ---- the train step with a frozen GPT-2 (reference train.py:344-354 with --only_prefix)
+    # ---- the train step (reference train.py:344-354): scope 0 = --only_prefix, scope 1 = the default run
     @staticmethod
     def train_tensor_names(mapping: str, num_layers: int = 8):
         """the mapper's trainable tensors in the order capdec_train_get indexes them (names as in ``clip_project.state_dict()``)"""
@@ -492,9 +492,11 @@ class Engine:
         return names
 
     def train_step(self, prefix: torch.Tensor, tokens: torch.Tensor, lr: float, betas=(0.9, 0.999), eps: float = 1e-6,
-                   weight_decay: float = 0.0, apply_update: bool = True) -> float:
-        """one iteration on the device-resident mapper (capdec_train_step): ``prefix`` [B, D] AFTER noise injection,
-        ``tokens`` [B, L] right-padded with 0; returns the loss of train.py:349"""
+                   weight_decay: float = 0.0, apply_update: bool = True, wait: bool = True) -> Optional[float]:
+        """one iteration on the device-resident weights (capdec_train_step): ``prefix`` [B, D] AFTER noise injection,
+        ``tokens`` [B, L] right-padded with 0; returns the loss of train.py:349.  ``wait=False`` only enqueues the step and
+        returns None (``train_loss`` reads the loss, and the running sum, later: no device round trip per step)"""
+        self._sync_stream()
         x = prefix.to(self.device, torch.float32).contiguous()
         tok = tokens.to(self.device, torch.int32).contiguous()
         if x.dim() != 2 or tok.dim() != 2 or x.shape[0] != tok.shape[0]:
@@ -502,8 +504,40 @@ class Engine:
         loss = C.c_float(0.0)
         self._chk(self.lib.capdec_train_step(self._h, x.data_ptr(), tok.data_ptr(), tok.shape[0], tok.shape[1], float(lr),
                                              float(betas[0]), float(betas[1]), float(eps), float(weight_decay),
-                                             int(bool(apply_update)), C.byref(loss)), "train_step")
+                                             int(bool(apply_update)), C.byref(loss) if wait else None), "train_step")
+        if not wait:
+            x.record_stream(torch.cuda.current_stream(self.device))      # (no-ops on the stream they were made on: kept
+            tok.record_stream(torch.cuda.current_stream(self.device))    #  for callers that build batches on a side stream)
+            return None
         return float(loss.value)
+
+    def train_loss(self, reset: bool = False):
+        """(loss of the last step, sum of the losses since the last reset, number of those steps) -- capdec_train_loss"""
+        last, total, n = C.c_float(0.0), C.c_double(0.0), C.c_longlong(0)
+        self._chk(self.lib.capdec_train_loss(self._h, C.byref(last), C.byref(total), C.byref(n), int(bool(reset))), "train_loss")
+        return float(last.value), float(total.value), int(n.value)
+
+    def train_set_dropout(self, p: float, seed: int = 0):
+        """GPT-2's dropouts in scope 1 (transformers' default 0.1); keep-masks from the Philox stream keyed by ``seed``"""
+        self._chk(self.lib.capdec_train_set_dropout(self._h, float(p), int(seed) & 0xFFFFFFFFFFFFFFFF), "train_set_dropout")
+
+    def train_set_dropout_masks(self, masks: torch.Tensor):
+        """keep-masks (uint8, 1 = keep) of the NEXT train step, all sites concatenated in call order (capdec.h)"""
+        self._sync_stream()
+        m = masks.to(self.device, torch.uint8).contiguous().flatten()
+        self._chk(self.lib.capdec_train_set_dropout_masks(self._h, m.data_ptr(), m.numel()), "train_set_dropout_masks")
+
+    def train_get_dropout_masks(self, n: int) -> torch.Tensor:
+        """the mask stream the last train step used (uint8 [n])"""
+        self._sync_stream()
+        out = torch.empty(n, device=self.device, dtype=torch.uint8)
+        self._chk(self.lib.capdec_train_get_dropout_masks(self._h, out.data_ptr(), n), "train_get_dropout_masks")
+        return out
+
+    @staticmethod
+    def dropout_stream_size(B: int, S: int, d: int, n_head: int, n_layer: int) -> int:
+        """bytes of one step's mask stream: embd [B, S, d] + per block attn [B, H, S, S], resid [B, S, d], mlp [B, S, d]"""
+        return B * S * d + n_layer * (B * n_head * S * S + 2 * B * S * d)
 
     def _train_get(self, kind: int, shapes) -> Dict[str, torch.Tensor]:
         """``shapes``: ordered {name: shape} in the order of train_tensor_names"""
@@ -534,12 +568,12 @@ class Engine:
         return names + ["transformer.ln_f.weight", "transformer.ln_f.bias"]
 
     def train_set_scope(self, train_gpt: bool):
-        """False: the mapper only, GPT-2 frozen (validated); True: GPT-2 as well, dropout-free (see capdec.h: not yet run
-        on a GPU)"""
+        """False: the mapper only, GPT-2 frozen and in eval mode (--only_prefix); True: GPT-2 as well (the reference's
+        default run; dropout per train_set_dropout)"""
         self._chk(self.lib.capdec_train_set_scope(self._h, int(bool(train_gpt))), "train_set_scope")
 
     def train_reset(self):
-        """a fresh optimizer: drops the AdamW moments and the step count"""
+        """a fresh optimizer: drops the AdamW moments and the step count (scope and dropout setting stay)"""
         self._chk(self.lib.capdec_train_reset(self._h), "train_reset")
 
     def second_pass_rows(self) -> int:

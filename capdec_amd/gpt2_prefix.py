@@ -182,6 +182,8 @@ class ClipCaptionModel(_HipModule):
     _device_ahead = False
 
     _train_gpt = False          # scope of the train steps run on this model (capdec_amd.train.train_step)
+    _drop_state = None          # (p, seed epoch) the engine's dropout stream was last set up with
+    _drop_seed_epoch = 0        # bump to re-seed the stream (e.g. after torch.manual_seed)
 
     def _train_shapes(self):
         """ordered {state-dict name: shape} of every tensor the current train scope updates, in the device's slot order"""
@@ -294,6 +296,9 @@ class _Gpt2Facade:
     def __init__(self, owner: ClipCaptionModel):
         self._owner = owner
         self.transformer = SimpleNamespace(wte=self._wte)
+        # what GPT2LMHeadModel.from_pretrained('gpt2').config says (reference gpt2_prefix.py:160): the train step of a
+        # plain ClipCaptionModel in train() mode applies these (capdec_amd.train.train_step)
+        self.config = SimpleNamespace(resid_pdrop=0.1, embd_pdrop=0.1, attn_pdrop=0.1)
 
     def _wte(self, ids: torch.Tensor) -> torch.Tensor:
         return self._owner.engine.wte(ids)

@@ -1,8 +1,9 @@
 """Drop-in surface of reference ``train.py``: ``noise_injection`` (:27-39), ``get_uniform_ball_noise`` (:18-24),
 ``MappingType`` (:42-44), the ``ClipCaptionModel`` ctor spelling with ``prefix_size`` (:262), and the train loop of
-:317-392 for the FROZEN-GPT-2 configuration (``--only_prefix``: ``ClipCaptionPrefix`` with either mapper): ``AdamW``,
-``get_linear_schedule_with_warmup``, ``train_step`` (= :345-353 as one device call) and ``train``.  Training GPT-2 itself
-(the default ``ClipCaptionModel`` run, with dropout) is not implemented."""
+:317-392: ``AdamW``, ``get_linear_schedule_with_warmup``, ``train_step`` (= :345-353 as one device call) and ``train``
+(with the validation pass and ``loss_per_epoch.json`` of :373-391).  Both configurations of the reference: ``--only_prefix``
+(``ClipCaptionPrefix``: the mapper is trained, GPT-2 frozen and in eval mode) and the default (``ClipCaptionModel``: GPT-2
+is trained too, with transformers' dropouts of 0.1 while the model is in ``train()`` mode)."""
 from __future__ import annotations
 
 import math
@@ -112,21 +113,38 @@ def get_linear_schedule_with_warmup(optimizer: AdamW, num_warmup_steps: int, num
 
 
 def train_step(model: ClipCaptionModel, optimizer: AdamW, tokens: torch.Tensor, mask: Optional[torch.Tensor],
-               prefix: torch.Tensor, *, apply_update: bool = True) -> float:
+               prefix: torch.Tensor, *, apply_update: bool = True, dropout_masks: Optional[torch.Tensor] = None,
+               wait: bool = True) -> Optional[float]:
     """reference train.py:345-351 and :353 for one batch -- ``model.zero_grad(); outputs = model(tokens, prefix, mask);
     loss = cross_entropy(outputs.logits[:, P-1:-1], tokens, ignore_index=0); loss.backward(); optimizer.step();
     optimizer.zero_grad()`` -- as ONE device call (capdec_train_step); returns ``loss.item()``.  ``prefix`` is the batch
     after ``noise_injection`` (:347); the caller steps the scheduler afterwards (:352), as the reference does.
-    ``mask`` must be the dataset's right-padding mask (or None): see ClipCaptionModel.forward."""
+    ``mask`` must be the dataset's right-padding mask (or None): see ClipCaptionModel.forward.
+
+    A ``ClipCaptionPrefix`` trains its mapper against a frozen GPT-2 in eval mode; a plain ``ClipCaptionModel`` trains
+    GPT-2 too (reference train.py:306-308) and, while ``model.training``, applies GPT-2's dropouts
+    (``model.gpt.config.resid_pdrop`` = embd_pdrop = attn_pdrop, 0.1 like ``GPT2LMHeadModel.from_pretrained('gpt2')``)
+    from a Philox stream seeded from torch's global seed -- or from ``dropout_masks`` (uint8, 1 = keep: every site of the
+    step concatenated in call order, include/capdec.h), the hook the parity test uses.  ``wait=False`` enqueues the step
+    and returns None (``model.engine.train_loss()`` reads losses later)."""
     full = not isinstance(model, ClipCaptionPrefix)      # a plain ClipCaptionModel trains GPT-2 too (reference train.py:306-308)
-    if full and not getattr(optimizer, "dropout_free_gpt2", False):
-        raise CapdecError("train_step: training GPT-2 itself exists only without dropout (the reference uses 0.1) and has not "
-                          "been validated on a GPU yet -- pass an optimizer with .dropout_free_gpt2 = True to use it; "
-                          "ClipCaptionPrefix (--only_prefix) is the validated configuration")
     if model._train_gpt != full:
         model._pull_mapper()
         model._train_gpt = full
-    model.engine.train_set_scope(full)
+    eng = model.engine
+    eng.train_set_scope(full)
+    p_drop = float(model.gpt.config.resid_pdrop) if (full and model.training) else 0.0
+    if full and (p_drop, model._drop_seed_epoch) != model._drop_state:
+        if not (model.gpt.config.embd_pdrop == model.gpt.config.attn_pdrop == model.gpt.config.resid_pdrop):
+            raise CapdecError("train_step: one dropout probability for embd / attn / resid (transformers' defaults are equal)")
+        eng.train_set_dropout(p_drop, _next_seed())
+        model._drop_state = (p_drop, model._drop_seed_epoch)
+    if dropout_masks is not None:
+        if p_drop <= 0.0:
+            raise CapdecError("train_step: dropout_masks need a ClipCaptionModel in train() mode with dropout > 0")
+        eng.train_set_dropout_masks(dropout_masks)
+    if not tokens.is_cuda and tokens.numel() and (int(tokens.min()) < 0 or int(tokens.max()) >= model.gpt_dims.vocab):
+        raise IndexError("train_step: token id out of range (the reference's embedding lookup raises here too)")
     tokens = tokens.to(torch.device("cuda", model._device_index))
     if mask is not None:
         m = mask.to(tokens.device) > 0
@@ -137,7 +155,10 @@ def train_step(model: ClipCaptionModel, optimizer: AdamW, tokens: torch.Tensor, 
             raise CapdecError("train_step: a non-zero token under a zero mask (the loss would read it, the reference's "
                               "attention would not)")
     g = optimizer.param_groups[0]
-    loss = model.engine.train_step(prefix, tokens, g["lr"], g["betas"], g["eps"], g["weight_decay"], apply_update)
+    loss = eng.train_step(prefix, tokens, g["lr"], g["betas"], g["eps"], g["weight_decay"], apply_update, wait=wait)
+    if loss is not None and math.isnan(loss) and bool(((tokens < 0) | (tokens >= model.gpt_dims.vocab)).any()):
+        raise IndexError("train_step: token id out of range (the reference's embedding lookup raises here too); "
+                         "no weight was updated")
     if apply_update:
         model._device_ahead = True
     return loss
@@ -154,15 +175,45 @@ def all_gradients(model: ClipCaptionModel):
     return model.engine.mapper_gradients(model._train_shapes())
 
 
-def train(dataset, model: ClipCaptionModel, args, warmup_steps: int = 5000, output_dir: str = ".", output_prefix: str = ""):
-    """reference train.py:317-392 (the loop; the validation pass of :373-390 is left to the caller): ``dataset`` yields
-    ``(tokens, mask, prefix)`` like train.ClipCocoDataset.__getitem__ (:66-75); ``args`` needs ``bs, epochs, lr,
-    noise_variance, uniform_noise, dont_norm, save_every`` (and optionally ``modality_offset``: the tensor the reference
-    reads from others/CLIP_embeddings_centers_info.pkl at :333-337)."""
+def validation_loss(model: ClipCaptionModel, val_dataset, batch_size: int, prefix_length: Optional[int] = None) -> float:
+    """the validation pass of reference train.py:373-388: eval mode, no noise injection, ``model(tokens, prefix, mask)`` ->
+    ``cross_entropy(logits[:, P-1:-1], tokens, ignore_index=0)`` per batch (the device kernel capdec_cross_entropy),
+    averaged over the batches of a shuffled, drop_last DataLoader"""
+    from torch.utils.data import DataLoader
+    P = model.prefix_length if prefix_length is None else prefix_length
+    loader = DataLoader(val_dataset, batch_size=batch_size, shuffle=True, drop_last=True)
+    was_training = model.training
+    model.eval()
+    val_loss = 0.0
+    try:
+        for tokens, mask, prefix in loader:
+            prefix = prefix.to(device, dtype=torch.float32)
+            outputs = model(tokens, prefix, mask)
+            logits = outputs.logits[:, P - 1:-1]
+            val_loss += float(model.engine.cross_entropy(logits, tokens, ignore_index=0))
+    finally:
+        if was_training:
+            model.train()
+    return val_loss / max(1, len(loader))
+
+
+def train(dataset, model: ClipCaptionModel, args, warmup_steps: int = 5000, output_dir: str = ".", output_prefix: str = "",
+          val_dataset=None):
+    """reference train.py:317-392: ``dataset`` yields ``(tokens, mask, prefix)`` like train.ClipCocoDataset.__getitem__
+    (:66-75); ``args`` needs ``bs, epochs, lr, noise_variance, uniform_noise, dont_norm, save_every`` (and optionally
+    ``modality_offset``: the tensor the reference reads from others/CLIP_embeddings_centers_info.pkl at :333-337).
+    ``val_dataset`` (same item layout) stands for ``ClipCocoDataset(args.val_pt, ...)`` of :374 -- parsing the embedding
+    pickle is the caller's; with it every epoch ends with the validation pass of :373-388, and ``loss_per_epoch.json``
+    (:390-391: ``{'train': [...], 'val': [...]}``) is rewritten after every epoch either way.  The steps of an epoch are
+    enqueued without waiting for the device; the epoch's mean loss is the device's running sum (capdec_train_loss)."""
+    import json
     import os
     import sys
     from torch.utils.data import DataLoader
     os.makedirs(output_dir, exist_ok=True)
+    if getattr(args, "val_pt", "") and val_dataset is None:
+        raise CapdecError("train: args.val_pt names an embedding pickle -- build the validation dataset from it and pass "
+                          "val_dataset= (dataset parsing is outside this package)")
     model.train()
     optimizer = AdamW(model.parameters(), lr=args.lr)
     loader = DataLoader(dataset, batch_size=args.bs, shuffle=True, drop_last=True)
@@ -170,20 +221,27 @@ def train(dataset, model: ClipCaptionModel, args, warmup_steps: int = 5000, outp
                                                 num_training_steps=args.epochs * len(loader))
     modality_offset = getattr(args, "modality_offset", None)
     loss_per_epoch_train = []
+    loss_per_epoch_val = []
     for epoch in range(args.epochs):
         print(f">>> Training epoch {epoch} / {args.epochs}")
         sys.stdout.flush()
-        accumulated_loss = 0.0
+        model.engine.train_loss(reset=True)              # the device's running loss sum starts at 0
         for idx, (tokens, mask, prefix) in enumerate(loader):
             prefix = prefix.to(device, dtype=torch.float32)
             prefix = noise_injection(prefix, args.noise_variance, modality_offset=modality_offset,
                                      uniform_noise=args.uniform_noise, dont_norm=args.dont_norm)
-            accumulated_loss += train_step(model, optimizer, tokens, mask, prefix)
+            train_step(model, optimizer, tokens, mask, prefix, wait=False)
             scheduler.step()
             if (idx + 1) % 10000 == 0:
                 torch.save(model.state_dict(), os.path.join(output_dir, f"{output_prefix}_latest.pt"))
-        loss_per_epoch_train.append(accumulated_loss / max(1, len(loader)))
+        _, total, _ = model.engine.train_loss()
+        loss_per_epoch_train.append(total / max(1, len(loader)))
         print('loss_per_epoch_train: ', loss_per_epoch_train)
         if epoch % args.save_every == 0 or epoch == args.epochs - 1:
             torch.save(model.state_dict(), os.path.join(output_dir, f"{output_prefix}-{epoch:03d}.pt"))
+        if val_dataset is not None:
+            loss_per_epoch_val.append(validation_loss(model, val_dataset, args.bs, getattr(dataset, "prefix_length", None)))
+            print('loss_per_epoch_val: ', loss_per_epoch_val)
+        with open(os.path.join(output_dir, "loss_per_epoch.json"), 'w') as f:
+            json.dump({'train': loss_per_epoch_train, 'val': loss_per_epoch_val}, f)
     return model

@@ -31,7 +31,9 @@
 extern "C" {
 #endif
 
-#define CAPDEC_ABI_VERSION 3   /* 3: the diverged-beam debug hook left the shipped library (measurement builds only);
+#define CAPDEC_ABI_VERSION 4   /* 4: train step -- GPT-2's dropouts (capdec_train_set_dropout / _masks), capdec_train_loss, loss == NULL
+                                     enqueues without waiting, the scope survives capdec_train_reset;
+                                  3: the diverged-beam debug hook left the shipped library (measurement builds only);
                                   2: capdec_profile_get takes the array capacity in *count; batch-invariant mode; decode counters */
 
 typedef struct capdec_ctx capdec_ctx;
@@ -239,34 +241,54 @@ int capdec_clip_encode_image(capdec_ctx *ctx, const float *d_pixels, int n, floa
  * materialises); 0 -> d_logits [n, vocab], last position only (what it uses). */
 int capdec_gpt2_logits(capdec_ctx *ctx, const float *d_embeds, int n, int L, int all_positions,
                        float *d_logits);
-/* ---- the train step with a frozen GPT-2 (reference train.py:344-354 run with --only_prefix: ClipCaptionPrefix,
- * train.py:279-287 -- parameters() are the mapper's, GPT-2 stays in eval mode, so the step is deterministic) -------------
- * One iteration for an MLP mapper (capdec_load_mapper_mlp): d_prefix [batch, D] is the embedding batch AFTER
- * noise_injection (train.py:347; capdec_noise_inject), d_tokens [batch, length] int32 right-padded with 0 as
- * train.ClipCocoDataset pads (:52-63; under the causal mask the padding mask of :348 changes nothing a real position
- * sees).  Computes logits[:, P-1:-1], the loss of :349 (cross_entropy with ignore_index = 0: padding AND real tokens with
- * id 0 are skipped; mean over the rest), its gradient with respect to the mapper's four tensors (:350), and -- with
- * apply_update != 0 -- one update of transformers-4.24 AdamW (:351; betas / eps / weight_decay as passed: the reference's
- * AdamW(params, lr) means 0.9, 0.999, 1e-6, 0.0; bias correction on; `lr` is the scheduler's current value, :352) on the
- * device-resident mapper weights, which the inference entry points then use.  *loss (host) receives the loss.
- * The optimizer state lives in the context; loading a mapper or GPT-2 again, or capdec_train_reset, drops it.
- * capdec_train_get copies a tensor of the mapper (kind 0) or its gradient from the last step (kind 1) to d_out (device):
- * which = 0 model.0.weight [hidden, D], 1 model.0.bias, 2 model.2.weight [P * d, hidden], 3 model.2.bias. */
+/* ---- the train step (reference train.py:344-354) ------------------------------------------------------------------
+ * One iteration: d_prefix [batch, D] is the embedding batch AFTER noise_injection (train.py:347; capdec_noise_inject),
+ * d_tokens [batch, length] int32 right-padded with 0 as train.ClipCocoDataset pads (:52-63; under the causal mask the
+ * padding mask of :348 changes nothing a real position sees).  Computes logits[:, P-1:-1], the loss of :349
+ * (cross_entropy with ignore_index = 0: padding AND real tokens with id 0 are skipped; mean over the rest), its gradient
+ * with respect to every tensor of the scope (:350), and -- with apply_update != 0 -- one update of transformers-4.24
+ * AdamW (:351; betas / eps / weight_decay as passed: the reference's AdamW(params, lr) means 0.9, 0.999, 1e-6, 0.0; bias
+ * correction on; `lr` is the scheduler's current value, :352) on the device-resident weights, which the inference entry
+ * points then use.  loss != NULL: *loss (host) receives the loss and the call waits for the device; loss == NULL: the
+ * call only enqueues (capdec_train_loss reads the loss, and the running sum, later).  An id outside [0, vocab) -- an
+ * IndexError in the reference -- makes the loss NaN and leaves every weight and the optimizer untouched.
+ * The optimizer state lives in the context; loading a mapper or GPT-2 again, or capdec_train_reset, drops it (the scope
+ * and the dropout setting stay).
+ *
+ * Scope (capdec_train_set_scope): 0 (default) = the mapper, GPT-2 frozen and in eval mode (--only_prefix:
+ * ClipCaptionPrefix, train.py:279-287; a deterministic step); 1 = GPT-2 as well -- the reference's DEFAULT run
+ * (train.py:326: AdamW(model.parameters()) of a ClipCaptionModel).  Changing the scope starts a fresh optimizer.
+ *
+ * capdec_train_get copies a tensor of the scope (kind 0) or its gradient from the last step (kind 1, = what
+ * loss.backward() leaves in .grad) to d_out (device).  MLP mapper: which = 0 model.0.weight [hidden, D], 1 model.0.bias,
+ * 2 model.2.weight [P * d, hidden], 3 model.2.bias.  TransformerMapper: linear.weight, linear.bias, prefix_const, then per
+ * layer norm1.weight, norm1.bias, attn.to_queries.weight, attn.to_keys_values.weight, attn.project.weight, .bias,
+ * norm2.weight, .bias, mlp.fc1.weight, .bias, mlp.fc2.weight, .bias.  Scope 1 continues with wte (the tied lm_head), wpe,
+ * per layer ln_1.weight, ln_1.bias, attn.c_attn.weight, .bias, attn.c_proj.weight, .bias, ln_2.weight, .bias,
+ * mlp.c_fc.weight, .bias, mlp.c_proj.weight, .bias, then ln_f.weight, ln_f.bias; Conv1D weights (and their gradients)
+ * are returned in the checkpoint's [in, out] layout. */
 int capdec_train_step(capdec_ctx *ctx, const float *d_prefix, const int32_t *d_tokens, int batch, int length, float lr,
                       float beta1, float beta2, float eps, float weight_decay, int apply_update, float *loss);
 int capdec_train_get(capdec_ctx *ctx, int kind, int which, float *d_out, size_t n);
 int capdec_train_reset(capdec_ctx *ctx);
-/* Scope of the train step: 0 (default) = the mapper, GPT-2 frozen (--only_prefix); 1 = GPT-2 as well -- the reference's
- * DEFAULT run (train.py:326: AdamW(model.parameters()) of a ClipCaptionModel), WITHOUT dropout: the reference trains with
- * transformers' default dropouts of 0.1, this path computes the step of a model whose GPT2Config has them at 0.  The
- * tensors of capdec_train_get then continue after the mapper's: wte (the tied lm_head), wpe, per layer ln_1.weight,
- * ln_1.bias, attn.c_attn.weight, .bias, attn.c_proj.weight, .bias, ln_2.weight, .bias, mlp.c_fc.weight, .bias,
- * mlp.c_proj.weight, .bias, then ln_f.weight, ln_f.bias; Conv1D weights (and their gradients) are returned in the
- * checkpoint's [in, out] layout.  Changing the scope starts a fresh optimizer.
- * STATUS: scope 1 was written after this round's GPU budget was spent -- it compiles and follows the oracle
- * (oracle/capdec_oracle.py: train_step_loss_and_grads(train_gpt=True), pinned against the reference), but has not run on a
- * GPU yet: its parity test is skipped unless CAPDEC_TEST_UNVALIDATED=1.  Scope 0 is the validated path. */
 int capdec_train_set_scope(capdec_ctx *ctx, int train_gpt);
+/* The loss of the last train step (*last), the sum of the losses and the number of steps since the last reset (the
+ * `accumulated_loss` of train.py:356 without a device round trip per step); reset != 0 clears sum and count.  Waits for
+ * the device.  Any pointer may be NULL. */
+int capdec_train_loss(capdec_ctx *ctx, float *last, double *sum, long long *steps, int reset);
+/* GPT-2's dropouts in scope 1 (GPT2Model in train() mode, train.py:321: `drop` after inputs_embeds + position_embeds;
+ * per block attn_dropout on the softmax weights, resid_dropout after attn.c_proj, the MLP's dropout after mlp.c_proj;
+ * transformers' default embd_pdrop = attn_pdrop = resid_pdrop = 0.1).  p = 0 (default) computes the step of a model whose
+ * GPT2Config has them at 0.  Keep-masks come from a Philox4x32-10 stream keyed by `seed` (counter: element group, number
+ * of mask streams drawn since the last capdec_train_reset / capdec_train_set_dropout), survivors scaled by 1 / (1 - p)
+ * like torch.  Scope 0 never applies dropout (GPT-2 stays in eval mode there).
+ * capdec_train_set_dropout_masks injects the keep-masks of the NEXT train step (consumed once; parity tests): one byte per
+ * element, 1 = keep, every site of the step concatenated in call order -- embd [B, S, d], then per block attn
+ * [B, heads, S, S], resid [B, S, d], mlp [B, S, d], with S = prefix_length + length; n must equal that total.
+ * capdec_train_get_dropout_masks copies the mask stream the last step used (same layout) to d_out. */
+int capdec_train_set_dropout(capdec_ctx *ctx, float p, uint64_t seed);
+int capdec_train_set_dropout_masks(capdec_ctx *ctx, const uint8_t *d_masks, size_t n);
+int capdec_train_get_dropout_masks(capdec_ctx *ctx, uint8_t *d_out, size_t n);
 
 /* The loss of the train step's forward (reference train.py:349 `nnf.cross_entropy(logits, tokens, ignore_index=0)`,
  * and GPT2LMHeadModel's shifted `labels=` loss used by gpt2_prefix.py:154): mean over the rows whose label differs
