@@ -76,7 +76,7 @@ bool tuning_from_env(Tuning *t, std::string *err) {
         }
     }
     env_int("CAPDEC_PP", &t->pp);
-    env_int("CAPDEC_PP_X1", &t->pp_x1);
+    env_flag("CAPDEC_ATT_G16", &t->att_g16);
     env_flag("CAPDEC_LMHEAD_WIDE", &t->lmhead_wide);
     env_flag("CAPDEC_TRAIN_F16X2", &t->train_f16x2);
     env_flag("CAPDEC_LMHEAD_K3", &t->lmhead_k3);

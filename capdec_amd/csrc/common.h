@@ -190,11 +190,6 @@ int launch_gemm_pp(hipStream_t st, int which, const void *Apacked, const void *B
 // planner: 0 = keep the kernels of rounds 2-3, else a ping-pong geometry (10 = 256x128, 14 = 256x192, 12 = 256x256)
 int pp_plan(int M, int N, int K, bool wide_ok, bool can_split, int mode = 2);
 size_t pp_splitk_ws_bytes(int which, int M, int N, int K);
-// ... and for the one-plane (bf16 / fp16) operand formats (gemm_pp.hip; mode = CAPDEC_PP_X1)
-int launch_gemm_pp_x1(hipStream_t st, int which, const void *Apacked, const void *Bpacked, float *C, int ldc, int M, int N,
-                      int K, const GemmEpilogue &epi, int fmt);
-int pp_plan_x1(int M, int N, int K, bool can_split, int mode);
-size_t pp_x1_splitk_ws_bytes(int M, int N, int K);
 // exact second pass of the fused lm_head (decode.hip): k = 5 lists for the *m_dev rows of a compacted packed A operand
 int launch_gemm_h2w_topk_dev(hipStream_t st, const void *Apacked, const void *Bpacked, const int *m_dev, int N, int K,
                              float inv_temp, float *tile_max, float *tile_sum, float *cand_val, int *cand_idx);

@@ -29,8 +29,8 @@ struct Tuning {
     int h2w = 1;                  // CAPDEC_H2W: 0 = round-2 kernels only, 1 = planners, 2 / 8 = force a round-3 wide tile,
                                   //             10 / 12 / 14 = force a round-4 ping-pong tile (tests)
     int pp = 2;                   // CAPDEC_PP: ping-pong planner: 0 never, 2 mid-size launches (default), 1 also large, 3 large only
-    int pp_x1 = 2;                // CAPDEC_PP_X1: ping-pong tiles for the one-plane (bf16 / f16) GEMMs: 0 never, 1 mid-size launches,
-                                  //   2 (default) mid-size and large, 3 large only
+    bool att_g16 = true;          // CAPDEC_ATT_G16=0: greedy rows on the bf16 KV cache take the beam kernel (BEAM = 1) instead of the
+                                  //   one-round-trip kernel of round 5
     bool lmhead_wide = true;      // CAPDEC_LMHEAD_WIDE=0: 128-row lm_head tiles at every size
     bool lmhead_k3 = true;        // CAPDEC_LMHEAD_K3=0: the wide lm_head keeps k candidates per tile (no exact second pass)
     int lmhead_k3_max = 60;       // CAPDEC_LMHEAD_K3_MAX: per mille of the rows taking the second pass above which a decode

@@ -585,7 +585,6 @@ size_t gemm_splitk_ws_bytes(int M, int N, int K, const Tuning &t) {
     const int s = gemm_splitk_slices(M, N, K, t);
     size_t b = s > 1 ? (size_t)s * M * N * sizeof(float) : 0;
     for (int which : {10, 12, 14}) b = std::max(b, pp_splitk_ws_bytes(which, M, N, K));     // (the ping-pong kernels' own split)
-    b = std::max(b, pp_x1_splitk_ws_bytes(M, N, K));                                        // (... in the one-plane modes)
     return b;
 }
 

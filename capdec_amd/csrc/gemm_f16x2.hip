@@ -578,16 +578,9 @@ int launch_gemm_x1(hipStream_t st, const void *Apacked, const void *Bpacked, flo
     const bool vec4 = N % 4 == 0 && ldc % 4 == 0 && ((uintptr_t)C & 15) == 0 &&
                       (epi.bias == nullptr || ((uintptr_t)epi.bias & 15) == 0) &&
                       (epi.resid == nullptr || (epi.ldr % 4 == 0 && ((uintptr_t)epi.resid & 15) == 0));
-    // ping-pong tiles (gemm_pp.hip): forced (CAPDEC_H2W >= 10: tests) or where the planner expects a gain from the larger
-    // wave tile; the small-batch regime M <= 512 keeps its batch-size independent kernels
-    if (vec4 && !epi.invariant) {
-        const Tuning &tn = tuning_of(epi);
-        const bool can_split = epi.splitk_ws && !epi.resid_packed && !epi.packed_out;
-        int which = 0;
-        if (tn.h2w >= 10) which = (N % 4 == 0) ? tn.h2w : 0;
-        else if (tn.h2w == 1 && tn.pp_x1 && M > 4 * GEMM_BM) which = pp_plan_x1(M, N, K, can_split, tn.pp_x1);
-        if (which == 10 || which == 12 || which == 14) return launch_gemm_pp_x1(st, which, Apacked, Bpacked, C, ldc, M, N, K, epi, fmt);
-    }
+    // (Round 5 measured the ping-pong tiles of gemm_pp.hip under one-plane operands -- 256 x 256 / 256 x 192 / 256 x 128,
+    //  rings of 4-5 and of 5-6 stages -- against this kernel inside the decode loop: 12-15 % SLOWER per launch at 5000 rows,
+    //  25 % at 25 000 (profiles/r5_x1_pingpong_ab.txt); the variant was removed again.)
     {
         int S = (vec4 && epi.splitk_ws && !epi.resid_packed) ? gemm_splitk_slices(M, N, K, tuning_of(epi)) : 1;
         if (S > 1 && ((K / X3_BK / S) % 4 != 0 || epi.splitk_ws_bytes < (size_t)S * M * N * sizeof(float))) S = 1;

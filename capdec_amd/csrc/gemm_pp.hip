@@ -65,26 +65,18 @@ struct PGeo {
 
 // acc (and ac for TWOACC) in the TR layout of gemm_epilogue.h when TR, the plain MFMA layout otherwise
 // (ks0, nks: the k-steps [ks0, ks0 + nks) of the product -- split-K; nks < 0: all of them)
-// KIND: 0 = the two-plane f16x2 operands above.  1 / 2 = ONE-plane fp16 / bf16 operands (PK_F16X1 / PK_BF16X1, the
-// reduced-precision modes: one MFMA per product): a stage then holds TWO consecutive k-steps of the single plane where
-// f16x2 holds the two planes of one k-step -- the same bytes per stage, the same DMA pieces and fragment reads ("plane p"
-// of a chunk = its k-step 2 ks + p) -- and carries 2 TI TJ MFMAs into ONE accumulator set.  Why these kernels exist for
-// the one-plane modes: a 64 x 64 wave tile (the 128 x 128 kernels of gemm_f16x2.hip) reads 8 KB of fragments per 8 MFMAs
-// -- 125 B per cycle and CU at the matrix pipe's peak rate, the whole LDS bandwidth -- and asks L2 for 64 flop/B; the
-// 128 x 64 wave tile of the 256 x 256 block halves both.
-template <class G, bool TR, int ABL = 0, int KIND = 0>
+template <class G, bool TR, int ABL = 0>
 __device__ __forceinline__ void pp_mainloop(const _Float16 *__restrict__ Apk, const _Float16 *__restrict__ Bpk, int K,
                                             int tm, int tn, int chunksA, int chunksB, char *smem,
                                             f32x16 (&acc)[G::TI][G::TJ], f32x16 (&ac)[G::TWOACC ? G::TI : 1][G::TWOACC ? G::TJ : 1],
                                             int ks0 = 0, int nks = -1, long long *stamp1 = nullptr) {
     constexpr int TI = G::TI, TJ = G::TJ, NS = G::NS, PPW = G::PPW, SB = G::STAGE_B, D = G::D;
-    static_assert(KIND == 0 || !G::TWOACC, "one-plane operands: one accumulator set");
     const int t = threadIdx.x;
     const int lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int wm = wave / G::WN, wn = wave % G::WN, grp = wave >> 2;
     const int half = lane >> 5, l32 = lane & 31;
-    const int nkf = K / (KIND == 0 ? X3_BK : 2 * X3_BK);   // stages of the whole K (panel stride)
-    const int nk = nks < 0 ? nkf : nks;            // stages of THIS block
+    const int nkf = K / X3_BK;                     // k-steps of the whole K (panel stride)
+    const int nk = nks < 0 ? nkf : nks;            // k-steps of THIS block
     // ---- LDS-DMA: piece p of a stage = plane (p & 1) of chunk (p >> 1); chunks 0 .. CA-1 = the A rows of the block tile,
     // CA .. CA+CB-1 its B rows.  Global chunk g of a packed operand = piece (g & 3) of each plane of its 128-row tile g >> 2.
     const char *src[PPW];
@@ -134,8 +126,7 @@ __device__ __forceinline__ void pp_mainloop(const _Float16 *__restrict__ Apk, co
             fa[i][1] = *reinterpret_cast<const f16x8 *>(rs + a_rd + (2 * i + 1) * 1024);                         \
         }                                                                                                        \
     }
-#define P_MM1(x, y, c) (KIND == 2 ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, x), __builtin_bit_cast(bf16x8, y), c, 0, 0, 0) \
-                                  : __builtin_amdgcn_mfma_f32_32x32x16_f16(x, y, c, 0, 0, 0))
+#define P_MM1(x, y, c) __builtin_amdgcn_mfma_f32_32x32x16_f16(x, y, c, 0, 0, 0)
 #define P_MM(x, y, c) (TR ? P_MM1(y, x, c) : P_MM1(x, y, c))
 #define P_BARRIER()                          \
     asm volatile("" ::: "memory");           \
@@ -174,15 +165,6 @@ __device__ __forceinline__ void pp_mainloop(const _Float16 *__restrict__ Apk, co
             for (int i = 0; i < TI; ++i)
 #pragma unroll
                 for (int j = 0; j < TJ; ++j) asm volatile("" ::"v"(fa[i][0]), "v"(fa[i][1]), "v"(fb[j][0]), "v"(fb[j][1]));
-        } else if constexpr (KIND != 0) {      // one plane: k-steps 2 ks and 2 ks + 1 of the stage, one accumulator set
-#pragma unroll
-            for (int i = 0; i < TI; ++i)
-#pragma unroll
-                for (int j = 0; j < TJ; ++j) acc[i][j] = P_MM(fa[i][0], fb[j][0], acc[i][j]);
-#pragma unroll
-            for (int i = 0; i < TI; ++i)
-#pragma unroll
-                for (int j = 0; j < TJ; ++j) acc[i][j] = P_MM(fa[i][1], fb[j][1], acc[i][j]);
         } else if constexpr (G::TWOACC) {
 #pragma unroll
             for (int i = 0; i < TI; ++i)
@@ -244,13 +226,13 @@ __device__ __forceinline__ void pp_join(f32x16 (&am)[G::TI][G::TJ], const f32x16
 
 // persistent form: grid = min(tiles, CUs) blocks, block b walks tiles b, b + grid, ...
 // (ABL / stamps: measurement builds only, -DCAPDEC_MEASURE; ABL 8 = the direct, uncoalesced epilogues of gemm_epilogue_w.h)
-template <class G, int ABL = 0, int KIND = 0>
+template <class G, int ABL = 0>
 __global__ __launch_bounds__(G::THREADS, G::MINW) void gemm_pp_kernel(const _Float16 *__restrict__ Apk,
                                                                      const _Float16 *__restrict__ Bpk, float *C, int ldc,
                                                                      int M, int N, int K, const float *__restrict__ bias,
                                                                      const float *resid, int ldr, int act, int tiles_m,
                                                                      int tiles_n, char *packed_out, float scale, QkvScatter sc,
-                                                                     long long *stamps, int out_fmt = PK_F16X2) {
+                                                                     long long *stamps) {
     __shared__ __attribute__((aligned(16))) char smem[G::SMEM_B];
     const int ntiles = tiles_m * tiles_n;
     const int chunksA = ((M + 127) >> 7) * 4, chunksB = ((N + 127) >> 7) * 4;
@@ -263,18 +245,17 @@ __global__ __launch_bounds__(G::THREADS, G::MINW) void gemm_pp_kernel(const _Flo
         f32x16 acc[G::TI][G::TJ], ac[G::TWOACC ? G::TI : 1][G::TWOACC ? G::TJ : 1];
 #ifdef CAPDEC_MEASURE
         const bool st1 = stamps && tile == (int)blockIdx.x;
-        pp_mainloop<G, true, (ABL >= 6 ? 0 : ABL), KIND>(Apk, Bpk, K, tm, tn, chunksA, chunksB, smem, acc, ac, 0, -1,
-                                                          st1 ? stamps + blockIdx.x * 4 + 1 : nullptr);
+        pp_mainloop<G, true, (ABL >= 6 ? 0 : ABL)>(Apk, Bpk, K, tm, tn, chunksA, chunksB, smem, acc, ac, 0, -1,
+                                                    st1 ? stamps + blockIdx.x * 4 + 1 : nullptr);
         if (st1 && threadIdx.x == 0) stamps[blockIdx.x * 4 + 2] = wall_clock64();
 #else
-        pp_mainloop<G, true, 0, KIND>(Apk, Bpk, K, tm, tn, chunksA, chunksB, smem, acc, ac);
+        pp_mainloop<G, true>(Apk, Bpk, K, tm, tn, chunksA, chunksB, smem, acc, ac);
 #endif
         pp_join<G>(acc, ac);
         EpiArgs ea;
         ea.C = C; ea.ldc = ldc; ea.M = M; ea.N = N; ea.m0 = tm * G::BM; ea.n0 = tn * G::BN;
         ea.bias = bias; ea.act = act; ea.scale = scale; ea.ldr = ldr;
         ea.packed = packed_out;
-        ea.fmt = out_fmt;
         if (packed_out) ea.resid_pk = reinterpret_cast<const char *>(resid);      // (with packed_out, `resid` is PACKED)
         else ea.resid = resid;
         ea.sc = &sc;
@@ -321,7 +302,7 @@ __global__ __launch_bounds__(G::THREADS, G::MINW) void gemm_pp_kernel(const _Flo
 // walks k-steps [slice nks, (slice + 1) nks) and writes its raw fp32 partial tile to part[slice][M][N]; the slices are
 // summed in a fixed order by launch_splitk_reduce (gemm_bf16x3.hip), which applies the epilogue -- and the LayerNorm that
 // follows, when there is one
-template <class G, int KIND = 0>
+template <class G>
 __global__ __launch_bounds__(G::THREADS, G::MINW) void gemm_pp_splitk_kernel(const _Float16 *__restrict__ Apk,
                                                                             const _Float16 *__restrict__ Bpk, float *part,
                                                                             int M, int N, int K, int tiles_m, int tiles_n,
@@ -331,9 +312,9 @@ __global__ __launch_bounds__(G::THREADS, G::MINW) void gemm_pp_splitk_kernel(con
     const int slice = blockIdx.x / ntiles;
     int tm, tn;
     tile_coords(tiles_m, tiles_n, tm, tn, blockIdx.x - slice * ntiles);
-    const int nks = K / (KIND == 0 ? X3_BK : 2 * X3_BK) / S;       // stages of this slice
+    const int nks = K / X3_BK / S;
     f32x16 acc[G::TI][G::TJ], ac[G::TWOACC ? G::TI : 1][G::TWOACC ? G::TJ : 1];
-    pp_mainloop<G, true, 0, KIND>(Apk, Bpk, K, tm, tn, ((M + 127) >> 7) * 4, ((N + 127) >> 7) * 4, smem, acc, ac, slice * nks, nks);
+    pp_mainloop<G, true>(Apk, Bpk, K, tm, tn, ((M + 127) >> 7) * 4, ((N + 127) >> 7) * 4, smem, acc, ac, slice * nks, nks);
     pp_join<G>(acc, ac);
     EpiArgs ea;
     ea.C = part + (size_t)slice * M * N; ea.ldc = N; ea.M = M; ea.N = N; ea.m0 = tm * G::BM; ea.n0 = tn * G::BN;
@@ -344,9 +325,8 @@ __global__ __launch_bounds__(G::THREADS, G::MINW) void gemm_pp_splitk_kernel(con
 using P256x128 = PGeo<4, 2, 2, 2, 5, true>;       // 8 waves x (64 x 64), two accumulator sets, 24 KB stages, 120 KB
 using P256x192s = PGeo<4, 2, 2, 3, 4, false>;     // 8 waves x (64 x 96), ONE accumulator set (two would spill), 28 KB stages, 112 KB
 using P256x256s = PGeo<2, 4, 4, 2, 4, false>;     // 8 waves x (128 x 64), ONE accumulator set (weights with max |w| < 16), 128 KB
-using P256x128s = PGeo<4, 2, 2, 2, 5, false>;     // f16x2: measured no faster than the two-set form (profiles/r4_gemm_pp.txt);
-                                                  // the 256 x 128 tile of the one-plane modes
 #ifdef CAPDEC_MEASURE
+using P256x128s = PGeo<4, 2, 2, 2, 5, false>;     // measured: no faster than the two-set form (profiles/r4_gemm_pp.txt)
 using P128x256s = PGeo<2, 4, 2, 2, 5, false>;
 #endif
 
@@ -357,28 +337,6 @@ int pp_splitk_slices(int which, int M, int N, int K);
 template <class G> constexpr int pp_abl_for(int a) {
     return (G::BM == 256 && G::BN == 128 && G::TWOACC) ? a : (a == 8 && G::BN == 256) ? 8 : 0;
 }
-// one-plane operands (KIND 1 fp16 / 2 bf16; fmt = their PackFmt, also the format of a packed output): product kernels only
-template <class G, int KIND>
-static int launch_pp_x1(hipStream_t st, const void *Apacked, const void *Bpacked, float *C, int ldc, int M, int N, int K,
-                        const GemmEpilogue &epi, int S, int fmt) {
-    const int tiles_m = (M + G::BM - 1) / G::BM, tiles_n = (N + G::BN - 1) / G::BN;
-    const int ntiles = tiles_m * tiles_n;
-    if (S > 1) {
-        float *part = (float *)epi.splitk_ws;
-        hipLaunchKernelGGL((gemm_pp_splitk_kernel<G, KIND>), dim3(ntiles * S), dim3(G::THREADS), 0, st, (const _Float16 *)Apacked,
-                           (const _Float16 *)Bpacked, part, M, N, K, tiles_m, tiles_n, S, 1.0f);
-        CAPDEC_HIP(hipGetLastError());
-        return launch_splitk_reduce(st, part, S, M, N, epi, C, ldc, fmt);
-    }
-    const int grid = ntiles <= 4 * 256 ? std::min(ntiles, 256) : ntiles;
-    const float *resid_arg = epi.packed_out ? (const float *)epi.resid_packed : epi.resid;
-    hipLaunchKernelGGL((gemm_pp_kernel<G, 0, KIND>), dim3(grid), dim3(G::THREADS), 0, st, (const _Float16 *)Apacked,
-                       (const _Float16 *)Bpacked, C, ldc, M, N, K, epi.bias, resid_arg, epi.ldr, epi.act, tiles_m, tiles_n,
-                       (char *)epi.packed_out, 1.0f, QkvScatter(), (long long *)nullptr, fmt);
-    CAPDEC_HIP(hipGetLastError());
-    return 0;
-}
-
 template <class G>
 static int launch_pp(hipStream_t st, const void *Apacked, const void *Bpacked, float *C, int ldc, int M, int N, int K,
                      const GemmEpilogue &epi, float scale, int S) {
@@ -520,74 +478,6 @@ int launch_gemm_pp(hipStream_t st, int which, const void *Apacked, const void *B
 #endif
         default: CAPDEC_CHECK(false, "gemm_pp: unknown geometry");
     }
-    return 0;
-}
-
-// ---- the one-plane (bf16 / fp16) modes on the same kernels
-// K slices of a one-plane launch (1 = none): like pp_splitk_slices, in stages of 32 k -- grids that leave most of the chip
-// idle are cut so that tiles x S fills one round; >= 4 stages per slice
-int pp_x1_splitk_slices(int which, int M, int N, int K) {
-    int bm, bn;
-    pp_tile(which, bm, bn);
-    const int tiles = ((M + bm - 1) / bm) * ((N + bn - 1) / bn), nst = K / (2 * X3_BK);
-    if (N % 4 != 0 || tiles * 2 > 256 || M <= 512) return 1;
-    int best = 1;
-    for (int s = 2; tiles * s <= 256 && s <= nst / 4; ++s)
-        if (nst % s == 0) best = s;
-    return best;
-}
-size_t pp_x1_splitk_ws_bytes(int M, int N, int K) {
-    size_t b = 0;
-    for (int which : {10, 12, 14}) {
-        const int s = pp_x1_splitk_slices(which, M, N, K);
-        if (s > 1) b = std::max(b, (size_t)s * M * N * sizeof(float));
-    }
-    return b;
-}
-// Which geometry for a one-plane GEMM of more than 512 rows (0 = the 128 x 128 kernels of gemm_f16x2.hip).
-// mode (CAPDEC_PP_X1): 0 never | 1 mid-size launches (513 .. 8191 rows: the tile / K cut whose grid fills one round of
-// the 256 CUs best, larger tile first) | 2 (default) also large launches: 256 x 256 for the wide projections (N >= 2048),
-// 256 x 128 for N = 768 | 3 large launches only
-int pp_plan_x1(int M, int N, int K, bool can_split, int mode) {
-    if (mode <= 0 || M <= 512 || N % 4 != 0) return 0;
-    if (M >= 8192) {
-        if (mode == 1) return 0;
-        return N >= 2048 ? 12 : (N % 128 == 0 ? 10 : 0);
-    }
-    if (mode == 3) return 0;
-    // candidates whose grid fills 176 .. 256 CUs in one round: the fewest K slices first (every slice is a partial result
-    // written and re-read), then the larger tile
-    int best = 0, best_s = 1 << 30;
-    for (int which : {12, 14, 10}) {
-        if (which == 14 && N % 192 != 0) continue;
-        if (which == 12 && N % 256 != 0) continue;
-        int bm, bn;
-        pp_tile(which, bm, bn);
-        const long tiles = (long)((M + bm - 1) / bm) * ((N + bn - 1) / bn);
-        const int sl = can_split ? pp_x1_splitk_slices(which, M, N, K) : 1;
-        const long b = tiles * sl;
-        if (b <= 256 && b >= 176 && sl < best_s) { best = which; best_s = sl; }
-    }
-    return best;
-}
-int launch_gemm_pp_x1(hipStream_t st, int which, const void *Apacked, const void *Bpacked, float *C, int ldc, int M, int N,
-                      int K, const GemmEpilogue &epi, int fmt) {
-    CAPDEC_CHECK(fmt == PK_F16X1 || fmt == PK_BF16X1, "gemm_pp_x1: one-plane operand formats only");
-    int S = 1;
-    if (epi.splitk_ws && !epi.resid_packed && !epi.packed_out) {
-        S = pp_x1_splitk_slices(which, M, N, K);
-        if (S > 1 && epi.splitk_ws_bytes < (size_t)S * M * N * sizeof(float)) S = 1;
-    }
-#define PP_X1(G)                                                                                      \
-    return fmt == PK_F16X1 ? launch_pp_x1<G, 1>(st, Apacked, Bpacked, C, ldc, M, N, K, epi, S, fmt)   \
-                           : launch_pp_x1<G, 2>(st, Apacked, Bpacked, C, ldc, M, N, K, epi, S, fmt)
-    switch (which) {
-        case 10: PP_X1(P256x128s);
-        case 14: PP_X1(P256x192s);
-        case 12: PP_X1(P256x256s);
-        default: CAPDEC_CHECK(false, "gemm_pp_x1: unknown geometry");
-    }
-#undef PP_X1
     return 0;
 }
 

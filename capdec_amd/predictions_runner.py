@@ -155,3 +155,39 @@ def make_preds_from_images(data: Sequence[Dict], images: Sequence, clip_model, p
         with open(out_path, 'w') as outfile:
             json.dump(new_data, outfile)
     return new_data
+
+
+def make_preds_from_captions(data: Sequence[Dict], clip_model, model: ClipCaptionModel, tokenizer, tokenize=None,
+                             out_path: Optional[str] = None, beam: bool = True, entry_length: int = 67,
+                             dont_normalize_prefix: bool = False, modality_offset: Optional[torch.Tensor] = None,
+                             rank: int = 0, world: int = 1, text_batch: int = 2048) -> List[Dict]:
+    """The TEXT-input branch of the reference loop (:215-218: ``args.text_autoencoder`` or ``dataset_mode == 5`` -- "the
+    image is actually text input"): ``caption_tokens = clip.tokenize(d['caption'])``; ``prefix =
+    clip_model.encode_text(caption_tokens).float()``; then the common tail (:221-234) -- normalise, modality offset,
+    ``clip_project``, ``generate_beam`` / ``generate2`` -- and the predictions JSON of :260-261.  ``tokenize`` defaults to
+    ``capdec_amd.clip.tokenize`` (needs the CLIP BPE vocabulary file); any callable ``list[str] -> int [N, 77]`` does.
+    This rank tokenises / encodes / decodes only its block of ``data``; the ids are gathered in caption order."""
+    if tokenize is None:
+        from .clip import tokenize
+    cdist.check_world(rank, world)
+    n = len(data)
+    lo, hi = cdist.shard_bounds(n, rank, world)
+    feats = []
+    for b0 in range(lo, hi, max(1, text_batch)):
+        toks = tokenize([d["caption"] for d in data[b0:min(hi, b0 + max(1, text_batch))]])
+        feats.append(clip_model.encode_text(toks).float())
+    stop = tokenizer.encode('.')[0]
+    if feats:
+        ids, lens, _ = caption_ids(model, torch.cat(feats), stop, beam, 5, entry_length, dont_normalize_prefix, modality_offset)
+    else:                              # an empty shard (more ranks than captions) still takes part in the gather
+        dev = next(model.parameters()).device
+        ids = torch.zeros(0, entry_length, dtype=torch.int32, device=dev)
+        lens = torch.zeros(0, dtype=torch.int32, device=dev)
+    ids, lens, _ = cdist.gather_ids(ids, lens, n)
+    ids, lens = ids.cpu().numpy(), lens.cpu().numpy()
+    new_data = [{"caption": tokenizer.decode(list(ids[i, :int(lens[i])])).lower(), "image_id": d["image_id"]}
+                for i, d in enumerate(data)]
+    if out_path and rank == 0:
+        with open(out_path, 'w') as outfile:
+            json.dump(new_data, outfile)
+    return new_data

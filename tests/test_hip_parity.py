@@ -1251,31 +1251,23 @@ def test_unknown_gemm_mode_is_an_error(monkeypatch):
     e.close()
 
 
-@pytest.mark.parametrize("geometry", ["2", "8", "10", "14", "12", "invariant", "x1:10", "x1:14", "x1:12"],
-                         ids=["w256x128", "w128x192", "pingpong256x128", "pingpong256x192", "pingpong256x256", "batch_invariant",
-                              "bf16_pingpong256x128", "bf16_pingpong256x192", "bf16_pingpong256x256"])
+@pytest.mark.parametrize("geometry", ["2", "8", "10", "14", "12", "invariant"],
+                         ids=["w256x128", "w128x192", "pingpong256x128", "pingpong256x192", "pingpong256x256", "batch_invariant"])
 def test_wide_single_accumulator_kernels_against_goldens(geometry):
     """the round-3 GEMM geometries (gemm_h2w.hip: one accumulator set, 256x128 / 128x192 block tiles, and the fused
     lm_head on the 256-row tile) and the round-4 ping-pong kernels (gemm_pp.hip: 256x128 with two accumulator sets,
     256x192 / 256x256 with one, their split-K, the K / V scatter and packed-output epilogues) are chosen by planners only
     for some launch sizes, so most parity tests never reach them: re-run the GEMM-vs-fp64, reference-golden (logits, greedy
     ids, beams) and batched oracle tests in a child process with CAPDEC_H2W forcing the geometry everywhere (the default
-    precision mode's parametrisations only: the forced geometry is a property of those kernels).  "bf16_*": the same
-    ping-pong tiles under ONE-plane operands (round 5: the bf16 / fp16 modes) against that mode's own oracle tests."""
+    precision mode's parametrisations only: the forced geometry is a property of those kernels)."""
     import subprocess, sys
     # ("invariant": the same tests with CAPDEC_BATCH_INVARIANT=1 -- unsplit 128x128 GEMMs at every size, which also puts
     #  the small reference goldens on the decode path of the big batches: K / V written by the qkv GEMM's epilogue)
-    if geometry.startswith("x1:"):
-        env = dict(os.environ, CAPDEC_H2W=geometry[3:])
-        sel = "test_bf16_mode_logits_and_decode_vs_bf16_oracle or test_bf16_mode_gemm_is_bf16"
-        if geometry != "x1:12":
-            sel = f"({sel}) and not small"
-    else:
-        env = dict(os.environ, CAPDEC_BATCH_INVARIANT="1") if geometry == "invariant" else dict(os.environ, CAPDEC_H2W=geometry)
-        sel = ("(test_gemm_packed_a_path or test_gpt2_logits or test_decode_small_vs_reference_golden or "
-               "test_decode_tiny or test_batched_decode_vs_oracle_and_chunking or "
-               "test_mlp_mapper or test_transformer_mapper or test_finished_caption_compaction or test_prompt_and_tokens) "
-               "and not bf16x3 and not f32")
+    env = dict(os.environ, CAPDEC_BATCH_INVARIANT="1") if geometry == "invariant" else dict(os.environ, CAPDEC_H2W=geometry)
+    sel = ("(test_gemm_packed_a_path or test_gpt2_logits or test_decode_small_vs_reference_golden or "
+           "test_decode_tiny or test_batched_decode_vs_oracle_and_chunking or "
+           "test_mlp_mapper or test_transformer_mapper or test_finished_caption_compaction or test_prompt_and_tokens) "
+           "and not bf16x3 and not f32")
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-m", "gpu", "-k", sel,
                         "-p", "no:cacheprovider", "--durations=8"], env=env, capture_output=True, text=True, timeout=1500)
     tail = r.stdout[-2500:]
@@ -1685,6 +1677,73 @@ def test_make_preds_from_images_rn_backbone(tmp_path):
     assert PR.make_preds(kept, feats, model, FakeTok(stop), None, beam=True, entry_length=12) == preds
     assert PR.make_preds(kept, feats, model, FakeTok(stop), None, beam=False, entry_length=12) != preds
     assert PR.make_preds_from_images([], [], clip_model, preprocess, model, FakeTok(stop)) == []
+
+
+def test_config4_chain_images_vit_transformer_mapper_beam(tmp_path):
+    """BASELINE configs[4] as ONE chain (reference predictions_runner.py:156-161, 207-234 with the ViT-B/32 backbone and a
+    TransformerMapper): synthetic photos -> preprocess -> ViT encode_image (B/32 widths, two layers per tower) ->
+    normalise -> + modality offset -> TransformerMapper -> beam 5 -> predictions JSON, against the oracle run ONE IMAGE AT
+    A TIME the way the reference does (its own preprocess / encode_image / mapper restatements, then the reference-shaped
+    generate_beam)."""
+    import json
+    from capdec_amd import clip as cclip, predictions_runner as PR
+    from oracle import capdec_oracle as O
+    dims, cdims = synth.GPT2_TINY, synth.CLIP_TINY
+    csd = synth.hot_clip_state_dict(43, cdims)
+    clip_model, preprocess = cclip.load(csd, device=0)
+    model, sd = _model(dims, "transformer_encoder", cdims.embed_dim, seed=9, num_layers=2)
+    photos = [synth.synthetic_photo(h, w, 500 + i) for i, (h, w) in enumerate([(240, 320), (224, 224), (300, 260), (231, 400)])]
+    data = [{"image_id": 40 + i} for i in range(len(photos))]
+    offset = torch.randn(cdims.embed_dim, generator=torch.Generator().manual_seed(4)) * 0.05
+    stop, T_ = dims.vocab + 5, 9
+    out = tmp_path / "c4.json"
+    preds = PR.make_preds_from_images(data, photos, clip_model, preprocess, model, FakeTok(stop), str(out), beam=True,
+                                      entry_length=T_, modality_offset=offset, image_batch=3)
+    assert json.load(open(out)) == preds and [p["image_id"] for p in preds] == [40, 41, 42, 43]
+    ok = 0
+    for i, im in enumerate(photos):
+        x = O.clip_encode_image(O.clip_preprocess(im, cdims.image_size).unsqueeze(0), csd, cdims.vision_heads)
+        x = O.normalize_prefix(x, offset)
+        pe = O.clip_project(x, sd, "transformer_encoder", 10, 10, 2).reshape(1, 10, -1)
+        tok, sl, sc, order = O.generate_beam_ref(sd, pe, 5, stop, T_, n_head=dims.n_head)
+        b = int(order[0])
+        want = " ".join(str(int(v)) for v in tok[b][:int(sl[b])])
+        ok += preds[i]["caption"] == want
+        if preds[i]["caption"] != want:      # a numerical near-tie between two beams may swap them; nothing else may differ
+            margin = float(sc[order[0]] - sc[order[1]])
+            assert margin < 1e-4, (i, preds[i]["caption"], want, margin)
+    assert ok >= len(photos) - 1
+
+
+def test_make_preds_from_captions_text_branch(tmp_path):
+    """the text-input branch of the reference loop (predictions_runner.py:215-218: `clip.tokenize(d['caption'])` ->
+    `encode_text` -> the common tail) as a driver: captions -> token rows -> CLIP text tower -> normalise -> MLP mapper ->
+    greedy -> JSON, against the oracle one caption at a time; sharded two ways it gives the same list"""
+    import json
+    from capdec_amd import clip as cclip, predictions_runner as PR
+    from oracle import capdec_oracle as O
+    dims, cdims = synth.GPT2_TINY, synth.CLIP_TINY
+    csd = synth.hot_clip_state_dict(43, cdims)
+    clip_model, _ = cclip.load(csd, device=0)
+    model, sd = _model(dims, "mlp", cdims.embed_dim, seed=7)
+    rows = synth.synthetic_clip_tokens(7, seed=21)
+    data = [{"image_id": 900 + i, "caption": f"caption number {i}"} for i in range(7)]
+    table = {d["caption"]: rows[i] for i, d in enumerate(data)}
+    tokenize = lambda texts: torch.stack([table[t] for t in texts])       # noqa: E731  (stands for clip.tokenize: no BPE file here)
+    stop, T_ = dims.vocab + 5, 11
+    out = tmp_path / "t.json"
+    preds = PR.make_preds_from_captions(data, clip_model, model, FakeTok(stop), tokenize, str(out), beam=False, entry_length=T_,
+                                        text_batch=3)
+    assert json.load(open(out)) == preds and [p["image_id"] for p in preds] == [900 + i for i in range(7)]
+    for i in range(7):
+        x = O.normalize_prefix(O.clip_encode_text(rows[i:i + 1], csd, cdims.text_heads))
+        pe = O.clip_project(x, sd, "mlp", 10).reshape(1, 10, -1)
+        want = O.generate2_ref(sd, pe, stop, T_, n_head=dims.n_head)
+        assert preds[i]["caption"] == " ".join(str(v) for v in want), i
+    # beam, and the default tokenizer without a vocabulary file is a clear error
+    assert PR.make_preds_from_captions(data[:3], clip_model, model, FakeTok(stop), tokenize, beam=True, entry_length=T_) != preds[:3]
+    with pytest.raises(Exception, match="CAPDEC_CLIP_BPE"):
+        PR.make_preds_from_captions(data[:1], clip_model, model, FakeTok(stop))
 
 
 @pytest.mark.parametrize("precision", ["fp16", "bf16"])
