@@ -332,162 +332,6 @@ __global__ __launch_bounds__(256, OCC) void attn_decode_beams_kernel(const float
 }
 
 
-// Greedy decode with the bf16 KV cache (BASELINE configs[1]): one wavefront per (caption, head), ONE memory round trip.
-// Why a kernel of its own (round 5): the beam kernel above walks the history 8 positions per iteration (4 groups x NA = 2)
-// with 8-byte loads -- 2 KB in flight per wavefront, five or six dependent round trips for a 43-position history; at 5000
-// captions the launch is 60 000 such wavefronts and runs at latency x iterations (150 us, 4.4 TB/s).  A greedy row has no
-// ancestor table (every position sits in its own slot), and a bf16 key is 128 bytes: EIGHT lanes hold a key as 16-byte
-// pieces, so one load instruction of the wavefront covers eight consecutive positions (1 KB, contiguous in the cache)
-// and the K and V of up to 8 NJ = 80 cached positions are ALL requested before the first one is used (80 registers; three
-// wavefronts per SIMD: 240 KB of loads in flight per CU where the beam kernel had 32).
-// Group g = lane / 8 owns the positions p = g (mod 8); per-group running softmax in the log2 domain, merged once at the
-// end (same scheme as above).  The row's own K / V are rounded to bf16, appended to the cache and start group 0's sum.
-__device__ __forceinline__ float group8_sum(float v) {
-    v += __shfl_xor(v, 1, 64);
-    v += __shfl_xor(v, 2, 64);
-    v += __shfl_xor(v, 4, 64);
-    return v;
-}
-__device__ __forceinline__ float groups8_sum(float v) {
-    v += __shfl_xor(v, 8, 64);
-    v += __shfl_xor(v, 16, 64);
-    v += __shfl_xor(v, 32, 64);
-    return v;
-}
-__device__ __forceinline__ void bf16x8_to_f32(const uint4 u, float (&f)[8]) {
-    const unsigned w[4] = {u.x, u.y, u.z, u.w};
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        f[2 * e] = __builtin_bit_cast(float, w[e] << 16);
-        f[2 * e + 1] = __builtin_bit_cast(float, w[e] & 0xffff0000u);
-    }
-}
-template <int NJ>
-__global__ __launch_bounds__(256, 3) void attn_decode_greedy_b16_kernel(const float *__restrict__ qkv, __bf16 *__restrict__ kc,
-                                                                        __bf16 *__restrict__ vc, int total, int heads, int ctx,
-                                                                        int d, int L, float *__restrict__ out,
-                                                                        char *__restrict__ packed_out,
-                                                                        const int *__restrict__ cmap, int fmt) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int grp = lane >> 3, sub = lane & 7;
-    const int gw = blockIdx.x * 4 + wave;
-    if (gw >= total) return;                                       // (no block-level synchronisation in this kernel)
-    const int cap = gw / heads, head = gw - cap * heads;
-    const int srow = cmap ? cmap[cap] : cap;                       // state row: KV cache (original caption index)
-    const int Lpast = L - 1;
-    const size_t hbase = ((size_t)srow * heads + head) * (size_t)ctx * 64 + sub * 8;
-    const __bf16 *kb = kc + hbase, *vb = vc + hbase;
-    uint4 kk[NJ], vv[NJ];
-    // ---- every cached position of the first chunk is requested up front
-#pragma unroll
-    for (int j = 0; j < NJ; ++j)
-        if (8 * j < Lpast) {
-            const int p = 8 * j + grp;
-            kk[j] = *reinterpret_cast<const uint4 *>(p < Lpast ? kb + (size_t)p * 64 : kb);
-        }
-#pragma unroll
-    for (int j = 0; j < NJ; ++j)
-        if (8 * j < Lpast) {
-            const int p = 8 * j + grp;
-            vv[j] = *reinterpret_cast<const uint4 *>(p < Lpast ? vb + (size_t)p * 64 : vb);
-        }
-    // ---- the row's own q / k / v (fp32 activations of the qkv GEMM)
-    const float *qrow = qkv + (size_t)cap * 3 * d + head * 64 + sub * 8;
-    float q[8], kcur[8], vcur[8];
-    {
-        const float4 a0 = reinterpret_cast<const float4 *>(qrow)[0], a1 = reinterpret_cast<const float4 *>(qrow)[1];
-        const float4 b0 = reinterpret_cast<const float4 *>(qrow + d)[0], b1 = reinterpret_cast<const float4 *>(qrow + d)[1];
-        const float4 c0 = reinterpret_cast<const float4 *>(qrow + 2 * d)[0], c1 = reinterpret_cast<const float4 *>(qrow + 2 * d)[1];
-        const float qa[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
-        const float ka[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
-        const float va[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
-        bf16x8 kst, vst;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            q[e] = qa[e] * ATT_QSCALE;
-            kst[e] = (__bf16)ka[e];
-            vst[e] = (__bf16)va[e];
-            kcur[e] = (float)kst[e];                               // the value that is cached is the value attended to
-            vcur[e] = (float)vst[e];
-        }
-        if (grp == 0) {
-            *reinterpret_cast<bf16x8 *>(kc + hbase + (size_t)Lpast * 64) = kst;
-            *reinterpret_cast<bf16x8 *>(vc + hbase + (size_t)Lpast * 64) = vst;
-        }
-    }
-    float s_own = 0.f;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) s_own += q[e] * kcur[e];
-    s_own = group8_sum(s_own);
-    float mrun = grp == 0 ? s_own : ATT_NEG, lrun = grp == 0 ? 1.f : 0.f;
-    float acc[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) acc[e] = grp == 0 ? vcur[e] : 0.f;
-    for (int c0 = 0; c0 < Lpast; c0 += 8 * NJ) {
-        if (c0 > 0) {                                              // (histories beyond 8 NJ positions: one more round trip each)
-#pragma unroll
-            for (int j = 0; j < NJ; ++j)
-                if (c0 + 8 * j < Lpast) {
-                    const int p = c0 + 8 * j + grp;
-                    kk[j] = *reinterpret_cast<const uint4 *>(p < Lpast ? kb + (size_t)p * 64 : kb);
-                    vv[j] = *reinterpret_cast<const uint4 *>(p < Lpast ? vb + (size_t)p * 64 : vb);
-                }
-        }
-        float sv[NJ];
-        float mx = fmaxf(mrun, ATT_NEG);
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) {
-            sv[j] = -INFINITY;
-            if (c0 + 8 * j < Lpast) {
-                float kf[8];
-                bf16x8_to_f32(kk[j], kf);
-                float t = 0.f;
-#pragma unroll
-                for (int e = 0; e < 8; ++e) t += q[e] * kf[e];
-                t = group8_sum(t);
-                sv[j] = c0 + 8 * j + grp < Lpast ? t : -INFINITY;
-                mx = fmaxf(mx, sv[j]);
-            }
-        }
-        const float sc = att_exp2(mrun - mx);
-        lrun *= sc;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) acc[e] *= sc;
-#pragma unroll
-        for (int j = 0; j < NJ; ++j)
-            if (c0 + 8 * j < Lpast) {                              // (a skipped j holds no data: never multiplied, not even by 0)
-                const float w = att_exp2(sv[j] - mx);
-                float vf[8];
-                bf16x8_to_f32(vv[j], vf);
-                lrun += w;
-#pragma unroll
-                for (int e = 0; e < 8; ++e) acc[e] += w * vf[e];
-            }
-        mrun = mx;
-    }
-    // ---- merge the eight groups
-    float M = mrun;
-    M = fmaxf(M, __shfl_xor(M, 8, 64));
-    M = fmaxf(M, __shfl_xor(M, 16, 64));
-    M = fmaxf(M, __shfl_xor(M, 32, 64));                           // finite: group 0 holds the row's own token
-    const float sc = att_exp2(mrun - M);
-    const float inv = 1.0f / groups8_sum(lrun * sc);
-    float o[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) o[e] = groups8_sum(acc[e] * sc) * inv;
-    if (grp == 0) {
-        const float4 o0 = make_float4(o[0], o[1], o[2], o[3]), o1 = make_float4(o[4], o[5], o[6], o[7]);
-        if (packed_out) {
-            x3_store_quad(packed_out, d >> 4, cap, head * 4 + (sub >> 1), (sub & 1) * 2, o0, fmt);
-            x3_store_quad(packed_out, d >> 4, cap, head * 4 + (sub >> 1), (sub & 1) * 2 + 1, o1, fmt);
-        } else {
-            float4 *dst = reinterpret_cast<float4 *>(out + (size_t)cap * d + head * 64 + sub * 8);
-            dst[0] = o0;
-            dst[1] = o1;
-        }
-    }
-}
-
 // Prefill / CLIP-tower attention: one wavefront per (caption, head, block of R query rows).  The R rows share every
 // K / V row they read (taken straight from the fused qkv activations -- no cache round trip), so a key is loaded once
 // per R queries instead of once per query: the per-row kernel above moved 61 GB per launch through L2 on the 77-token
@@ -639,16 +483,10 @@ static int attn_decode_typed(hipStream_t st, const float *qkv, const KvCache &c,
     const Tuning &tn = c.tune ? *c.tune : default_tuning();     // (the overrides below exist in measurement builds only)
     const int pre_on = tn.att_preload;
     const int npre = !pre_on ? 0 : (anc == nullptr ? L : c.prefix_len);
-    if constexpr (sizeof(KV) == 2) {
-        // greedy rows on the bf16 cache: the one-round-trip kernel (CAPDEC_ATT_G16=0: the beam kernel with BEAM = 1, for A/B)
-        if (beam == 1 && anc == nullptr && tn.att_g16 && rows > 0) {
-            const int total = rows * c.heads;
-            hipLaunchKernelGGL((attn_decode_greedy_b16_kernel<10>), dim3((total + 3) / 4), dim3(256), 0, st, qkv, (__bf16 *)kl,
-                               (__bf16 *)vl, total, c.heads, c.ctx, c.heads * c.hd, L, out, (char *)packed_out, cmap, fmt);
-            CAPDEC_HIP(hipGetLastError());
-            return 0;
-        }
-    }
+    // (Round 5 tried a kernel of its own for greedy rows on the bf16 cache -- eight lanes per key, 16-byte loads, the K / V
+    //  of the whole history requested before the first use -- and CAPDEC_ATT_NA=4 here: 157 / 143 us against 150 / 141 us per
+    //  launch at 5000 captions.  That launch is not latency-bound: 5.5 KB runs at a 9.7 KB stride read at 4.4 TB/s whatever
+    //  the structure (profiles/r5_att_greedy_b16_ab.txt).)
     {
         const int ncap = rows / beam, total = ncap * c.heads;
         if (total <= 0) return 0;

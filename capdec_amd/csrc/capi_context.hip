@@ -76,9 +76,9 @@ bool tuning_from_env(Tuning *t, std::string *err) {
         }
     }
     env_int("CAPDEC_PP", &t->pp);
-    env_flag("CAPDEC_ATT_G16", &t->att_g16);
     env_flag("CAPDEC_LMHEAD_WIDE", &t->lmhead_wide);
     env_flag("CAPDEC_TRAIN_F16X2", &t->train_f16x2);
+    env_flag("CAPDEC_TRAIN_ATTN_BLK", &t->train_attn_blk);
     env_flag("CAPDEC_LMHEAD_K3", &t->lmhead_k3);
     env_int("CAPDEC_LMHEAD_K3_MAX", &t->lmhead_k3_max);
     env_flag("CAPDEC_KV_DIRECT", &t->kv_direct);

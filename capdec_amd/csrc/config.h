@@ -29,8 +29,6 @@ struct Tuning {
     int h2w = 1;                  // CAPDEC_H2W: 0 = round-2 kernels only, 1 = planners, 2 / 8 = force a round-3 wide tile,
                                   //             10 / 12 / 14 = force a round-4 ping-pong tile (tests)
     int pp = 2;                   // CAPDEC_PP: ping-pong planner: 0 never, 2 mid-size launches (default), 1 also large, 3 large only
-    bool att_g16 = true;          // CAPDEC_ATT_G16=0: greedy rows on the bf16 KV cache take the beam kernel (BEAM = 1) instead of the
-                                  //   one-round-trip kernel of round 5
     bool lmhead_wide = true;      // CAPDEC_LMHEAD_WIDE=0: 128-row lm_head tiles at every size
     bool lmhead_k3 = true;        // CAPDEC_LMHEAD_K3=0: the wide lm_head keeps k candidates per tile (no exact second pass)
     int lmhead_k3_max = 60;       // CAPDEC_LMHEAD_K3_MAX: per mille of the rows taking the second pass above which a decode
@@ -40,6 +38,8 @@ struct Tuning {
     bool rn_implicit = true;      // CAPDEC_RN_IMPLICIT=0: fp32 activations in the ResNet tower
     bool train_f16x2 = true;      // CAPDEC_TRAIN_F16X2=0: the train step's backward GEMMs on the native fp32 MFMA GEMM instead of the
                                   //   two-fp16-plane kernels (A/B: 39.4 vs 23.6 ms per step; both parity-tested)
+    bool train_attn_blk = true;   // CAPDEC_TRAIN_ATTN_BLK=0: the train step's attention on the per-query wavefront kernels at every sequence
+                                  //   length (the fallback above 128 positions) instead of the block-per-(sample, head) kernels
     bool hook_packa = false;      // CAPDEC_HOOK_PACKA: capdec_gemm_f32 (test hook) packs A first (the LayerNorm -> GEMM path)
     bool hook_cache = false;      // CAPDEC_HOOK_CACHE: ... and treats both operands as resident (micro-benchmarks)
     std::string rccl_lib;         // CAPDEC_RCCL_LIB: path of librccl for the C-ABI communicator

@@ -464,6 +464,270 @@ __global__ __launch_bounds__(256) void attn_bwd_kv_kernel(const float *__restric
         }
 }
 
+// ---------------------------------------------------------------------------------------------- attention, block form
+// The train step's sequences are short (S = prefix_length + caption <= ~100; the TransformerMapper's 80): ONE BLOCK per
+// (sample, head) stages the head's K and V (later Q and dO) in LDS once and its eight wavefronts walk the queries (keys) --
+// where the per-(sample, head, query) wavefronts above re-read every key from L2 and spend two 64-lane reductions per
+// (query, key) pair (TransformerMapper, S = 80, 8 x 96: 319 + 173 us per layer backward, 310 us forward).  Lane-per-key
+// for the scores (a key's row of the LDS tile per lane, row stride HD + 1: conflict-free; the query is broadcast from a
+// per-wavefront buffer), lane-per-dimension for the products with V / K / Q / dO (the weight is the broadcast).
+//   forward:  P = softmax(q K^T scale) [mask / keep], out = P V
+//   backward: phase 1 per query i -- p, dP = (dO_i . v_j) [mask / keep], D = sum p dP, dS = p (dP - D), dq_i = scale dS K;
+//             P[i][j] (as it multiplied V) and dS[i][j] stay in LDS;  phase 2 per key j -- Q / dO take K / V's place:
+//             dk_j = scale sum_i dS[i][j] q_i,  dv_j = sum_i P[i][j] dO_i
+// mask: GPT-2's attn_dropout keep bytes [B, H, S, S] (nullptr: none).  Layout of qkv / dqkv as above.
+constexpr int ATTN_BLK_NW = 8;                                      // wavefronts per block (512 threads)
+template <int HD> struct AttnBlk {
+    static constexpr int LD = HD + 1;
+    static size_t fwd_bytes(int S) { return ((size_t)2 * S * LD + ATTN_BLK_NW * (HD + S)) * sizeof(float); }
+    static size_t bwd_bytes(int S) {
+        return ((size_t)2 * S * LD + (size_t)2 * S * (S + 1) + ATTN_BLK_NW * (2 * HD + S)) * sizeof(float);
+    }
+};
+template <int HD>
+__device__ __forceinline__ void attn_blk_stage(float *__restrict__ dst, const float *__restrict__ src, int ld, int S) {
+    // dst[j][e] = src[j * ld + e], j < S, e < HD   (consecutive threads read consecutive e: coalesced rows)
+    for (int i = threadIdx.x; i < S * HD; i += 64 * ATTN_BLK_NW) {
+        const int j = i / HD, e = i - j * HD;
+        dst[j * (HD + 1) + e] = src[(size_t)j * ld + e];
+    }
+}
+// sum_e x[e] y[e] over HD (a multiple of 16): the loop is bound by LDS latency, not by its FMAs -- left alone the compiler
+// reuses one register pair per step and waits for every read (load, s_waitcnt lgkmcnt(0), fma, ...), so 16 elements of each
+// vector are read into registers FIRST (the sched_barrier keeps the reads ahead of the arithmetic), then four independent
+// chains consume them
+template <int HD>
+__device__ __forceinline__ float dot_lds(const float *__restrict__ x, const float *__restrict__ y) {
+    static_assert(HD % 16 == 0, "head dimension");
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#pragma unroll 2
+    for (int e0 = 0; e0 < HD; e0 += 16) {
+        float xv[16], yv[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) { xv[u] = x[e0 + u]; yv[u] = y[e0 + u]; }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < 16; u += 4) {
+            a0 += xv[u] * yv[u];
+            a1 += xv[u + 1] * yv[u + 1];
+            a2 += xv[u + 2] * yv[u + 2];
+            a3 += xv[u + 3] * yv[u + 3];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    return (a0 + a1) + (a2 + a3);
+}
+// acc[e] += sum_{j in [j0, j1)} w[j ws] M[j LD + lane + 64 e]: rows of an LDS tile weighted by a broadcast column, eight
+// rows read before they are used
+template <int HD>
+__device__ __forceinline__ void wsum_rows(const float *__restrict__ w, int ws, const float *__restrict__ M, int j0, int j1, int lane,
+                                          float (&acc)[(HD + 63) / 64]) {
+    constexpr int LD = HD + 1, NE = (HD + 63) / 64, U = 8;
+    float p[2][NE];
+#pragma unroll
+    for (int e = 0; e < NE; ++e) p[0][e] = p[1][e] = 0.f;
+    int j = j0;
+    for (; j + U - 1 < j1; j += U) {
+        float wv[U], mv[U][NE];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            wv[u] = w[(j + u) * ws];
+#pragma unroll
+            for (int e = 0; e < NE; ++e) mv[u][e] = lane + 64 * e < HD ? M[(j + u) * LD + lane + 64 * e] : 0.f;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int e = 0; e < NE; ++e) p[u & 1][e] += wv[u] * mv[u][e];
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    for (; j < j1; ++j) {
+        const float wj = w[j * ws];
+#pragma unroll
+        for (int e = 0; e < NE; ++e)
+            if (lane + 64 * e < HD) p[0][e] += wj * M[j * LD + lane + 64 * e];
+    }
+#pragma unroll
+    for (int e = 0; e < NE; ++e) acc[e] += p[0][e] + p[1][e];
+}
+#define ATTN_WAVE_SYNC()                                        \
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");      \
+    __builtin_amdgcn_wave_barrier();                            \
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+template <int HD, bool CAUSAL>
+__global__ __launch_bounds__(64 * ATTN_BLK_NW) void attn_blk_fwd_kernel(const float *__restrict__ qkv, float *__restrict__ out, int S,
+                                                                       int heads, float scale,
+                                                                       const uint8_t *__restrict__ mask, float inv_keep) {
+    constexpr int LD = HD + 1, NE = (HD + 63) / 64, NW = ATTN_BLK_NW;
+    static_assert(HD % 4 == 0, "head dimension");
+    extern __shared__ float sh[];
+    float *Ks = sh, *Vs = Ks + S * LD, *qb = Vs + S * LD, *pb = qb + NW * HD;     // [S][LD] x 2, [NW][HD], [NW][S]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int bh = blockIdx.x, h = bh % heads, b = bh / heads, d = heads * HD;
+    const float *base = qkv + (size_t)b * S * 3 * d + h * HD;
+    attn_blk_stage<HD>(Ks, base + d, 3 * d, S);
+    attn_blk_stage<HD>(Vs, base + 2 * d, 3 * d, S);
+    __syncthreads();
+    float *q = qb + wave * HD, *p = pb + wave * S;
+    for (int i = wave; i < S; i += NW) {
+        const int nk = CAUSAL ? i + 1 : S;
+#pragma unroll
+        for (int e = 0; e < NE; ++e)
+            if (lane + 64 * e < HD) q[lane + 64 * e] = base[(size_t)i * 3 * d + lane + 64 * e] * scale;
+        ATTN_WAVE_SYNC()
+        float sc[2], mx = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const int j = lane + 64 * r;
+            sc[r] = j < nk ? dot_lds<HD>(q, Ks + j * LD) : -INFINITY;
+            mx = fmaxf(mx, sc[r]);
+        }
+        mx = wave_max(mx);
+        float l = 0.f;
+#pragma unroll
+        for (int r = 0; r < 2; ++r) { sc[r] = lane + 64 * r < nk ? expf(sc[r] - mx) : 0.f; l += sc[r]; }
+        const float inv = 1.0f / wave_sum(l);
+        const uint8_t *mr = mask ? mask + ((size_t)bh * S + i) * S : nullptr;
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const int j = lane + 64 * r;
+            if (j < nk) p[j] = sc[r] * inv * (mr ? (mr[j] ? inv_keep : 0.f) : 1.f);
+        }
+        ATTN_WAVE_SYNC()
+        float o[NE];
+#pragma unroll
+        for (int e = 0; e < NE; ++e) o[e] = 0.f;
+        wsum_rows<HD>(p, 1, Vs, 0, nk, lane, o);
+#pragma unroll
+        for (int e = 0; e < NE; ++e)
+            if (lane + 64 * e < HD) out[((size_t)b * S + i) * d + h * HD + lane + 64 * e] = o[e];
+    }
+}
+template <int HD, bool CAUSAL>
+__global__ __launch_bounds__(64 * ATTN_BLK_NW) void attn_blk_bwd_kernel(const float *__restrict__ qkv, const float *__restrict__ dout,
+                                                                       float *__restrict__ dqkv, int S, int heads, float scale,
+                                                                       const uint8_t *__restrict__ mask, float inv_keep) {
+    constexpr int LD = HD + 1, NE = (HD + 63) / 64, NW = ATTN_BLK_NW;
+    extern __shared__ float sh[];
+    const int SP = S + 1;
+    float *A = sh, *Bm = A + S * LD, *P = Bm + S * LD, *dS = P + S * SP, *qb = dS + S * SP, *gb = qb + NW * HD,
+          *sb = gb + NW * HD;                                       // [S][LD] x 2, [S][S + 1] x 2, [NW][HD] x 2, [NW][S]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int bh = blockIdx.x, h = bh % heads, b = bh / heads, d = heads * HD;
+    const float *base = qkv + (size_t)b * S * 3 * d + h * HD;
+    const float *gbase = dout + (size_t)b * S * d + h * HD;
+    float *obase = dqkv + (size_t)b * S * 3 * d + h * HD;
+    attn_blk_stage<HD>(A, base + d, 3 * d, S);                      // K
+    attn_blk_stage<HD>(Bm, base + 2 * d, 3 * d, S);                 // V
+    __syncthreads();
+    float *q = qb + wave * HD, *g = gb + wave * HD, *ds = sb + wave * S;
+    // ---- phase 1: one query per wavefront pass
+    for (int i = wave; i < S; i += NW) {
+        const int nk = CAUSAL ? i + 1 : S;
+#pragma unroll
+        for (int e = 0; e < NE; ++e)
+            if (lane + 64 * e < HD) {
+                q[lane + 64 * e] = base[(size_t)i * 3 * d + lane + 64 * e] * scale;
+                g[lane + 64 * e] = gbase[(size_t)i * d + lane + 64 * e];
+            }
+        ATTN_WAVE_SYNC()
+        const uint8_t *mr = mask ? mask + ((size_t)bh * S + i) * S : nullptr;
+        float sc[2], dp[2], mx = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const int j = lane + 64 * r;
+            float a = -INFINITY, t = 0.f;
+            if (j < nk) {
+                a = dot_lds<HD>(q, A + j * LD);
+                t = dot_lds<HD>(g, Bm + j * LD);
+                if (mr) t *= mr[j] ? inv_keep : 0.f;
+            }
+            sc[r] = a;
+            dp[r] = t;
+            mx = fmaxf(mx, sc[r]);
+        }
+        mx = wave_max(mx);
+        float l = 0.f;
+#pragma unroll
+        for (int r = 0; r < 2; ++r) { sc[r] = lane + 64 * r < nk ? expf(sc[r] - mx) : 0.f; l += sc[r]; }
+        const float inv = 1.0f / wave_sum(l);
+        float D = 0.f;
+#pragma unroll
+        for (int r = 0; r < 2; ++r) { sc[r] *= inv; D += sc[r] * dp[r]; }
+        D = wave_sum(D);
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const int j = lane + 64 * r;
+            if (j < S) {            // (columns past the causal limit hold zeros)
+                const float w = j < nk ? sc[r] * (dp[r] - D) : 0.f;
+                ds[j] = w;
+                dS[i * SP + j] = w;
+                P[i * SP + j] = j < nk ? sc[r] * (mr ? (mr[j] ? inv_keep : 0.f) : 1.f) : 0.f;
+            }
+        }
+        ATTN_WAVE_SYNC()
+        float dq[NE];
+#pragma unroll
+        for (int e = 0; e < NE; ++e) dq[e] = 0.f;
+        wsum_rows<HD>(ds, 1, A, 0, nk, lane, dq);
+#pragma unroll
+        for (int e = 0; e < NE; ++e)
+            if (lane + 64 * e < HD) obase[(size_t)i * 3 * d + lane + 64 * e] = dq[e] * scale;
+    }
+    __syncthreads();
+    // ---- phase 2: Q and dO take the place of K and V; one key per wavefront pass
+    attn_blk_stage<HD>(A, base, 3 * d, S);                          // Q
+    attn_blk_stage<HD>(Bm, gbase, d, S);                            // dO
+    __syncthreads();
+    for (int j = wave; j < S; j += NW) {
+        float dk[NE], dv[NE];
+#pragma unroll
+        for (int e = 0; e < NE; ++e) dk[e] = dv[e] = 0.f;
+        const int i0 = CAUSAL ? j : 0;
+        wsum_rows<HD>(dS + j, SP, A, i0, S, lane, dk);              // column j of dS against the rows of Q
+        wsum_rows<HD>(P + j, SP, Bm, i0, S, lane, dv);              // column j of P against the rows of dO
+#pragma unroll
+        for (int e = 0; e < NE; ++e)
+            if (lane + 64 * e < HD) {
+                obase[(size_t)j * 3 * d + d + lane + 64 * e] = dk[e] * scale;
+                obase[(size_t)j * 3 * d + 2 * d + lane + 64 * e] = dv[e];
+            }
+    }
+}
+#undef ATTN_WAVE_SYNC
+// the block kernels when a head's tiles fit the CU's LDS (S <= 128), the per-query wavefront kernels otherwise
+constexpr size_t ATTN_BLK_LDS_MAX = 150 * 1024;
+template <int HD, bool CAUSAL>
+static int attn_blk_fwd(hipStream_t st, const float *qkv, float *out, int B, int S, int heads, float scale, const uint8_t *mask,
+                        float inv_keep) {
+    const size_t lds = AttnBlk<HD>::fwd_bytes(S);
+    static bool attr = false;
+    if (!attr) {
+        CAPDEC_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&attn_blk_fwd_kernel<HD, CAUSAL>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)ATTN_BLK_LDS_MAX));
+        attr = true;
+    }
+    hipLaunchKernelGGL((attn_blk_fwd_kernel<HD, CAUSAL>), dim3(B * heads), dim3(64 * ATTN_BLK_NW), lds, st, qkv, out, S, heads, scale, mask, inv_keep);
+    CAPDEC_HIP(hipGetLastError());
+    return 0;
+}
+template <int HD, bool CAUSAL>
+static int attn_blk_bwd(hipStream_t st, const float *qkv, const float *dout, float *dqkv, int B, int S, int heads, float scale,
+                        const uint8_t *mask, float inv_keep) {
+    const size_t lds = AttnBlk<HD>::bwd_bytes(S);
+    static bool attr = false;
+    if (!attr) {
+        CAPDEC_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&attn_blk_bwd_kernel<HD, CAUSAL>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)ATTN_BLK_LDS_MAX));
+        attr = true;
+    }
+    hipLaunchKernelGGL((attn_blk_bwd_kernel<HD, CAUSAL>), dim3(B * heads), dim3(64 * ATTN_BLK_NW), lds, st, qkv, dout, dqkv, S, heads, scale, mask,
+                       inv_keep);
+    CAPDEC_HIP(hipGetLastError());
+    return 0;
+}
+
 // ---------------------------------------------------------------------------------------------- cross-entropy
 // logits [rows, ld] (columns >= V are padding) -> in place: (softmax - onehot) x ls for rows whose label != ignore, 0 for
 // the others and for the padding; row_loss[r] = lse - logit[label] (0 for ignored rows).  One block per row.
@@ -790,7 +1054,13 @@ static int mapper_forward_saved(capdec_ctx *c, TrainState &t, const float *x, in
               *r = t.t_r.as<float>() + (size_t)M * hid * l;
         { ProfScope ps(c, F_LN); CAPDEC_TRY(launch_layernorm(st, h, d, w.n1w, w.n1b, 1e-5f, a1, d, M, d)); }
         CAPDEC_TRY(gemm(c, a1, d, w.wqkv, d, qkv, 3 * d, M, 3 * d, d, nullptr, CAPDEC_ACT_NONE, nullptr, 0, false));
-        { ProfScope ps(c, F_MAP_ATTN); CAPDEC_TRY(launch_attn_mapper(st, qkv, 3 * d, qkv + d, qkv + 2 * d, 3 * d, att, B, S, m.heads, hd)); }
+        {
+            ProfScope ps(c, F_MAP_ATTN);
+            if (c->tune.train_attn_blk && hd == 96 && S <= 128 && AttnBlk<96>::fwd_bytes(S) <= ATTN_BLK_LDS_MAX)
+                CAPDEC_TRY((attn_blk_fwd<96, false>(st, qkv, att, B, S, m.heads, (float)pow(96.0, -0.5), nullptr, 1.f)));
+            else
+                CAPDEC_TRY(launch_attn_mapper(st, qkv, 3 * d, qkv + d, qkv + 2 * d, 3 * d, att, B, S, m.heads, hd));
+        }
         CAPDEC_TRY(gemm(c, att, d, w.wproj, d, mid, d, M, d, d, w.bproj, CAPDEC_ACT_NONE, h, d, false));
         { ProfScope ps(c, F_LN); CAPDEC_TRY(launch_layernorm(st, mid, d, w.n2w, w.n2b, 1e-5f, a2, d, M, d)); }
         CAPDEC_TRY(gemm(c, a2, d, w.wfc1, d, r, hid, M, hid, d, w.bfc1, CAPDEC_ACT_RELU, nullptr, 0, false));
@@ -848,10 +1118,14 @@ static int mapper_backward(capdec_ctx *c, TrainState &t, const float *x, const f
         // attention: mid = h + project(att)
         CAPDEC_TRY(linear_dw(c, t, ds2, att, M, d, d, t.grad(s0 + 4), t.grad(s0 + 5)));
         CAPDEC_TRY(linear_dx(c, t, ds2, w.wproj, datt, M, d, d));
-        hipLaunchKernelGGL((attn_bwd_q_kernel<96, false>), dim3((nbh + 3) / 4), dim3(256), (size_t)4 * 2 * S * sizeof(float), st,
-                           qkv, datt, dqkv, t.lse.as<float>(), t.dsum.as<float>(), nbh, S, m.heads, scale);
-        hipLaunchKernelGGL((attn_bwd_kv_kernel<96, false>), dim3((nbh + 3) / 4), dim3(256), 0, st, qkv, datt, dqkv,
-                           t.lse.as<float>(), t.dsum.as<float>(), nbh, S, m.heads, scale);
+        if (c->tune.train_attn_blk && S <= 128 && AttnBlk<96>::bwd_bytes(S) <= ATTN_BLK_LDS_MAX) {
+            CAPDEC_TRY((attn_blk_bwd<96, false>(st, qkv, datt, dqkv, B, S, m.heads, scale, nullptr, 1.f)));
+        } else {
+            hipLaunchKernelGGL((attn_bwd_q_kernel<96, false>), dim3((nbh + 3) / 4), dim3(256), (size_t)4 * 2 * S * sizeof(float), st,
+                               qkv, datt, dqkv, t.lse.as<float>(), t.dsum.as<float>(), nbh, S, m.heads, scale);
+            hipLaunchKernelGGL((attn_bwd_kv_kernel<96, false>), dim3((nbh + 3) / 4), dim3(256), 0, st, qkv, datt, dqkv,
+                               t.lse.as<float>(), t.dsum.as<float>(), nbh, S, m.heads, scale);
+        }
         CAPDEC_TRY(linear_dw(c, t, dqkv, a1, M, 3 * d, d, t.grad(s0 + 2), nullptr));      // [to_queries ; to_keys_values]: no bias
         CAPDEC_TRY(linear_dx(c, t, dqkv, w.wqkv, da, M, 3 * d, d));
         CAPDEC_TRY(ln_bwd(c, h, w.n1w, da, ds2, ds, M, d, 1e-5f, t.grad(s0 + 0), t.grad(s0 + 1)));          // ds = d h
@@ -976,8 +1250,11 @@ static int train_step(capdec_ctx *c, const float *prefix, const int *tokens, int
         CAPDEC_TRY(gemm(c, a, d, w.wqkv, d, qkv, 3 * d, R, 3 * d, d, w.bqkv, CAPDEC_ACT_NONE, nullptr, 0, !full));
         if (drop) {
             ProfScope ps(c, F_ATTN_PRE);
-            hipLaunchKernelGGL(attn_fwd_drop_kernel, dim3((nbh + 3) / 4), dim3(256), (size_t)4 * S * sizeof(float), st, qkv, m_att, att,
-                               nbh, S, g.n_head, 0.125f, inv_keep);
+            if (c->tune.train_attn_blk && S <= 128 && AttnBlk<64>::fwd_bytes(S) <= ATTN_BLK_LDS_MAX)
+                CAPDEC_TRY((attn_blk_fwd<64, true>(st, qkv, att, B, S, g.n_head, 0.125f, m_att, inv_keep)));
+            else
+                hipLaunchKernelGGL(attn_fwd_drop_kernel, dim3((nbh + 3) / 4), dim3(256), (size_t)4 * S * sizeof(float), st, qkv, m_att, att,
+                                   nbh, S, g.n_head, 0.125f, inv_keep);
             CAPDEC_TRY(gemm(c, att, d, w.wproj, d, ytmp, d, R, d, d, w.bproj, CAPDEC_ACT_NONE, nullptr, 0, false));
             dropout_apply(st, ytmp, m_res, h, hmid, Rd, inv_keep);                      // h + resid_dropout(c_proj(att))
         } else {
@@ -1049,10 +1326,14 @@ static int train_step(capdec_ctx *c, const float *prefix, const int *tokens, int
         if (drop) { dropout_apply(st, dh2, m_res, nullptr, dtmp, Rd, inv_keep); dy1 = dtmp; }
         if (full) CAPDEC_TRY(linear_dw(c, t, dy1, t.att.as<float>() + Rd * i, R, d, d, t.grad(s0 + 4), t.grad(s0 + 5)));   // attn.c_proj
         CAPDEC_TRY(gemm_fp32(c, dy1, d, wt.wproj_t, d, datt, d, R, d, d, !full));                 // d att
-        hipLaunchKernelGGL((attn_bwd_q_kernel<64, true>), dim3((nbh + 3) / 4), dim3(256), (size_t)4 * 2 * S * sizeof(float), st, qkv,
-                           datt, dqkv, t.lse.as<float>(), t.dsum.as<float>(), nbh, S, g.n_head, 0.125f, drop ? m_att : nullptr, inv_keep);
-        hipLaunchKernelGGL((attn_bwd_kv_kernel<64, true>), dim3((nbh + 3) / 4), dim3(256), 0, st, qkv, datt, dqkv,
-                           t.lse.as<float>(), t.dsum.as<float>(), nbh, S, g.n_head, 0.125f, drop ? m_att : nullptr, inv_keep);
+        if (c->tune.train_attn_blk && S <= 128 && AttnBlk<64>::bwd_bytes(S) <= ATTN_BLK_LDS_MAX) {
+            CAPDEC_TRY((attn_blk_bwd<64, true>(st, qkv, datt, dqkv, B, S, g.n_head, 0.125f, drop ? m_att : nullptr, inv_keep)));
+        } else {
+            hipLaunchKernelGGL((attn_bwd_q_kernel<64, true>), dim3((nbh + 3) / 4), dim3(256), (size_t)4 * 2 * S * sizeof(float), st, qkv,
+                               datt, dqkv, t.lse.as<float>(), t.dsum.as<float>(), nbh, S, g.n_head, 0.125f, drop ? m_att : nullptr, inv_keep);
+            hipLaunchKernelGGL((attn_bwd_kv_kernel<64, true>), dim3((nbh + 3) / 4), dim3(256), 0, st, qkv, datt, dqkv,
+                               t.lse.as<float>(), t.dsum.as<float>(), nbh, S, g.n_head, 0.125f, drop ? m_att : nullptr, inv_keep);
+        }
         if (full) {                                   // attn.c_attn: input ln_1(h)
             CAPDEC_TRY(launch_layernorm(st, h, d, w.ln1w, w.ln1b, g.eps, a, d, R, d));
             CAPDEC_TRY(linear_dw(c, t, dqkv, a, R, 3 * d, d, t.grad(s0 + 2), t.grad(s0 + 3)));

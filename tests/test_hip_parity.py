@@ -566,12 +566,14 @@ def test_train_step_full_model_with_dropout_vs_reference_golden(golden):
     assert abs(l_eval - float(want0)) < 3e-4 and abs(l_eval - l1) > 1e-3
 
 
-def test_train_step_on_the_native_fp32_gemm():
+def test_train_step_on_the_native_fp32_gemm_and_the_wavefront_attention():
     """CAPDEC_TRAIN_F16X2=0 puts the backward GEMMs of the train step on the native fp32 MFMA kernel (the default is the
-    fp32-accurate two-fp16-plane family): the same goldens in a child process with the knob"""
+    fp32-accurate two-fp16-plane family) and CAPDEC_TRAIN_ATTN_BLK=0 its attention on the per-query wavefront kernels (the
+    fallback of sequences beyond 128 positions; the default is one block per (sample, head)): the same goldens -- frozen
+    scope with both mappers, full scope with and without dropout -- in a child process with both knobs"""
     import subprocess
     import sys
-    env = dict(os.environ, CAPDEC_TRAIN_F16X2="0")
+    env = dict(os.environ, CAPDEC_TRAIN_F16X2="0", CAPDEC_TRAIN_ATTN_BLK="0")
     sel = "(test_train_step_frozen_gpt2_vs_reference_golden and tiny) or test_train_step_full_model"
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-m", "gpu", "-k", sel,
                         "-p", "no:cacheprovider"], env=env, capture_output=True, text=True, timeout=900)
