@@ -17,6 +17,7 @@ $B --workload text_embed --captions 20000 --gemm-mode f16 > "$OUT/${TAG}_side_te
 $B --workload image_beam --captions 2014 > "$OUT/${TAG}_side_image_f16x2.json" 2>/dev/null
 $B --workload image_beam --clip rn50x4 --captions 2014 > "$OUT/${TAG}_side_image_rn50x4.json" 2>/dev/null
 timeout 120 python bench.py --workload train_step --steps 10 --warmup 2 --cpu-seconds 5 > "$OUT/${TAG}_side_train_step.json" 2>/dev/null
+timeout 120 python bench.py --workload train_step --train-scope full --steps 10 --warmup 2 --cpu-seconds 5 > "$OUT/${TAG}_side_train_step_full.json" 2>/dev/null
 CAPDEC_FORCE_DIST=1 timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29513 \
    bench.py --gpus 1 --cpu-seconds 0 --cpu-captions 0 --no-checks --steps 2 --warmup 1 > "$OUT/${TAG}_side_dist1.json" 2>/dev/null
 python - "$OUT" "$TAG" <<'PY'
