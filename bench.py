@@ -42,7 +42,7 @@ PEAK_BF16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA (not the 
 # back-to-back MFMAs sustains 1650 TFLOP/s (profiles/r3_mfma_power_ceiling.txt, tools/probes/mfma_energy.hip; zeros: 2451)
 F16_MFMA_AT_POWER_CAP_TFLOPS = 1650.0
 STOP_ID, D_EMB = 13, 768
-PMC_TRAFFIC_FILE = "r4_pmc_traffic.json"   # rocprofv3 --pmc summary the `roofline.traffic` field is read from
+PMC_TRAFFIC_FILE = "r5_pmc_traffic.json"   # rocprofv3 --pmc summary the `roofline.traffic` field is read from
 
 
 def algorithmic_flops_per_caption(P, T, beam, mapper, dims=synth.GPT2_SMALL, D=512, clip_len=10):

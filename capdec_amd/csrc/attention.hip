@@ -512,7 +512,7 @@ static int attn_decode_typed(hipStream_t st, const float *qkv, const KvCache &c,
                        (char *)packed_out, cmap, fmt, npre, (int)lds)
 #define LAUNCH_BEAMS(B, OCC)                                                                                    \
     if (cur_cached && (B == 1 || B == 5)) {       /* (the widths the decode drivers use most: greedy and beam 5) */ \
-        if (dma_on) LAUNCH_BEAMS_DMA(B, OCC);                                                                   \
+        if (dma_on && sizeof(KV) == 4) LAUNCH_BEAMS_DMA(B, OCC);    /* (the LDS-DMA ring is laid out for fp32 keys) */  \
         else if (na4) LAUNCH_BEAMS_V(B, OCC, 4, true); else LAUNCH_BEAMS_V(B, OCC, 2, true);                     \
     } else if (na4 && B <= 5) LAUNCH_BEAMS_V(B, OCC, 4, false);                                                 \
     else LAUNCH_BEAMS_V(B, OCC, 2, false)
@@ -540,8 +540,8 @@ int launch_attn_decode(hipStream_t st, const float *qkv, const KvCache &c, int l
                        bool cur_cached) {
     CAPDEC_CHECK(c.hd == 64, "attention: head_dim must be 64");
     CAPDEC_CHECK(L >= 1 && L <= ATT_CTX_MAX && L <= c.ctx, "attention: context length out of range");
-    CAPDEC_CHECK(!cur_cached || (!c.bf16 && (beam == 1 || beam == 5)), "attention: cur_cached needs an fp32 cache and beam 1 or 5");
-    return c.bf16 ? attn_decode_typed<__bf16>(st, qkv, c, layer, rows, beam, L, anc, anc_stride, out, packed_out, cmap, fmt, false)
+    CAPDEC_CHECK(!cur_cached || beam == 1 || beam == 5, "attention: cur_cached needs beam 1 or 5");
+    return c.bf16 ? attn_decode_typed<__bf16>(st, qkv, c, layer, rows, beam, L, anc, anc_stride, out, packed_out, cmap, fmt, cur_cached)
                   : attn_decode_typed<float>(st, qkv, c, layer, rows, beam, L, anc, anc_stride, out, packed_out, cmap, fmt, cur_cached);
 }
 

@@ -105,9 +105,10 @@ constexpr int TOPK_MAX = 8;
 // neither re-writes them (154 MB per layer-step at 25 000 rows) nor treats the current token apart: it is simply the
 // last cached position.  The q third still goes to C.
 struct QkvScatter {
-    float *kc = nullptr, *vc = nullptr;     // this layer's K / V cache (fp32)
+    float *kc = nullptr, *vc = nullptr;     // this layer's K / V cache (fp32; bf16 elements when `bf16` is set)
     const int *cmap = nullptr;
     int beam = 1, heads = 0, ctx = 0, pos = 0, d = 0;
+    bool bf16 = false;                      // bf16 mode: the cache holds bf16 -- K / V are rounded (RNE) as they are written
 };
 
 // gemm_f32.hip

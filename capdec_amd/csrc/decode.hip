@@ -41,13 +41,18 @@ int stack_body(capdec_ctx *c, const StackCfg &g, const StepShape &s, const KvCac
         // (QkvScatter) when that GEMM runs unsplit -- the attention then reads them like any other position
         QkvScatter sc;
             // (the scatter epilogue is float4-only: a host whose c_attn bias is not 16-byte aligned keeps the other path)
-        const bool scatter = kv_direct && !s.prefill && g.keep_kv && c->gemm_mode == GEMM_F16X2 && use_packed_a(c, d) && !kv.bf16 && w.bqkv &&
+        // (round 5: also in bf16 mode -- the one-plane qkv GEMM rounds K / V to bf16 as it writes them into the bf16 cache)
+        const bool mode_ok = (c->gemm_mode == GEMM_F16X2 && !kv.bf16) || (c->gemm_mode == GEMM_BF16 && kv.bf16);
+        const bool scatter = kv_direct && !s.prefill && g.keep_kv && mode_ok && use_packed_a(c, d) && w.bqkv &&
                              (((uintptr_t)w.bqkv | (uintptr_t)qkv) & 15) == 0 &&
                              d % GEMM_BN == 0 && (s.beam == 1 || s.beam == 5) &&
                              (c->batch_invariant || gemm_splitk_slices(M, 3 * d, d, c->tune) == 1);
         if (scatter) {
-            sc.kc = kv.kp<float>(kl); sc.vc = kv.vp<float>(kl); sc.cmap = s.cmap;
+            sc.kc = reinterpret_cast<float *>(kv.bf16 ? (void *)kv.kp<__bf16>(kl) : (void *)kv.kp<float>(kl));
+            sc.vc = reinterpret_cast<float *>(kv.bf16 ? (void *)kv.vp<__bf16>(kl) : (void *)kv.vp<float>(kl));
+            sc.cmap = s.cmap;
             sc.beam = s.beam; sc.heads = kv.heads; sc.ctx = kv.ctx; sc.pos = s.L - 1; sc.d = d;
+            sc.bf16 = kv.bf16;
         }
         if (use_packed_a(c, d)) {
             CAPDEC_TRY(ln_gemm_packed(c, h, d, w.ln1w, w.ln1b, g.eps, w.wqkv, qkv, 3 * d, M, 3 * d, d, w.bqkv, CAPDEC_ACT_NONE,

@@ -117,7 +117,13 @@ __device__ __forceinline__ void epilogue_lds_wave(const f32x16 (&acc)[TI][TJ], f
                     const size_t srow = (size_t)(sc.cmap ? sc.cmap[cap] : cap) * sc.beam + b;
                     float *cache = col >= 2 * sc.d ? sc.vc : sc.kc;
                     const int hc = col - (col >= 2 * sc.d ? 2 * sc.d : sc.d), head = hc >> 6;
-                    *reinterpret_cast<float4 *>(cache + ((srow * sc.heads + head) * sc.ctx + sc.pos) * 64 + (hc & 63)) = v[0];
+                    const size_t el = ((srow * sc.heads + head) * sc.ctx + sc.pos) * 64 + (hc & 63);
+                    if (sc.bf16) {
+                        bf16x4 t;
+                        t[0] = (__bf16)v[0].x; t[1] = (__bf16)v[0].y; t[2] = (__bf16)v[0].z; t[3] = (__bf16)v[0].w;
+                        *reinterpret_cast<bf16x4 *>(reinterpret_cast<__bf16 *>(cache) + el) = t;
+                    } else
+                        *reinterpret_cast<float4 *>(cache + el) = v[0];
                 }
             } else {
                 // one 16-byte half of a (row, k-step) chunk per plane: k-step = col / 16, half = (col / 8) & 1, swizzled

@@ -475,7 +475,8 @@ template <bool VEC4, int KIND, int NS>
 __global__ __launch_bounds__(256, (NS == 3 ? 3 : 2)) void gemm_x1_kernel(const _Float16 *__restrict__ Apk, const _Float16 *__restrict__ Bpk,
                                                          float *C, int ldc, int M, int N, int K,
                                                          const float *__restrict__ bias, const float *resid, int ldr,
-                                                         int act, int tiles_m, int tiles_n, char *packed_out, int out_fmt) {
+                                                         int act, int tiles_m, int tiles_n, char *packed_out, int out_fmt,
+                                                         QkvScatter sc) {
     __shared__ __attribute__((aligned(16))) char smem[NS * H2_STAGE_B];
     const int ntiles = tiles_m * tiles_n;
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {          // persistent form: see gemm_f16x2p_kernel
@@ -484,7 +485,7 @@ __global__ __launch_bounds__(256, (NS == 3 ? 3 : 2)) void gemm_x1_kernel(const _
         f32x16 am[2][2], ac[2][2];
         h2p_mainloop<true, NS, 0, KIND>(Apk, Bpk, K, tm, tn, smem, am, ac);
         if constexpr (VEC4) {
-            const EpiArgs ea = h2_epi_args(C, ldc, M, N, tm * GEMM_BM, tn * GEMM_BN, bias, resid, ldr, act, packed_out, out_fmt, nullptr);
+            const EpiArgs ea = h2_epi_args(C, ldc, M, N, tm * GEMM_BM, tn * GEMM_BN, bias, resid, ldr, act, packed_out, out_fmt, &sc);
             epilogue_lds<H2Tile>(am, smem, ea);
             h2_slab_release(tile + (int)gridDim.x < ntiles);
         } else if (packed_out) {
@@ -581,6 +582,10 @@ int launch_gemm_x1(hipStream_t st, const void *Apacked, const void *Bpacked, flo
     // (Round 5 measured the ping-pong tiles of gemm_pp.hip under one-plane operands -- 256 x 256 / 256 x 192 / 256 x 128,
     //  rings of 4-5 and of 5-6 stages -- against this kernel inside the decode loop: 12-15 % SLOWER per launch at 5000 rows,
     //  25 % at 25 000 (profiles/r5_x1_pingpong_ab.txt); the variant was removed again.)
+    const QkvScatter sc = epi.qkv_scatter ? *epi.qkv_scatter : QkvScatter();
+    CAPDEC_CHECK(!sc.kc || (vec4 && epi.bias && !epi.resid && !epi.packed_out && epi.act == CAPDEC_ACT_NONE && N == 3 * sc.d &&
+                            sc.d % GEMM_BN == 0 && !epi.splitk_ws),
+                 "gemm_x1: the qkv scatter epilogue needs an unsplit, biased, plain [M, 3d] projection");
     {
         int S = (vec4 && epi.splitk_ws && !epi.resid_packed) ? gemm_splitk_slices(M, N, K, tuning_of(epi)) : 1;
         if (S > 1 && ((K / X3_BK / S) % 4 != 0 || epi.splitk_ws_bytes < (size_t)S * M * N * sizeof(float))) S = 1;
@@ -606,7 +611,7 @@ int launch_gemm_x1(hipStream_t st, const void *Apacked, const void *Bpacked, flo
     hipLaunchKernelGGL((gemm_x1_kernel<V4, KD, NSV>), dim3(grid_x1), dim3(256), 0, st, (const _Float16 *)Apacked, \
                        (const _Float16 *)Bpacked, C, ldc, M, N, K, epi.bias,                                           \
                        epi.packed_out ? (const float *)epi.resid_packed : epi.resid, epi.ldr, epi.act, tiles_m,       \
-                       tiles_n, (char *)epi.packed_out, fmt)
+                       tiles_n, (char *)epi.packed_out, fmt, sc)
 #define LAUNCH_X1K(KD)                                                                        \
     if (vec4) { if (ns3) LAUNCH_X1V(true, KD, 3); else LAUNCH_X1V(true, KD, 4); }             \
     else LAUNCH_X1V(false, KD, 4)
