@@ -66,12 +66,12 @@ bool tuning_from_env(Tuning *t, std::string *err) {
     env_int("CAPDEC_H2_PERSIST", &t->h2_persist);
     if (env_int("CAPDEC_H2W", &t->h2w)) {
         const int v = t->h2w;
-        bool ok = v == 0 || v == 1 || v == 2 || v == 8 || v == 10 || v == 12 || v == 14;
+        bool ok = v == 0 || v == 1 || v == 2 || v == 8 || v == 10 || v == 14;
 #ifdef CAPDEC_MEASURE
-        ok = ok || v == 3 || v == 6 || v == 11 || v == 13;
+        ok = ok || v == 3 || v == 6 || v == 11 || v == 12 || v == 13;
 #endif
         if (!ok) {
-            *err = "create: CAPDEC_H2W=" + std::to_string(v) + " is not a geometry of this build (0, 1, 2, 8, 10, 12, 14)";
+            *err = "create: CAPDEC_H2W=" + std::to_string(v) + " is not a geometry of this build (0, 1, 2, 8, 10, 14)";
             return false;
         }
     }

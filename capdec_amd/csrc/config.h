@@ -27,8 +27,9 @@ struct Tuning {
     bool fuse_ln = true;          // CAPDEC_FUSE_LN=0: separate split-K reduce and LayerNorm
     int h2_persist = 512;         // CAPDEC_H2_PERSIST: blocks of the persistent form (0 = one block per tile)
     int h2w = 1;                  // CAPDEC_H2W: 0 = round-2 kernels only, 1 = planners, 2 / 8 = force a round-3 wide tile,
-                                  //             10 / 12 / 14 = force a round-4 ping-pong tile (tests)
-    int pp = 2;                   // CAPDEC_PP: ping-pong planner: 0 never, 2 mid-size launches (default), 1 also large, 3 large only
+                                  //             10 / 14 = force a round-4 ping-pong tile (tests)
+    int pp = 2;                   // CAPDEC_PP: ping-pong planner: 0 never, 2 mid-size launches (default); 1 / 3 (also / only large
+                                  //             launches: the 256 x 256 tile) act in measurement builds only
     bool lmhead_wide = true;      // CAPDEC_LMHEAD_WIDE=0: 128-row lm_head tiles at every size
     bool lmhead_k3 = true;        // CAPDEC_LMHEAD_K3=0: the wide lm_head keeps k candidates per tile (no exact second pass)
     int lmhead_k3_max = 60;       // CAPDEC_LMHEAD_K3_MAX: per mille of the rows taking the second pass above which a decode

@@ -584,7 +584,7 @@ int gemm_splitk_slices(int M, int N, int K, const Tuning &t) {
 size_t gemm_splitk_ws_bytes(int M, int N, int K, const Tuning &t) {
     const int s = gemm_splitk_slices(M, N, K, t);
     size_t b = s > 1 ? (size_t)s * M * N * sizeof(float) : 0;
-    for (int which : {10, 12, 14}) b = std::max(b, pp_splitk_ws_bytes(which, M, N, K));     // (the ping-pong kernels' own split)
+    for (int which : {10, 14}) b = std::max(b, pp_splitk_ws_bytes(which, M, N, K));         // (the ping-pong kernels' own split)
     return b;
 }
 

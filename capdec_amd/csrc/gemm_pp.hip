@@ -324,8 +324,12 @@ __global__ __launch_bounds__(G::THREADS, G::MINW) void gemm_pp_splitk_kernel(con
 
 using P256x128 = PGeo<4, 2, 2, 2, 5, true>;       // 8 waves x (64 x 64), two accumulator sets, 24 KB stages, 120 KB
 using P256x192s = PGeo<4, 2, 2, 3, 4, false>;     // 8 waves x (64 x 96), ONE accumulator set (two would spill), 28 KB stages, 112 KB
-using P256x256s = PGeo<2, 4, 4, 2, 4, false>;     // 8 waves x (128 x 64), ONE accumulator set (weights with max |w| < 16), 128 KB
 #ifdef CAPDEC_MEASURE
+// 256 x 256: wins the isolated micro-benchmark (+12 % on mlp.c_fc at 25 000 rows), loses 2 % inside the decode loop, and the
+// remedy the stamps suggest -- storing tile i while tile i + 1's MFMAs run -- needs a second set of 128 accumulator registers
+// (2 x 128 + fragments > the 256 a wavefront has at two per SIMD) or 256 KB of LDS to park them: out of the product build
+// since round 5 (profiles/r4_gemm_pp.txt, docs/rounds.md)
+using P256x256s = PGeo<2, 4, 4, 2, 4, false>;     // 8 waves x (128 x 64), ONE accumulator set (weights with max |w| < 16), 128 KB
 using P256x128s = PGeo<4, 2, 2, 2, 5, false>;     // measured: no faster than the two-set form (profiles/r4_gemm_pp.txt)
 using P128x256s = PGeo<2, 4, 2, 2, 5, false>;
 #endif
@@ -437,8 +441,10 @@ size_t pp_splitk_ws_bytes(int which, int M, int N, int K) {
 // 2 % slower than the round-2 kernels although it wins the isolated micro-benchmark), 1 = both regimes, 3 = large only
 int pp_plan(int M, int N, int K, bool wide_ok, bool can_split, int mode) {
     if (M >= 8192) {
-        if (mode == 2) return 0;
-        return (wide_ok && N >= 2048) ? 12 : 0;
+#ifdef CAPDEC_MEASURE
+        if (mode != 2) return (wide_ok && N >= 2048) ? 12 : 0;      // (the 256 x 256 tile: measurement builds only)
+#endif
+        return 0;
     }
     if (mode == 3) return 0;
     const int nk = K / X3_BK;
@@ -459,7 +465,7 @@ int pp_plan(int M, int N, int K, bool wide_ok, bool can_split, int mode) {
     return 0;
 }
 
-// `which`: 10 = 256x128 (two accumulator sets), 14 = 256x192, 12 = 256x256 (one set: wide_ok weights); measurement builds: 11, 13.
+// `which`: 10 = 256x128 (two accumulator sets), 14 = 256x192 (one set: wide_ok weights); measurement builds: 11, 12 (256x256), 13.
 // scale = 2^-11 (single-set geometries; ignored by the two-set ones).  Requires the float4 epilogue (caller checks).
 int launch_gemm_pp(hipStream_t st, int which, const void *Apacked, const void *Bpacked, float *C, int ldc, int M, int N,
                    int K, const GemmEpilogue &epi, float scale) {
@@ -471,8 +477,8 @@ int launch_gemm_pp(hipStream_t st, int which, const void *Apacked, const void *B
     switch (which) {
         case 10: return launch_pp<P256x128>(st, Apacked, Bpacked, C, ldc, M, N, K, epi, scale, S);
         case 14: return launch_pp<P256x192s>(st, Apacked, Bpacked, C, ldc, M, N, K, epi, scale, S);
-        case 12: return launch_pp<P256x256s>(st, Apacked, Bpacked, C, ldc, M, N, K, epi, scale, S);
 #ifdef CAPDEC_MEASURE
+        case 12: return launch_pp<P256x256s>(st, Apacked, Bpacked, C, ldc, M, N, K, epi, scale, S);
         case 11: return launch_pp<P256x128s>(st, Apacked, Bpacked, C, ldc, M, N, K, epi, scale, 1);
         case 13: return launch_pp<P128x256s>(st, Apacked, Bpacked, C, ldc, M, N, K, epi, scale, 1);
 #endif

@@ -1253,12 +1253,12 @@ def test_unknown_gemm_mode_is_an_error(monkeypatch):
     e.close()
 
 
-@pytest.mark.parametrize("geometry", ["2", "8", "10", "14", "12", "invariant"],
-                         ids=["w256x128", "w128x192", "pingpong256x128", "pingpong256x192", "pingpong256x256", "batch_invariant"])
+@pytest.mark.parametrize("geometry", ["2", "8", "10", "14", "invariant"],
+                         ids=["w256x128", "w128x192", "pingpong256x128", "pingpong256x192", "batch_invariant"])
 def test_wide_single_accumulator_kernels_against_goldens(geometry):
     """the round-3 GEMM geometries (gemm_h2w.hip: one accumulator set, 256x128 / 128x192 block tiles, and the fused
     lm_head on the 256-row tile) and the round-4 ping-pong kernels (gemm_pp.hip: 256x128 with two accumulator sets,
-    256x192 / 256x256 with one, their split-K, the K / V scatter and packed-output epilogues) are chosen by planners only
+    256x192 with one, their split-K, the K / V scatter and packed-output epilogues) are chosen by planners only
     for some launch sizes, so most parity tests never reach them: re-run the GEMM-vs-fp64, reference-golden (logits, greedy
     ids, beams) and batched oracle tests in a child process with CAPDEC_H2W forcing the geometry everywhere (the default
     precision mode's parametrisations only: the forced geometry is a property of those kernels)."""

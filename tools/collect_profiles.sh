@@ -40,8 +40,8 @@ python tools/pmc_summary.py "$OUT" "$OUT/${TAG}_pmc_traffic.json" \
     "python bench.py --cpu-seconds 0 --no-checks --steps 1 --warmup 0 (default workload: 5000 captions, beam 5, T=67)" f16x2 5000 "${TAG}"
 find "$OUT" -name "*counter_collection.csv" -delete
 export CAPDEC_HOOK_PACKA=1 CAPDEC_HOOK_CACHE=1
-for h in 0 2 10 12; do for data in random zeros; do
-    CAPDEC_H2W=$h timeout 200 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE \
+for h in 0 2 10 12; do for data in random zeros; do      # (12 = the 256 x 256 ping-pong tile: measurement build only since round 5)
+    CAPDEC_MEASURE_LIB=1 CAPDEC_H2W=$h timeout 200 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE \
        --output-format csv -d "$OUT/${TAG}_pmc_sq_${h}_${data}" -- python tools/gemm_one.py 16384 2048 768 6 $data > "$OUT/${TAG}_pmc_sq_${h}_${data}.log" 2>&1
 done; done
 unset CAPDEC_HOOK_PACKA CAPDEC_HOOK_CACHE
