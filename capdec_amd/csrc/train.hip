@@ -787,8 +787,10 @@ __global__ __launch_bounds__(256) void ce_finish_kernel(const float *__restrict_
         sc->loss = loss;
         sc->gscale = 1.0f / ((float)max(c, 1) * ls);
         sc->bad = b;
-        sc->loss_sum += loss;
-        sc->loss_steps += 1;
+        if (!b) {               // (a flagged step neither updates nor counts: the running mean stays a mean of real losses)
+            sc->loss_sum += loss;
+            sc->loss_steps += 1;
+        }
     }
 }
 
