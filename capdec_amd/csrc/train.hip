@@ -476,7 +476,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kv_kernel(const float *__restric
 //             P[i][j] (as it multiplied V) and dS[i][j] stay in LDS;  phase 2 per key j -- Q / dO take K / V's place:
 //             dk_j = scale sum_i dS[i][j] q_i,  dv_j = sum_i P[i][j] dO_i
 // mask: GPT-2's attn_dropout keep bytes [B, H, S, S] (nullptr: none).  Layout of qkv / dqkv as above.
-constexpr int ATTN_BLK_NW = 8;                                      // wavefronts per block (512 threads)
+constexpr int ATTN_BLK_NW = 16;                                     // wavefronts per block (1024 threads: the loops are LDS-latency-bound)
 template <int HD> struct AttnBlk {
     static constexpr int LD = HD + 1;
     static size_t fwd_bytes(int S) { return ((size_t)2 * S * LD + ATTN_BLK_NW * (HD + S)) * sizeof(float); }
