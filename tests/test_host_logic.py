@@ -729,3 +729,17 @@ def test_pmc_summary_tool(tmp_path):
     assert k["traffic_bytes_per_launch"] == (2 * 2000 + 600) * 1024
     assert rec["gemm_bf16x3p_kernel"] == k                       # alias without template arguments (what bench.py reads)
     assert rec["kernels"]["layernorm_packed_kernel"]["traffic_bytes_per_launch"] == 20 * 1024
+
+
+def test_dropout_stream_layout_matches_the_oracle_call_order():
+    """the mask stream capdec_train_set_dropout_masks expects (Engine.dropout_stream_size; include/capdec.h) is the
+    oracle's dropout_sites -- transformers' GPT2Model call order -- flattened: same total, embd first, then per block
+    attn [B, H, S, S], resid, mlp"""
+    import numpy as np
+    from capdec_amd.engine import Engine
+    from oracle import capdec_oracle as O
+    for (L, B, S, d, H) in [(2, 4, 19, 768, 12), (12, 34, 60, 768, 12), (1, 1, 11, 768, 12)]:
+        sites = O.dropout_sites(L, B, S, d, H)
+        assert Engine.dropout_stream_size(B, S, d, H, L) == sum(int(np.prod(sh)) for _, sh in sites)
+        assert [n for n, _ in sites][:4] == ["embd", "h.0.attn", "h.0.resid", "h.0.mlp"]
+        assert sites[1][1] == (B, H, S, S) and sites[0][1] == sites[2][1] == sites[3][1] == (B, S, d)
