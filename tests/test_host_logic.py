@@ -521,6 +521,67 @@ def test_image_driver_shards_the_tower_gloo_world_size_2(tmp_path):
     assert all("OK" in o for o in outs)
 
 
+_TXT_WORKER = r"""
+import os, sys, json, torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+from capdec_amd import predictions_runner as PR
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{sys.argv[2]}", rank=rank, world_size=world)
+# fakes for the device pieces: a caption "c<v>" tokenises to a row starting with v, its embedding is [v, v, v, v], its ids [v, v + 1]
+tokenised, encoded = [], []
+def tokenize(texts):
+    tokenised.extend(texts)
+    return torch.tensor([[int(t[1:])] + [0] * 76 for t in texts])
+class Clip:
+    def encode_text(self, toks):
+        encoded.extend(int(v) for v in toks[:, 0].tolist())
+        return toks[:, :1].float().repeat(1, 4)
+class Model:
+    prefix_length = 10
+    def parameters(self): yield torch.zeros(0)
+def fake_caption_ids(model, emb, stop, beam, beam_size, T, dont_norm, off, rank=0, world=1):
+    v = emb[:, 0].to(torch.int32)
+    ids = torch.zeros(emb.shape[0], T, dtype=torch.int32)
+    ids[:, 0], ids[:, 1] = v, v + 1
+    return ids, torch.full((emb.shape[0],), 2, dtype=torch.int32), None
+PR.caption_ids = fake_caption_ids
+class Tok:
+    def encode(self, s): return [13]
+    def decode(self, ids): return " ".join(str(int(i)) for i in ids)
+data = [{"image_id": 500 + i, "caption": f"c{10 * (i + 1)}"} for i in range(5)]
+out = sys.argv[3]
+preds = PR.make_preds_from_captions(data, Clip(), Model(), Tok(), tokenize, out if rank == 0 else None, beam=False, entry_length=4,
+                                    rank=rank, world=world, text_batch=2)
+want = [{"caption": f"{10 * (i + 1)} {10 * (i + 1) + 1}", "image_id": 500 + i} for i in range(5)]
+assert preds == want, (rank, preds)
+lo, hi = (0, 3) if rank == 0 else (3, 5)                     # 5 captions over 2 ranks: 3 + 2, each tokenised / encoded once
+assert tokenised == [d["caption"] for d in data[lo:hi]] and encoded == [10 * (i + 1) for i in range(lo, hi)], (rank, tokenised, encoded)
+if rank == 0:
+    assert json.load(open(out)) == want
+one = PR.make_preds_from_captions(data[:1], Clip(), Model(), Tok(), tokenize, None, beam=False, entry_length=4, rank=rank, world=world)
+assert one == want[:1], (rank, one)                          # more ranks than captions: the empty shard joins the gather
+dist.destroy_process_group()
+print("OK", rank)
+"""
+
+
+def test_text_driver_shards_gloo_world_size_2(tmp_path):
+    """make_preds_from_captions (the text-input branch, reference predictions_runner.py:215-218) over two gloo ranks with
+    fake device pieces: every rank tokenises / encodes / decodes only its block, the gathered predictions equal the
+    single-process list in caption order, rank 0 writes the JSON, an empty shard still joins the gather"""
+    script = tmp_path / "txt_worker.py"
+    script.write_text(_TXT_WORKER)
+    port = 33500 + (os.getpid() % 2000)
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, str(script), ROOT, str(port), str(tmp_path / "preds.json")], env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=180)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    assert all("OK" in o for o in outs)
+
+
 def test_shard_consistency_checks():
     """a partial shard without a process group must not be returned as if it were the whole result"""
     from capdec_amd import distributed as cd
