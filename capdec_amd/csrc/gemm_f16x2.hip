@@ -75,6 +75,49 @@ int launch_pack_planes_h2(hipStream_t st, const float *w, int ldw, int N, int K,
     return 0;
 }
 
+// The TRANSPOSE of an fp32 matrix as a packed operand: src [rows][cols] row-major  ->  the two fp16 planes of
+// Mt [cols][Kp] (Mt[n][k] = src[k][n]; k >= rows zero-filled up to Kp, a multiple of 64; rows n >= cols of the last 128-row
+// tile zero) -- the operands of a weight-gradient product dW = dY^T X, whose K runs over the ROWS of dY and X.  One block
+// per 64 x 64 tile: rows read coalesced, transposed through LDS, every thread splits one (n, k-step) = 16 consecutive k.
+// (Replaces a transpose_pad launch -- fp32 written and read back -- in front of the packer, train.hip.)
+__global__ __launch_bounds__(256) void pack_planes_h2_t_kernel(const float *__restrict__ src, int rows, int cols,
+                                                               _Float16 *__restrict__ out, int nk) {
+    __shared__ float tile[64][65];
+    const int t = threadIdx.x, n0 = blockIdx.x * 64, k0 = blockIdx.y * 64;
+    for (int i = t; i < 64 * 64; i += 256) {
+        const int kk = i >> 6, nn = i & 63, k = k0 + kk, n = n0 + nn;
+        tile[kk][nn] = (k < rows && n < cols) ? src[(size_t)k * cols + n] : 0.f;
+    }
+    __syncthreads();
+    const int nn = t & 63, kq = t >> 6, n = n0 + nn;
+    const int tl = n >> 7, r = n & 127, ks = (k0 >> 4) + kq;
+    _Float16 *dst = out + ((size_t)tl * nk + ks) * (2 * 128 * 16) + r * 16;
+#pragma unroll
+    for (int hk = 0; hk < 2; ++hk) {
+        float4 v0, v1;
+        v0.x = tile[kq * 16 + hk * 8 + 0][nn]; v0.y = tile[kq * 16 + hk * 8 + 1][nn];
+        v0.z = tile[kq * 16 + hk * 8 + 2][nn]; v0.w = tile[kq * 16 + hk * 8 + 3][nn];
+        v1.x = tile[kq * 16 + hk * 8 + 4][nn]; v1.y = tile[kq * 16 + hk * 8 + 5][nn];
+        v1.z = tile[kq * 16 + hk * 8 + 6][nn]; v1.w = tile[kq * 16 + hk * 8 + 7][nn];
+        f16x4 h0, l0, h1, l1;
+        split2h(v0, h0, l0);
+        split2h(v1, h1, l1);
+        _Float16 *d = dst + ((hk ^ ((r >> 3) & 1)) << 3);
+        reinterpret_cast<f16x4 *>(d)[0] = h0;
+        reinterpret_cast<f16x4 *>(d)[1] = h1;
+        reinterpret_cast<f16x4 *>(d + 2048)[0] = l0;
+        reinterpret_cast<f16x4 *>(d + 2048)[1] = l1;
+    }
+}
+// out: x3_packed_bytes(cols, Kp, PK_F16X2) bytes
+int launch_pack_planes_h2_t(hipStream_t st, const float *src, int rows, int cols, int Kp, void *out) {
+    CAPDEC_CHECK(Kp % 64 == 0 && Kp >= rows && rows > 0 && cols > 0, "pack_planes_h2_t: K (padded rows) must be a multiple of 64");
+    const int npad = (cols + 127) / 128 * 128;
+    hipLaunchKernelGGL(pack_planes_h2_t_kernel, dim3(npad / 64, Kp / 64), dim3(256), 0, st, src, rows, cols, (_Float16 *)out, Kp / X3_BK);
+    CAPDEC_HIP(hipGetLastError());
+    return 0;
+}
+
 // s_waitcnt immediate (gfx9 encoding): vmcnt(N) expcnt(none) lgkmcnt(L: 0 = wait for all, 15 = do not wait)
 __host__ __device__ constexpr int waitcnt_imm(int vm, int lgkm) {
     return (vm & 15) | (7 << 4) | ((lgkm & 15) << 8) | ((vm >> 4) << 14);

@@ -1010,12 +1010,17 @@ static int linear_dx(capdec_ctx *c, TrainState &t, const float *dy, const float 
 // dW = dY^T X ([out, in]; dY [rows, out], X [rows, in]; the GEMM's K = rows, zero-padded to a multiple of 32), db = colsum(dY)
 static int linear_dw(capdec_ctx *c, TrainState &t, const float *dy, const float *x, int rows, int out, int in, float *gW,
                      float *gb) {
-    const int Kp = pad_rows(c, rows);
-    CAPDEC_TRY(t.tA.ensure((size_t)out * Kp * 4));
-    CAPDEC_TRY(t.tB.ensure((size_t)in * Kp * 4));
-    CAPDEC_TRY(transpose_pad(c, dy, rows, out, t.tA.as<float>(), Kp));
-    CAPDEC_TRY(transpose_pad(c, x, rows, in, t.tB.as<float>(), Kp));
-    CAPDEC_TRY(gemm_fp32(c, t.tA.as<float>(), Kp, t.tB.as<float>(), Kp, gW, in, out, in, Kp));
+    if (c->tune.train_f16x2 && in % 4 == 0) {
+        // both operands packed transposed from their row-major form: no fp32 transposed copies (a "TN" operand loader)
+        CAPDEC_TRY(gemm_tn(c, dy, x, rows, out, in, gW, in));
+    } else {
+        const int Kp = pad_rows(c, rows);
+        CAPDEC_TRY(t.tA.ensure((size_t)out * Kp * 4));
+        CAPDEC_TRY(t.tB.ensure((size_t)in * Kp * 4));
+        CAPDEC_TRY(transpose_pad(c, dy, rows, out, t.tA.as<float>(), Kp));
+        CAPDEC_TRY(transpose_pad(c, x, rows, in, t.tB.as<float>(), Kp));
+        CAPDEC_TRY(gemm_fp32(c, t.tA.as<float>(), Kp, t.tB.as<float>(), Kp, gW, in, out, in, Kp));
+    }
     if (gb)
         hipLaunchKernelGGL(colsum_kernel, dim3((out + 255) / 256, (rows + COLSUM_ROWS - 1) / COLSUM_ROWS), dim3(256), 0, c->stream,
                            dy, rows, out, gb);
