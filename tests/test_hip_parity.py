@@ -927,6 +927,39 @@ def test_bf16_mode_at_the_size_of_baseline_config_1():
     assert bool((got_ids[clear] == want_ids[clear]).all())
 
 
+def test_bf16_kv_through_the_qkv_epilogue_matches_the_attention_append(monkeypatch):
+    """bf16 mode, launches large enough for the unsplit qkv GEMM (round 5): K / V of the decoded token written by the
+    one-plane GEMM's epilogue into the bf16 cache (CAPDEC_KV_DIRECT=1, default) against the attention kernel appending
+    them itself (=0).  Both store the same bf16-rounded values; only the summation order of the own-token term differs --
+    an fp32 round-off that the mode's rounding chaos turns into logit noise of a few hundredths (see the bf16 tests above).
+    Greedy rows TEACHER-FORCED (2000 rows: per-step top-1 / top-2 / logsumexp within 0.15, mean deviation below 0.005),
+    beam 5 free-running (700 captions: the best beam's mean log-prob within 0.05 for >= 95 % of them).  A wrong cache slot,
+    head, position or beam row in the scatter moves these numbers by whole units."""
+    from capdec_amd.engine import Engine
+    dims = synth.GPT2_TINY
+    sd = synth.hot_gpt2_state_dict(21, dims)
+    g = torch.Generator().manual_seed(5)
+    pe = torch.randn(2000, 10, dims.n_embd, generator=g) * 0.3
+    forced = torch.randint(0, dims.vocab, (2000, 8), generator=g).to(torch.int32)
+    outs = {}
+    for kvd in ("1", "0"):
+        monkeypatch.setenv("CAPDEC_GEMM_MODE", "bf16")
+        monkeypatch.setenv("CAPDEC_KV_DIRECT", kvd)
+        e = Engine(0)
+        e.load_gpt2(sd)
+        ids, st = e.decode_greedy_forced(pe, forced)
+        _, _, bs, _ = e.decode_beam(pe[:700], dims.vocab + 5, 5, 9)
+        outs[kvd] = (ids.cpu(), st.cpu(), bs.cpu())
+        e.close()
+    dst = (outs["1"][1] - outs["0"][1]).abs()
+    agree = float((outs["1"][0] == outs["0"][0]).float().mean())
+    dbs = (outs["1"][2][:, 0] - outs["0"][2][:, 0]).abs()
+    _report(f"[bf16 K/V through the qkv epilogue vs attention append] teacher-forced stats: max {float(dst.max()):.4f} mean {float(dst.mean()):.5f}, "
+            f"arg-max agreement {agree:.4f}; best-beam score |diff| < 0.05 for {float((dbs < 0.05).float().mean()):.4f} of 700")
+    assert float(dst.max()) < 0.15 and float(dst.mean()) < 0.005 and agree > 0.99      # (observed: 0.039, 0.0003, 0.9998)
+    assert float((dbs < 0.05).float().mean()) >= 0.95 and bool(torch.isfinite(outs["1"][2]).all())
+
+
 def test_teacher_forced_decode_fp32_modes():
     """the teacher-forcing hook in the fp32-accurate default mode: arg-max ids and (top-1, top-2, logsumexp) of every step
     equal the fp32 oracle's (1e-4), with forced tokens that are NOT the arg-max (the hook really feeds them)"""
