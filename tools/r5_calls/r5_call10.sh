@@ -1,7 +1,7 @@
 #!/bin/bash
 # round 5, call 10: the one-plane 256 x 128 kernel (gemm_x1w_kernel) -- isolated timing, parity (forced at every size), A/B in the loop
 # (the variant it measures -- gemm_x1w_kernel behind CAPDEC_X1_WIDE -- was removed after this call: profiles/r5_x1_pingpong_ab.txt, "call 10";
-#  the same holds for CAPDEC_PP_X1 in tools/r5_call3.sh / r5_call4.sh and CAPDEC_ATT_G16 in tools/r5_call5.sh)
+#  the same holds for CAPDEC_PP_X1 in tools/r5_calls/r5_call3.sh / r5_call4.sh and CAPDEC_ATT_G16 in tools/r5_calls/r5_call5.sh)
 set -u
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$R/gpurun_out; mkdir -p "$OUT"; cd "$R"
