@@ -1,5 +1,5 @@
 #!/bin/bash
-# Round 5: everything the round's inference numbers come from, one gpurun call (after tools/r5_suite.sh):
+# Round 5: everything the round's inference numbers come from, one gpurun call (after tools/r5_last2.sh):
 #   gpurun --timeout 2400 -- 'bash tools/r5_final.sh'
 # the driver-style bench line (+ CPU baseline), the 625-caption shard, the same command under rocprofv3 --kernel-trace
 # --stats, FETCH_SIZE / WRITE_SIZE in their own passes (default mode and BASELINE configs[1]: greedy, bf16), the bf16
