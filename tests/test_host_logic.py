@@ -804,3 +804,70 @@ def test_dropout_stream_layout_matches_the_oracle_call_order():
         assert Engine.dropout_stream_size(B, S, d, H, L) == sum(int(np.prod(sh)) for _, sh in sites)
         assert [n for n, _ in sites][:4] == ["embd", "h.0.attn", "h.0.resid", "h.0.mlp"]
         assert sites[1][1] == (B, H, S, S) and sites[0][1] == sites[2][1] == sites[3][1] == (B, S, d)
+
+
+def test_train_loop_control_flow_with_fake_device(tmp_path, monkeypatch):
+    """capdec_amd.train.train (reference train.py:317-392) on CPU with the device pieces faked: epochs x batches of a
+    drop_last DataLoader, scheduler stepped after every batch, steps enqueued (wait=False) and the epoch mean taken from the
+    engine's running sum, checkpoints `{prefix}-{epoch:03d}.pt` at save_every and at the last epoch, the validation pass once
+    per epoch when a validation dataset is given, `loss_per_epoch.json` = {'train': [...], 'val': [...]} rewritten every
+    epoch, and args.val_pt without a dataset refused"""
+    import json
+    from types import SimpleNamespace
+    from capdec_amd import train as Tr
+    from capdec_amd._capi import CapdecError
+    calls = {"steps": [], "lrs": [], "val": 0}
+
+    class FakeEngine:
+        def __init__(self):
+            self.sum, self.n = 0.0, 0
+
+        def train_loss(self, reset=False):
+            out = (0.0, self.sum, self.n)
+            if reset:
+                self.sum, self.n = 0.0, 0
+            return out
+
+    class FakeModel:
+        prefix_length = 10
+
+        def __init__(self):
+            self.engine, self.training = FakeEngine(), False
+
+        def train(self, mode=True):
+            self.training = mode
+            return self
+
+        def parameters(self):
+            return iter(())
+
+        def state_dict(self):
+            return {"clip_project.w": torch.zeros(1)}
+
+    def fake_train_step(model, optimizer, tokens, mask, prefix, *, apply_update=True, dropout_masks=None, wait=True):
+        assert wait is False and model.training
+        calls["steps"].append(tokens.shape[0])
+        calls["lrs"].append(optimizer.param_groups[0]["lr"])
+        model.engine.sum += 2.0 + 0.5 * len(calls["steps"])
+        model.engine.n += 1
+
+    def fake_validation_loss(model, ds, bs, P=None):
+        calls["val"] += 1
+        return 7.0 + calls["val"]
+
+    monkeypatch.setattr(Tr, "train_step", fake_train_step)
+    monkeypatch.setattr(Tr, "validation_loss", fake_validation_loss)
+    monkeypatch.setattr(Tr, "noise_injection", lambda x, *a, **k: x)
+    monkeypatch.setattr(Tr, "device", torch.device("cpu"))
+    ds = [(torch.ones(5, dtype=torch.int64), torch.ones(15), torch.zeros(512)) for _ in range(10)]     # bs 4 -> 2 batches (drop_last)
+    args = SimpleNamespace(bs=4, epochs=3, lr=1e-3, noise_variance=0.016, uniform_noise=False, dont_norm=False, save_every=2, val_pt="")
+    model = FakeModel()
+    Tr.train(ds, model, args, warmup_steps=2, output_dir=str(tmp_path), output_prefix="run", val_dataset=ds[:4])
+    assert calls["steps"] == [4] * 6 and calls["val"] == 3
+    assert calls["lrs"][0] == 0.0 and abs(calls["lrs"][2] - 1e-3) < 1e-12 and calls["lrs"][3] < 1e-3      # warm-up, then linear decay
+    rec = json.load(open(tmp_path / "loss_per_epoch.json"))
+    assert rec["val"] == [8.0, 9.0, 10.0]
+    np.testing.assert_allclose(rec["train"], [(2.5 + 3.0) / 2, (3.5 + 4.0) / 2, (4.5 + 5.0) / 2])
+    assert sorted(f for f in os.listdir(tmp_path) if f.endswith(".pt")) == ["run-000.pt", "run-002.pt"]
+    with pytest.raises(CapdecError):
+        Tr.train(ds, model, SimpleNamespace(**dict(vars(args), val_pt="val.pkl")), output_dir=str(tmp_path))
