@@ -171,8 +171,8 @@ int launch_splitk_reduce(hipStream_t st, const float *part, int S, int M, int N,
 // fp32-accurate.  launch_pack_planes_h2 packs an fp32 [N, K] matrix (row stride ldw) -- weights once, fp32 activations
 // (mapper, patch embedding) per call.
 int launch_pack_planes_h2(hipStream_t st, const float *w, int ldw, int N, int K, void *out);
-// ... and the TRANSPOSE of src [rows][cols] as the packed matrix [cols][Kp] (k = the rows of src, zero-padded to Kp)
-int launch_pack_planes_h2_t(hipStream_t st, const float *src, int rows, int cols, int Kp, void *out);
+// ... and the TRANSPOSE of src [rows][cols] (row stride ld) as the packed matrix [cols][Kp] (k = the rows of src, zero-padded to Kp)
+int launch_pack_planes_h2_t(hipStream_t st, const float *src, int ld, int rows, int cols, int Kp, void *out);
 int launch_gemm_f16x2p(hipStream_t st, const void *Apacked, const void *Bpacked, float *C, int ldc, int M, int N, int K,
                        const GemmEpilogue &epi);
 int launch_gemm_f16x2p_topk(hipStream_t st, const void *Apacked, const void *Bpacked, int M, int N, int K, int k,

@@ -228,8 +228,8 @@ int planes_of(capdec_ctx *c, const float *W, int N, int K, bool cache, const voi
 // C = act(A . Bt^T + bias) + resid with fp32 A in HBM (mapper, patch embedding, projections)
 int gemm(capdec_ctx *c, const float *A, int lda, const float *Bt, int ldb, float *C, int ldc, int M, int N, int K,
          const float *bias, int act, const float *resid = nullptr, int ldr = 0, bool weight = true);
-// C [N1, N2] = Xa^T Xb (fp32 Xa [rows, N1], Xb [rows, N2]): weight-gradient products, operands packed transposed
-int gemm_tn(capdec_ctx *c, const float *Xa, const float *Xb, int rows, int N1, int N2, float *C, int ldc);
+// C [N1, N2] = Xa^T Xb (fp32 Xa [rows, N1] / Xb [rows, N2], row strides lda / ldb): weight-gradient products, operands packed transposed
+int gemm_tn(capdec_ctx *c, const float *Xa, int lda, const float *Xb, int ldb, int rows, int N1, int N2, float *C, int ldc);
 bool use_packed_a(capdec_ctx *c, int K);
 struct NextLn { const float *w, *b; float eps; int *done; };
 int gemm_packed(capdec_ctx *c, const void *Apk, const float *W, float *C, int ldc, int M, int N, int K, const float *bias,

@@ -121,17 +121,17 @@ int gemm(capdec_ctx *c, const float *A, int lda, const float *Bt, int ldb, float
     return launch_gemm_f32(c->stream, A, lda, Bt, ldb, C, ldc, M, N, K, e);
 }
 
-// C [N1, N2] = Xa^T Xb for fp32 Xa [rows, N1], Xb [rows, N2] (row-major, dense): the weight-gradient product of the train
+// C [N1, N2] = Xa^T Xb for fp32 Xa [rows, N1], Xb [rows, N2] (row-major, row strides lda / ldb): the weight-gradient product of the train
 // step (dW = dY^T X, K = the token rows).  Both operands are packed TRANSPOSED straight from their row-major form
 // (launch_pack_planes_h2_t: no fp32 transposed copies), then the two-fp16-plane kernels run with K = rows padded to 64.
-int gemm_tn(capdec_ctx *c, const float *Xa, const float *Xb, int rows, int N1, int N2, float *C, int ldc) {
+int gemm_tn(capdec_ctx *c, const float *Xa, int lda, const float *Xb, int ldb, int rows, int N1, int N2, float *C, int ldc) {
     const int Kp = (rows + 63) / 64 * 64;
     CAPDEC_TRY(c->a_tmp.ensure(x3_packed_bytes(N1, Kp, PK_F16X2)));
     CAPDEC_TRY(c->x3_tmp.ensure(x3_packed_bytes(N2, Kp, PK_F16X2)));
     {
         ProfScope ps(c, F_PACK);
-        CAPDEC_TRY(launch_pack_planes_h2_t(c->stream, Xa, rows, N1, Kp, c->a_tmp.p));
-        CAPDEC_TRY(launch_pack_planes_h2_t(c->stream, Xb, rows, N2, Kp, c->x3_tmp.p));
+        CAPDEC_TRY(launch_pack_planes_h2_t(c->stream, Xa, lda, rows, N1, Kp, c->a_tmp.p));
+        CAPDEC_TRY(launch_pack_planes_h2_t(c->stream, Xb, ldb, rows, N2, Kp, c->x3_tmp.p));
     }
     GemmEpilogue e;
     e.tune = &c->tune;

@@ -75,18 +75,18 @@ int launch_pack_planes_h2(hipStream_t st, const float *w, int ldw, int N, int K,
     return 0;
 }
 
-// The TRANSPOSE of an fp32 matrix as a packed operand: src [rows][cols] row-major  ->  the two fp16 planes of
+// The TRANSPOSE of an fp32 matrix as a packed operand: src [rows][cols] row-major (row stride ld)  ->  the two fp16 planes of
 // Mt [cols][Kp] (Mt[n][k] = src[k][n]; k >= rows zero-filled up to Kp, a multiple of 64; rows n >= cols of the last 128-row
 // tile zero) -- the operands of a weight-gradient product dW = dY^T X, whose K runs over the ROWS of dY and X.  One block
 // per 64 x 64 tile: rows read coalesced, transposed through LDS, every thread splits one (n, k-step) = 16 consecutive k.
 // (Replaces a transpose_pad launch -- fp32 written and read back -- in front of the packer, train.hip.)
-__global__ __launch_bounds__(256) void pack_planes_h2_t_kernel(const float *__restrict__ src, int rows, int cols,
+__global__ __launch_bounds__(256) void pack_planes_h2_t_kernel(const float *__restrict__ src, int ld, int rows, int cols,
                                                                _Float16 *__restrict__ out, int nk) {
     __shared__ float tile[64][65];
     const int t = threadIdx.x, n0 = blockIdx.x * 64, k0 = blockIdx.y * 64;
     for (int i = t; i < 64 * 64; i += 256) {
         const int kk = i >> 6, nn = i & 63, k = k0 + kk, n = n0 + nn;
-        tile[kk][nn] = (k < rows && n < cols) ? src[(size_t)k * cols + n] : 0.f;
+        tile[kk][nn] = (k < rows && n < cols) ? src[(size_t)k * ld + n] : 0.f;
     }
     __syncthreads();
     const int nn = t & 63, kq = t >> 6, n = n0 + nn;
@@ -110,10 +110,10 @@ __global__ __launch_bounds__(256) void pack_planes_h2_t_kernel(const float *__re
     }
 }
 // out: x3_packed_bytes(cols, Kp, PK_F16X2) bytes
-int launch_pack_planes_h2_t(hipStream_t st, const float *src, int rows, int cols, int Kp, void *out) {
-    CAPDEC_CHECK(Kp % 64 == 0 && Kp >= rows && rows > 0 && cols > 0, "pack_planes_h2_t: K (padded rows) must be a multiple of 64");
+int launch_pack_planes_h2_t(hipStream_t st, const float *src, int ld, int rows, int cols, int Kp, void *out) {
+    CAPDEC_CHECK(Kp % 64 == 0 && Kp >= rows && rows > 0 && cols > 0 && ld >= cols, "pack_planes_h2_t: K (padded rows) must be a multiple of 64");
     const int npad = (cols + 127) / 128 * 128;
-    hipLaunchKernelGGL(pack_planes_h2_t_kernel, dim3(npad / 64, Kp / 64), dim3(256), 0, st, src, rows, cols, (_Float16 *)out, Kp / X3_BK);
+    hipLaunchKernelGGL(pack_planes_h2_t_kernel, dim3(npad / 64, Kp / 64), dim3(256), 0, st, src, ld, rows, cols, (_Float16 *)out, Kp / X3_BK);
     CAPDEC_HIP(hipGetLastError());
     return 0;
 }

@@ -1038,7 +1038,7 @@ static int linear_dw(capdec_ctx *c, TrainState &t, const float *dy, const float 
                      float *gb) {
     if (c->tune.train_f16x2 && in % 4 == 0) {
         // both operands packed transposed from their row-major form: no fp32 transposed copies (a "TN" operand loader)
-        CAPDEC_TRY(gemm_tn(c, dy, x, rows, out, in, gW, in));
+        CAPDEC_TRY(gemm_tn(c, dy, out, x, in, rows, out, in, gW, in));
     } else {
         const int Kp = pad_rows(c, rows);
         CAPDEC_TRY(t.tA.ensure((size_t)out * Kp * 4));
@@ -1321,12 +1321,16 @@ static int train_step(capdec_ctx *c, const float *prefix, const int *tokens, int
     CAPDEC_HIP(hipMemsetAsync(t.G.p, 0, t.n_params * 4, st));        // (bias / LayerNorm / wte gradients are accumulated)
     if (full) {
         // the lm_head's share of the tied wte: d logits^T hf  ([V, d]; K = the loss rows)
-        const int Kp = pad_rows(c, Rl);
-        CAPDEC_TRY(t.tA.ensure((size_t)Vp * Kp * 4));
-        CAPDEC_TRY(t.tB.ensure((size_t)d * Kp * 4));
-        CAPDEC_TRY(transpose_pad(c, logits, Rl, Vp, t.tA.as<float>(), Kp));
-        CAPDEC_TRY(transpose_pad(c, hfl, Rl, d, t.tB.as<float>(), Kp));
-        CAPDEC_TRY(gemm_fp32(c, t.tA.as<float>(), Kp, t.tB.as<float>(), Kp, t.grad(gs), d, g.vocab, d, Kp));
+        if (c->tune.train_f16x2) {
+            CAPDEC_TRY(gemm_tn(c, logits, Vp, hfl, d, Rl, g.vocab, d, t.grad(gs), d));      // (logits rows are padded to Vp columns)
+        } else {
+            const int Kp = pad_rows(c, Rl);
+            CAPDEC_TRY(t.tA.ensure((size_t)Vp * Kp * 4));
+            CAPDEC_TRY(t.tB.ensure((size_t)d * Kp * 4));
+            CAPDEC_TRY(transpose_pad(c, logits, Rl, Vp, t.tA.as<float>(), Kp));
+            CAPDEC_TRY(transpose_pad(c, hfl, Rl, d, t.tB.as<float>(), Kp));
+            CAPDEC_TRY(gemm_fp32(c, t.tA.as<float>(), Kp, t.tB.as<float>(), Kp, t.grad(gs), d, g.vocab, d, Kp));
+        }
     }
     CAPDEC_TRY(gemm_fp32(c, logits, Vp, t.wte_t, Vp, dhfl, d, Rl, d, Vp, !full));
     hipLaunchKernelGGL(put_loss_rows_kernel, grid1(Rd / 4), dim3(256), 0, st, dhfl, da, B, P, L, d / 4);
