@@ -871,3 +871,65 @@ def test_train_loop_control_flow_with_fake_device(tmp_path, monkeypatch):
     assert sorted(f for f in os.listdir(tmp_path) if f.endswith(".pt")) == ["run-000.pt", "run-002.pt"]
     with pytest.raises(CapdecError):
         Tr.train(ds, model, SimpleNamespace(**dict(vars(args), val_pt="val.pkl")), output_dir=str(tmp_path))
+
+
+def test_train_step_facade_scope_and_dropout_decisions_without_a_device():
+    """capdec_amd.train.train_step up to the first device transfer, with a recording fake engine: a ClipCaptionPrefix asks for
+    scope 0 and never touches the dropout setting; a plain ClipCaptionModel asks for scope 1 and -- in train() mode -- for
+    model.gpt.config.resid_pdrop (0.1) exactly once, for 0 after eval(); injected masks need dropout to be on; host-side token
+    ids outside the vocabulary raise IndexError before anything reaches the device (the reference's embedding lookup)"""
+    from capdec_amd import train as Tr, synth
+    from capdec_amd._capi import CapdecError
+    from capdec_amd.gpt2_prefix import ClipCaptionModel, ClipCaptionPrefix, MappingType
+
+    class Rec:
+        def __init__(self):
+            self.calls = []
+
+        def train_set_scope(self, full):
+            self.calls.append(("scope", bool(full)))
+
+        def train_set_dropout(self, p, seed):
+            self.calls.append(("dropout", round(float(p), 6)))
+
+        def train_set_dropout_masks(self, m):
+            self.calls.append(("masks", int(m.numel())))
+
+    def make(cls):
+        m = cls(10, clip_length=10, prefix_size=512, num_layers=8, mapping_type=MappingType.MLP, gpt2_dims=synth.GPT2_TINY)
+        m._engine = Rec()
+        m._dirty = False
+        return m
+
+    tokens = torch.randint(1, synth.GPT2_TINY.vocab, (2, 5))
+    prefix = torch.zeros(2, 512)
+    opt = Tr.AdamW(None, lr=1e-3)
+
+    def run(model, **kw):
+        try:
+            Tr.train_step(model, opt, tokens, None, prefix, **kw)
+        except (IndexError, CapdecError):
+            raise
+        except Exception:
+            pass                                  # (no GPU here: the transfer of `tokens` is where the CPU run ends)
+        return model._engine.calls
+
+    pre = make(ClipCaptionPrefix)
+    if not hasattr(type(pre), "engine") or not isinstance(getattr(type(pre), "engine", None), property):
+        pytest.skip("engine is not a property on this build of the facade")
+    pre.train()
+    assert run(pre) == [("scope", False)]
+    full = make(ClipCaptionModel)
+    full.train()
+    assert run(full) == [("scope", True), ("dropout", 0.1)]
+    assert run(full) == [("scope", True), ("dropout", 0.1), ("scope", True)]            # same setting: not re-seeded
+    full.eval()
+    assert run(full)[-2:] == [("scope", True), ("dropout", 0.0)]
+    with pytest.raises(CapdecError):
+        run(full, dropout_masks=torch.ones(8, dtype=torch.uint8))                       # eval mode: no dropout to inject into
+    full.train()
+    assert ("masks", 8) in run(full, dropout_masks=torch.ones(8, dtype=torch.uint8))
+    bad = tokens.clone()
+    bad[0, 0] = synth.GPT2_TINY.vocab
+    with pytest.raises(IndexError):
+        Tr.train_step(full, opt, bad, None, prefix)
