@@ -65,7 +65,7 @@ def algorithmic_flops_per_caption(P, T, beam, mapper, dims=synth.GPT2_SMALL, D=5
     return f
 
 
-def oracle_compare(model, emb, out, mapper, beam, P, T, rows):
+def oracle_compare(model, emb, out, mapper, beam, P, T, rows, stop_id=None):
     """captions `rows` of a timed step's result against the CPU oracle run on their own prefixes (the oracle is the checker,
     never the thing measured).  Every caption is compared; a difference is tolerated only on a numerical tie -- selected /
     rejected candidate keys (beam) or top-1 / top-2 logits (greedy) within 1e-4 of each other at some step: which side of
@@ -76,6 +76,7 @@ def oracle_compare(model, emb, out, mapper, beam, P, T, rows):
     from capdec_amd.predictions_runner import prefix_from_embeddings
     from oracle import capdec_oracle as O
     sd = synth.hot_state_dict(42, mapper, 512, P)
+    stop_id = STOP_ID if stop_id is None else int(stop_id)
     rows = sorted(set(int(r) for r in rows))
     pe = prefix_from_embeddings(model, emb[rows]).float().cpu()
     ids, lens = out[0][rows].cpu().numpy(), out[1][rows].cpu().numpy()
@@ -83,7 +84,7 @@ def oracle_compare(model, emb, out, mapper, beam, P, T, rows):
     equal = ties = 0
     if beam:
         mg = []
-        tok, seq, sc = O.beam_cached(sd, pe, 5, STOP_ID, T, margins=mg)
+        tok, seq, sc = O.beam_cached(sd, pe, 5, stop_id, T, margins=mg)
         order = O.beam_output_order(sc)
         clear = (mg[0] > 1e-4).numpy()
         scores = out[2][rows].cpu().numpy()
@@ -94,7 +95,7 @@ def oracle_compare(model, emb, out, mapper, beam, P, T, rows):
             equal += int(good)
             ties += int((not good) and (not clear[j]))
     else:
-        gi, gl = O.greedy_cached(sd, pe, stop_id=STOP_ID, entry_length=T)
+        gi, gl = O.greedy_cached(sd, pe, stop_id=stop_id, entry_length=T)
         _, st = O.greedy_forced(sd, pe, gi)
         live = torch.arange(T)[None, :] < gl[:, None]
         gap = torch.where(live, st[:, :, 0] - st[:, :, 1], torch.full((1, 1), 1e9))
@@ -169,6 +170,120 @@ def cpu_baseline(mapper, beam, P, T, budget_s=20.0, D=512, captions=8):
             "sample": f"{whole} of the same workload (reference-shaped: batch 1, no KV cache, fp32, T={T}, "
                       f"beam={beam}; {rows} token-rows) in {dt:.1f} s wall on {best[0]} threads (count chosen by a "
                       f"1.5 s probe among {{all, 64, 32, 16}} of the {ncpu} host threads: the batch-1 GEMVs of this path do not scale past a few dozen threads, and a run on all of a 256-thread host does not finish one caption inside a bounded sample -- not measurable, so not reported); warm-up captions discarded"}
+
+
+def stop_profile(model, emb, mapper, beam, P, T, steps, note, target=11.0, oracle_rows=32):
+    """The workload in which captions STOP (reference gpt2_prefix_eval.py:107-109,187-188: a caption ends at its stop
+    token; real COCO captions are ~11 tokens).  The hot-init weights never emit id 13, so the metric line runs all T steps;
+    here the stop id is chosen so that the same weights' captions have a mean length of ~`target` tokens:
+      * candidates: one decode of a 1024-caption sample with the ordinary stop id (never emitted); for every token v,
+        the mean over captions of (first position of v in the best beam) + 1 predicts the mean length with stop = v;
+        the 6 best predictions are decoded for real and the one whose MEASURED mean length is closest to the target wins
+        (deterministic: seeded weights, seeded embeddings);
+      * timed: the whole batch with that stop id, finished-caption compaction on and off (capdec_set_compact), `steps`
+        passes each, inputs resident, same timing rule as the metric;
+      * per decode step: the activation rows the loop launched (capdec_decode_step_rows) next to the rows still alive;
+      * the 8-GPU shard imbalance SURVEY section 8 E warns about, on the one-GPU proxy: the eight contiguous 625-caption
+        shards are decoded one after the other on this GPU and timed -- max / mean of their times, of their step counts
+        and of their row-steps; the slowest shard sets the whole-node rate;
+      * `oracle_rows` captions of the timed compaction-on run against the CPU oracle run with the same stop id."""
+    import numpy as np
+    from capdec_amd.gpt2_prefix_eval import decode_beam_ids, decode_greedy_ids
+    from capdec_amd.predictions_runner import prefix_from_embeddings
+    eng = model.engine
+    n = emb.shape[0]
+    B = 5 if beam else 1
+
+    def decode(pe, stop):
+        if beam:
+            ids, lens, sc, _ = decode_beam_ids(model, pe, stop, 5, T)
+            return ids, lens, sc
+        ids, lens = decode_greedy_ids(model, pe, stop, T)
+        return ids[:, None], lens[:, None], None
+
+    note("stop profile: choosing the stop id")
+    m = min(n, 1024)
+    pe_s = prefix_from_embeddings(model, emb[:m])
+    ids0 = decode(pe_s, STOP_ID)[0][:, 0].cpu().numpy()                    # best beam, all T tokens
+    first = {}
+    for r in range(m):
+        seen = set()
+        for t, v in enumerate(ids0[r].tolist()):
+            if v not in seen:
+                seen.add(v)
+                first.setdefault(v, []).append(t + 1)
+    pred = {v: (sum(p) + T * (m - len(p))) / m for v, p in first.items()}
+    cands = sorted(pred, key=lambda v: (abs(pred[v] - target), v))[:6]
+    tried = []
+    for v in cands:
+        lens = decode(pe_s, v)[1][:, 0].float()
+        tried.append({"stop_id": int(v), "predicted_mean_len": round(pred[v], 2), "measured_mean_len": round(float(lens.mean()), 2)})
+    stop = min(tried, key=lambda d: (abs(d["measured_mean_len"] - target), d["stop_id"]))["stop_id"]
+
+    def timed(compact, e):
+        eng.set_compact(compact)
+        pe = prefix_from_embeddings(model, e)
+        decode(pe, stop)                                                  # warm-up (buffers of this size)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            pe = prefix_from_embeddings(model, e)
+            out = decode(pe, stop)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / steps
+        st = eng.decode_stats()
+        return out, dt, st, eng.decode_step_rows()
+
+    note("stop profile: timed passes (stop id %d)" % stop)
+    out_on, dt_on, st_on, rows_on = timed(True, emb)
+    out_off, dt_off, st_off, rows_off = timed(False, emb)
+    eng.set_compact(True)
+    same = bool((out_on[0] == out_off[0]).all()) and bool((out_on[1] == out_off[1]).all())
+    lens_best = out_on[1][:, 0].cpu().numpy()
+    done_at = out_on[1].max(dim=1).values.cpu().numpy()                   # step after which every beam of the caption has stopped
+    alive = [int((done_at > i).sum()) * B for i in range(1, st_on["steps"])]
+    # ---- shard imbalance (one-GPU proxy of the 8-rank run): each shard alone, back to back
+    note("stop profile: the eight 625-caption shards, one after the other")
+    from capdec_amd import distributed as cdist
+    shards = []
+    for r in range(8):
+        lo, hi = cdist.shard_bounds(n, r, 8)
+        if hi <= lo:
+            continue
+        _, dt_r, st_r, _ = timed(True, emb[lo:hi])
+        shards.append({"rank": r, "captions": hi - lo, "ms": round(dt_r * 1e3, 2), "steps": st_r["steps"], "row_steps": st_r["row_steps"]})
+    eng.set_compact(True)
+    mx = lambda k: max(s_[k] for s_ in shards)
+    mean = lambda k: sum(s_[k] for s_ in shards) / len(shards)
+    rec = {"stop_id": int(stop), "target_mean_len": target, "candidates": tried,
+           "mean_len_best_beam": round(float(lens_best.mean()), 2),
+           "len_percentiles_10_50_90_max": [int(np.percentile(lens_best, q)) for q in (10, 50, 90)] + [int(lens_best.max())],
+           "captions": n, "entry_length": T, "timed_passes": steps,
+           "compaction_on": {"value": round(n / dt_on, 1), "unit": "captions/s", "ms_per_pass": round(dt_on * 1e3, 2),
+                             "steps_run": st_on["steps"], "compactions": st_on["compactions"], "row_steps": st_on["row_steps"]},
+           "compaction_off": {"value": round(n / dt_off, 1), "unit": "captions/s", "ms_per_pass": round(dt_off * 1e3, 2),
+                              "steps_run": st_off["steps"], "row_steps": st_off["row_steps"]},
+           "results_identical_on_vs_off": same,
+           "rows_launched_per_step": rows_on, "rows_alive_per_step": alive,
+           "row_steps_if_every_caption_left_at_its_own_stop": int(sum(alive)),
+           "shards_of_8": {"per_rank": shards,
+                           "ms_max_over_mean": round(mx("ms") / mean("ms"), 3),
+                           "steps_max_over_mean": round(mx("steps") / mean("steps"), 3),
+                           "row_steps_max_over_mean": round(mx("row_steps") / mean("row_steps"), 3),
+                           "whole_node_captions_per_s_if_8_gpus": round(n / (mx("ms") * 1e-3), 1),
+                           "note": "one-GPU proxy: rank r's contiguous shard decoded alone on this GPU; an 8-GPU pass ends "
+                                   "when its slowest rank does (max), perfect balance would be the mean"},
+           "note": "untimed extra of the metric line: same weights, same embeddings, stop id chosen so that captions end "
+                   "(mean best-beam length ~%g tokens); `value` of the metric line is the all-steps workload" % target}
+    if oracle_rows > 0:
+        try:
+            note("stop profile: oracle check of %d captions" % oracle_rows)
+            rows = sorted(set(int(round(i * (n - 1) / max(1, oracle_rows - 1))) for i in range(oracle_rows)))
+            o = (out_on[0][:, 0].contiguous(), out_on[1][:, 0].contiguous(), out_on[2][:, 0].contiguous() if beam else None)
+            rec["oracle_check"] = oracle_compare(model, emb, o, mapper, beam, P, T, rows, stop_id=stop)
+        except Exception as ex:
+            rec["oracle_check"] = {"ok": False, "error": str(ex)[:300]}
+    return rec
 
 
 class SmiSampler:
@@ -520,6 +635,11 @@ def main():
                     help="skip the untimed passes after the timed region (ids_checked: 16 captions decoded alone in "
                          "batch-invariant mode against the big batch; attn_decode_diverged: one step with beams that never "
                          "share history)")
+    ap.add_argument("--stop-profile", choices=["coco", "none"], default="coco",
+                    help="coco (default, N = 1, beam workload at its default sizes): after the timed region, the workload in which "
+                         "captions stop -- a stop id chosen so that the mean caption length is ~11 tokens; captions/s with "
+                         "finished-caption compaction on / off, rows per step, shard imbalance, an oracle check (`stop_profile`); "
+                         "and the entry_length = 12 point SURVEY D.2 asks for (`entry_length_12`).  none: skip both")
     ap.add_argument("--no-smi", action="store_true", help="do not sample rocm-smi (clock / power) during the timed region")
     ap.add_argument("--rank-timeout", type=float, default=1500.0,
                     help="N > 1: a rank still running after this many seconds prints the phase it is stuck in and exits "
@@ -686,6 +806,31 @@ def main():
                 print("bench.py: oracle_check FAILED: %s" % oracle_check, file=sys.stderr)
         except Exception as ex:
             oracle_check = {"ok": False, "error": str(ex)[:300]}
+    # ---- the workload in which captions stop, and the entry_length = 12 point: untimed extras of the line
+    stop_prof = t12 = None
+    if world == 1 and beam and args.stop_profile == "coco" and not args.no_checks:
+        try:
+            stop_prof = stop_profile(model, emb, mapper, beam, P, T, max(1, min(args.steps, 5)), note)
+            if stop_prof.get("oracle_check") and not stop_prof["oracle_check"].get("ok"):
+                print("bench.py: stop_profile oracle_check FAILED: %s" % stop_prof["oracle_check"], file=sys.stderr)
+        except Exception as ex:
+            eng.set_compact(True)
+            stop_prof = {"error": str(ex)[:300]}
+        try:
+            note("entry_length 12")
+            k12 = max(1, min(args.steps, 5))
+            caption_ids(model, emb, STOP_ID, beam=beam, beam_size=5, entry_length=12)
+            torch.cuda.synchronize()
+            ta = time.perf_counter()
+            for _ in range(k12):
+                caption_ids(model, emb, STOP_ID, beam=beam, beam_size=5, entry_length=12)
+            torch.cuda.synchronize()
+            d12 = (time.perf_counter() - ta) / k12
+            t12 = {"value": round(n_global / d12, 1), "unit": "captions/s", "ms_per_pass": round(d12 * 1e3, 2), "timed_passes": k12,
+                   "entry_length": 12,
+                   "note": "the same workload with entry_length 12 (SURVEY D.2: real COCO captions are ~11 tokens; all 12 steps run)"}
+        except Exception as ex:
+            t12 = {"error": str(ex)[:300]}
     # ---- reduced-precision modes (configs[1]: bf16): agreement with the fp32-accurate path on the same captions -- free
     # running (sequences diverge after the first flipped token) and teacher-forced (per-step arg-max given the fp32 ids)
     match = None
@@ -890,6 +1035,8 @@ def main():
             rec["kernels"]["gemm_f16x2p_lmhead_topk"]["second_pass_rows"] = second_pass[0]
             rec["kernels"]["gemm_f16x2p_lmhead_topk"]["row_steps"] = second_pass[1]
         rec["oracle_check"] = oracle_check
+        rec["stop_profile"] = stop_prof
+        rec["entry_length_12"] = t12
         if power and power.get("sclk_mhz"):
             # the dominant kernel against the peak AT THE CLOCK THE CHIP ACTUALLY HELD (it runs at its package power cap)
             rec["roofline"]["frac_at_measured_clock"] = round(achieved / (peak * power["sclk_mhz"] / 2400.0), 4)

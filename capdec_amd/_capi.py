@@ -79,7 +79,7 @@ class ClipResNetWeights(C.Structure):
 
 #: every symbol include/capdec.h declares: name -> (restype, argtypes)
 _VP = C.c_void_p
-ABI_VERSION = 4          # include/capdec.h: CAPDEC_ABI_VERSION
+ABI_VERSION = 5          # include/capdec.h: CAPDEC_ABI_VERSION
 SIGNATURES = {
     "capdec_abi_version": (C.c_int, []),
     "capdec_build_id": (C.c_char_p, []),
@@ -139,6 +139,8 @@ SIGNATURES = {
     "capdec_gather_rows": (C.c_int, [_VP, _VP, C.c_int, C.c_int, C.c_int, _VP]),
     "capdec_gather_ids": (C.c_int, [_VP, _VP, _VP, _VP, C.c_int, C.c_int, C.c_int, _VP, _VP, _VP]),
     "capdec_decode_stats": (C.c_int, [_VP, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_longlong)]),
+    "capdec_set_compact": (C.c_int, [_VP, C.c_int]),
+    "capdec_decode_step_rows": (C.c_int, [_VP, C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_int)]),
     "capdec_timer_start": (C.c_int, [_VP]),
     "capdec_timer_stop_ms": (C.c_int, [_VP, c_float_p]),
     "capdec_profile_enable": (C.c_int, [_VP, C.c_int]),

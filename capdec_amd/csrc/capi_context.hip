@@ -262,6 +262,19 @@ int capdec_decode_stats(capdec_ctx *c, int *steps, int *compactions, long long *
     return 0;
 }
 
+int capdec_set_compact(capdec_ctx *c, int on) {
+    CAPDEC_CHECK(c, "null context");
+    c->compact = on != 0;
+    return 0;
+}
+
+int capdec_decode_step_rows(capdec_ctx *c, int *rows, int cap, int *n) {
+    CAPDEC_CHECK(c && n && (rows || cap <= 0), "null argument");
+    *n = (int)c->stat_step_rows.size();
+    for (int i = 0; i < *n && i < cap; ++i) rows[i] = c->stat_step_rows[i];
+    return 0;
+}
+
 int capdec_decode_second_pass_rows(capdec_ctx *c, long long *rows) {
     CAPDEC_CHECK(c && rows, "null argument");
     *rows = 0;

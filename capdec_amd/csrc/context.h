@@ -143,6 +143,7 @@ struct capdec_ctx {
     DBuf x3_tmp, xpk, apk, fpk, a_tmp;   // scratch planes for un-cached matrices; packed LayerNorm output; packed fp32-A
     int stat_steps = 0, stat_compactions = 0;      // last decode call: steps run, compactions done,
     long long stat_row_steps = 0;                  // activation rows pushed through the GPT-2 body (prefill excluded)
+    std::vector<int> stat_step_rows;               // ... per decode step (capdec_decode_step_rows)
     bool batch_invariant = false;   // capdec_set_batch_invariant: no launch-size dependent summation order (no split-K, pinned kernel variants)
     int diverge = 0;                // measurement: beams never share history (capdec_set_debug_diverge)
     double stat_kv_slots = 0.0, stat_kv_pos = 0.0;   // last beam decode: sums behind capdec_decode_counters (filled lazily)

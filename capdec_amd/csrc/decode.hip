@@ -352,6 +352,8 @@ static int decode_chunk(capdec_ctx *c, const float *prefix, int nc, int P, int b
         const int arows = na * beam;
         c->stat_steps = std::max(c->stat_steps, i + 1);
         c->stat_row_steps += arows;
+        if ((int)c->stat_step_rows.size() < i) c->stat_step_rows.resize(i, 0);     // (chunks of one call add up step by step)
+        c->stat_step_rows[i - 1] += arows;
         CAPDEC_HIP(hipMemsetAsync(c->alive.p, 0, sizeof(int), c->stream));
         {
             ProfScope ps(c, F_EMBED);
@@ -398,6 +400,7 @@ static int decode_common(capdec_ctx *c, const float *prefix, int n, int P, int b
     c->stat_steps = n > 0 ? 1 : 0;
     c->stat_compactions = 0;
     c->stat_row_steps = 0;
+    c->stat_step_rows.clear();
     c->stat_kv_slots = c->stat_kv_pos = 0.0;
     c->kvstat_n = 0;
     if (n == 0) return 0;

@@ -469,6 +469,16 @@ class Engine:
         self._chk(self.lib.capdec_decode_stats(self._h, C.byref(a), C.byref(b), C.byref(r)), "decode_stats")
         return dict(steps=a.value, compactions=b.value, row_steps=r.value)
 
+    def set_compact(self, on: bool = True):
+        """finished-caption compaction at the decode loop's poll points on / off (capdec_set_compact; default on)"""
+        self._chk(self.lib.capdec_set_compact(self._h, int(bool(on))), "set_compact")
+
+    def decode_step_rows(self):
+        """activation rows of every decode step (after the prefill) of the last decode call (capdec_decode_step_rows)"""
+        buf, n = (C.c_int * 1024)(), C.c_int(0)
+        self._chk(self.lib.capdec_decode_step_rows(self._h, buf, 1024, C.byref(n)), "decode_step_rows")
+        return [int(buf[i]) for i in range(min(n.value, 1024))]
+
     def decode_counters(self) -> Dict[str, float]:
         """kv_slots_per_position: mean number of distinct K/V slots a (caption, position) of the last beam decode read
         (1 = beams share their whole history, beam = nothing); saturated_quads: GEMM-operand quads clamped to the fp16

@@ -31,7 +31,8 @@
 extern "C" {
 #endif
 
-#define CAPDEC_ABI_VERSION 4   /* 4: train step -- GPT-2's dropouts (capdec_train_set_dropout / _masks), capdec_train_loss, loss == NULL
+#define CAPDEC_ABI_VERSION 5   /* 5: capdec_set_compact, capdec_decode_step_rows (the workload in which captions stop);
+                                  4: train step -- GPT-2's dropouts (capdec_train_set_dropout / _masks), capdec_train_loss, loss == NULL
                                      enqueues without waiting, the scope survives capdec_train_reset;
                                   3: the diverged-beam debug hook left the shipped library (measurement builds only);
                                   2: capdec_profile_get takes the array capacity in *count; batch-invariant mode; decode counters */
@@ -343,6 +344,14 @@ int capdec_preprocess_images(capdec_ctx *ctx, const uint8_t *d_rgb, const int64_
  * how many times finished captions were compacted out of the batch, and the activation rows pushed through the
  * GPT-2 body after the prefill (n * beam * (steps - 1) without early stopping).  CAPDEC_COMPACT=0 disables compaction. */
 int capdec_decode_stats(capdec_ctx *ctx, int *steps, int *compactions, long long *row_steps);
+/* finished-caption compaction on / off for the following decode calls (default on; CAPDEC_COMPACT=0 sets it off at
+ * capdec_create): with it off every caption stays in the batch until ALL have stopped -- the reference's behaviour per
+ * caption is the same either way (reference gpt2_prefix_eval.py:107-109,187-188 stop one caption at a time). */
+int capdec_set_compact(capdec_ctx *ctx, int on);
+/* rows[i] = activation rows the (i + 1)-th decode step of the last decode call pushed through the GPT-2 body (step 0 is the
+ * prefill); *n = how many steps there were (<= entry_length - 1).  At most `cap` entries are written.  With compaction the
+ * sequence steps down at the poll points (every 8 steps) as captions finish; without it it is constant. */
+int capdec_decode_step_rows(capdec_ctx *ctx, int *rows, int cap, int *n);
 /* kv_slots_per_position: over the last capdec_decode_beam call, the mean number of DISTINCT K/V cache slots one
  * (caption, position) of the decode attention read (1.0 = all beams of a caption share their whole history, `beam` =
  * none of it): the decode attention loads each distinct slot once, so its HBM traffic -- and its roofline -- scale with
