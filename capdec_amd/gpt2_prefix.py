@@ -182,7 +182,6 @@ class ClipCaptionModel(_HipModule):
     _device_ahead = False
 
     _train_gpt = False          # scope of the train steps run on this model (capdec_amd.train.train_step)
-    _drop_state = None          # (p, seed epoch) the engine's dropout stream was last set up with
     _drop_seed_epoch = 0        # bump to re-seed the stream (e.g. after torch.manual_seed)
 
     def _train_shapes(self):
@@ -304,6 +303,7 @@ class _Gpt2Facade:
         return self._owner.engine.wte(ids)
 
     def get_input_embeddings(self):
+        self._owner._pull_mapper()          # (after full-scope train steps the current wte lives on the device)
         w = self._owner._sd["gpt.transformer.wte.weight"]
         return SimpleNamespace(weight=w.to(torch.device("cuda", self._owner._device_index)))
 

@@ -134,26 +134,31 @@ def train_step(model: ClipCaptionModel, optimizer: AdamW, tokens: torch.Tensor, 
     eng = model.engine
     eng.train_set_scope(full)
     p_drop = float(model.gpt.config.resid_pdrop) if (full and model.training) else 0.0
-    if full and (p_drop, model._drop_seed_epoch) != model._drop_state:
+    # (the probability and the Philox key live in the HIP CONTEXT and a new context starts at p = 0: what was last set is
+    #  remembered on the Engine object, so a model that moved to another device / build sets its dropouts up again)
+    if full and (p_drop, model._drop_seed_epoch) != getattr(eng, "_drop_state", None):
         if not (model.gpt.config.embd_pdrop == model.gpt.config.attn_pdrop == model.gpt.config.resid_pdrop):
             raise CapdecError("train_step: one dropout probability for embd / attn / resid (transformers' defaults are equal)")
         eng.train_set_dropout(p_drop, _next_seed())
-        model._drop_state = (p_drop, model._drop_seed_epoch)
+        eng._drop_state = (p_drop, model._drop_seed_epoch)
     if dropout_masks is not None:
         if p_drop <= 0.0:
             raise CapdecError("train_step: dropout_masks need a ClipCaptionModel in train() mode with dropout > 0")
         eng.train_set_dropout_masks(dropout_masks)
     if not tokens.is_cuda and tokens.numel() and (int(tokens.min()) < 0 or int(tokens.max()) >= model.gpt_dims.vocab):
         raise IndexError("train_step: token id out of range (the reference's embedding lookup raises here too)")
-    tokens = tokens.to(torch.device("cuda", model._device_index))
     if mask is not None:
-        m = mask.to(tokens.device) > 0
+        # (checked where the tensors ARE: the DataLoader's host tensors cost no device round trip, so train()'s steps stay
+        #  enqueued; device tensors are checked on the device)
+        m = mask > 0
+        tokens = tokens.to(m.device)
         P = model.prefix_length
         if m.shape != (tokens.shape[0], P + tokens.shape[1]) or bool((m[:, 1:] & ~m[:, :-1]).any()) or not bool(m[:, :P].all()):
             raise CapdecError("train_step: only the reference dataset's right-padding mask is supported")
         if bool(((tokens != 0) & ~m[:, P:]).any()):
             raise CapdecError("train_step: a non-zero token under a zero mask (the loss would read it, the reference's "
                               "attention would not)")
+    tokens = tokens.to(torch.device("cuda", model._device_index))
     g = optimizer.param_groups[0]
     loss = eng.train_step(prefix, tokens, g["lr"], g["betas"], g["eps"], g["weight_decay"], apply_update, wait=wait)
     if loss is not None and math.isnan(loss) and bool(((tokens < 0) | (tokens >= model.gpt_dims.vocab)).any()):
@@ -234,7 +239,10 @@ def train(dataset, model: ClipCaptionModel, args, warmup_steps: int = 5000, outp
             scheduler.step()
             if (idx + 1) % 10000 == 0:
                 torch.save(model.state_dict(), os.path.join(output_dir, f"{output_prefix}_latest.pt"))
-        _, total, _ = model.engine.train_loss()
+        _, total, counted = model.engine.train_loss()
+        if counted != len(loader):      # a step whose token ids were out of range is flagged on the device and left out of the sum
+            raise IndexError(f"train: {len(loader) - counted} batch(es) of epoch {epoch} held a token id out of range (the "
+                             "reference's embedding lookup raises on the first of them); no weight was updated by those steps")
         loss_per_epoch_train.append(total / max(1, len(loader)))
         print('loss_per_epoch_train: ', loss_per_epoch_train)
         if epoch % args.save_every == 0 or epoch == args.epochs - 1:

@@ -929,6 +929,10 @@ def test_train_step_facade_scope_and_dropout_decisions_without_a_device():
         run(full, dropout_masks=torch.ones(8, dtype=torch.uint8))                       # eval mode: no dropout to inject into
     full.train()
     assert ("masks", 8) in run(full, dropout_masks=torch.ones(8, dtype=torch.uint8))
+    # a NEW context (model.to(other device), use_measurement_build: the engine object is replaced) starts at p = 0 on the
+    # device: the same (p, epoch) must be set up again, or full-scope training would silently run without dropout
+    full._engine = Rec()
+    assert run(full) == [("scope", True), ("dropout", 0.1)]
     bad = tokens.clone()
     bad[0, 0] = synth.GPT2_TINY.vocab
     with pytest.raises(IndexError):
