@@ -65,7 +65,7 @@ def algorithmic_flops_per_caption(P, T, beam, mapper, dims=synth.GPT2_SMALL, D=5
     return f
 
 
-def oracle_compare(model, emb, out, mapper, beam, P, T, rows, stop_id=None):
+def oracle_compare(model, emb, out, mapper, beam, P, T, rows, stop_id=None, sd=None):
     """captions `rows` of a timed step's result against the CPU oracle run on their own prefixes (the oracle is the checker,
     never the thing measured).  Every caption is compared; a difference is tolerated only on a numerical tie -- selected /
     rejected candidate keys (beam) or top-1 / top-2 logits (greedy) within 1e-4 of each other at some step: which side of
@@ -75,7 +75,7 @@ def oracle_compare(model, emb, out, mapper, beam, P, T, rows, stop_id=None):
     from capdec_amd import synth
     from capdec_amd.predictions_runner import prefix_from_embeddings
     from oracle import capdec_oracle as O
-    sd = synth.hot_state_dict(42, mapper, 512, P)
+    sd = synth.hot_state_dict(42, mapper, 512, P) if sd is None else sd
     stop_id = STOP_ID if stop_id is None else int(stop_id)
     rows = sorted(set(int(r) for r in rows))
     pe = prefix_from_embeddings(model, emb[rows]).float().cpu()
@@ -174,25 +174,29 @@ def cpu_baseline(mapper, beam, P, T, budget_s=20.0, D=512, captions=8):
 
 def stop_profile(model, emb, mapper, beam, P, T, steps, note, target=11.0, oracle_rows=32):
     """The workload in which captions STOP (reference gpt2_prefix_eval.py:107-109,187-188: a caption ends at its stop
-    token; real COCO captions are ~11 tokens).  The hot-init weights never emit id 13, so the metric line runs all T steps;
-    here the stop id is chosen so that the same weights' captions have a mean length of ~`target` tokens:
-      * candidates: one decode of a 1024-caption sample with the ordinary stop id (never emitted); for every token v,
-        the mean over captions of (first position of v in the best beam) + 1 predicts the mean length with stop = v;
-        the 6 best predictions are decoded for real and the one whose MEASURED mean length is closest to the target wins
-        (deterministic: seeded weights, seeded embeddings);
-      * timed: the whole batch with that stop id, finished-caption compaction on and off (capdec_set_compact), `steps`
+    token; real COCO captions are ~11 tokens).  The hot-init weights never emit id 13, so the metric line runs all T steps.
+      * no single id of these weights ends captions early: for every token v of a 1024-caption sample's best beams, the mean
+        of (first position of v) + 1 predicts the mean length with stop = v; the three best predictions are decoded for real
+        and listed (`candidate_ids`: mean lengths of ~43-55 tokens) -- every vocabulary row is an i.i.d. Gaussian, so no
+        token is frequent;
+      * so the profile uses synth.with_stop_row_scaled: the SAME weights with the stop row (id 13, '.') scaled by s; s is
+        found by bisection on the sample so that the MEASURED mean best-beam length is `target` +- 0.5 tokens (seeded
+        weights, seeded embeddings: deterministic);
+      * timed: the whole batch with those weights, finished-caption compaction on and off (capdec_set_compact), `steps`
         passes each, inputs resident, same timing rule as the metric;
       * per decode step: the activation rows the loop launched (capdec_decode_step_rows) next to the rows still alive;
       * the 8-GPU shard imbalance SURVEY section 8 E warns about, on the one-GPU proxy: the eight contiguous 625-caption
         shards are decoded one after the other on this GPU and timed -- max / mean of their times, of their step counts
         and of their row-steps; the slowest shard sets the whole-node rate;
-      * `oracle_rows` captions of the timed compaction-on run against the CPU oracle run with the same stop id."""
+      * `oracle_rows` captions of the timed compaction-on run against the CPU oracle run on the same weights.
+    The model gets its original weights back before the function returns."""
     import numpy as np
     from capdec_amd.gpt2_prefix_eval import decode_beam_ids, decode_greedy_ids
     from capdec_amd.predictions_runner import prefix_from_embeddings
     eng = model.engine
     n = emb.shape[0]
     B = 5 if beam else 1
+    sd0 = synth.hot_state_dict(42, mapper, 512, P)
 
     def decode(pe, stop):
         if beam:
@@ -201,7 +205,7 @@ def stop_profile(model, emb, mapper, beam, P, T, steps, note, target=11.0, oracl
         ids, lens = decode_greedy_ids(model, pe, stop, T)
         return ids[:, None], lens[:, None], None
 
-    note("stop profile: choosing the stop id")
+    note("stop profile: candidate stop ids of the unmodified weights")
     m = min(n, 1024)
     pe_s = prefix_from_embeddings(model, emb[:m])
     ids0 = decode(pe_s, STOP_ID)[0][:, 0].cpu().numpy()                    # best beam, all T tokens
@@ -213,76 +217,100 @@ def stop_profile(model, emb, mapper, beam, P, T, steps, note, target=11.0, oracl
                 seen.add(v)
                 first.setdefault(v, []).append(t + 1)
     pred = {v: (sum(p) + T * (m - len(p))) / m for v, p in first.items()}
-    cands = sorted(pred, key=lambda v: (abs(pred[v] - target), v))[:6]
     tried = []
-    for v in cands:
+    for v in sorted(pred, key=lambda v: (abs(pred[v] - target), v))[:3]:
         lens = decode(pe_s, v)[1][:, 0].float()
         tried.append({"stop_id": int(v), "predicted_mean_len": round(pred[v], 2), "measured_mean_len": round(float(lens.mean()), 2)})
-    stop = min(tried, key=lambda d: (abs(d["measured_mean_len"] - target), d["stop_id"]))["stop_id"]
 
-    def timed(compact, e):
-        eng.set_compact(compact)
-        pe = prefix_from_embeddings(model, e)
-        decode(pe, stop)                                                  # warm-up (buffers of this size)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(steps):
+    def mean_len_at(scale):
+        model.load_state_dict(synth.with_stop_row_scaled(sd0, STOP_ID, scale))
+        return float(decode(prefix_from_embeddings(model, emb[:m]), STOP_ID)[1][:, 0].float().mean())
+
+    try:
+        note("stop profile: scale of the stop row for a mean length of %g" % target)
+        lo, hi, search = 1.0, 8.0, []
+        scale, got = hi, mean_len_at(hi)
+        search.append([hi, round(got, 2)])
+        for _ in range(10):
+            if abs(got - target) <= 0.5:
+                break
+            mid = 0.5 * (lo + hi)
+            got = mean_len_at(mid)
+            search.append([round(mid, 4), round(got, 2)])
+            scale = mid
+            if got > target:        # captions still too long: the stop row must win more often
+                lo = mid
+            else:
+                hi = mid
+        sd1 = synth.with_stop_row_scaled(sd0, STOP_ID, scale)
+        model.load_state_dict(sd1)
+
+        def timed(compact, e):
+            eng.set_compact(compact)
             pe = prefix_from_embeddings(model, e)
-            out = decode(pe, stop)
-        torch.cuda.synchronize()
-        dt = (time.perf_counter() - t0) / steps
-        st = eng.decode_stats()
-        return out, dt, st, eng.decode_step_rows()
+            decode(pe, STOP_ID)                                           # warm-up (buffers of this size)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                pe = prefix_from_embeddings(model, e)
+                out = decode(pe, STOP_ID)
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / steps
+            return out, dt, eng.decode_stats(), eng.decode_step_rows()
 
-    note("stop profile: timed passes (stop id %d)" % stop)
-    out_on, dt_on, st_on, rows_on = timed(True, emb)
-    out_off, dt_off, st_off, rows_off = timed(False, emb)
-    eng.set_compact(True)
-    same = bool((out_on[0] == out_off[0]).all()) and bool((out_on[1] == out_off[1]).all())
-    lens_best = out_on[1][:, 0].cpu().numpy()
-    done_at = out_on[1].max(dim=1).values.cpu().numpy()                   # step after which every beam of the caption has stopped
-    alive = [int((done_at > i).sum()) * B for i in range(1, st_on["steps"])]
-    # ---- shard imbalance (one-GPU proxy of the 8-rank run): each shard alone, back to back
-    note("stop profile: the eight 625-caption shards, one after the other")
-    from capdec_amd import distributed as cdist
-    shards = []
-    for r in range(8):
-        lo, hi = cdist.shard_bounds(n, r, 8)
-        if hi <= lo:
-            continue
-        _, dt_r, st_r, _ = timed(True, emb[lo:hi])
-        shards.append({"rank": r, "captions": hi - lo, "ms": round(dt_r * 1e3, 2), "steps": st_r["steps"], "row_steps": st_r["row_steps"]})
-    eng.set_compact(True)
-    mx = lambda k: max(s_[k] for s_ in shards)
-    mean = lambda k: sum(s_[k] for s_ in shards) / len(shards)
-    rec = {"stop_id": int(stop), "target_mean_len": target, "candidates": tried,
-           "mean_len_best_beam": round(float(lens_best.mean()), 2),
-           "len_percentiles_10_50_90_max": [int(np.percentile(lens_best, q)) for q in (10, 50, 90)] + [int(lens_best.max())],
-           "captions": n, "entry_length": T, "timed_passes": steps,
-           "compaction_on": {"value": round(n / dt_on, 1), "unit": "captions/s", "ms_per_pass": round(dt_on * 1e3, 2),
-                             "steps_run": st_on["steps"], "compactions": st_on["compactions"], "row_steps": st_on["row_steps"]},
-           "compaction_off": {"value": round(n / dt_off, 1), "unit": "captions/s", "ms_per_pass": round(dt_off * 1e3, 2),
-                              "steps_run": st_off["steps"], "row_steps": st_off["row_steps"]},
-           "results_identical_on_vs_off": same,
-           "rows_launched_per_step": rows_on, "rows_alive_per_step": alive,
-           "row_steps_if_every_caption_left_at_its_own_stop": int(sum(alive)),
-           "shards_of_8": {"per_rank": shards,
-                           "ms_max_over_mean": round(mx("ms") / mean("ms"), 3),
-                           "steps_max_over_mean": round(mx("steps") / mean("steps"), 3),
-                           "row_steps_max_over_mean": round(mx("row_steps") / mean("row_steps"), 3),
-                           "whole_node_captions_per_s_if_8_gpus": round(n / (mx("ms") * 1e-3), 1),
-                           "note": "one-GPU proxy: rank r's contiguous shard decoded alone on this GPU; an 8-GPU pass ends "
-                                   "when its slowest rank does (max), perfect balance would be the mean"},
-           "note": "untimed extra of the metric line: same weights, same embeddings, stop id chosen so that captions end "
-                   "(mean best-beam length ~%g tokens); `value` of the metric line is the all-steps workload" % target}
-    if oracle_rows > 0:
-        try:
-            note("stop profile: oracle check of %d captions" % oracle_rows)
-            rows = sorted(set(int(round(i * (n - 1) / max(1, oracle_rows - 1))) for i in range(oracle_rows)))
-            o = (out_on[0][:, 0].contiguous(), out_on[1][:, 0].contiguous(), out_on[2][:, 0].contiguous() if beam else None)
-            rec["oracle_check"] = oracle_compare(model, emb, o, mapper, beam, P, T, rows, stop_id=stop)
-        except Exception as ex:
-            rec["oracle_check"] = {"ok": False, "error": str(ex)[:300]}
+        note("stop profile: timed passes (stop row x %.4g)" % scale)
+        out_on, dt_on, st_on, rows_on = timed(True, emb)
+        out_off, dt_off, st_off, rows_off = timed(False, emb)
+        eng.set_compact(True)
+        same = bool((out_on[0] == out_off[0]).all()) and bool((out_on[1] == out_off[1]).all())
+        lens_best = out_on[1][:, 0].cpu().numpy()
+        done_at = out_on[1].max(dim=1).values.cpu().numpy()               # step after which every beam of the caption has stopped
+        alive = [int((done_at > i).sum()) * B for i in range(1, st_on["steps"])]
+        # ---- shard imbalance (one-GPU proxy of the 8-rank run): each shard alone, back to back
+        note("stop profile: the eight 625-caption shards, one after the other")
+        from capdec_amd import distributed as cdist
+        shards = []
+        for r in range(8):
+            lo_r, hi_r = cdist.shard_bounds(n, r, 8)
+            if hi_r <= lo_r:
+                continue
+            _, dt_r, st_r, _ = timed(True, emb[lo_r:hi_r])
+            shards.append({"rank": r, "captions": hi_r - lo_r, "ms": round(dt_r * 1e3, 2), "steps": st_r["steps"], "row_steps": st_r["row_steps"]})
+        eng.set_compact(True)
+        mx = lambda k: max(s_[k] for s_ in shards)
+        mean = lambda k: sum(s_[k] for s_ in shards) / len(shards)
+        rec = {"stop_id": STOP_ID, "stop_row_scale": round(scale, 4), "scale_search": search, "target_mean_len": target,
+               "candidate_ids_of_the_unmodified_weights": tried,
+               "mean_len_best_beam": round(float(lens_best.mean()), 2),
+               "len_percentiles_10_50_90_max": [int(np.percentile(lens_best, q)) for q in (10, 50, 90)] + [int(lens_best.max())],
+               "captions": n, "entry_length": T, "timed_passes": steps,
+               "compaction_on": {"value": round(n / dt_on, 1), "unit": "captions/s", "ms_per_pass": round(dt_on * 1e3, 2),
+                                 "steps_run": st_on["steps"], "compactions": st_on["compactions"], "row_steps": st_on["row_steps"]},
+               "compaction_off": {"value": round(n / dt_off, 1), "unit": "captions/s", "ms_per_pass": round(dt_off * 1e3, 2),
+                                  "steps_run": st_off["steps"], "row_steps": st_off["row_steps"]},
+               "results_identical_on_vs_off": same,
+               "rows_launched_per_step": rows_on, "rows_alive_per_step": alive,
+               "row_steps_if_every_caption_left_at_its_own_stop": int(sum(alive)),
+               "shards_of_8": {"per_rank": shards,
+                               "ms_max_over_mean": round(mx("ms") / mean("ms"), 3),
+                               "steps_max_over_mean": round(mx("steps") / mean("steps"), 3),
+                               "row_steps_max_over_mean": round(mx("row_steps") / mean("row_steps"), 3),
+                               "whole_node_captions_per_s_if_8_gpus": round(n / (mx("ms") * 1e-3), 1),
+                               "note": "one-GPU proxy: rank r's contiguous shard decoded alone on this GPU; an 8-GPU pass ends "
+                                       "when its slowest rank does (max), perfect balance would be the mean"},
+               "note": "untimed extra of the metric line: same embeddings, the hot-init weights with the stop row (id 13) scaled so "
+                       "that captions end (mean best-beam length ~%g tokens); `value` of the metric line is the all-steps workload" % target}
+        if oracle_rows > 0:
+            try:
+                note("stop profile: oracle check of %d captions" % oracle_rows)
+                rows = sorted(set(int(round(i * (n - 1) / max(1, oracle_rows - 1))) for i in range(oracle_rows)))
+                o = (out_on[0][:, 0].contiguous(), out_on[1][:, 0].contiguous(), out_on[2][:, 0].contiguous() if beam else None)
+                rec["oracle_check"] = oracle_compare(model, emb, o, mapper, beam, P, T, rows, sd=sd1)
+            except Exception as ex:
+                rec["oracle_check"] = {"ok": False, "error": str(ex)[:300]}
+    finally:
+        eng.set_compact(True)
+        model.load_state_dict(sd0)
     return rec
 
 

@@ -15,6 +15,8 @@
 namespace capdec {
 
 constexpr int ATT_CTX_MAX = 256;
+constexpr int ATT_LANES_MIN_P = 24;  // prefill sequences from this length on take the lane-per-query kernel (shorter ones
+                                     // -- the 10-token caption prefix -- would leave most lanes idle)
 
 __device__ __forceinline__ float dot4(const float4 &a, const float4 &b) {
     return (a.x * b.x + a.y * b.y) + (a.z * b.z + a.w * b.w);
@@ -422,6 +424,89 @@ __global__ __launch_bounds__(256) void attn_prefill_rows_kernel(const float *__r
     }
 }
 
+// Prefill / CLIP-tower attention for sequences that fill a wavefront's lanes (the 77-token text tower, the 50-token ViT;
+// round 6).  LANE PER QUERY: lane i keeps its query row (64 registers, pre-scaled) and its output row (64 accumulators);
+// the keys are walked in order and a key's K row and V row are WAVE-UNIFORM -- read straight from the fused qkv
+// activations through the scalar cache (s_load: no vector registers, no LDS, no lane shuffles), so the inner loop is
+// 64 + 64 FMAs per key with a scalar operand each, an online softmax per lane (chunks of 4 keys share one rescale), and
+// no reduction at all: the per-(row block) wavefront kernel above spends four xor-shuffle reductions per (query, key)
+// pair and re-reads its scores through LDS (2.4 ms per launch of 4000 x 8 heads x 77 tokens, 38 % of the text tower).
+// One wavefront per (caption, head, slice of the queries); causal rows stop at their own position (keys beyond the
+// slice's last query are never read).  Summation order: k ascending inside a dot product, keys ascending in the output.
+template <bool CAUSAL>
+__global__ __launch_bounds__(256) void attn_prefill_lanes_kernel(const float *__restrict__ qkv, int total, int heads, int P,
+                                                                 int d, int nslice, int qps, float *__restrict__ out,
+                                                                 char *__restrict__ packed_out, int fmt) {
+    const int lane = threadIdx.x & 63;
+    const int gw = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);      // wave-uniform
+    if (gw >= total) return;
+    const int sl = gw % nslice, ch = gw / nslice;
+    const int head = ch % heads, cap = ch / heads;
+    const int i0 = sl * qps;                                           // first query of the slice
+    const int nq = min(qps, P - i0);
+    const int i = i0 + min(lane, nq - 1);                              // (idle lanes shadow the slice's last query)
+    const int nk = CAUSAL ? i0 + nq : P;                               // keys any query of the slice can see
+    const float *__restrict__ base = qkv + (size_t)cap * P * 3 * d + head * 64;
+    float q[64], acc[64];
+    {
+        const float4 *qr = reinterpret_cast<const float4 *>(base + (size_t)i * 3 * d);
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const float4 t = qr[e];
+            q[4 * e] = t.x * ATT_QSCALE; q[4 * e + 1] = t.y * ATT_QSCALE; q[4 * e + 2] = t.z * ATT_QSCALE; q[4 * e + 3] = t.w * ATT_QSCALE;
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 64; ++e) acc[e] = 0.f;
+    float m = ATT_NEG, l = 0.f;
+    constexpr int KC = 4;
+    for (int j0 = 0; j0 < nk; j0 += KC) {
+        float s[KC];
+#pragma unroll
+        for (int u = 0; u < KC; ++u) {
+            const int j = min(j0 + u, nk - 1);                         // uniform
+            const float *__restrict__ kr = base + (size_t)j * 3 * d + d;
+            float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#pragma unroll
+            for (int e = 0; e < 64; e += 4) {
+                a0 += q[e] * kr[e];
+                a1 += q[e + 1] * kr[e + 1];
+                a2 += q[e + 2] * kr[e + 2];
+                a3 += q[e + 3] * kr[e + 3];
+            }
+            const bool vis = j0 + u < nk && (!CAUSAL || j0 + u <= i);
+            s[u] = vis ? (a0 + a1) + (a2 + a3) : -INFINITY;
+        }
+        float mx = m;
+#pragma unroll
+        for (int u = 0; u < KC; ++u) mx = fmaxf(mx, s[u]);
+        const float corr = att_exp2(m - mx);                           // (first chunk: 2^(-1e30 - mx) = 0, key 0 is visible to every query)
+        float w[KC];
+        l *= corr;
+#pragma unroll
+        for (int u = 0; u < KC; ++u) { w[u] = att_exp2(s[u] - mx); l += w[u]; }
+        m = mx;
+#pragma unroll
+        for (int e = 0; e < 64; ++e) acc[e] *= corr;
+#pragma unroll
+        for (int u = 0; u < KC; ++u) {
+            const int j = min(j0 + u, nk - 1);
+            const float *__restrict__ vr = base + (size_t)j * 3 * d + 2 * d;
+#pragma unroll
+            for (int e = 0; e < 64; ++e) acc[e] += w[u] * vr[e];
+        }
+    }
+    if (lane >= nq) return;
+    const float inv = 1.0f / l;
+    const int row = cap * P + i;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        const float4 o = make_float4(acc[4 * e] * inv, acc[4 * e + 1] * inv, acc[4 * e + 2] * inv, acc[4 * e + 3] * inv);
+        if (packed_out) x3_store_quad(packed_out, d >> 4, row, head * 4 + (e >> 2), e & 3, o, fmt);
+        else reinterpret_cast<float4 *>(out + (size_t)row * d + head * 64)[e] = o;
+    }
+}
+
 // K/V of prefill row (cap, i) -> cache[phys = cap*beam][head][i][:]
 template <typename KV>
 __global__ void kv_scatter_prefill_kernel(const float *__restrict__ qkv, KV *__restrict__ kc,
@@ -459,6 +544,20 @@ int launch_attn_prefill(hipStream_t st, const float *qkv, const KvCache &c, int 
     CAPDEC_CHECK(c.hd == 64, "attention: head_dim must be 64");
     CAPDEC_CHECK(P <= ATT_CTX_MAX && P <= c.ctx, "attention: prefix longer than the supported context");
     (void)layer; (void)beam;                      // K / V come straight from qkv (the cache is filled by kv_scatter_prefill)
+    if (!c.bf16 && P >= ATT_LANES_MIN_P && ncap > 0) {
+        // lane-per-query form: the queries are cut into equal slices of at most 64 (77 tokens: 39 + 38 -- a causal
+        // slice reads only the keys up to its last query)
+        const int nslice = (P + 63) / 64, qps = (P + nslice - 1) / nslice;
+        const int total = ncap * c.heads * nslice;
+        if (causal)
+            hipLaunchKernelGGL((attn_prefill_lanes_kernel<true>), dim3((total + 3) / 4), dim3(256), 0, st, qkv, total, c.heads, P,
+                               c.heads * c.hd, nslice, qps, out, (char *)packed_out, fmt);
+        else
+            hipLaunchKernelGGL((attn_prefill_lanes_kernel<false>), dim3((total + 3) / 4), dim3(256), 0, st, qkv, total, c.heads, P,
+                               c.heads * c.hd, nslice, qps, out, (char *)packed_out, fmt);
+        CAPDEC_HIP(hipGetLastError());
+        return 0;
+    }
     constexpr int R = 8;
     const int total = ncap * c.heads * ((P + R - 1) / R);
     if (total <= 0) return 0;

@@ -130,6 +130,23 @@ def hot_state_dict(seed: int = 42, mapping_type: str = "mlp", prefix_dim: int = 
     return sd
 
 
+def with_stop_row_scaled(sd, stop_id: int = 13, scale: float = 1.0, prefix: str = "gpt."):
+    """A shallow copy of a ClipCaptionModel state dict whose wte row ``stop_id`` (and with it the tied lm_head row) is
+    multiplied by ``scale``.  Under the hot-init law every vocabulary row is an i.i.d. Gaussian, so each of the 50 257 tokens
+    wins a step with probability ~1/V and NO single id ends captions early (bench.py's stop profile lists the best
+    candidates: mean length 43 of 67).  Scaling one row by s makes its logit N(0, s^2 sigma^2) against the maximum of
+    the others (~4.3 sigma): the stop token then wins a step with a probability the scale sets (s ~ 3: about 1 step in 11),
+    independently of the step -- caption lengths become geometric-like, the shape real COCO captions have around their
+    mean of ~11 tokens (reference gpt2_prefix_eval.py:107-109,187-188 end a caption at its stop token)."""
+    out = OrderedDict(sd)
+    w = sd[prefix + "transformer.wte.weight"].clone()
+    w[stop_id] *= float(scale)
+    out[prefix + "transformer.wte.weight"] = w
+    if prefix + "lm_head.weight" in out:
+        out[prefix + "lm_head.weight"] = w
+    return out
+
+
 def synthetic_clip_embeddings(n: int, dim: int = 512, seed: int = 0, normalize: bool = True) -> torch.Tensor:
     """[n, dim] fp32 Gaussian rows, L2-normalised like CLIP embeddings after
     reference predictions_runner.py:222."""

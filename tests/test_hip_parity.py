@@ -566,6 +566,56 @@ def test_train_step_full_model_with_dropout_vs_reference_golden(golden):
     assert abs(l_eval - float(want0)) < 3e-4 and abs(l_eval - l1) > 1e-3
 
 
+def test_train_step_full_model_at_gpt2_small_geometry_vs_oracle():
+    """The reference's default train step (train.py:344-354: GPT-2 trained too, dropouts 0.1) at the geometry it really runs
+    at -- 12 layers, 768-d, V = 50 257: one step, batch 4, injected keep-masks.  The tied wte's gradient is the product the
+    transposing packer feeds with the loss rows at a row stride of the PADDED vocabulary (50 304), a path the tiny
+    geometry (V = 1531 -> 1536) cannot exercise.  Checker: the oracle's hand-written forward / backward, which is pinned to the
+    reference's own loss.backward() at the tiny geometry (tests/golden/train_full*_tiny.npz).  Loss, every gradient's norm,
+    and 4096-entry subsamples of wte, h.0.attn.c_attn.weight, h.11.mlp.c_proj.weight and ln_f.weight."""
+    from capdec_amd import train as Tr
+    from oracle import capdec_oracle as O
+    dims = synth.GPT2_SMALL
+    model, sd = _full_model(dims, 0.1)
+    B, L, P = 4, 9, 10
+    gen = torch.Generator().manual_seed(77)
+    tokens = torch.randint(1, dims.vocab, (B, L), generator=gen)
+    tokens[0, -1] = dims.vocab - 1                        # the last vocabulary row takes part (the padded tail must not)
+    lens = torch.tensor([L, 7, 5, 8])
+    tokens[torch.arange(L)[None, :] >= lens[:, None]] = 0
+    mask = torch.cat((torch.ones(B, P), (tokens != 0).float()), dim=1)
+    prefix = synth.synthetic_clip_embeddings(B, 512, seed=12)
+    masks, flat = [], []
+    for _, shape in O.dropout_sites(dims.n_layer, B, P + L, dims.n_embd, dims.n_head):
+        m = (torch.rand(shape, generator=gen) >= 0.1).to(torch.uint8)
+        masks.append(m)
+        flat.append(m.flatten())
+    flat = torch.cat(flat)
+    assert flat.numel() == model.engine.dropout_stream_size(B, P + L, dims.n_embd, dims.n_head, dims.n_layer)
+    want_loss, want = O.train_step_loss_and_grads(sd, tokens, prefix, "mlp", P, n_head=dims.n_head, train_gpt=True, drop=(0.1, masks))
+    opt = Tr.AdamW(model.parameters(), lr=1e-3)
+    loss = Tr.train_step(model, opt, tokens, mask, prefix, apply_update=False, dropout_masks=flat)
+    assert abs(loss - float(want_loss)) < 3e-4, (loss, float(want_loss))
+    grads = Tr.all_gradients(model)
+    assert sorted(grads) == sorted(want)
+    worst = 0.0
+    for k, ref in want.items():
+        r = float(grads[k].double().norm().cpu()) / max(float(ref.double().norm()), 1e-30)
+        worst = max(worst, abs(r - 1.0))
+        assert abs(r - 1.0) < 2e-3, (k, r)
+    for k in ("gpt.transformer.wte.weight", "gpt.transformer.h.0.attn.c_attn.weight", "gpt.transformer.h.11.mlp.c_proj.weight",
+              "gpt.transformer.ln_f.weight"):
+        ref, got = want[k].flatten(), grads[k].cpu().flatten()
+        step = max(1, ref.numel() // 4096)
+        np.testing.assert_allclose(got[::step].numpy(), ref[::step].numpy(), atol=3e-3 * float(ref.abs().max()), rtol=0, err_msg=k)
+    # the rows of wte the batch touched (token lookup + lm_head) and the LAST row, entry by entry
+    gw, rw = grads["gpt.transformer.wte.weight"].cpu(), want["gpt.transformer.wte.weight"]
+    rows = torch.unique(torch.cat((tokens.flatten(), torch.tensor([dims.vocab - 1, dims.vocab - 2, 0]))))
+    np.testing.assert_allclose(gw[rows].numpy(), rw[rows].numpy(), atol=3e-3 * float(rw.abs().max()), rtol=0)
+    _report("train step, full scope, GPT-2-small geometry (V = 50257): loss %.6f vs oracle %.6f; worst |gradient norm ratio - 1| over %d "
+            "tensors %.2e" % (loss, float(want_loss), len(want), worst))
+
+
 def test_train_step_long_sequences_vs_oracle():
     """Sequences beyond one wavefront's 64 lanes -- the reference's default geometry has prefix_length = clip_length = 40,
     i.e. 80-position TransformerMapper sequences and GPT-2 sequences of 40 + caption tokens -- where the block-form
