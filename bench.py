@@ -179,9 +179,9 @@ def stop_profile(model, emb, mapper, beam, P, T, steps, note, target=11.0, oracl
         of (first position of v) + 1 predicts the mean length with stop = v; the three best predictions are decoded for real
         and listed (`candidate_ids`: mean lengths of ~43-55 tokens) -- every vocabulary row is an i.i.d. Gaussian, so no
         token is frequent;
-      * so the profile uses synth.with_stop_row_scaled: the SAME weights with the stop row (id 13, '.') scaled by s; s is
-        found by bisection on the sample so that the MEASURED mean best-beam length is `target` +- 0.5 tokens (seeded
-        weights, seeded embeddings: deterministic);
+      * so the profile uses synth.with_stop_bias: the SAME weights with a constant added to the logit of the stop token
+        (id 13, '.'); the constant is found by bracketing + bisection on the sample so that the MEASURED mean best-beam
+        length is `target` +- 0.5 tokens (seeded weights, seeded embeddings: deterministic);
       * timed: the whole batch with those weights, finished-caption compaction on and off (capdec_set_compact), `steps`
         passes each, inputs resident, same timing rule as the metric;
       * per decode step: the activation rows the loop launched (capdec_decode_step_rows) next to the rows still alive;
@@ -222,27 +222,31 @@ def stop_profile(model, emb, mapper, beam, P, T, steps, note, target=11.0, oracl
         lens = decode(pe_s, v)[1][:, 0].float()
         tried.append({"stop_id": int(v), "predicted_mean_len": round(pred[v], 2), "measured_mean_len": round(float(lens.mean()), 2)})
 
-    def mean_len_at(scale):
-        model.load_state_dict(synth.with_stop_row_scaled(sd0, STOP_ID, scale))
+    def mean_len_at(alpha):
+        model.load_state_dict(synth.with_stop_bias(sd0, STOP_ID, alpha))
         return float(decode(prefix_from_embeddings(model, emb[:m]), STOP_ID)[1][:, 0].float().mean())
 
     try:
-        note("stop profile: scale of the stop row for a mean length of %g" % target)
-        lo, hi, search = 1.0, 8.0, []
-        scale, got = hi, mean_len_at(hi)
+        note("stop profile: logit offset of the stop token for a mean length of %g" % target)
+        search, lo, hi = [], 0.0, 1.0
+        got = mean_len_at(hi)
         search.append([hi, round(got, 2)])
-        for _ in range(10):
+        while got > target and hi < 4096.0:          # bracket: the mean length falls as the offset grows
+            lo, hi = hi, hi * 2.0
+            got = mean_len_at(hi)
+            search.append([hi, round(got, 2)])
+        alpha = hi
+        for _ in range(12):
             if abs(got - target) <= 0.5:
                 break
-            mid = 0.5 * (lo + hi)
-            got = mean_len_at(mid)
-            search.append([round(mid, 4), round(got, 2)])
-            scale = mid
-            if got > target:        # captions still too long: the stop row must win more often
-                lo = mid
+            alpha = 0.5 * (lo + hi)
+            got = mean_len_at(alpha)
+            search.append([round(alpha, 4), round(got, 2)])
+            if got > target:
+                lo = alpha
             else:
-                hi = mid
-        sd1 = synth.with_stop_row_scaled(sd0, STOP_ID, scale)
+                hi = alpha
+        sd1 = synth.with_stop_bias(sd0, STOP_ID, alpha)
         model.load_state_dict(sd1)
 
         def timed(compact, e):
@@ -258,11 +262,13 @@ def stop_profile(model, emb, mapper, beam, P, T, steps, note, target=11.0, oracl
             dt = (time.perf_counter() - t0) / steps
             return out, dt, eng.decode_stats(), eng.decode_step_rows()
 
-        note("stop profile: timed passes (stop row x %.4g)" % scale)
+        note("stop profile: timed passes (stop logit + %.4g)" % alpha)
         out_on, dt_on, st_on, rows_on = timed(True, emb)
         out_off, dt_off, st_off, rows_off = timed(False, emb)
         eng.set_compact(True)
-        same = bool((out_on[0] == out_off[0]).all()) and bool((out_on[1] == out_off[1]).all())
+        # (a compacted step launches fewer rows: other GEMM tile geometries / split-K -- the fp32 round-off of a row may
+        #  differ in the last bit, and on a numerical near-tie a beam; capdec_set_batch_invariant removes that, capdec.h)
+        same = float(((out_on[0] == out_off[0]).flatten(1).all(1) & (out_on[1] == out_off[1]).all(1)).float().mean())
         lens_best = out_on[1][:, 0].cpu().numpy()
         done_at = out_on[1].max(dim=1).values.cpu().numpy()               # step after which every beam of the caption has stopped
         alive = [int((done_at > i).sum()) * B for i in range(1, st_on["steps"])]
@@ -279,7 +285,7 @@ def stop_profile(model, emb, mapper, beam, P, T, steps, note, target=11.0, oracl
         eng.set_compact(True)
         mx = lambda k: max(s_[k] for s_ in shards)
         mean = lambda k: sum(s_[k] for s_ in shards) / len(shards)
-        rec = {"stop_id": STOP_ID, "stop_row_scale": round(scale, 4), "scale_search": search, "target_mean_len": target,
+        rec = {"stop_id": STOP_ID, "stop_logit_offset": round(alpha, 4), "offset_search": search, "target_mean_len": target,
                "candidate_ids_of_the_unmodified_weights": tried,
                "mean_len_best_beam": round(float(lens_best.mean()), 2),
                "len_percentiles_10_50_90_max": [int(np.percentile(lens_best, q)) for q in (10, 50, 90)] + [int(lens_best.max())],
@@ -288,7 +294,7 @@ def stop_profile(model, emb, mapper, beam, P, T, steps, note, target=11.0, oracl
                                  "steps_run": st_on["steps"], "compactions": st_on["compactions"], "row_steps": st_on["row_steps"]},
                "compaction_off": {"value": round(n / dt_off, 1), "unit": "captions/s", "ms_per_pass": round(dt_off * 1e3, 2),
                                   "steps_run": st_off["steps"], "row_steps": st_off["row_steps"]},
-               "results_identical_on_vs_off": same,
+               "captions_identical_on_vs_off": round(same, 5),
                "rows_launched_per_step": rows_on, "rows_alive_per_step": alive,
                "row_steps_if_every_caption_left_at_its_own_stop": int(sum(alive)),
                "shards_of_8": {"per_rank": shards,
@@ -298,8 +304,9 @@ def stop_profile(model, emb, mapper, beam, P, T, steps, note, target=11.0, oracl
                                "whole_node_captions_per_s_if_8_gpus": round(n / (mx("ms") * 1e-3), 1),
                                "note": "one-GPU proxy: rank r's contiguous shard decoded alone on this GPU; an 8-GPU pass ends "
                                        "when its slowest rank does (max), perfect balance would be the mean"},
-               "note": "untimed extra of the metric line: same embeddings, the hot-init weights with the stop row (id 13) scaled so "
-                       "that captions end (mean best-beam length ~%g tokens); `value` of the metric line is the all-steps workload" % target}
+               "note": "untimed extra of the metric line: same embeddings, the hot-init weights with a constant added to the stop "
+                       "token's logit (synth.with_stop_bias) so that captions end (mean best-beam length ~%g tokens); `value` of the "
+                       "metric line is the all-steps workload" % target}
         if oracle_rows > 0:
             try:
                 note("stop profile: oracle check of %d captions" % oracle_rows)
@@ -404,12 +411,67 @@ def side_workload(args, world, rank, dev, emit=print):
     dt = time.perf_counter() - t0
     prof = cm._engine.profile_get()
     if rank == 0:
+        # ---- roofline of the tower's dominant kernel family (hipEvent-timed launches on the launch stream)
+        fams = {k: v for k, v in prof.items() if v["launches"]}
+        est = lambda v: v["ms"] * v["calls"] / v["launches"]
+        roof = None
+        if fams:
+            k, v = max(fams.items(), key=lambda kv: est(kv[1]))
+            tower_ms = sum(est(x) for x in fams.values())
+            if v["flops"] > 0:
+                peak = PEAK_BF16_MFMA_TFLOPS / 3.0 if "f16x2" in k else (PEAK_BF16_MFMA_TFLOPS / 6.0 if "x3" in k else
+                                                                       (PEAK_F32_MFMA_TFLOPS if k == "gemm_f32" else PEAK_BF16_MFMA_TFLOPS))
+                ach = v["flops"] / v["ms"] * 1e-9
+                roof = {"bound": "mfma", "kernel": k, "achieved": round(ach, 1), "peak": round(peak, 1), "unit": "TFLOP/s",
+                        "frac": round(ach / peak, 4), "traffic": None, "avg_launch_ms": round(v["ms"] / v["launches"], 4),
+                        "launches_timed": v["launches"], "share_of_tower": round(est(v) / tower_ms, 3),
+                        "note": "algorithmic 2 M N K of every GEMM of the family / hipEvent time of the timed launches; peak = dense "
+                                "16-bit MFMA 2.5 PFLOP/s (one plane per operand) or / 3 (two fp16 planes, fp32-accurate)"}
+            else:       # attention / LayerNorm dominant: HBM-side bytes are not counted by the launchers -- time share only
+                roof = {"bound": "hbm", "kernel": k, "achieved": None, "peak": 8000.0, "unit": "GB/s", "frac": None, "traffic": None,
+                        "avg_launch_ms": round(v["ms"] / v["launches"], 4), "share_of_tower": round(est(v) / tower_ms, 3)}
+        # ---- CPU baseline: the oracle's restatement of the same chain on a bounded sample, host cores of this box
+        cpu = None
+        if args.cpu_seconds > 0:
+            try:
+                from oracle import capdec_oracle as O
+                th = min(32, os.cpu_count() or 1)
+                torch.set_num_threads(th)
+                sdm = synth.hot_state_dict(42, "mlp" if text else "transformer_encoder", D, P)
+                done_items, t1 = 0, time.perf_counter()
+                with torch.no_grad():
+                    if text:        # embeddings_generator.py:81-89 + train.py:347,253-254, 16 captions per CPU batch
+                        g = torch.Generator().manual_seed(3)
+                        while done_items < 16 or (time.perf_counter() - t1 < args.cpu_seconds and done_items < 4096):
+                            tk = inp[done_items % n_global:done_items % n_global + 16].cpu()
+                            e = O.clip_encode_text(tk, clip_sd)
+                            e = O.noise_injection(e, 0.016, noise=torch.randn(e.shape, generator=g))
+                            O.clip_project(e, sdm, "mlp", P)
+                            done_items += tk.shape[0]
+                    else:           # predictions_runner.py:207-232: one image at a time, reference-shaped beam search
+                        enc = O.clip_encode_image_resnet if rn else O.clip_encode_image
+                        while done_items < 1 or (time.perf_counter() - t1 < args.cpu_seconds and done_items < 64):
+                            e = enc(inp[done_items:done_items + 1].cpu(), clip_sd)
+                            pe = O.clip_project(O.normalize_prefix(e.float()), sdm, "transformer_encoder", P)
+                            O.generate_beam_ref(sdm, pe, 5, STOP_ID, T)
+                            done_items += 1
+                cdt = time.perf_counter() - t1
+                cpu = {"value": round(done_items / cdt, 4), "unit": "items/s", "cores": th, "kind": "port", "host_cpus": os.cpu_count(),
+                       "sample": f"{done_items} {'captions (batches of 16)' if text else 'images (one at a time, reference-shaped beam search without KV cache)'} "
+                                 f"of the same chain through oracle/capdec_oracle.py in {cdt:.1f} s wall on {th} threads"}
+            except Exception as ex:
+                cpu = {"value": None, "unit": "items/s", "cores": 0, "kind": "port", "sample": "failed: " + str(ex)[:200]}
         emit(json.dumps({"metric": f"{'captions' if text else 'images'}/sec, side workload {args.workload}",
                           "clip_tower_kernels": {k: {"ms_est": round(v["ms"] * v["calls"] / v["launches"], 2),
-                                                     "launches": v["calls"], "avg_ms": round(v["ms"] / v["launches"], 4)}
+                                                     "launches": v["calls"], "avg_ms": round(v["ms"] / v["launches"], 4),
+                                                     **({"tflops": round(v["flops"] / v["ms"] * 1e-9, 1)} if v["flops"] > 0 and v["ms"] > 0 else {})}
                                                  for k, v in prof.items() if v["launches"]},
                           "value": round(n_global * args.steps / dt, 2), "unit": "items/s", "n_gpus": world,
                           "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 2),
+                          "higher_is_better": True, "data": "synthetic",
+                          "dtype": {"fp16": "f16 towers (one fp16 plane per GEMM operand, fp32 accumulate: the reference's CLIP arithmetic on a GPU)",
+                                    "bf16": "bf16 towers"}.get(prec, "f32 towers (two fp16 planes, 3 MFMAs per product)"),
+                          "roofline": roof, "cpu_baseline": cpu,
                           "config": {"workload": args.workload, "clip": "RN50x4" if rn else "ViT-B/32",
                                      "items_per_step": n_global, "clip_precision": prec,
                                      "gemm_mode": model.engine.gemm_mode()}}))

@@ -15,8 +15,9 @@
 namespace capdec {
 
 constexpr int ATT_CTX_MAX = 256;
-constexpr int ATT_LANES_MIN_P = 24;  // prefill sequences from this length on take the lane-per-query kernel (shorter ones
-                                     // -- the 10-token caption prefix -- would leave most lanes idle)
+constexpr int ATT_MFMA_MIN_P = 24;   // prefill sequences of 24 .. 128 positions take the matrix-core kernel (shorter ones -- the
+constexpr int ATT_MFMA_MAX_P = 128;  // 10-token caption prefix -- would leave most of a 32 x 32 tile empty; longer ones keep the
+                                     // per-row kernel: the score registers of a lane are sized for four key tiles)
 
 __device__ __forceinline__ float dot4(const float4 &a, const float4 &b) {
     return (a.x * b.x + a.y * b.y) + (a.z * b.z + a.w * b.w);
@@ -424,86 +425,182 @@ __global__ __launch_bounds__(256) void attn_prefill_rows_kernel(const float *__r
     }
 }
 
-// Prefill / CLIP-tower attention for sequences that fill a wavefront's lanes (the 77-token text tower, the 50-token ViT;
-// round 6).  LANE PER QUERY: lane i keeps its query row (64 registers, pre-scaled) and its output row (64 accumulators);
-// the keys are walked in order and a key's K row and V row are WAVE-UNIFORM -- read straight from the fused qkv
-// activations through the scalar cache (s_load: no vector registers, no LDS, no lane shuffles), so the inner loop is
-// 64 + 64 FMAs per key with a scalar operand each, an online softmax per lane (chunks of 4 keys share one rescale), and
-// no reduction at all: the per-(row block) wavefront kernel above spends four xor-shuffle reductions per (query, key)
-// pair and re-reads its scores through LDS (2.4 ms per launch of 4000 x 8 heads x 77 tokens, 38 % of the text tower).
-// One wavefront per (caption, head, slice of the queries); causal rows stop at their own position (keys beyond the
-// slice's last query are never read).  Summation order: k ascending inside a dot product, keys ascending in the output.
+// Prefill / CLIP-tower attention on the matrix cores (round 6) for sequences of 24 .. 128 positions (the 77-token text
+// tower, the 50-token ViT, long caption prefixes): the scores and the weighted sum of a head ARE two dense GEMMs
+// (S x 64 x S and S x S x 64), and the per-row wavefront kernel above spends four xor-shuffle reductions per (query, key)
+// pair on them (2.4 ms per launch of 4000 captions x 8 heads x 77 tokens: 38 % of the text tower).
+//   block = one (caption, head); wavefront w = the 32 queries [32 w, 32 w + 32).
+//   K and V of the head are staged in LDS ONCE per block as two fp16 planes each (a = hi + 2^-11 lo, bf16x3.h: three MFMAs
+//   per product, fp32-accurate like the default GEMM mode -- whatever the tower's GEMM precision, the attention keeps it):
+//   K row-major [key][64] (144-byte rows: conflict-free 16-byte fragment reads), V TRANSPOSED [dim][key] with the keys of
+//   every 16-key group stored in the order the score accumulators hold them (below), so a V fragment is one 16-byte read.
+//   scores^T tile = K_tile (A operand: rows = keys) x Q_tile^T (B operand: columns = queries; fragments straight from the
+//   qkv activations, pre-scaled by 1/8 log2 e): in the 32 x 32 accumulator layout lane l then holds, for ITS query
+//   i = l & 31, the keys (r & 3) + 8 (r >> 2) + 4 (l >> 5) of the tile in registers r = 0 .. 15 -- a softmax row is spread
+//   over one lane's registers and its partner lane l ^ 32 only: max and sum are register loops plus ONE shuffle.
+//   The un-normalised weights are already the A operand of P x V (row = query l & 31, eight k values per lane half): registers
+//   8 s .. 8 s + 7 cover keys 16 s .. 16 s + 15 of the tile in the order (e & 3) + 8 (e >> 2) + 4 half -- the order V^T is
+//   stored in.  out tile = P x V lands row = query, column = dimension; it goes through a per-wavefront LDS slab (the K / V
+//   area, after a block barrier) so that rows leave as whole 16-byte quads: fp32 or the packed A operand of c_proj.
+//   Causal rows never touch key tiles above their own (wavefront w computes w + 1 of them).
+constexpr int AM_KST = 72;      // halfs per staged K row (64 + 8: 144 bytes)
+constexpr int AM_OST = 68;      // floats per row of the output slab (64 + 4)
+inline size_t attn_mfma_lds_bytes(int S) {
+    const int nqt = (S + 31) / 32, Spad = nqt * 32;
+    const size_t kv = (size_t)2 * Spad * AM_KST * 2 + (size_t)2 * 64 * (Spad + 8) * 2;
+    const size_t slab = (size_t)nqt * 32 * AM_OST * 4;
+    return kv > slab ? kv : slab;
+}
 template <bool CAUSAL>
-__global__ __launch_bounds__(256) void attn_prefill_lanes_kernel(const float *__restrict__ qkv, int total, int heads, int P,
-                                                                 int d, int nslice, int qps, float *__restrict__ out,
-                                                                 char *__restrict__ packed_out, int fmt) {
-    const int lane = threadIdx.x & 63;
-    const int gw = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);      // wave-uniform
-    if (gw >= total) return;
-    const int sl = gw % nslice, ch = gw / nslice;
-    const int head = ch % heads, cap = ch / heads;
-    const int i0 = sl * qps;                                           // first query of the slice
-    const int nq = min(qps, P - i0);
-    const int i = i0 + min(lane, nq - 1);                              // (idle lanes shadow the slice's last query)
-    const int nk = CAUSAL ? i0 + nq : P;                               // keys any query of the slice can see
-    const float *__restrict__ base = qkv + (size_t)cap * P * 3 * d + head * 64;
-    float q[64], acc[64];
+__global__ __launch_bounds__(256) void attn_prefill_mfma_kernel(const float *__restrict__ qkv, int heads, int S, int d,
+                                                                float *__restrict__ out, char *__restrict__ packed_out, int fmt) {
+    extern __shared__ __attribute__((aligned(16))) char am_smem[];
+    typedef float f32x16a __attribute__((ext_vector_type(16)));
+    const int nqt = (S + 31) >> 5, Spad = nqt * 32, VST = Spad + 8;       // VST: halfs per V^T row
+    _Float16 *Kp = reinterpret_cast<_Float16 *>(am_smem);                 // [2 planes][Spad][AM_KST]
+    _Float16 *Vt = Kp + (size_t)2 * Spad * AM_KST;                        // [2 planes][64][VST]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l32 = lane & 31, half = lane >> 5;
+    const int head = blockIdx.x % heads, cap = blockIdx.x / heads;
+    const float *__restrict__ base = qkv + (size_t)cap * S * 3 * d + head * 64;
+    constexpr float LO = 1.0f / H2_LO_SCALE;
+    // ---- stage K and V^T (rows past S: zeros -- a zero weight times a NaN would still poison the P x V accumulators)
+    for (int idx = tid; idx < Spad * 16; idx += blockDim.x) {
+        const int key = idx >> 4, q4 = idx & 15;
+        float4 kv = make_float4(0.f, 0.f, 0.f, 0.f), vv = kv;
+        if (key < S) {
+            const float *r = base + (size_t)key * 3 * d + q4 * 4;
+            kv = *reinterpret_cast<const float4 *>(r + d);
+            vv = *reinterpret_cast<const float4 *>(r + 2 * d);
+        }
+        f16x4 kh, kl, vh, vl;
+        split2h(kv, kh, kl);
+        split2h(vv, vh, vl);
+        *reinterpret_cast<f16x4 *>(Kp + (size_t)key * AM_KST + q4 * 4) = kh;
+        *reinterpret_cast<f16x4 *>(Kp + (size_t)(Spad + key) * AM_KST + q4 * 4) = kl;
+        const int w = key & 15;
+        const int pos = (key & ~15) + 8 * ((w >> 2) & 1) + (w & 3) + 4 * (w >> 3);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            Vt[(size_t)(q4 * 4 + u) * VST + pos] = vh[u];
+            Vt[(size_t)(64 + q4 * 4 + u) * VST + pos] = vl[u];
+        }
+    }
+    // ---- this wavefront's query fragments (B operand of the score product): row i, k = 16 s + 8 half .. + 7
+    const int i = wave * 32 + l32;
+    f16x8 qh[4], ql[4];
     {
-        const float4 *qr = reinterpret_cast<const float4 *>(base + (size_t)i * 3 * d);
+        const float *qr = base + (size_t)min(i, S - 1) * 3 * d + 8 * half;
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const float4 t = qr[e];
-            q[4 * e] = t.x * ATT_QSCALE; q[4 * e + 1] = t.y * ATT_QSCALE; q[4 * e + 2] = t.z * ATT_QSCALE; q[4 * e + 3] = t.w * ATT_QSCALE;
+        for (int s = 0; s < 4; ++s) {
+            float4 a = *reinterpret_cast<const float4 *>(qr + 16 * s), b = *reinterpret_cast<const float4 *>(qr + 16 * s + 4);
+            a.x *= ATT_QSCALE; a.y *= ATT_QSCALE; a.z *= ATT_QSCALE; a.w *= ATT_QSCALE;
+            b.x *= ATT_QSCALE; b.y *= ATT_QSCALE; b.z *= ATT_QSCALE; b.w *= ATT_QSCALE;
+            f16x4 h0, l0, h1, l1;
+            split2h(a, h0, l0);
+            split2h(b, h1, l1);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { qh[s][e] = h0[e]; qh[s][4 + e] = h1[e]; ql[s][e] = l0[e]; ql[s][4 + e] = l1[e]; }
         }
     }
+    __syncthreads();
+    // ---- scores^T = K Q^T, tile by tile; sc[t][r]: query i, key 32 t + (r & 3) + 8 (r >> 2) + 4 half
+    const int nt = CAUSAL ? wave + 1 : nqt;
+    float sc[4][16];
 #pragma unroll
-    for (int e = 0; e < 64; ++e) acc[e] = 0.f;
-    float m = ATT_NEG, l = 0.f;
-    constexpr int KC = 4;
-    for (int j0 = 0; j0 < nk; j0 += KC) {
-        float s[KC];
+    for (int t = 0; t < 4; ++t) {
+        if (t < nt) {
+            f32x16a am, ac;
 #pragma unroll
-        for (int u = 0; u < KC; ++u) {
-            const int j = min(j0 + u, nk - 1);                         // uniform
-            const float *__restrict__ kr = base + (size_t)j * 3 * d + d;
-            float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+            for (int r = 0; r < 16; ++r) { am[r] = 0.f; ac[r] = 0.f; }
+            const _Float16 *kr = Kp + (size_t)(32 * t + l32) * AM_KST + 8 * half;
 #pragma unroll
-            for (int e = 0; e < 64; e += 4) {
-                a0 += q[e] * kr[e];
-                a1 += q[e + 1] * kr[e + 1];
-                a2 += q[e + 2] * kr[e + 2];
-                a3 += q[e + 3] * kr[e + 3];
+            for (int s = 0; s < 4; ++s) {
+                const f16x8 kh = *reinterpret_cast<const f16x8 *>(kr + 16 * s);
+                const f16x8 kl = *reinterpret_cast<const f16x8 *>(kr + (size_t)Spad * AM_KST + 16 * s);
+                ac = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl, qh[s], ac, 0, 0, 0);
+                am = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, qh[s], am, 0, 0, 0);
+                ac = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, ql[s], ac, 0, 0, 0);
             }
-            const bool vis = j0 + u < nk && (!CAUSAL || j0 + u <= i);
-            s[u] = vis ? (a0 + a1) + (a2 + a3) : -INFINITY;
-        }
-        float mx = m;
 #pragma unroll
-        for (int u = 0; u < KC; ++u) mx = fmaxf(mx, s[u]);
-        const float corr = att_exp2(m - mx);                           // (first chunk: 2^(-1e30 - mx) = 0, key 0 is visible to every query)
-        float w[KC];
-        l *= corr;
+            for (int r = 0; r < 16; ++r) {
+                const int key = 32 * t + (r & 3) + 8 * (r >> 2) + 4 * half;
+                const bool vis = key < S && (!CAUSAL || key <= i);
+                sc[t][r] = vis ? am[r] + ac[r] * LO : -INFINITY;
+            }
+        } else {
 #pragma unroll
-        for (int u = 0; u < KC; ++u) { w[u] = att_exp2(s[u] - mx); l += w[u]; }
-        m = mx;
-#pragma unroll
-        for (int e = 0; e < 64; ++e) acc[e] *= corr;
-#pragma unroll
-        for (int u = 0; u < KC; ++u) {
-            const int j = min(j0 + u, nk - 1);
-            const float *__restrict__ vr = base + (size_t)j * 3 * d + 2 * d;
-#pragma unroll
-            for (int e = 0; e < 64; ++e) acc[e] += w[u] * vr[e];
+            for (int r = 0; r < 16; ++r) sc[t][r] = -INFINITY;
         }
     }
-    if (lane >= nq) return;
-    const float inv = 1.0f / l;
-    const int row = cap * P + i;
+    // ---- softmax over the row: this lane's registers and the partner lane's (key 0 is visible to every query: finite max)
+    float m = -INFINITY;
 #pragma unroll
-    for (int e = 0; e < 16; ++e) {
-        const float4 o = make_float4(acc[4 * e] * inv, acc[4 * e + 1] * inv, acc[4 * e + 2] * inv, acc[4 * e + 3] * inv);
-        if (packed_out) x3_store_quad(packed_out, d >> 4, row, head * 4 + (e >> 2), e & 3, o, fmt);
-        else reinterpret_cast<float4 *>(out + (size_t)row * d + head * 64)[e] = o;
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) m = fmaxf(m, sc[t][r]);
+    m = fmaxf(m, __shfl_xor(m, 32, 64));
+    float lsum = 0.f;
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float p = att_exp2(sc[t][r] - m);
+            sc[t][r] = p;
+            lsum += p;
+        }
+    lsum += __shfl_xor(lsum, 32, 64);
+    const float linv = 1.0f / lsum;
+    // ---- out = P V: the weights of registers 8 s2 .. 8 s2 + 7 are the A fragment of k-step (t, s2)
+    f32x16a om[2], oc[2];
+#pragma unroll
+    for (int n = 0; n < 2; ++n)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { om[n][r] = 0.f; oc[n][r] = 0.f; }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        if (t < nt) {
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                f16x8 ph, pl;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float p = sc[t][8 * s2 + e];                     // 0 <= p <= 1
+                    const _Float16 hh = p < 0x1p-14f ? (_Float16)0.f : (_Float16)p;
+                    ph[e] = hh;
+                    pl[e] = (_Float16)((p - (float)hh) * H2_LO_SCALE);
+                }
+#pragma unroll
+                for (int n = 0; n < 2; ++n) {
+                    const _Float16 *vr = Vt + (size_t)(32 * n + l32) * VST + 32 * t + 16 * s2 + 8 * half;
+                    const f16x8 vh = *reinterpret_cast<const f16x8 *>(vr);
+                    const f16x8 vl = *reinterpret_cast<const f16x8 *>(vr + (size_t)64 * VST);
+                    oc[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(pl, vh, oc[n], 0, 0, 0);
+                    om[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ph, vh, om[n], 0, 0, 0);
+                    oc[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ph, vl, oc[n], 0, 0, 0);
+                }
+            }
+        }
+    }
+    // ---- rows out through this wavefront's slab: accumulator (row = query (r & 3) + 8 (r >> 2) + 4 half, column = l32 + 32 n)
+    __syncthreads();                                   // every wavefront is done with K / V
+    float *ost = reinterpret_cast<float *>(am_smem) + (size_t)wave * 32 * AM_OST;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
+        const float li = __shfl(linv, row, 64);        // lane `row` holds the sum of query 32 w + row
+#pragma unroll
+        for (int n = 0; n < 2; ++n) ost[row * AM_OST + 32 * n + l32] = (om[n][r] + oc[n][r] * LO) * li;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    for (int q = lane; q < 32 * 16; q += 64) {
+        const int row = q >> 4, c4 = q & 15, grow = wave * 32 + row;
+        if (grow >= S) continue;
+        const float4 o = *reinterpret_cast<const float4 *>(ost + row * AM_OST + c4 * 4);
+        const int orow = cap * S + grow;
+        if (packed_out) x3_store_quad(packed_out, d >> 4, orow, head * 4 + (c4 >> 2), c4 & 3, o, fmt);
+        else reinterpret_cast<float4 *>(out + (size_t)orow * d + head * 64)[c4] = o;
     }
 }
 
@@ -544,17 +641,19 @@ int launch_attn_prefill(hipStream_t st, const float *qkv, const KvCache &c, int 
     CAPDEC_CHECK(c.hd == 64, "attention: head_dim must be 64");
     CAPDEC_CHECK(P <= ATT_CTX_MAX && P <= c.ctx, "attention: prefix longer than the supported context");
     (void)layer; (void)beam;                      // K / V come straight from qkv (the cache is filled by kv_scatter_prefill)
-    if (!c.bf16 && P >= ATT_LANES_MIN_P && ncap > 0) {
-        // lane-per-query form: the queries are cut into equal slices of at most 64 (77 tokens: 39 + 38 -- a causal
-        // slice reads only the keys up to its last query)
-        const int nslice = (P + 63) / 64, qps = (P + nslice - 1) / nslice;
-        const int total = ncap * c.heads * nslice;
+    if (!c.bf16 && P >= ATT_MFMA_MIN_P && P <= ATT_MFMA_MAX_P && ncap > 0) {
+        const int nqt = (P + 31) / 32;
+        const size_t lds = attn_mfma_lds_bytes(P);
+        if (lds > 64 * 1024) {      // (per launch, not latched: the limit is a property of the function on the CURRENT device)
+            CAPDEC_HIP(hipFuncSetAttribute(causal ? (const void *)attn_prefill_mfma_kernel<true> : (const void *)attn_prefill_mfma_kernel<false>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        }
         if (causal)
-            hipLaunchKernelGGL((attn_prefill_lanes_kernel<true>), dim3((total + 3) / 4), dim3(256), 0, st, qkv, total, c.heads, P,
-                               c.heads * c.hd, nslice, qps, out, (char *)packed_out, fmt);
+            hipLaunchKernelGGL((attn_prefill_mfma_kernel<true>), dim3(ncap * c.heads), dim3(64 * nqt), lds, st, qkv, c.heads, P,
+                               c.heads * c.hd, out, (char *)packed_out, fmt);
         else
-            hipLaunchKernelGGL((attn_prefill_lanes_kernel<false>), dim3((total + 3) / 4), dim3(256), 0, st, qkv, total, c.heads, P,
-                               c.heads * c.hd, nslice, qps, out, (char *)packed_out, fmt);
+            hipLaunchKernelGGL((attn_prefill_mfma_kernel<false>), dim3(ncap * c.heads), dim3(64 * nqt), lds, st, qkv, c.heads, P,
+                               c.heads * c.hd, out, (char *)packed_out, fmt);
         CAPDEC_HIP(hipGetLastError());
         return 0;
     }

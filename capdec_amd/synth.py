@@ -130,17 +130,21 @@ def hot_state_dict(seed: int = 42, mapping_type: str = "mlp", prefix_dim: int = 
     return sd
 
 
-def with_stop_row_scaled(sd, stop_id: int = 13, scale: float = 1.0, prefix: str = "gpt."):
-    """A shallow copy of a ClipCaptionModel state dict whose wte row ``stop_id`` (and with it the tied lm_head row) is
-    multiplied by ``scale``.  Under the hot-init law every vocabulary row is an i.i.d. Gaussian, so each of the 50 257 tokens
-    wins a step with probability ~1/V and NO single id ends captions early (bench.py's stop profile lists the best
-    candidates: mean length 43 of 67).  Scaling one row by s makes its logit N(0, s^2 sigma^2) against the maximum of
-    the others (~4.3 sigma): the stop token then wins a step with a probability the scale sets (s ~ 3: about 1 step in 11),
-    independently of the step -- caption lengths become geometric-like, the shape real COCO captions have around their
-    mean of ~11 tokens (reference gpt2_prefix_eval.py:107-109,187-188 end a caption at its stop token)."""
+def with_stop_bias(sd, stop_id: int = 13, alpha: float = 0.0, prefix: str = "gpt."):
+    """A shallow copy of a ClipCaptionModel state dict whose wte row ``stop_id`` (and with it the tied lm_head row) gets
+    ``alpha * b / (b . b)`` added, b = ln_f.bias: the stop token's logit (ln_f(h) . wte[stop]) rises by ``alpha`` at EVERY
+    step, whatever the hidden state (plus a zero-mean term ~0.36 alpha from the normalised part).  Under the hot-init law
+    every vocabulary row is an i.i.d. Gaussian, each of the 50 257 tokens wins a step with probability ~1/V and NO single
+    id ends captions early (bench.py's stop profile lists the best candidates: mean length 43 of 67); scaling the stop row
+    instead makes its logit follow the sign of one projection of the hidden state, which persists over a caption's steps
+    (half the captions stop at once, half never).  A constant offset gives every caption the same per-step chance that
+    the stop token beats the best of the others -- caption lengths spread around a mean the offset sets, the shape real
+    COCO captions have around their ~11 tokens (reference gpt2_prefix_eval.py:107-109,187-188 end a caption at its stop
+    token)."""
     out = OrderedDict(sd)
     w = sd[prefix + "transformer.wte.weight"].clone()
-    w[stop_id] *= float(scale)
+    b = sd[prefix + "transformer.ln_f.bias"].float()
+    w[stop_id] += float(alpha) * b / float(b @ b)
     out[prefix + "transformer.wte.weight"] = w
     if prefix + "lm_head.weight" in out:
         out[prefix + "lm_head.weight"] = w

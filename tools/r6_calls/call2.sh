@@ -1,5 +1,5 @@
 #!/bin/bash
-# Round 6, call 2: the lane-per-query prefill attention (CLIP towers, long prefixes) -- parity tests that run it, the
+# Round 6, call 2 (and 3, after the matrix-core rewrite): the prefill attention for 24..128 positions (CLIP towers, long prefixes) -- parity tests that run it, the
 # tower lines after the change, a kernel table of the text tower; the GPT-2-small train parity case; knob A/Bs for
 # review items 1a / 3a (split-K of the N = 768 projections off); the reworked stop profile.
 set -u
