@@ -451,7 +451,7 @@ inline size_t attn_mfma_lds_bytes(int S) {
     const size_t slab = (size_t)nqt * 32 * AM_OST * 4;
     return kv > slab ? kv : slab;
 }
-template <bool CAUSAL>
+template <bool CAUSAL, int NT>      // NT: key tiles the score registers are sized for (S <= 32 NT)
 __global__ __launch_bounds__(256) void attn_prefill_mfma_kernel(const float *__restrict__ qkv, int heads, int S, int d,
                                                                 float *__restrict__ out, char *__restrict__ packed_out, int fmt) {
     extern __shared__ __attribute__((aligned(16))) char am_smem[];
@@ -463,15 +463,32 @@ __global__ __launch_bounds__(256) void attn_prefill_mfma_kernel(const float *__r
     const int head = blockIdx.x % heads, cap = blockIdx.x / heads;
     const float *__restrict__ base = qkv + (size_t)cap * S * 3 * d + head * 64;
     constexpr float LO = 1.0f / H2_LO_SCALE;
-    // ---- stage K and V^T (rows past S: zeros -- a zero weight times a NaN would still poison the P x V accumulators)
-    for (int idx = tid; idx < Spad * 16; idx += blockDim.x) {
-        const int key = idx >> 4, q4 = idx & 15;
-        float4 kv = make_float4(0.f, 0.f, 0.f, 0.f), vv = kv;
-        if (key < S) {
-            const float *r = base + (size_t)key * 3 * d + q4 * 4;
-            kv = *reinterpret_cast<const float4 *>(r + d);
-            vv = *reinterpret_cast<const float4 *>(r + 2 * d);
+    // ---- every global load of the block is issued BEFORE the first one is used (the block is 64 nqt threads and the head
+    // Spad = 32 nqt keys of 16 quads: exactly eight (key, quad) items per thread, whatever S) -- the first version waited
+    // for each item's K / V pair in turn: eight dependent memory round trips per block, 19 us of a block's 20
+    const int i = wave * 32 + l32;                                        // this lane's query
+    float4 qa[4], qb[4], kx[8], vx[8];
+    {
+        const float *qr = base + (size_t)min(i, S - 1) * 3 * d + 8 * half;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            qa[s] = *reinterpret_cast<const float4 *>(qr + 16 * s);
+            qb[s] = *reinterpret_cast<const float4 *>(qr + 16 * s + 4);
         }
+    }
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+        const int idx = tid + it * (int)blockDim.x, key = idx >> 4, q4 = idx & 15;
+        const float *r = base + (size_t)min(key, S - 1) * 3 * d + q4 * 4;
+        kx[it] = *reinterpret_cast<const float4 *>(r + d);
+        vx[it] = *reinterpret_cast<const float4 *>(r + 2 * d);
+    }
+    // ---- stage K and V^T (rows past S: zeros -- a zero weight times a NaN would still poison the P x V accumulators)
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+        const int idx = tid + it * (int)blockDim.x, key = idx >> 4, q4 = idx & 15;
+        float4 kv = kx[it], vv = vx[it];
+        if (key >= S) { kv = make_float4(0.f, 0.f, 0.f, 0.f); vv = kv; }
         f16x4 kh, kl, vh, vl;
         split2h(kv, kh, kl);
         split2h(vv, vh, vl);
@@ -486,28 +503,24 @@ __global__ __launch_bounds__(256) void attn_prefill_mfma_kernel(const float *__r
         }
     }
     // ---- this wavefront's query fragments (B operand of the score product): row i, k = 16 s + 8 half .. + 7
-    const int i = wave * 32 + l32;
     f16x8 qh[4], ql[4];
-    {
-        const float *qr = base + (size_t)min(i, S - 1) * 3 * d + 8 * half;
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            float4 a = *reinterpret_cast<const float4 *>(qr + 16 * s), b = *reinterpret_cast<const float4 *>(qr + 16 * s + 4);
-            a.x *= ATT_QSCALE; a.y *= ATT_QSCALE; a.z *= ATT_QSCALE; a.w *= ATT_QSCALE;
-            b.x *= ATT_QSCALE; b.y *= ATT_QSCALE; b.z *= ATT_QSCALE; b.w *= ATT_QSCALE;
-            f16x4 h0, l0, h1, l1;
-            split2h(a, h0, l0);
-            split2h(b, h1, l1);
+    for (int s = 0; s < 4; ++s) {
+        float4 a = qa[s], b = qb[s];
+        a.x *= ATT_QSCALE; a.y *= ATT_QSCALE; a.z *= ATT_QSCALE; a.w *= ATT_QSCALE;
+        b.x *= ATT_QSCALE; b.y *= ATT_QSCALE; b.z *= ATT_QSCALE; b.w *= ATT_QSCALE;
+        f16x4 h0, l0, h1, l1;
+        split2h(a, h0, l0);
+        split2h(b, h1, l1);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) { qh[s][e] = h0[e]; qh[s][4 + e] = h1[e]; ql[s][e] = l0[e]; ql[s][4 + e] = l1[e]; }
-        }
+        for (int e = 0; e < 4; ++e) { qh[s][e] = h0[e]; qh[s][4 + e] = h1[e]; ql[s][e] = l0[e]; ql[s][4 + e] = l1[e]; }
     }
     __syncthreads();
     // ---- scores^T = K Q^T, tile by tile; sc[t][r]: query i, key 32 t + (r & 3) + 8 (r >> 2) + 4 half
     const int nt = CAUSAL ? wave + 1 : nqt;
-    float sc[4][16];
+    float sc[NT][16];
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
+    for (int t = 0; t < NT; ++t) {
         if (t < nt) {
             f32x16a am, ac;
 #pragma unroll
@@ -535,13 +548,13 @@ __global__ __launch_bounds__(256) void attn_prefill_mfma_kernel(const float *__r
     // ---- softmax over the row: this lane's registers and the partner lane's (key 0 is visible to every query: finite max)
     float m = -INFINITY;
 #pragma unroll
-    for (int t = 0; t < 4; ++t)
+    for (int t = 0; t < NT; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) m = fmaxf(m, sc[t][r]);
     m = fmaxf(m, __shfl_xor(m, 32, 64));
     float lsum = 0.f;
 #pragma unroll
-    for (int t = 0; t < 4; ++t)
+    for (int t = 0; t < NT; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const float p = att_exp2(sc[t][r] - m);
@@ -557,7 +570,7 @@ __global__ __launch_bounds__(256) void attn_prefill_mfma_kernel(const float *__r
 #pragma unroll
         for (int r = 0; r < 16; ++r) { om[n][r] = 0.f; oc[n][r] = 0.f; }
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
+    for (int t = 0; t < NT; ++t) {
         if (t < nt) {
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
@@ -644,16 +657,24 @@ int launch_attn_prefill(hipStream_t st, const float *qkv, const KvCache &c, int 
     if (!c.bf16 && P >= ATT_MFMA_MIN_P && P <= ATT_MFMA_MAX_P && ncap > 0) {
         const int nqt = (P + 31) / 32;
         const size_t lds = attn_mfma_lds_bytes(P);
-        if (lds > 64 * 1024) {      // (per launch, not latched: the limit is a property of the function on the CURRENT device)
-            CAPDEC_HIP(hipFuncSetAttribute(causal ? (const void *)attn_prefill_mfma_kernel<true> : (const void *)attn_prefill_mfma_kernel<false>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        }
-        if (causal)
-            hipLaunchKernelGGL((attn_prefill_mfma_kernel<true>), dim3(ncap * c.heads), dim3(64 * nqt), lds, st, qkv, c.heads, P,
-                               c.heads * c.hd, out, (char *)packed_out, fmt);
-        else
-            hipLaunchKernelGGL((attn_prefill_mfma_kernel<false>), dim3(ncap * c.heads), dim3(64 * nqt), lds, st, qkv, c.heads, P,
-                               c.heads * c.hd, out, (char *)packed_out, fmt);
+#define LAUNCH_AM(CZ, NTV)                                                                                          \
+    {                                                                                                               \
+        if (lds > 64 * 1024)      /* (per launch, not latched: the limit belongs to the function on the CURRENT device) */ \
+            CAPDEC_HIP(hipFuncSetAttribute((const void *)attn_prefill_mfma_kernel<CZ, NTV>,                         \
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                  \
+        hipLaunchKernelGGL((attn_prefill_mfma_kernel<CZ, NTV>), dim3(ncap * c.heads), dim3(64 * nqt), lds, st, qkv,  \
+                           c.heads, P, c.heads * c.hd, out, (char *)packed_out, fmt);                                \
+    }
+#define LAUNCH_AM_NT(CZ)                                                                                            \
+    switch (nqt) {                                                                                                  \
+        case 1: LAUNCH_AM(CZ, 1) break;                                                                             \
+        case 2: LAUNCH_AM(CZ, 2) break;                                                                             \
+        case 3: LAUNCH_AM(CZ, 3) break;                                                                             \
+        default: LAUNCH_AM(CZ, 4) break;                                                                            \
+    }
+        if (causal) { LAUNCH_AM_NT(true) } else { LAUNCH_AM_NT(false) }
+#undef LAUNCH_AM_NT
+#undef LAUNCH_AM
         CAPDEC_HIP(hipGetLastError());
         return 0;
     }

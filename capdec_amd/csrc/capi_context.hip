@@ -68,7 +68,7 @@ bool tuning_from_env(Tuning *t, std::string *err) {
         const int v = t->h2w;
         bool ok = v == 0 || v == 1 || v == 2 || v == 8 || v == 10 || v == 14;
 #ifdef CAPDEC_MEASURE
-        ok = ok || v == 3 || v == 6 || v == 11 || v == 12 || v == 13;
+        ok = ok || v == 3 || v == 6 || v == 12;
 #endif
         if (!ok) {
             *err = "create: CAPDEC_H2W=" + std::to_string(v) + " is not a geometry of this build (0, 1, 2, 8, 10, 14)";

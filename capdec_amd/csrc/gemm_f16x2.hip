@@ -434,7 +434,7 @@ int launch_gemm_f16x2p(hipStream_t st, const void *Apacked, const void *Bpacked,
     if (vec4 && !epi.invariant) {
         const bool can_split = epi.splitk_ws && !epi.resid_packed && !epi.packed_out && !sc.kc;
         int which = 0;
-        if (tn.h2w >= 10) which = (tn.h2w == 10 || tn.h2w == 11 || epi.wide_ok) ? tn.h2w : 0;
+        if (tn.h2w >= 10) which = (tn.h2w == 10 || epi.wide_ok) ? tn.h2w : 0;
         else if (tn.h2w == 1 && tn.pp && M > 4 * GEMM_BM) which = pp_plan(M, N, K, epi.wide_ok, can_split, tn.pp);
         if (which) return launch_gemm_pp(st, which, Apacked, Bpacked, C, ldc, M, N, K, epi, 1.0f / H2_LO_SCALE);
     }

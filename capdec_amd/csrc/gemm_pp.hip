@@ -330,8 +330,8 @@ using P256x192s = PGeo<4, 2, 2, 3, 4, false>;     // 8 waves x (64 x 96), ONE ac
 // (2 x 128 + fragments > the 256 a wavefront has at two per SIMD) or 256 KB of LDS to park them: out of the product build
 // since round 5 (profiles/r4_gemm_pp.txt, docs/rounds.md)
 using P256x256s = PGeo<2, 4, 4, 2, 4, false>;     // 8 waves x (128 x 64), ONE accumulator set (weights with max |w| < 16), 128 KB
-using P256x128s = PGeo<4, 2, 2, 2, 5, false>;     // measured: no faster than the two-set form (profiles/r4_gemm_pp.txt)
-using P128x256s = PGeo<2, 4, 2, 2, 5, false>;
+// (round 6: the one-set 256 x 128 and the 128 x 256 forms -- measured no faster than the two-set 256 x 128 tile in round 4,
+//  never planned -- are gone from the measurement build too)
 #endif
 
 int pp_splitk_slices(int which, int M, int N, int K);
@@ -465,7 +465,7 @@ int pp_plan(int M, int N, int K, bool wide_ok, bool can_split, int mode) {
     return 0;
 }
 
-// `which`: 10 = 256x128 (two accumulator sets), 14 = 256x192 (one set: wide_ok weights); measurement builds: 11, 12 (256x256), 13.
+// `which`: 10 = 256x128 (two accumulator sets), 14 = 256x192 (one set: wide_ok weights); measurement builds: 12 (256x256).
 // scale = 2^-11 (single-set geometries; ignored by the two-set ones).  Requires the float4 epilogue (caller checks).
 int launch_gemm_pp(hipStream_t st, int which, const void *Apacked, const void *Bpacked, float *C, int ldc, int M, int N,
                    int K, const GemmEpilogue &epi, float scale) {
@@ -479,8 +479,6 @@ int launch_gemm_pp(hipStream_t st, int which, const void *Apacked, const void *B
         case 14: return launch_pp<P256x192s>(st, Apacked, Bpacked, C, ldc, M, N, K, epi, scale, S);
 #ifdef CAPDEC_MEASURE
         case 12: return launch_pp<P256x256s>(st, Apacked, Bpacked, C, ldc, M, N, K, epi, scale, S);
-        case 11: return launch_pp<P256x128s>(st, Apacked, Bpacked, C, ldc, M, N, K, epi, scale, 1);
-        case 13: return launch_pp<P128x256s>(st, Apacked, Bpacked, C, ldc, M, N, K, epi, scale, 1);
 #endif
         default: CAPDEC_CHECK(false, "gemm_pp: unknown geometry");
     }
