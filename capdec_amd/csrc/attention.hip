@@ -451,8 +451,11 @@ inline size_t attn_mfma_lds_bytes(int S) {
     const size_t slab = (size_t)nqt * 32 * AM_OST * 4;
     return kv > slab ? kv : slab;
 }
+// (__launch_bounds__(256, 3): <= 168 registers, so that three of the 77-token tower's 192-thread blocks -- 3 x 54 KB of LDS --
+//  share a CU; left alone the compiler takes 194-258 registers: two blocks per CU, or ONE wavefront per SIMD for the
+//  non-causal forms)
 template <bool CAUSAL, int NT>      // NT: key tiles the score registers are sized for (S <= 32 NT)
-__global__ __launch_bounds__(256) void attn_prefill_mfma_kernel(const float *__restrict__ qkv, int heads, int S, int d,
+__global__ __launch_bounds__(256, 3) void attn_prefill_mfma_kernel(const float *__restrict__ qkv, int heads, int S, int d,
                                                                 float *__restrict__ out, char *__restrict__ packed_out, int fmt) {
     extern __shared__ __attribute__((aligned(16))) char am_smem[];
     typedef float f32x16a __attribute__((ext_vector_type(16)));

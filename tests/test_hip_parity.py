@@ -1524,6 +1524,46 @@ def test_finished_caption_compaction(monkeypatch):
     np.testing.assert_array_equal(outs["1"][2], outs["0"][2])          # scores bit-identical with and without compaction
 
 
+def test_captions_that_stop_at_the_headline_size():
+    """The headline batch (5000 captions x beam 5 = 25 000-row launches, GPT-2 small, TransformerMapper) on weights whose
+    captions STOP (synth.with_stop_bias: a constant on the stop token's logit; mean best-beam length ~11 tokens, a long
+    tail): finished captions leave the batch at the poll points -- every step while a step is >= 8192 rows, then every
+    2 / 4 / 8 -- so the launches shrink through every GEMM / attention / lm_head variant on the way down.  24 captions
+    spread over the batch against the oracle (tokens, lengths, scores; numerical ties counted), compaction on against off
+    (capdec_set_compact), the per-step row counts (capdec_decode_step_rows) against what the results say was still alive."""
+    from capdec_amd import gpt2_prefix_eval as E
+    from capdec_amd.predictions_runner import prefix_from_embeddings
+    dims, n, T_ = synth.GPT2_SMALL, 5000, 67
+    sd = synth.with_stop_bias(synth.hot_state_dict(42, "transformer_encoder", 512, 10), 13, 33.0)
+    model, _ = _model(dims, "transformer_encoder", 512, seed=42)
+    model.load_state_dict(sd)
+    emb = synth.synthetic_clip_embeddings(n, 512, seed=0, normalize=False)
+    pe = prefix_from_embeddings(model, emb)
+    eng = model.engine
+    eng.set_compact(True)
+    i, l, s_, o = E.decode_beam_ids(model, pe, 13, 5, T_)
+    st, rows = eng.decode_stats(), eng.decode_step_rows()
+    lens = l.cpu().numpy()
+    assert 6.0 < float(lens[:, 0].mean()) < 20.0 and int((lens[:, 0] == T_).sum()) >= 1, float(lens[:, 0].mean())
+    assert len(rows) == st["steps"] - 1 and sum(rows) == st["row_steps"] and rows[0] == n * 5
+    assert all(a >= b for a, b in zip(rows, rows[1:])) and rows[-1] < n * 5 // 4 and st["compactions"] >= 6, (rows, st)
+    done_at = lens.max(axis=1)                                  # the step after which every beam of a caption has stopped
+    for k, r in enumerate(rows):                                # never fewer rows than captions still generating
+        assert r >= int((done_at > k + 1).sum()) * 5, (k, r)
+    assert st["row_steps"] < 1.35 * sum(int((done_at > k + 1).sum()) * 5 for k in range(len(rows))), st
+    pick = list(range(0, n, n // 24))[:24]
+    got = tuple(t.cpu().numpy() for t in (i, l, s_, o))
+    ok, ties = _beam_rows_vs_oracle(got, sd, pe.cpu(), pick, 13, T_, dims.n_head, "captions that stop: 24 of 5000 x beam 5")
+    assert ok >= len(pick) - ties
+    eng.set_compact(False)
+    i2, l2, s2, _ = E.decode_beam_ids(model, pe[:1200], 13, 5, T_)
+    eng.set_compact(True)
+    assert eng.decode_stats()["compactions"] == 0 and len(set(eng.decode_step_rows())) == 1
+    i1, l1, s1, _ = E.decode_beam_ids(model, pe[:1200], 13, 5, T_)
+    same = ((i1 == i2).flatten(1).all(1) & (l1 == l2).all(1)).float().mean()
+    assert float(same) >= 0.99, float(same)          # (other launch sizes: a numerical tie may flip; everything else is identical)
+
+
 def test_capi_rccl_communicator_single_rank():
     """SURVEY section 8 B': capdec_comm_unique_id / capdec_comm_init / capdec_gather_rows / capdec_gather_ids over RCCL
     itself (dlopen'ed librccl, no torch.distributed): a one-rank communicator on the one GPU of this box -- ncclAllGather
