@@ -697,7 +697,8 @@ def test_train_step_on_the_native_fp32_gemm_and_the_wavefront_attention():
     """CAPDEC_TRAIN_F16X2=0 puts the backward GEMMs of the train step on the native fp32 MFMA kernel (the default is the
     fp32-accurate two-fp16-plane family) and CAPDEC_TRAIN_ATTN_BLK=0 its attention on the per-query wavefront kernels (the
     fallback of sequences beyond 128 positions; the default is one block per (sample, head)): the same goldens -- frozen
-    scope with both mappers, full scope with and without dropout -- in a child process with both knobs"""
+    scope with both mappers, full scope with and without dropout, the GPT-2-small-geometry case -- in a child process with
+    both knobs"""
     import subprocess
     import sys
     env = dict(os.environ, CAPDEC_TRAIN_F16X2="0", CAPDEC_TRAIN_ATTN_BLK="0")
@@ -705,7 +706,7 @@ def test_train_step_on_the_native_fp32_gemm_and_the_wavefront_attention():
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-m", "gpu", "-k", sel,
                         "-p", "no:cacheprovider"], env=env, capture_output=True, text=True, timeout=900)
     tail = r.stdout[-1500:]
-    assert r.returncode == 0 and "4 passed" in tail and "failed" not in tail, tail
+    assert r.returncode == 0 and "5 passed" in tail and "failed" not in tail, tail
 
 
 def test_train_loop_with_validation_pass(tmp_path):

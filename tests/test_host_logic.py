@@ -937,3 +937,30 @@ def test_train_step_facade_scope_and_dropout_decisions_without_a_device():
     bad[0, 0] = synth.GPT2_TINY.vocab
     with pytest.raises(IndexError):
         Tr.train_step(full, opt, bad, None, prefix)
+
+
+def test_stop_bias_variant_of_the_synthetic_weights_ends_captions():
+    """synth.with_stop_bias (bench.py's stop profile, the headline-size stop test): only the stop row changes, the tied
+    lm_head follows, the stop token's logit rises by ~alpha at every position, and under the oracle's greedy decode the
+    captions of the tiny geometry end (they never do on the unmodified weights, whose stop id is never emitted)"""
+    from oracle import capdec_oracle as O
+    dims = synth.GPT2_TINY
+    sd0 = synth.hot_state_dict(42, "mlp", 512, 10, dims=dims)
+    sd1 = synth.with_stop_bias(sd0, 13, 20.0)
+    w0, w1 = sd0["gpt.transformer.wte.weight"], sd1["gpt.transformer.wte.weight"]
+    assert sd1["gpt.lm_head.weight"] is w1 and torch.equal(w0[:13], w1[:13]) and torch.equal(w0[14:], w1[14:])
+    b = sd0["gpt.transformer.ln_f.bias"]
+    assert abs(float((w1[13] - w0[13]) @ b) - 20.0) < 1e-3
+    assert all(sd1[k] is sd0[k] for k in sd0 if k not in ("gpt.transformer.wte.weight", "gpt.lm_head.weight"))
+    x = synth.synthetic_clip_embeddings(6, 512, seed=0)
+    pe = O.clip_project(O.normalize_prefix(x), sd0, "mlp", 10)
+    d = O.gpt2_logits(pe, sd1, dims.n_head)[:, :, 13] - O.gpt2_logits(pe, sd0, dims.n_head)[:, :, 13]
+    assert 10.0 < float(d.mean()) < 30.0 and float(d.min()) > 0.0
+    _, l0 = O.greedy_cached(sd0, pe, stop_id=13, entry_length=24, alt_stop_id=-1, n_head=dims.n_head)
+    assert int(l0.min()) == 24
+    lens = None
+    for alpha in (8.0, 16.0, 32.0, 64.0, 128.0):          # (the offset that ends captions depends on the geometry's logit scale)
+        _, lens = O.greedy_cached(synth.with_stop_bias(sd0, 13, alpha), pe, stop_id=13, entry_length=24, alt_stop_id=-1, n_head=dims.n_head)
+        if float(lens.float().mean()) < 12.0:
+            break
+    assert float(lens.float().mean()) < 12.0
