@@ -42,7 +42,7 @@ PEAK_BF16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA (not the 
 # back-to-back MFMAs sustains 1650 TFLOP/s (profiles/r3_mfma_power_ceiling.txt, tools/probes/mfma_energy.hip; zeros: 2451)
 F16_MFMA_AT_POWER_CAP_TFLOPS = 1650.0
 STOP_ID, D_EMB = 13, 768
-PMC_TRAFFIC_FILE = "r5_pmc_traffic.json"   # rocprofv3 --pmc summary the `roofline.traffic` field is read from
+PMC_TRAFFIC_FILE = "r6_pmc_traffic.json"   # rocprofv3 --pmc summary the `roofline.traffic` field is read from
 
 
 def algorithmic_flops_per_caption(P, T, beam, mapper, dims=synth.GPT2_SMALL, D=512, clip_len=10):
@@ -477,6 +477,62 @@ def side_workload(args, world, rank, dev, emit=print):
                                      "gemm_mode": model.engine.gemm_mode()}}))
 
 
+def other_configs(args, dev, note):
+    """BASELINE.json's other configurations next to the metric line (N = 1; `other_configs` of the record): configs[1]
+    (5000 greedy captions, MLP mapper, bf16 operands + bf16 KV cache), configs[3] (CLIP ViT-B/32 encode_text + noise + MLP
+    mapper, 20 000 captions, fp16 towers) and configs[4] (ViT-B/32 encode_image + TransformerMapper + beam 5, 2014 images) --
+    two timed passes each, inputs resident, a `roofline` of each tower's dominant kernel family; their own full lines (more
+    passes, cpu_baseline) come from `bench.py --workload ...`.  Failures are recorded, never raised."""
+    import copy
+    from capdec_amd.gpt2_prefix import ClipCaptionModel, MappingType
+    from capdec_amd.predictions_runner import caption_ids
+    res = {}
+    for name, over in (("configs[3] text_embed f16", dict(workload="text_embed", captions=20000, gemm_mode="f16")),
+                       ("configs[4] image_beam vit_b32", dict(workload="image_beam", captions=2014, gemm_mode=None, clip="vit_b32"))):
+        try:
+            note("other configs: " + name)
+            a = copy.copy(args)
+            a.steps, a.warmup, a.cpu_seconds, a.profile_every = 2, 1, 0.0, 1
+            for k, v in over.items():
+                setattr(a, k, v)
+            got = []
+            side_workload(a, 1, 0, dev, got.append)
+            r = json.loads(got[-1])
+            res[name] = {k: r[k] for k in ("value", "unit", "ms_per_step", "steps", "dtype", "roofline", "config")}
+        except Exception as ex:
+            res[name] = {"error": str(ex)[:300]}
+        torch.cuda.empty_cache()
+    try:
+        note("other configs: configs[1] greedy_mlp bf16")
+        P, T = args.prefix_length, args.entry_length
+        m = ClipCaptionModel(P, clip_length=10, prefix_dim=512, num_layers=8, mapping_type=MappingType.MLP).to(dev).eval()
+        m.load_state_dict(synth.hot_state_dict(42, "mlp", 512, P))
+        m.engine.set_gemm_mode("bf16")
+        e = synth.synthetic_clip_embeddings(5000, 512, seed=0, normalize=False).to(dev)
+        caption_ids(m, e, STOP_ID, beam=False, entry_length=T)
+        m.engine.profile_enable(7)
+        m.engine.profile_reset()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            caption_ids(m, e, STOP_ID, beam=False, entry_length=T)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / 3
+        pf = m.engine.profile_get()
+        m.engine.profile_enable(False)
+        g = pf.get("gemm_x1")
+        ach = g["flops"] / g["ms"] * 1e-9 if g and g["ms"] > 0 else None
+        res["configs[1] greedy_mlp bf16"] = {
+            "value": round(5000 / dt, 1), "unit": "captions/s", "ms_per_step": round(dt * 1e3, 2), "steps": 3,
+            "dtype": "bf16 (GEMM operands and KV cache bf16, fp32 accumulate)",
+            "roofline": {"bound": "mfma", "kernel": "gemm_x1", "achieved": round(ach, 1) if ach else None, "peak": PEAK_BF16_MFMA_TFLOPS,
+                         "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_MFMA_TFLOPS, 4) if ach else None, "traffic": None},
+            "config": {"workload": "greedy_mlp", "captions_per_step": 5000, "gemm_mode": "bf16"}}
+    except Exception as ex:
+        res["configs[1] greedy_mlp bf16"] = {"error": str(ex)[:300]}
+    return res
+
+
 def train_workload(args, world, rank, dev, emit=print):
     """Side workload: the train step (reference train.py:344-354) at the reference's default geometry -- batch 34
     (train.py:411), prefix_length = prefix_length_clip = 40, TransformerMapper with 8 layers on 640-d (RN50x4) embeddings,
@@ -730,6 +786,8 @@ def main():
                          "captions stop -- a stop id chosen so that the mean caption length is ~11 tokens; captions/s with "
                          "finished-caption compaction on / off, rows per step, shard imbalance, an oracle check (`stop_profile`); "
                          "and the entry_length = 12 point SURVEY D.2 asks for (`entry_length_12`).  none: skip both")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="N = 1, default workload: skip the short runs of BASELINE configs[1], [3], [4] that fill `other_configs`")
     ap.add_argument("--no-smi", action="store_true", help="do not sample rocm-smi (clock / power) during the timed region")
     ap.add_argument("--rank-timeout", type=float, default=1500.0,
                     help="N > 1: a rank still running after this many seconds prints the phase it is stuck in and exits "
@@ -1130,6 +1188,12 @@ def main():
         if power and power.get("sclk_mhz"):
             # the dominant kernel against the peak AT THE CLOCK THE CHIP ACTUALLY HELD (it runs at its package power cap)
             rec["roofline"]["frac_at_measured_clock"] = round(achieved / (peak * power["sclk_mhz"] / 2400.0), 4)
+        if world == 1 and beam and not args.no_checks and not args.no_other_configs and args.captions == 5000 and not args.gemm_mode:
+            try:
+                model.release()                 # (the 140 GB KV cache of the metric's batch: the towers get the whole device)
+                rec["other_configs"] = other_configs(args, dev, note)
+            except Exception as ex:
+                rec["other_configs"] = {"error": str(ex)[:300]}
         note("cpu baseline")
         if args.cpu_captions is None:      # not given: whole captions by default, nothing at all with --cpu-seconds 0
             args.cpu_captions = 8 if args.cpu_seconds > 0 else 0

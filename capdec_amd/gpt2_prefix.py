@@ -100,6 +100,16 @@ class _HipModule:
             self._dirty = True
         return self
 
+    def release(self):
+        """drop this module's device context -- weights, KV cache, workspaces (the decode of 5000 captions x beam 5 holds
+        140 GB) -- keeping the host copy: the next use creates a context and uploads the weights again"""
+        if self._engine is not None:
+            self._before_engine_close()
+            self._engine.close()
+            self._engine = None
+        self._dirty = True
+        return self
+
     @property
     def engine(self) -> Engine:
         if self._engine is None:
