@@ -330,21 +330,26 @@ static int decode_chunk(capdec_ctx *c, const float *prefix, int nc, int P, int b
     // ---- steps 1..T-1: one token per row per step.  Finished captions (stop token on every beam) are dropped from
     // the batch at the poll points: `cmap` lists the captions still generating, the activations of a step are the
     // na * beam rows of those captions only, while KV cache / ancestor table / beam state keep their original rows.
-    // Poll cadence: a poll drains the stream (one 4-byte copy + a synchronisation: the GPU idles for the ~20-50 us the host
-    // needs to refill the queue); a step of >= 8192 rows takes >= 8 ms, one of ~3000 rows ~4 ms -- there the poll is < 1 % and
-    // every step that still carries finished captions costs more (round 6, captions that stop after ~11 tokens: 25 000 rows
-    // launched for 8 steps while 40 % of them had finished; 519 k row-steps against 427 k alive).  Small launches keep the
-    // sparse cadence: their steps are launch-bound and a drained queue shows.
-    int na = nc, next_poll = 1;
+    // Poll cadence: a poll drains the stream (a 4-byte copy + a synchronisation: ~150 us of idle GPU by the time the host has
+    // woken up and refilled the queue).  While captions ARE finishing a poll pays for itself -- every step that still carries
+    // finished captions costs more: a step of >= 8192 rows takes >= 8 ms, one of ~3000 rows ~4 ms (round 6, captions that
+    // stop after ~11 tokens: with a poll every 8 steps 25 000 rows were launched for 8 steps while 40 % of them had
+    // finished; 519 k row-steps against 427 k alive) -- so the base interval is 1 step at >= 8192 rows, 2 at >= 2048, 4 at
+    // >= 512, 8 below.  While NOTHING finishes (the synthetic headline weights never emit the stop id) every poll is pure
+    // loss: each poll that finds no finished caption doubles the interval (up to 8), the first one that does resets it.
+    int na = nc, next_poll = 1, backoff = 1, last_alive = nc;
     const int *cmap = nullptr;
     CAPDEC_TRY(c->cmap.ensure(((size_t)nc + 1) * 4));
     for (int i = 1; i < T; ++i) {
         if (i >= next_poll) {
-            const int rows_now = na * beam;
-            next_poll = i + (rows_now >= 8192 ? 1 : rows_now >= 2048 ? 2 : rows_now >= 512 ? 4 : 8);
             int alive = 0;
             CAPDEC_TRY(poll_alive(c, &alive));
             if (alive == 0) break;
+            const int rows_now = alive * beam;
+            const int base = rows_now >= 8192 ? 1 : rows_now >= 2048 ? 2 : rows_now >= 512 ? 4 : 8;
+            backoff = alive < last_alive ? 1 : std::min(8, backoff * 2);
+            last_alive = alive;
+            next_poll = i + std::min(8, std::max(base, backoff));
             if (c->compact && alive <= na - std::max(1, na / 32)) {
                 ProfScope ps(c, F_SELECT);
                 CAPDEC_TRY(launch_compact_alive(c->stream, c->done.as<uint8_t>(), nc, c->cmap.as<int>(),
