@@ -337,7 +337,7 @@ static int decode_chunk(capdec_ctx *c, const float *prefix, int nc, int P, int b
     // finished; 519 k row-steps against 427 k alive) -- so the base interval is 1 step at >= 8192 rows, 2 at >= 2048, 4 at
     // >= 512, 8 below.  While NOTHING finishes (the synthetic headline weights never emit the stop id) every poll is pure
     // loss: each poll that finds no finished caption doubles the interval (up to 8), the first one that does resets it.
-    int na = nc, next_poll = 1, backoff = 1, last_alive = nc;
+    int na = nc, next_poll = 1, backoff = 1, last_alive = nc + 1;      // (+ 1: the first poll never backs off)
     const int *cmap = nullptr;
     CAPDEC_TRY(c->cmap.ensure(((size_t)nc + 1) * 4));
     for (int i = 1; i < T; ++i) {
