@@ -10,8 +10,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB_DIR = os.path.join(HERE, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libcapdec_hip.so")
-SOURCES = ["capi_context.hip", "weights.hip", "gemm_dispatch.hip", "decode.hip", "train.hip", "clip.hip", "comm.hip", "gemm_f32.hip", "gemm_bf16x3.hip", "gemm_f16x2.hip", "gemm_h2w.hip", "gemm_pp.hip", "elementwise.hip", "attention.hip", "resnet.hip", "select.hip", "preprocess.hip"]
-HEADERS = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "config.h"), os.path.join(CSRC, "context.h"), os.path.join(CSRC, "gemm_epilogue.h"), os.path.join(CSRC, "gemm_epilogue_w.h"), os.path.join(CSRC, "gemm_epilogue_lds.h"), os.path.join(CSRC, "bf16x3.h"), os.path.join(os.path.dirname(HERE), "include", "capdec.h")]
+SOURCES = ["capi_context.hip", "weights.hip", "gemm_dispatch.hip", "decode.hip", "train_step.hip", "train_mapper.hip", "train_ops.hip", "train_optim.hip", "clip.hip", "comm.hip", "gemm_f32.hip", "gemm_bf16x3.hip", "gemm_f16x2.hip", "gemm_h2w.hip", "gemm_pp.hip", "elementwise.hip", "attention.hip", "resnet.hip", "select.hip", "preprocess.hip"]
+HEADERS = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "config.h"), os.path.join(CSRC, "context.h"), os.path.join(CSRC, "train.h"), os.path.join(CSRC, "gemm_epilogue.h"), os.path.join(CSRC, "gemm_epilogue_w.h"), os.path.join(CSRC, "gemm_epilogue_lds.h"), os.path.join(CSRC, "bf16x3.h"), os.path.join(os.path.dirname(HERE), "include", "capdec.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 # measurement variant (-DCAPDEC_MEASURE: ablations that compute wrong results on purpose, ring-depth / occupancy overrides,
 # per-block phase stamps, the diverged-beam hook): tools/ and bench.py's untimed tail load it explicitly; the product path

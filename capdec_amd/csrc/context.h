@@ -4,6 +4,7 @@
 //   weights.hip       capdec_load_* (uploads; Conv1D transposes; BatchNorm folding)
 //   gemm_dispatch.hip the GEMM planner: operand planes cache, which kernel / split for a projection, capdec_gemm_f32
 //   decode.hip        the pre-LN block stack, fused lm_head + selection, the KV-cached greedy / beam decode loop, mapper
+//   train_*.hip       the train step (train.h): step, mapping networks, shared backward pieces, optimizer + C entry points
 //   clip.hip          CLIP ViT-B/32 towers, the ModifiedResNet tower, image preprocessing
 //   comm.hip          caption-shard bounds and the RCCL all-gather (librccl dlopen'ed)
 #pragma once
@@ -123,7 +124,7 @@ struct Prof {
 
 using namespace capdec;
 
-namespace capdec { struct TrainState; }      // train.hip: saved activations, gradients, AdamW moments of the train step
+namespace capdec { struct TrainState; }      // train.h: saved activations, gradients, AdamW moments of the train step
 struct capdec_ctx {
     capdec::Tuning tune;            // the environment knobs, parsed once by capdec_create (config.h)
     int device = 0;
@@ -205,7 +206,7 @@ struct ProfScope {
 };
 int prof_collect(capdec_ctx *c);
 
-// ---- train.hip
+// ---- train_optim.hip (the train step: train.h)
 void train_release(capdec_ctx *c);      // frees the train-step state (a mapper / GPT-2 reload invalidates it)
 
 // ---- comm.hip
@@ -220,7 +221,7 @@ void free_all(std::vector<void *> &owned);
 
 // ---- gemm_dispatch.hip: the planner
 void drop_planes(capdec_ctx *c);
-void drop_planes_of(capdec_ctx *c, const void *weight);      // one cached weight (its values changed: train.hip)
+void drop_planes_of(capdec_ctx *c, const void *weight);      // one cached weight (its values changed: train_optim.hip)
 int pack_fmt(const capdec_ctx *c);
 inline bool mode_single(const capdec_ctx *c) { return c->gemm_mode == GEMM_BF16 || c->gemm_mode == GEMM_F16; }
 int pack_any(capdec_ctx *c, const float *W, int N, int K, int fmt, void *out);

@@ -79,7 +79,7 @@ int launch_pack_planes_h2(hipStream_t st, const float *w, int ldw, int N, int K,
 // Mt [cols][Kp] (Mt[n][k] = src[k][n]; k >= rows zero-filled up to Kp, a multiple of 64; rows n >= cols of the last 128-row
 // tile zero) -- the operands of a weight-gradient product dW = dY^T X, whose K runs over the ROWS of dY and X.  One block
 // per 64 x 64 tile: rows read coalesced, transposed through LDS, every thread splits one (n, k-step) = 16 consecutive k.
-// (Replaces a transpose_pad launch -- fp32 written and read back -- in front of the packer, train.hip.)
+// (Replaces a transpose_pad launch -- fp32 written and read back -- in front of the packer, train_ops.hip.)
 __global__ __launch_bounds__(256) void pack_planes_h2_t_kernel(const float *__restrict__ src, int ld, int rows, int cols,
                                                                _Float16 *__restrict__ out, int nk) {
     __shared__ float tile[64][65];

@@ -183,6 +183,23 @@ def test_gpt2_logits_small(eng, golden):
     _check_logits(eng, golden("gpt2_logits_small"), synth.GPT2_SMALL)
 
 
+def test_gpt2_logits_every_prefill_attention_form_vs_oracle(eng):
+    """capdec_gpt2_logits over sequence lengths that take every form of the prefill attention: the per-row wavefront kernel
+    (L = 10, 23; and L = 160, beyond the matrix-core kernel's four key tiles) and the matrix-core kernel with one to four
+    key tiles (L = 24, 33, 64, 65, 96, 97, 128 -- the last ones need more than 64 KB of dynamic LDS), ragged batch of 3;
+    causal masking across tile borders; every position's logits against the oracle"""
+    from oracle import capdec_oracle as O
+    dims = synth.GPT2Dims(n_layer=2, vocab=1531, n_pos=256)
+    sd = synth.hot_gpt2_state_dict(42, dims)
+    eng.load_gpt2(sd)
+    gen = torch.Generator().manual_seed(5)
+    for L in (10, 23, 24, 33, 64, 65, 96, 97, 128, 160):
+        x = torch.randn(3, L, dims.n_embd, generator=gen) * 0.6
+        got = eng.gpt2_logits(x, all_positions=True).cpu()
+        want = O.gpt2_logits(x, sd, dims.n_head)
+        np.testing.assert_allclose(got.numpy(), want.numpy(), atol=3e-4, err_msg=f"L = {L}")
+
+
 def test_wte_lookup(eng):
     sd = synth.hot_gpt2_state_dict(42, synth.GPT2_TINY)
     eng.load_gpt2(sd)
