@@ -77,7 +77,7 @@ __device__ __forceinline__ float att_exp2(float x) { return __builtin_amdgcn_exp
 // the converged case is latency-bound (5.4 TB/s; the diverged tail with its 2 BEAM loads per lane reaches 5.8-6.2).
 // Every lane reads back exactly the 16 bytes it asked for (LDS image = lane order): the LDS is a landing buffer, not a
 // sharing stage -- each key / value is still used by one wavefront only.
-template <int BEAM, typename KV, int OCC, int NA = 2, bool CUR = false, bool DMA = false, int RING = 2>
+template <int BEAM, typename KV, int OCC, int NA = 2, bool CUR = false, bool DMA = false>
 __global__ __launch_bounds__(256, OCC) void attn_decode_beams_kernel(const float *__restrict__ qkv, KV *__restrict__ kc,
                                                                 KV *__restrict__ vc, int total, int heads,
                                                                 int ctx, int d, int L,
@@ -212,13 +212,11 @@ __global__ __launch_bounds__(256, OCC) void attn_decode_beams_kernel(const float
         typedef __attribute__((address_space(3))) void lds_void_a;
         typedef const __attribute__((address_space(1))) void glb_void_a;
         constexpr int BUF = 2 * NA * 1024;                        // one iteration: NA K pieces + NA V pieces of 1 KB
-        // RING buffers of one iteration each (2: round 3; 3 -- CAPDEC_ATT_RING=3 -- keeps TWO iterations in flight per wavefront
-        // while a third is reduced, for 12 instead of 8 KB of LDS per wavefront: three blocks per CU instead of four)
-        char *ring = reinterpret_cast<char *>(sl_all) + ring_off + __builtin_amdgcn_readfirstlane(wave) * (RING * BUF);
+        char *ring = reinterpret_cast<char *>(sl_all) + ring_off + __builtin_amdgcn_readfirstlane(wave) * (2 * BUF);
         const int n_it = (nconv - npe + 4 * NA - 1) / (4 * NA);
-#define ATT_ISSUE(it_, slot_)                                                                                   \
+#define ATT_ISSUE(it_)                                                                                          \
         {                                                                                                       \
-            char *dst = ring + (slot_) * BUF;                                                                   \
+            char *dst = ring + ((it_) & 1) * BUF;                                                               \
             _Pragma("unroll") for (int j = 0; j < NA; ++j) {                                                    \
                 const int pj = npe + (it_) * 4 * NA + 4 * j + grp;                                              \
                 const bool v = pj < nconv;                                                                      \
@@ -227,18 +225,12 @@ __global__ __launch_bounds__(256, OCC) void attn_decode_beams_kernel(const float
                 __builtin_amdgcn_global_load_lds((glb_void_a *)(v ? vbase + o : dummy), (lds_void_a *)(dst + (NA + j) * 1024), 16, 0, 0);      \
             }                                                                                                   \
         }
-#pragma unroll
-        for (int r = 0; r < RING - 1; ++r)
-            if (r < n_it) ATT_ISSUE(r, r)
-        int rd = 0, wr = RING - 1;                                 // ring slots of iteration it / it + RING - 1
+        if (n_it > 0) ATT_ISSUE(0)
         for (int it = 0; it < n_it; ++it) {
-            if (it + RING - 1 < n_it) {
-                ATT_ISSUE(it + RING - 1, wr)
+            if (it + 1 < n_it) {
+                ATT_ISSUE(it + 1)
                 asm volatile("" ::: "memory");
-                __builtin_amdgcn_s_waitcnt(0x0F70 | ((RING - 1) * 2 * NA));    // this iteration's pieces have landed
-            } else if (RING == 3 && it + 1 < n_it) {
-                asm volatile("" ::: "memory");
-                __builtin_amdgcn_s_waitcnt(0x0F70 | (2 * NA));
+                __builtin_amdgcn_s_waitcnt(0x0F70 | (2 * NA));    // vmcnt(2 NA): this iteration's pieces have landed
             } else {
                 asm volatile("" ::: "memory");
                 __builtin_amdgcn_s_waitcnt(0x0F70);               // vmcnt(0)
@@ -248,7 +240,7 @@ __global__ __launch_bounds__(256, OCC) void attn_decode_beams_kernel(const float
             // pass cannot tell which LDS-DMA it may alias and waits vmcnt(0) -- the very drain the double buffer avoids
             static_assert(NA == 2, "the LDS-DMA variant reads two K and two V pieces per iteration");
             typedef float f4v __attribute__((ext_vector_type(4)));
-            const unsigned laddr = (unsigned)(uintptr_t)(ring + rd * BUF + lane * 16);
+            const unsigned laddr = (unsigned)(uintptr_t)(ring + (it & 1) * BUF + lane * 16);
             f4v k0, k1, v0, v1;
             asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:1024\n\tds_read_b128 %2, %4 offset:2048\n\t"
                          "ds_read_b128 %3, %4 offset:3072\n\ts_waitcnt lgkmcnt(0)"
@@ -269,9 +261,7 @@ __global__ __launch_bounds__(256, OCC) void attn_decode_beams_kernel(const float
                 }
                 ATT_UPDATE(b, NA, sv, vv)
             }
-            asm volatile("" ::: "memory");                        // (the buffer is re-filled by a later ATT_ISSUE)
-            rd = rd + 1 == RING ? 0 : rd + 1;
-            wr = wr + 1 == RING ? 0 : wr + 1;
+            asm volatile("" ::: "memory");                        // (the buffer is re-filled by the next ATT_ISSUE)
         }
 #undef ATT_ISSUE
     } else
@@ -738,12 +728,10 @@ static int attn_decode_typed(hipStream_t st, const float *qkv, const KvCache &c,
                        c.heads, c.ctx, c.heads * c.hd, L, anc, anc_stride, out, (char *)packed_out, cmap, fmt, npre, wsync ? 0 : -1)
     // (LDS-DMA variant: NA = 2 for every launch size -- with its double buffer 16 positions per group are in flight, what
     //  NA = 4 gives the register-landed loop, and 38 KB of LDS per block still lets four blocks share a CU)
-#define LAUNCH_BEAMS_DMA_R(B, OCC, RG)                                                                          \
-    hipLaunchKernelGGL((attn_decode_beams_kernel<B, float, OCC, 2, true, true, RG>), grid, block, lds + 4 * RG * (2 * 2 * 1024), st, \
+#define LAUNCH_BEAMS_DMA(B, OCC)                                                                                \
+    hipLaunchKernelGGL((attn_decode_beams_kernel<B, float, OCC, 2, true, true>), grid, block, lds + 4 * 2 * (2 * 2 * 1024), st, \
                        qkv, (float *)kl, (float *)vl, total, c.heads, c.ctx, c.heads * c.hd, L, anc, anc_stride, out,  \
                        (char *)packed_out, cmap, fmt, npre, (int)lds)
-#define LAUNCH_BEAMS_DMA(B, OCC)                                                                                \
-    if (tn.att_ring == 3) LAUNCH_BEAMS_DMA_R(B, OCC, 3); else LAUNCH_BEAMS_DMA_R(B, OCC, 2)
 #define LAUNCH_BEAMS(B, OCC)                                                                                    \
     if (cur_cached && (B == 1 || B == 5)) {       /* (the widths the decode drivers use most: greedy and beam 5) */ \
         if (dma_on && sizeof(KV) == 4) LAUNCH_BEAMS_DMA(B, OCC);    /* (the LDS-DMA ring is laid out for fp32 keys) */  \
@@ -763,7 +751,6 @@ static int attn_decode_typed(hipStream_t st, const float *qkv, const KvCache &c,
         }
 #undef LAUNCH_BEAMS
 #undef LAUNCH_BEAMS_DMA
-#undef LAUNCH_BEAMS_DMA_R
 #undef LAUNCH_BEAMS_V
         CAPDEC_HIP(hipGetLastError());
         return 0;
