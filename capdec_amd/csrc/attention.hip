@@ -3,7 +3,7 @@
 // GPT-2 decode / prefill: head_dim 64.  One wavefront per (row, head).  The wavefront is four
 // 16-lane groups; a group owns one key position per iteration and its 16 lanes each hold a
 // float4 of the 64-wide head (so a key is one 256-byte coalesced read), dot products are
-// reduced with 4 xor-shuffles, the softmax over <= 256 positions with 64-lane shuffles.
+// reduced with 4 xor-shuffles, the softmax over <= 1024 positions with 64-lane shuffles.
 // The KV cache is [layer][phys_row][head][ctx][64]: consecutive positions of a head are
 // contiguous.  Beam search never copies K/V: row r reads position p from physical row
 // caption*beam + anc[r][p] (ancestor table maintained by the beam-step kernel).
@@ -14,7 +14,11 @@
 
 namespace capdec {
 
-constexpr int ATT_CTX_MAX = 256;
+constexpr int ATT_CTX_MAX = 1024;    // GPT-2's n_positions (contexts beyond ~400 positions need more than 64 KB of LDS per block for
+                                     // the slot table / the score rows: the launchers raise the kernel's limit per launch, fewer blocks share a CU)
+#define ATT_BIG_LDS(K, bytes)                                                                                   \
+    if ((bytes) > 64 * 1024)                                                                                    \
+    CAPDEC_HIP(hipFuncSetAttribute((const void *)(K), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(bytes)))
 constexpr int ATT_MFMA_MIN_P = 24;   // prefill sequences of 24 .. 128 positions take the matrix-core kernel (shorter ones -- the
 constexpr int ATT_MFMA_MAX_P = 128;  // 10-token caption prefix -- would leave most of a 32 x 32 tile empty; longer ones keep the
                                      // per-row kernel: the score registers of a lane are sized for four key tiles)
@@ -685,6 +689,9 @@ int launch_attn_prefill(hipStream_t st, const float *qkv, const KvCache &c, int 
     const int total = ncap * c.heads * ((P + R - 1) / R);
     if (total <= 0) return 0;
     const size_t lds = (size_t)4 * R * P * sizeof(float);
+    CAPDEC_CHECK(lds <= 160 * 1024, "attention: prefix too long for the score rows in LDS");
+    ATT_BIG_LDS((attn_prefill_rows_kernel<R, __bf16>), lds);
+    ATT_BIG_LDS((attn_prefill_rows_kernel<R, float>), lds);
     if (c.bf16)     // the keys / values this pass attends to are the bf16-rounded ones the cache will hold
         hipLaunchKernelGGL((attn_prefill_rows_kernel<R, __bf16>), dim3((total + 3) / 4), dim3(256), lds, st, qkv, total,
                            c.heads, P, c.heads * c.hd, causal ? 1 : 0, out, (char *)packed_out, fmt);
@@ -713,6 +720,7 @@ static int attn_decode_typed(hipStream_t st, const float *qkv, const KvCache &c,
         const int ncap = rows / beam, total = ncap * c.heads;
         if (total <= 0) return 0;
         size_t lds = ((size_t)4 * beam * L * sizeof(int) + 1023) & ~(size_t)1023;   // ancestor slots (the DMA ring, if any, follows)
+        CAPDEC_CHECK(lds + 32 * 1024 <= 160 * 1024, "attention: context too long for the slot table in LDS");
         const int wsync = tn.att_wsync;
         const int dma_on = tn.att_dma && wsync;
         dim3 grid((total + 3) / 4), block(256);
@@ -724,26 +732,28 @@ static int attn_decode_typed(hipStream_t st, const float *qkv, const KvCache &c,
         const int na_env = tn.att_na;
         const int na4 = na_env ? (na_env == 4) : (!c.fixed_variant && total <= 16384);
 #define LAUNCH_BEAMS_V(B, OCC, NAV, CURV)                                                                       \
+    ATT_BIG_LDS((attn_decode_beams_kernel<B, KV, OCC, NAV, CURV, false>), lds);                                    \
     hipLaunchKernelGGL((attn_decode_beams_kernel<B, KV, OCC, NAV, CURV, false>), grid, block, lds, st, qkv, kl, vl, total, \
                        c.heads, c.ctx, c.heads * c.hd, L, anc, anc_stride, out, (char *)packed_out, cmap, fmt, npre, wsync ? 0 : -1)
     // (LDS-DMA variant: NA = 2 for every launch size -- with its double buffer 16 positions per group are in flight, what
     //  NA = 4 gives the register-landed loop, and 38 KB of LDS per block still lets four blocks share a CU)
 #define LAUNCH_BEAMS_DMA(B, OCC)                                                                                \
+    ATT_BIG_LDS((attn_decode_beams_kernel<B, float, OCC, 2, true, true>), lds + 4 * 2 * (2 * 2 * 1024));          \
     hipLaunchKernelGGL((attn_decode_beams_kernel<B, float, OCC, 2, true, true>), grid, block, lds + 4 * 2 * (2 * 2 * 1024), st, \
                        qkv, (float *)kl, (float *)vl, total, c.heads, c.ctx, c.heads * c.hd, L, anc, anc_stride, out,  \
                        (char *)packed_out, cmap, fmt, npre, (int)lds)
 #define LAUNCH_BEAMS(B, OCC)                                                                                    \
     if (cur_cached && (B == 1 || B == 5)) {       /* (the widths the decode drivers use most: greedy and beam 5) */ \
-        if (dma_on && sizeof(KV) == 4) LAUNCH_BEAMS_DMA(B, OCC);    /* (the LDS-DMA ring is laid out for fp32 keys) */  \
-        else if (na4) LAUNCH_BEAMS_V(B, OCC, 4, true); else LAUNCH_BEAMS_V(B, OCC, 2, true);                     \
-    } else if (na4 && B <= 5) LAUNCH_BEAMS_V(B, OCC, 4, false);                                                 \
-    else LAUNCH_BEAMS_V(B, OCC, 2, false)
+        if (dma_on && sizeof(KV) == 4) { LAUNCH_BEAMS_DMA(B, OCC); }    /* (the LDS-DMA ring is laid out for fp32 keys) */  \
+        else if (na4) { LAUNCH_BEAMS_V(B, OCC, 4, true); } else { LAUNCH_BEAMS_V(B, OCC, 2, true); }             \
+    } else if (na4 && B <= 5) { LAUNCH_BEAMS_V(B, OCC, 4, false); }                                             \
+    else { LAUNCH_BEAMS_V(B, OCC, 2, false); }
         switch (beam) {
             case 1: LAUNCH_BEAMS(1, 4); break;      // greedy: the same single-pass kernel with one row per caption
             case 2: LAUNCH_BEAMS(2, 4); break;
             case 3: LAUNCH_BEAMS(3, 4); break;
             case 4: LAUNCH_BEAMS(4, 4); break;
-            case 5: if (occ5 == 3) LAUNCH_BEAMS(5, 3); else LAUNCH_BEAMS(5, 4); break;
+            case 5: if (occ5 == 3) { LAUNCH_BEAMS(5, 3); } else { LAUNCH_BEAMS(5, 4); } break;
             case 6: LAUNCH_BEAMS(6, 2); break;
             case 7: LAUNCH_BEAMS(7, 2); break;
             case 8: LAUNCH_BEAMS(8, 2); break;

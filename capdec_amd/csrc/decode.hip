@@ -404,7 +404,7 @@ static int decode_common(capdec_ctx *c, const float *prefix, int n, int P, int b
     CAPDEC_CHECK(c && c->gpt.loaded, "decode: GPT-2 weights not loaded");
     CAPDEC_CHECK(n >= 0 && P >= 1 && T >= 1, "decode: bad sizes");
     CAPDEC_CHECK(P + T - 1 <= c->gpt.n_pos, "decode: prefix + entry_length exceeds n_positions");
-    CAPDEC_CHECK(P + T - 1 <= 256 && T <= 128, "decode: context > 256 or entry_length > 128 not supported");
+    CAPDEC_CHECK(P + T - 1 <= 1024 && T <= 1024, "decode: context or entry_length > 1024 not supported");
     CAPDEC_CHECK(beam >= 1 && beam <= 8, "decode: beam size must be in 1..8");
     CAPDEC_CHECK(c->gpt.d / c->gpt.n_head == 64, "decode: head_dim must be 64");
     CAPDEC_HIP(hipSetDevice(c->device));
@@ -519,7 +519,7 @@ int capdec_mapper_forward(capdec_ctx *c, const float *x, int n, float *out) {
 
 int capdec_gpt2_logits(capdec_ctx *c, const float *embeds, int n, int L, int all_positions, float *logits) {
     CAPDEC_CHECK(c && c->gpt.loaded, "gpt2_logits: GPT-2 weights not loaded");
-    CAPDEC_CHECK(embeds && logits && n >= 1 && L >= 1 && L <= 256 && L <= c->gpt.n_pos, "gpt2_logits: bad argument");
+    CAPDEC_CHECK(embeds && logits && n >= 1 && L >= 1 && L <= 1024 && L <= c->gpt.n_pos, "gpt2_logits: bad argument");
     CAPDEC_HIP(hipSetDevice(c->device));
     const Gpt2 &g = c->gpt;
     const int d = g.d;

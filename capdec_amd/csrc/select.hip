@@ -5,8 +5,9 @@
 
 namespace capdec {
 
-constexpr int SEL_T_MAX = 128;     // max entry_length
-constexpr int SEL_CTX_MAX = 256;   // max context (prefix + generated)
+constexpr int SEL_T_MAX = 1024;    // max entry_length
+constexpr int SEL_CTX_MAX = 1024;  // max context (prefix + generated): GPT-2's n_positions, the reference's only limit
+                                   // (the beam step stages beam x (T ints + ctx bytes) of state in dynamic LDS: <= 40 KB)
 constexpr int SEL_BEAM_MAX = 8;
 
 __device__ __forceinline__ bool better(float v, int i, float bv, int bi) { return v > bv || (v == bv && i < bi); }
@@ -316,8 +317,9 @@ __global__ __launch_bounds__(64) void beam_step_kernel(BeamState s, const float 
                                                        const int *__restrict__ top_idx, int ncap, int beam, int k,
                                                        int T, int ctx, int step, int pos_cur, int vocab,
                                                        int stop_id, const int *__restrict__ cmap) {
-    __shared__ int tok_old[SEL_BEAM_MAX * SEL_T_MAX];
-    __shared__ uint8_t anc_old[SEL_BEAM_MAX * SEL_CTX_MAX];
+    extern __shared__ int sel_dyn[];                            // [beam][T] token history, then [beam][ctx] ancestor bytes
+    int *tok_old = sel_dyn;
+    uint8_t *anc_old = reinterpret_cast<uint8_t *>(sel_dyn + beam * T);
     __shared__ int w_src[SEL_BEAM_MAX], w_tok[SEL_BEAM_MAX];
     __shared__ float w_key[SEL_BEAM_MAX], seq_new[SEL_BEAM_MAX];
     __shared__ uint8_t st_old[SEL_BEAM_MAX];
@@ -329,11 +331,11 @@ __global__ __launch_bounds__(64) void beam_step_kernel(BeamState s, const float 
     // stage the state that is permuted in place
     for (int i = lane; i < beam * step; i += 64) {
         const int b = i / step, t = i - b * step;
-        tok_old[b * SEL_T_MAX + t] = s.tokens[(cb0 + b) * T + t];
+        tok_old[b * T + t] = s.tokens[(cb0 + b) * T + t];
     }
     for (int i = lane; i < beam * pos_cur; i += 64) {
         const int b = i / pos_cur, p = i - b * pos_cur;
-        anc_old[b * SEL_CTX_MAX + p] = s.anc[(cb0 + b) * ctx + p];
+        anc_old[b * ctx + p] = s.anc[(cb0 + b) * ctx + p];
     }
     if (lane < beam) {
         const bool stp = s.stopped[cb0 + lane];
@@ -387,18 +389,18 @@ __global__ __launch_bounds__(64) void beam_step_kernel(BeamState s, const float 
     }
     for (int i = lane; i < beam * step; i += 64) {
         const int b = i / step, t = i - b * step;
-        s.tokens[(cb0 + b) * T + t] = tok_old[w_src[b] * SEL_T_MAX + t];
+        s.tokens[(cb0 + b) * T + t] = tok_old[w_src[b] * T + t];
     }
     for (int i = lane; i < beam * (pos_cur + 1); i += 64) {
         const int b = i / (pos_cur + 1), p = i - b * (pos_cur + 1);
-        s.anc[(cb0 + b) * ctx + p] = (p < pos_cur) ? anc_old[w_src[b] * SEL_CTX_MAX + p] : (uint8_t)w_src[b];
+        s.anc[(cb0 + b) * ctx + p] = (p < pos_cur) ? anc_old[w_src[b] * ctx + p] : (uint8_t)w_src[b];
     }
     if (s.kv_stat) {     // distinct slots the NEXT step's attention reads at each of its pos_cur + 1 cached positions
         int cnt = 0;
         for (int p = lane; p <= pos_cur; p += 64) {
             unsigned seen = 0;
             for (int b = 0; b < beam; ++b)
-                seen |= 1u << ((p < pos_cur) ? anc_old[w_src[b] * SEL_CTX_MAX + p] : (uint8_t)w_src[b]);
+                seen |= 1u << ((p < pos_cur) ? anc_old[w_src[b] * ctx + p] : (uint8_t)w_src[b]);
             cnt += __popc(seen);
         }
 #pragma unroll
@@ -419,7 +421,8 @@ int launch_beam_step(hipStream_t st, const BeamState &s, const float *lse, const
     CAPDEC_CHECK(T <= SEL_T_MAX && ctx <= SEL_CTX_MAX, "beam: entry_length / context too long");
     CAPDEC_CHECK((long long)beam * vocab < 0x7fffffffLL, "beam: beam*vocab overflows int");
     if (ncap <= 0) return 0;
-    hipLaunchKernelGGL(beam_step_kernel, dim3(ncap), dim3(64), 0, st, s, lse, top_val, top_idx, ncap, beam, k, T, ctx,
+    const size_t lds = (size_t)beam * T * sizeof(int) + (((size_t)beam * ctx + 3) & ~(size_t)3);
+    hipLaunchKernelGGL(beam_step_kernel, dim3(ncap), dim3(64), lds, st, s, lse, top_val, top_idx, ncap, beam, k, T, ctx,
                        step, pos_cur, vocab, stop_id, cmap);
     CAPDEC_HIP(hipGetLastError());
     return 0;

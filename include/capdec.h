@@ -319,7 +319,8 @@ int capdec_decode_greedy_forced(capdec_ctx *ctx, const float *d_prefix, int n, i
 
 /* Limits of the decode entry points (the reference has none, gpt2_prefix_eval.py:50-51,118-129; each is checked and
  * reported through capdec_last_error): beam size 1..8; head_dim = 64 (GPT-2 / CLIP ViT-B/32); context prefix_length +
- * entry_length - 1 <= 256 and <= n_positions; entry_length <= 128; n_embd a multiple of 32, <= 1024.  In the default
+ * entry_length - 1 <= n_positions (<= 1024, GPT-2's own limit; beyond ~400 positions the attention's per-block tables need
+ * most of a CU's LDS and run at lower occupancy); n_embd a multiple of 32, <= 1024.  In the default
  * f16x2 GEMM mode GEMM inputs are clamped to +-65504 (fp16's range; LayerNorm / attention / GELU outputs and weights
  * are orders of magnitude below it). */
 
