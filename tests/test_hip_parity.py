@@ -1750,8 +1750,8 @@ def test_full_size_properties():
 def test_contexts_up_to_gpt2_n_positions_vs_oracle():
     """The reference's only context limit is GPT-2's n_positions = 1024 (gpt2_prefix_eval.py:50-51,118-129 take any prefix and
     entry_length); until round 6 this library stopped at 256 / 128.  A prefix of 600 positions (prefill: the score rows of
-    eight queries need 77 KB of LDS per block) and 200 decode steps (context 799: the decode attention's slot table of beam 3
-    x 799 positions x four wavefronts, the beam step's history of 3 x 200 tokens + 3 x 799 ancestor bytes), greedy and beam 3,
+    eight queries need 77 KB of LDS per block) and 120 decode steps (context 719: the decode attention's slot table of beam 3
+    x 719 positions x four wavefronts, the beam step's history of 3 x 120 tokens + 3 x 719 ancestor bytes), greedy and beam 3,
     against the oracle; plus capdec_gpt2_logits at 700 positions."""
     from capdec_amd import gpt2_prefix_eval as E
     from capdec_amd.gpt2_prefix import ClipCaptionModel, MappingType
@@ -1762,12 +1762,12 @@ def test_contexts_up_to_gpt2_n_positions_vs_oracle():
     model.load_state_dict(sd)
     gen = torch.Generator().manual_seed(2)
     pe = torch.randn(2, 600, 768, generator=gen) * 0.5
-    ids_o, lens_o = O.greedy_cached(sd, pe, stop_id=10 ** 6, entry_length=200, alt_stop_id=-1, n_head=dims.n_head)
-    ids, lens = E.decode_greedy_ids(model, pe, 10 ** 6, 200, alt_stop_id=-1)
+    ids_o, lens_o = O.greedy_cached(sd, pe, stop_id=10 ** 6, entry_length=120, alt_stop_id=-1, n_head=dims.n_head)
+    ids, lens = E.decode_greedy_ids(model, pe, 10 ** 6, 120, alt_stop_id=-1)
     np.testing.assert_array_equal(ids.cpu().numpy(), ids_o.numpy())
-    tok_o, seq_o, sc_o = O.beam_cached(sd, pe, 3, 10 ** 6, 200, n_head=dims.n_head)
+    tok_o, seq_o, sc_o = O.beam_cached(sd, pe, 3, 10 ** 6, 120, n_head=dims.n_head)
     od = O.beam_output_order(sc_o)
-    bi, bl, bs, bo = E.decode_beam_ids(model, pe, 10 ** 6, 3, 200)
+    bi, bl, bs, bo = E.decode_beam_ids(model, pe, 10 ** 6, 3, 120)
     for r in range(2):
         np.testing.assert_array_equal(bi[r].cpu().numpy(), tok_o[r][od[r]].numpy())
         np.testing.assert_allclose(bs[r].cpu().numpy(), sc_o[r][od[r]].numpy(), atol=1e-4)
