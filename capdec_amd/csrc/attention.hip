@@ -447,25 +447,37 @@ __global__ __launch_bounds__(256) void attn_prefill_rows_kernel(const float *__r
 //   stored in.  out tile = P x V lands row = query, column = dimension; it goes through a per-wavefront LDS slab (the K / V
 //   area, after a block barrier) so that rows leave as whole 16-byte quads: fp32 or the packed A operand of c_proj.
 //   Causal rows never touch key tiles above their own (wavefront w computes w + 1 of them).
+// one fp16 plane (RNE), clamped to fp16's range and counted like every 16-bit GEMM operand of this library
+__device__ __forceinline__ f16x4 round1h(const float4 v) {
+    (void)h2_clamp_count(v);
+    f16x4 h;
+    h[0] = (_Float16)h2_clamp(v.x); h[1] = (_Float16)h2_clamp(v.y); h[2] = (_Float16)h2_clamp(v.z); h[3] = (_Float16)h2_clamp(v.w);
+    return h;
+}
 constexpr int AM_KST = 72;      // halfs per staged K row (64 + 8: 144 bytes)
 constexpr int AM_OST = 68;      // floats per row of the output slab (64 + 4)
-inline size_t attn_mfma_lds_bytes(int S) {
+inline size_t attn_mfma_lds_bytes(int S, int planes) {
     const int nqt = (S + 31) / 32, Spad = nqt * 32;
-    const size_t kv = (size_t)2 * Spad * AM_KST * 2 + (size_t)2 * 64 * (Spad + 8) * 2;
+    const size_t kv = (size_t)planes * Spad * AM_KST * 2 + (size_t)planes * 64 * (Spad + 8) * 2;
     const size_t slab = (size_t)nqt * 32 * AM_OST * 4;
     return kv > slab ? kv : slab;
 }
 // (__launch_bounds__(256, 3): <= 168 registers, so that three of the 77-token tower's 192-thread blocks -- 3 x 54 KB of LDS --
 //  share a CU; left alone the compiler takes 194-258 registers: two blocks per CU, or ONE wavefront per SIMD for the
 //  non-causal forms)
-template <bool CAUSAL, int NT>      // NT: key tiles the score registers are sized for (S <= 32 NT)
+// SPLIT = false (the towers' fp16 / bf16 precision modes, where every GEMM operand of the block stack is 16 bits already):
+// ONE fp16 plane per operand of the two attention products -- q, k, v and the un-normalised softmax weights rounded to fp16
+// (RNE, clamped to +-65504), one MFMA per product: the arithmetic class of the reference's CLIP on a GPU; half the LDS, a
+// third of the MFMAs and -- what matters: the kernel is bound by its VALU conversions -- less than half the conversion work.
+template <bool CAUSAL, int NT, bool SPLIT>      // NT: key tiles the score registers are sized for (S <= 32 NT)
 __global__ __launch_bounds__(256, 3) void attn_prefill_mfma_kernel(const float *__restrict__ qkv, int heads, int S, int d,
                                                                 float *__restrict__ out, char *__restrict__ packed_out, int fmt) {
     extern __shared__ __attribute__((aligned(16))) char am_smem[];
     typedef float f32x16a __attribute__((ext_vector_type(16)));
     const int nqt = (S + 31) >> 5, Spad = nqt * 32, VST = Spad + 8;       // VST: halfs per V^T row
-    _Float16 *Kp = reinterpret_cast<_Float16 *>(am_smem);                 // [2 planes][Spad][AM_KST]
-    _Float16 *Vt = Kp + (size_t)2 * Spad * AM_KST;                        // [2 planes][64][VST]
+    constexpr int NPL = SPLIT ? 2 : 1;
+    _Float16 *Kp = reinterpret_cast<_Float16 *>(am_smem);                 // [NPL planes][Spad][AM_KST]
+    _Float16 *Vt = Kp + (size_t)NPL * Spad * AM_KST;                      // [NPL planes][64][VST]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l32 = lane & 31, half = lane >> 5;
     const int head = blockIdx.x % heads, cap = blockIdx.x / heads;
     const float *__restrict__ base = qkv + (size_t)cap * S * 3 * d + head * 64;
@@ -497,16 +509,16 @@ __global__ __launch_bounds__(256, 3) void attn_prefill_mfma_kernel(const float *
         float4 kv = kx[it], vv = vx[it];
         if (key >= S) { kv = make_float4(0.f, 0.f, 0.f, 0.f); vv = kv; }
         f16x4 kh, kl, vh, vl;
-        split2h(kv, kh, kl);
-        split2h(vv, vh, vl);
+        if constexpr (SPLIT) { split2h(kv, kh, kl); split2h(vv, vh, vl); }
+        else { kh = round1h(kv); vh = round1h(vv); }
         *reinterpret_cast<f16x4 *>(Kp + (size_t)key * AM_KST + q4 * 4) = kh;
-        *reinterpret_cast<f16x4 *>(Kp + (size_t)(Spad + key) * AM_KST + q4 * 4) = kl;
+        if constexpr (SPLIT) *reinterpret_cast<f16x4 *>(Kp + (size_t)(Spad + key) * AM_KST + q4 * 4) = kl;
         const int w = key & 15;
         const int pos = (key & ~15) + 8 * ((w >> 2) & 1) + (w & 3) + 4 * (w >> 3);
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             Vt[(size_t)(q4 * 4 + u) * VST + pos] = vh[u];
-            Vt[(size_t)(64 + q4 * 4 + u) * VST + pos] = vl[u];
+            if constexpr (SPLIT) Vt[(size_t)(64 + q4 * 4 + u) * VST + pos] = vl[u];
         }
     }
     // ---- this wavefront's query fragments (B operand of the score product): row i, k = 16 s + 8 half .. + 7
@@ -517,8 +529,8 @@ __global__ __launch_bounds__(256, 3) void attn_prefill_mfma_kernel(const float *
         a.x *= ATT_QSCALE; a.y *= ATT_QSCALE; a.z *= ATT_QSCALE; a.w *= ATT_QSCALE;
         b.x *= ATT_QSCALE; b.y *= ATT_QSCALE; b.z *= ATT_QSCALE; b.w *= ATT_QSCALE;
         f16x4 h0, l0, h1, l1;
-        split2h(a, h0, l0);
-        split2h(b, h1, l1);
+        if constexpr (SPLIT) { split2h(a, h0, l0); split2h(b, h1, l1); }
+        else { h0 = round1h(a); h1 = round1h(b); l0 = h0; l1 = h1; }
 #pragma unroll
         for (int e = 0; e < 4; ++e) { qh[s][e] = h0[e]; qh[s][4 + e] = h1[e]; ql[s][e] = l0[e]; ql[s][4 + e] = l1[e]; }
     }
@@ -536,16 +548,19 @@ __global__ __launch_bounds__(256, 3) void attn_prefill_mfma_kernel(const float *
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
                 const f16x8 kh = *reinterpret_cast<const f16x8 *>(kr + 16 * s);
-                const f16x8 kl = *reinterpret_cast<const f16x8 *>(kr + (size_t)Spad * AM_KST + 16 * s);
-                ac = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl, qh[s], ac, 0, 0, 0);
-                am = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, qh[s], am, 0, 0, 0);
-                ac = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, ql[s], ac, 0, 0, 0);
+                if constexpr (SPLIT) {
+                    const f16x8 kl = *reinterpret_cast<const f16x8 *>(kr + (size_t)Spad * AM_KST + 16 * s);
+                    ac = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl, qh[s], ac, 0, 0, 0);
+                    am = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, qh[s], am, 0, 0, 0);
+                    ac = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, ql[s], ac, 0, 0, 0);
+                } else
+                    am = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, qh[s], am, 0, 0, 0);
             }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int key = 32 * t + (r & 3) + 8 * (r >> 2) + 4 * half;
                 const bool vis = key < S && (!CAUSAL || key <= i);
-                sc[t][r] = vis ? am[r] + ac[r] * LO : -INFINITY;
+                sc[t][r] = vis ? (SPLIT ? am[r] + ac[r] * LO : am[r]) : -INFINITY;
             }
         } else {
 #pragma unroll
@@ -585,18 +600,24 @@ __global__ __launch_bounds__(256, 3) void attn_prefill_mfma_kernel(const float *
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
                     const float p = sc[t][8 * s2 + e];                     // 0 <= p <= 1
-                    const _Float16 hh = p < 0x1p-14f ? (_Float16)0.f : (_Float16)p;
-                    ph[e] = hh;
-                    pl[e] = (_Float16)((p - (float)hh) * H2_LO_SCALE);
+                    if constexpr (SPLIT) {
+                        const _Float16 hh = p < 0x1p-14f ? (_Float16)0.f : (_Float16)p;
+                        ph[e] = hh;
+                        pl[e] = (_Float16)((p - (float)hh) * H2_LO_SCALE);
+                    } else
+                        ph[e] = (_Float16)p;
                 }
 #pragma unroll
                 for (int n = 0; n < 2; ++n) {
                     const _Float16 *vr = Vt + (size_t)(32 * n + l32) * VST + 32 * t + 16 * s2 + 8 * half;
                     const f16x8 vh = *reinterpret_cast<const f16x8 *>(vr);
-                    const f16x8 vl = *reinterpret_cast<const f16x8 *>(vr + (size_t)64 * VST);
-                    oc[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(pl, vh, oc[n], 0, 0, 0);
-                    om[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ph, vh, om[n], 0, 0, 0);
-                    oc[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ph, vl, oc[n], 0, 0, 0);
+                    if constexpr (SPLIT) {
+                        const f16x8 vl = *reinterpret_cast<const f16x8 *>(vr + (size_t)64 * VST);
+                        oc[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(pl, vh, oc[n], 0, 0, 0);
+                        om[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ph, vh, om[n], 0, 0, 0);
+                        oc[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ph, vl, oc[n], 0, 0, 0);
+                    } else
+                        om[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ph, vh, om[n], 0, 0, 0);
                 }
             }
         }
@@ -609,7 +630,7 @@ __global__ __launch_bounds__(256, 3) void attn_prefill_mfma_kernel(const float *
         const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
         const float li = __shfl(linv, row, 64);        // lane `row` holds the sum of query 32 w + row
 #pragma unroll
-        for (int n = 0; n < 2; ++n) ost[row * AM_OST + 32 * n + l32] = (om[n][r] + oc[n][r] * LO) * li;
+        for (int n = 0; n < 2; ++n) ost[row * AM_OST + 32 * n + l32] = (SPLIT ? om[n][r] + oc[n][r] * LO : om[n][r]) * li;
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -663,14 +684,20 @@ int launch_attn_prefill(hipStream_t st, const float *qkv, const KvCache &c, int 
     (void)layer; (void)beam;                      // K / V come straight from qkv (the cache is filled by kv_scatter_prefill)
     if (!c.bf16 && P >= ATT_MFMA_MIN_P && P <= ATT_MFMA_MAX_P && ncap > 0) {
         const int nqt = (P + 31) / 32;
-        const size_t lds = attn_mfma_lds_bytes(P);
+        // one fp16 plane per operand in the towers' 16-bit precision modes, two (fp32-accurate) otherwise
+        const bool split = !(fmt == PK_F16X1 || fmt == PK_BF16X1);
+        const size_t lds = attn_mfma_lds_bytes(P, split ? 2 : 1);
 #define LAUNCH_AM(CZ, NTV)                                                                                          \
     {                                                                                                               \
         if (lds > 64 * 1024)      /* (per launch, not latched: the limit belongs to the function on the CURRENT device) */ \
-            CAPDEC_HIP(hipFuncSetAttribute((const void *)attn_prefill_mfma_kernel<CZ, NTV>,                         \
+            CAPDEC_HIP(hipFuncSetAttribute((const void *)attn_prefill_mfma_kernel<CZ, NTV, true>,                   \
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                  \
-        hipLaunchKernelGGL((attn_prefill_mfma_kernel<CZ, NTV>), dim3(ncap * c.heads), dim3(64 * nqt), lds, st, qkv,  \
-                           c.heads, P, c.heads * c.hd, out, (char *)packed_out, fmt);                                \
+        if (split)                                                                                                  \
+            hipLaunchKernelGGL((attn_prefill_mfma_kernel<CZ, NTV, true>), dim3(ncap * c.heads), dim3(64 * nqt), lds, st, qkv, \
+                               c.heads, P, c.heads * c.hd, out, (char *)packed_out, fmt);                            \
+        else                                                                                                        \
+            hipLaunchKernelGGL((attn_prefill_mfma_kernel<CZ, NTV, false>), dim3(ncap * c.heads), dim3(64 * nqt), lds, st, qkv, \
+                               c.heads, P, c.heads * c.hd, out, (char *)packed_out, fmt);                            \
     }
 #define LAUNCH_AM_NT(CZ)                                                                                            \
     switch (nqt) {                                                                                                  \

@@ -70,6 +70,9 @@ int capdec_synchronize(capdec_ctx *ctx);
  *     the fp32 reference (teacher-forced tolerance tests, capdec_decode_greedy_forced);
  * 4 = "f16": fp16 GEMM operands, fp32 everything else (KV cache included): the precision class of the reference's
  *     CLIP towers on a GPU (clip.load converts to fp16).
+ * In the two 16-bit modes the CLIP towers' attention (sequences of 24 .. 128 positions: the 77-token text tower, the
+ * 50-token ViT) also takes fp16 operands for its two products -- q, k, v and the un-normalised softmax weights, fp32
+ * accumulate, fp32 softmax; GPT-2's attention keeps fp32 operands (bf16 mode: the bf16-rounded K / V of its cache).
  * The mapper, patch-embedding and projection GEMMs are fp32-accurate in every mode.
  * The environment variable CAPDEC_GEMM_MODE=f16x2|bf16x3|f32|bf16|f16 overrides the default at capdec_create (any
  * other value makes capdec_create fail: a typo must not silently select another precision). */

@@ -771,13 +771,26 @@ def _clip_resblocks(x: Tensor, sd: SD, prefix: str, n_head: int, causal: bool) -
         # (_r / _rw: 16-bit GEMM operands inside ``bf16_gemm_operands(dtype)`` -- the HIP f16 / bf16 tower modes)
         qkv = F.linear(_r(a), _rw(sd[b + "attn.in_proj_weight"]), sd[b + "attn.in_proj_bias"])
         q, k, v = qkv.split(d, dim=2)
-        q = q.view(N, L, n_head, hd).transpose(1, 2) * (hd ** -0.5)     # nn.MultiheadAttention scales q
+        q = q.view(N, L, n_head, hd).transpose(1, 2)
         k = k.view(N, L, n_head, hd).transpose(1, 2)
         v = v.view(N, L, n_head, hd).transpose(1, 2)
-        w = torch.matmul(q, k.transpose(-1, -2))
-        if causal:                                                        # build_attention_mask: -inf above the diagonal
-            w = w + torch.full((L, L), float("-inf")).triu_(1)
-        o = torch.matmul(w.softmax(dim=-1), v).transpose(1, 2).reshape(N, L, d)
+        if _GEMM_BF16:
+            # the towers' 16-bit modes (HIP attn_prefill_mfma_kernel<.., SPLIT = false>): both attention products take fp16
+            # operands too -- q (scaled by 1 / sqrt(hd) and log2 e: the scores live in the log2 domain), k, v and the
+            # UN-NORMALISED weights 2^(s - max) are rounded to fp16 (whatever the GEMM dtype), products and sums fp32, the
+            # row sum is taken over the unrounded weights and divides the result
+            h16 = lambda t: t.to(torch.float16).to(torch.float32)         # noqa: E731
+            w = torch.matmul(h16(q * (hd ** -0.5 * 1.4426950408889634)), h16(k).transpose(-1, -2))
+            if causal:
+                w = w + torch.full((L, L), float("-inf")).triu_(1)
+            pw = torch.exp2(w - w.max(dim=-1, keepdim=True).values)
+            o = (torch.matmul(h16(pw), h16(v)) / pw.sum(dim=-1, keepdim=True)).transpose(1, 2).reshape(N, L, d)
+        else:
+            q = q * (hd ** -0.5)                                          # nn.MultiheadAttention scales q
+            w = torch.matmul(q, k.transpose(-1, -2))
+            if causal:                                                    # build_attention_mask: -inf above the diagonal
+                w = w + torch.full((L, L), float("-inf")).triu_(1)
+            o = torch.matmul(w.softmax(dim=-1), v).transpose(1, 2).reshape(N, L, d)
         x = x + F.linear(_r(o), _rw(sd[b + "attn.out_proj.weight"]), sd[b + "attn.out_proj.bias"])
         m = F.layer_norm(x, (d,), sd[b + "ln_2.weight"], sd[b + "ln_2.bias"], 1e-5)
         m = F.linear(_r(m), _rw(sd[b + "mlp.c_fc.weight"]), sd[b + "mlp.c_fc.bias"])
