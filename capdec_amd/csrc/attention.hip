@@ -682,10 +682,12 @@ int launch_attn_prefill(hipStream_t st, const float *qkv, const KvCache &c, int 
     CAPDEC_CHECK(c.hd == 64, "attention: head_dim must be 64");
     CAPDEC_CHECK(P <= ATT_CTX_MAX && P <= c.ctx, "attention: prefix longer than the supported context");
     (void)layer; (void)beam;                      // K / V come straight from qkv (the cache is filled by kv_scatter_prefill)
-    if (!c.bf16 && P >= ATT_MFMA_MIN_P && P <= ATT_MFMA_MAX_P && ncap > 0) {
+    // one fp16 plane per operand in the TOWERS' 16-bit precision modes (a tower keeps no KV cache: c.k == nullptr), two
+    // (fp32-accurate) otherwise; the one-plane form takes every length up to 128 -- the text tower computes as many positions
+    // as its chunk's longest caption has, and a row's arithmetic class must not depend on that
+    const bool split = !((fmt == PK_F16X1 || fmt == PK_BF16X1) && c.k == nullptr);
+    if (!c.bf16 && (P >= ATT_MFMA_MIN_P || !split) && P <= ATT_MFMA_MAX_P && ncap > 0) {
         const int nqt = (P + 31) / 32;
-        // one fp16 plane per operand in the towers' 16-bit precision modes, two (fp32-accurate) otherwise
-        const bool split = !(fmt == PK_F16X1 || fmt == PK_BF16X1);
         const size_t lds = attn_mfma_lds_bytes(P, split ? 2 : 1);
 #define LAUNCH_AM(CZ, NTV)                                                                                          \
     {                                                                                                               \

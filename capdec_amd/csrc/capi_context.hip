@@ -82,6 +82,7 @@ bool tuning_from_env(Tuning *t, std::string *err) {
     env_flag("CAPDEC_LMHEAD_K3", &t->lmhead_k3);
     env_int("CAPDEC_LMHEAD_K3_MAX", &t->lmhead_k3_max);
     env_flag("CAPDEC_KV_DIRECT", &t->kv_direct);
+    env_flag("CAPDEC_CLIP_TRUNC", &t->clip_trunc);
     env_flag("CAPDEC_RN_PACKED", &t->rn_packed);
     env_flag("CAPDEC_RN_IMPLICIT", &t->rn_implicit);
     t->hook_packa = getenv("CAPDEC_HOOK_PACKA") != nullptr;

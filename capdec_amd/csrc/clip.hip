@@ -4,30 +4,42 @@
 
 namespace capdec {
 
-static int clip_text_chunk(capdec_ctx *c, const int *tokens, int n, float *out) {
+// One chunk of captions through the text tower.  perm == nullptr: captions [0, n) of `tokens` with all L positions, features
+// to out[0 .. n).  perm != nullptr (device, n entries; pos = every caption's EOT position, device): caption i of the chunk is
+// row perm[i] of `tokens`, only positions [0, P) are computed -- P > the largest EOT position of the chunk: the tower is
+// causal and the feature is read at the EOT row, so nothing behind a caption's EOT can reach it -- and the features are
+// scattered to out[perm[i]].
+static int clip_text_chunk(capdec_ctx *c, const int *tokens, int n, float *out, const int *perm = nullptr, const int *pos = nullptr,
+                           int P = 0) {
     Tower &t = c->clip_text;
     const int d = t.d, L = t.ctx;
+    if (!perm) P = L;
     KvCache kv;
-    kv_geometry(kv, n, L, t.n_head, d / t.n_head);
-    CAPDEC_TRY(ensure_body_ws(c, n * L, d));
+    kv_geometry(kv, n, P, t.n_head, d / t.n_head);
+    CAPDEC_TRY(ensure_body_ws(c, n * P, d));
     CAPDEC_TRY(c->t_idx.ensure((size_t)n * 4));
     CAPDEC_TRY(c->xl.ensure((size_t)2 * n * d * 4));
-    { ProfScope ps(c, F_EMBED); CAPDEC_TRY(launch_clip_text_embed(c->stream, tokens, t.tok_emb, t.pos_emb, c->h.as<float>(), n, L, d)); }
+    { ProfScope ps(c, F_EMBED); CAPDEC_TRY(launch_clip_text_embed(c->stream, tokens, t.tok_emb, t.pos_emb, c->h.as<float>(), n, L, d, P, perm)); }
     StepShape sp{};
     sp.prefill = true;
     sp.ncap = n;
-    sp.P = L;
+    sp.P = P;
     sp.beam = 1;
     StackCfg cfg{&t.layers, t.n_layer, d, 1e-5f, CAPDEC_ACT_QUICK_GELU, true, false};
     CAPDEC_TRY(stack_body(c, cfg, sp, kv));
     float *rows = c->xl.as<float>(), *rows_ln = c->xl.as<float>() + (size_t)n * d;
     {
         ProfScope ps(c, F_EMBED);
-        CAPDEC_TRY(launch_eot_index(c->stream, tokens, c->t_idx.as<int>(), n, L));
+        if (perm) CAPDEC_TRY(launch_eot_rows(c->stream, pos, perm, c->t_idx.as<int>(), n, P));
+        else CAPDEC_TRY(launch_eot_index(c->stream, tokens, c->t_idx.as<int>(), n, L));
         CAPDEC_TRY(launch_gather_rows(c->stream, c->h.as<float>(), c->t_idx.as<int>(), rows, n, d));
     }
     { ProfScope ps(c, F_LN); CAPDEC_TRY(launch_layernorm(c->stream, rows, d, t.lnf_w, t.lnf_b, 1e-5f, rows_ln, d, n, d)); }
-    return gemm(c, rows_ln, d, t.proj_t, d, out, t.embed, n, t.embed, d, nullptr, CAPDEC_ACT_NONE);
+    if (!perm) return gemm(c, rows_ln, d, t.proj_t, d, out, t.embed, n, t.embed, d, nullptr, CAPDEC_ACT_NONE);
+    CAPDEC_TRY(c->t_pout.ensure((size_t)n * t.embed * 4));
+    CAPDEC_TRY(gemm(c, rows_ln, d, t.proj_t, d, c->t_pout.as<float>(), t.embed, n, t.embed, d, nullptr, CAPDEC_ACT_NONE));
+    ProfScope ps(c, F_EMBED);
+    return launch_scatter_rows(c->stream, c->t_pout.as<float>(), perm, out, n, t.embed);
 }
 
 // one chunk of images through the vision tower: pixels [n, 3, S, S] -> out [n, embed]
@@ -282,10 +294,39 @@ int capdec_clip_encode_text(capdec_ctx *c, const int32_t *tokens, int n, float *
     CAPDEC_CHECK(n >= 0 && (n == 0 || (tokens && out)), "clip_encode_text: bad argument");
     CAPDEC_HIP(hipSetDevice(c->device));
     const Tower &t = c->clip_text;
-    const int chunk = 4096;
-    for (int c0 = 0; c0 < n; c0 += chunk) {
-        const int nc = std::min(chunk, n - c0);
-        CAPDEC_TRY(clip_text_chunk(c, tokens + (size_t)c0 * t.ctx, nc, out + (size_t)c0 * t.embed));
+    const int L = t.ctx;
+    const int row_budget = 4096 * L;            // token rows per chunk (4096 full-length captions: the workspaces' size class)
+    if (!c->tune.clip_trunc || n == 0 || t.embed % 4 != 0) {
+        const int chunk = 4096;
+        for (int c0 = 0; c0 < n; c0 += chunk) {
+            const int nc = std::min(chunk, n - c0);
+            CAPDEC_TRY(clip_text_chunk(c, tokens + (size_t)c0 * L, nc, out + (size_t)c0 * t.embed));
+        }
+        return 0;
+    }
+    // Captions are short (COCO: ~14 tokens with SOT / EOT of the 77 the reference pads to, embeddings_generator.py:80-86) and
+    // the tower is causal: a caption's feature is its EOT row, which sees positions <= EOT only.  So: every caption's EOT
+    // position (one small kernel + an n-int copy), captions sorted by it on the host, chunks of neighbours in that order, each
+    // computed with P = its own largest EOT + 1 positions per caption instead of 77 -- the GEMM / LayerNorm / attention rows of
+    // a chunk shrink by 77 / P; features identical to the full-length computation up to fp32 summation order (the launch sizes
+    // differ).  CAPDEC_CLIP_TRUNC=0 computes all 77 positions.
+    DBuf &ib = c->p_inter;                      // [pos n][perm n] ints
+    CAPDEC_TRY(ib.ensure((size_t)2 * n * sizeof(int)));
+    int *pos_d = ib.as<int>(), *perm_d = pos_d + n;
+    { ProfScope ps(c, F_EMBED); CAPDEC_TRY(launch_eot_index(c->stream, tokens, pos_d, n, L, /*flat=*/0)); }
+    std::vector<int> pos((size_t)n), order((size_t)n);
+    CAPDEC_HIP(hipMemcpyAsync(pos.data(), pos_d, (size_t)n * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    CAPDEC_HIP(hipStreamSynchronize(c->stream));
+    for (int i = 0; i < n; ++i) order[(size_t)i] = i;
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return pos[(size_t)a] < pos[(size_t)b]; });
+    CAPDEC_HIP(hipMemcpyAsync(perm_d, order.data(), (size_t)n * sizeof(int), hipMemcpyHostToDevice, c->stream));
+    CAPDEC_HIP(hipStreamSynchronize(c->stream));                    // (`order` is pageable host memory: it must outlive the copy)
+    for (int i0 = 0; i0 < n;) {
+        int m = 1;
+        while (i0 + m < n && m < 65536 && (long long)(m + 1) * (pos[(size_t)order[(size_t)(i0 + m)]] + 1) <= row_budget) ++m;
+        const int P = pos[(size_t)order[(size_t)(i0 + m - 1)]] + 1;
+        CAPDEC_TRY(clip_text_chunk(c, tokens, m, out, perm_d + i0, pos_d, P));
+        i0 += m;
     }
     return 0;
 }

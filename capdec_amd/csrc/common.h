@@ -227,8 +227,10 @@ int launch_tmapper_take(hipStream_t st, const float *seq, float *out, int n, int
 int launch_transpose(hipStream_t st, const float *in, float *out, int rows, int cols);  // out[c][r] = in[r][c]
 // CLIP glue
 int launch_clip_text_embed(hipStream_t st, const int *tokens, const float *tok_emb, const float *pos_emb, float *h,
-                           int n, int L, int d);
-int launch_eot_index(hipStream_t st, const int *tokens, int *flat_idx, int n, int L);   // n*L + argmax_t tokens[n,t]
+                           int n, int L, int d, int P = 0, const int *perm = nullptr);
+int launch_eot_index(hipStream_t st, const int *tokens, int *flat_idx, int n, int L, int flat = 1);   // (flat: n*L +) argmax_t tokens[n,t]
+int launch_eot_rows(hipStream_t st, const int *pos, const int *perm, int *rows, int m, int P);
+int launch_scatter_rows(hipStream_t st, const float *src, const int *perm, float *dst, int rows, int d);
 int launch_im2col_patches(hipStream_t st, const float *pixels, float *patches, int n, int S, int patch);
 int launch_vision_assemble(hipStream_t st, const float *patch_out, const float *cls, const float *pos, float *seq,
                            int n, int ntok, int d);

@@ -35,6 +35,8 @@ struct Tuning {
     int lmhead_k3_max = 60;       // CAPDEC_LMHEAD_K3_MAX: per mille of the rows taking the second pass above which a decode
                                   //   call goes back to k per tile (checked at the poll points; break-even is ~80)
     bool kv_direct = true;        // CAPDEC_KV_DIRECT=0: the attention kernel appends K / V itself
+    bool clip_trunc = true;       // CAPDEC_CLIP_TRUNC=0: the CLIP text tower computes all 77 positions of every caption (default: only
+                                  //   the positions up to a chunk's last EOT; captions sorted by length)
     bool rn_packed = true;        // CAPDEC_RN_PACKED=0: fp32 im2col in the ResNet tower
     bool rn_implicit = true;      // CAPDEC_RN_IMPLICIT=0: fp32 activations in the ResNet tower
     bool train_f16x2 = true;      // CAPDEC_TRAIN_F16X2=0: the train step's backward GEMMs on the native fp32 MFMA GEMM instead of the

@@ -365,29 +365,32 @@ int launch_transpose(hipStream_t st, const float *in, float *out, int rows, int 
 }
 
 // ---------------------------------------------------------------------------- CLIP glue
-// h[(n, t)] = token_embedding[tokens[n, t]] + positional_embedding[t]
+// h[(i, t)] = token_embedding[tokens[cap(i), t]] + positional_embedding[t] for t < P (P <= L: the positions up to the chunk's
+// last EOT -- nothing behind a caption's EOT can reach its feature through causal attention); cap(i) = perm ? perm[i] : i
 __global__ void clip_text_embed_kernel(const int *__restrict__ tokens, const float *__restrict__ tok_emb,
-                                       const float *__restrict__ pos_emb, float *__restrict__ h, int n, int L,
-                                       int nv) {
+                                       const float *__restrict__ pos_emb, float *__restrict__ h, int n, int L, int P,
+                                       const int *__restrict__ perm, int nv) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n * L * nv) return;
-    const int c = i % nv, row = i / nv, t = row % L;
-    const float4 a = reinterpret_cast<const float4 *>(tok_emb + (size_t)tokens[row] * nv * 4)[c];
+    if (i >= n * P * nv) return;
+    const int c = i % nv, row = i / nv, t = row % P, cap = row / P;
+    const int tok = tokens[(size_t)(perm ? perm[cap] : cap) * L + t];
+    const float4 a = reinterpret_cast<const float4 *>(tok_emb + (size_t)tok * nv * 4)[c];
     const float4 p = reinterpret_cast<const float4 *>(pos_emb + (size_t)t * nv * 4)[c];
     reinterpret_cast<float4 *>(h)[i] = make_float4(a.x + p.x, a.y + p.y, a.z + p.z, a.w + p.w);
 }
 int launch_clip_text_embed(hipStream_t st, const int *tokens, const float *tok_emb, const float *pos_emb, float *h,
-                           int n, int L, int d) {
-    const int tot = n * L * (d / 4);
+                           int n, int L, int d, int P, const int *perm) {
+    if (P <= 0) P = L;
+    const int tot = n * P * (d / 4);
     if (tot <= 0) return 0;
     hipLaunchKernelGGL(clip_text_embed_kernel, dim3((tot + 255) / 256), dim3(256), 0, st, tokens, tok_emb, pos_emb, h, n,
-                       L, d / 4);
+                       L, P, perm, d / 4);
     CAPDEC_HIP(hipGetLastError());
     return 0;
 }
 
-// flat_idx[n] = n*L + argmax_t tokens[n, t]  (first maximum, like torch.argmax: the EOT position)
-__global__ void eot_index_kernel(const int *__restrict__ tokens, int *__restrict__ flat_idx, int n, int L) {
+// flat_idx[n] = n*L + argmax_t tokens[n, t]  (first maximum, like torch.argmax: the EOT position); flat = 0: the bare position
+__global__ void eot_index_kernel(const int *__restrict__ tokens, int *__restrict__ flat_idx, int n, int L, int flat) {
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= n) return;
     int best = tokens[(size_t)r * L], bi = 0;
@@ -395,11 +398,36 @@ __global__ void eot_index_kernel(const int *__restrict__ tokens, int *__restrict
         const int v = tokens[(size_t)r * L + t];
         if (v > best) { best = v; bi = t; }
     }
-    flat_idx[r] = r * L + bi;
+    flat_idx[r] = (flat ? r * L : 0) + bi;
 }
-int launch_eot_index(hipStream_t st, const int *tokens, int *flat_idx, int n, int L) {
+int launch_eot_index(hipStream_t st, const int *tokens, int *flat_idx, int n, int L, int flat) {
     if (n <= 0) return 0;
-    hipLaunchKernelGGL(eot_index_kernel, dim3((n + 255) / 256), dim3(256), 0, st, tokens, flat_idx, n, L);
+    hipLaunchKernelGGL(eot_index_kernel, dim3((n + 255) / 256), dim3(256), 0, st, tokens, flat_idx, n, L, flat);
+    CAPDEC_HIP(hipGetLastError());
+    return 0;
+}
+// rows[i] = i P + pos[perm[i]]: the EOT row of caption perm[i] inside a chunk computed with P positions per caption
+__global__ void eot_rows_kernel(const int *__restrict__ pos, const int *__restrict__ perm, int *__restrict__ rows, int m, int P) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < m) rows[i] = i * P + pos[perm[i]];
+}
+int launch_eot_rows(hipStream_t st, const int *pos, const int *perm, int *rows, int m, int P) {
+    if (m <= 0) return 0;
+    hipLaunchKernelGGL(eot_rows_kernel, dim3((m + 255) / 256), dim3(256), 0, st, pos, perm, rows, m, P);
+    CAPDEC_HIP(hipGetLastError());
+    return 0;
+}
+// dst[perm[i], :] = src[i, :]   (d a multiple of 4)
+__global__ void scatter_rows_kernel(const float *__restrict__ src, const int *__restrict__ perm, float *__restrict__ dst, int rows, int nv) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows * nv) return;
+    const int row = i / nv, c = i - row * nv;
+    reinterpret_cast<float4 *>(dst + (size_t)perm[row] * nv * 4)[c] = reinterpret_cast<const float4 *>(src)[i];
+}
+int launch_scatter_rows(hipStream_t st, const float *src, const int *perm, float *dst, int rows, int d) {
+    if (rows <= 0) return 0;
+    const int n = rows * (d / 4);
+    hipLaunchKernelGGL(scatter_rows_kernel, dim3((n + 255) / 256), dim3(256), 0, st, src, perm, dst, rows, d / 4);
     CAPDEC_HIP(hipGetLastError());
     return 0;
 }

@@ -1833,6 +1833,42 @@ def test_clip_b32_batches_and_shards(golden):
     assert float((fi[0] - fi[1]).abs().max()) > 1e-3 * si and float((full[0] - full[1]).abs().max()) > 1e-3 * scale
 
 
+def test_clip_text_tower_computes_only_up_to_the_eot(golden, monkeypatch):
+    """Round 6: the text tower sorts a call's captions by EOT position and computes each chunk with as many positions as its
+    longest caption needs (causal tower, feature read at the EOT row) instead of the 77 the reference pads to.  Same features
+    as the full-length computation (CAPDEC_CLIP_TRUNC=0, a second context) and as the oracle, on a batch with every length
+    from an EOT at position 1 to one at position 76, a row without any EOT-like maximum (all zeros: position 0) included,
+    in the input order; fp32-accurate and fp16 towers."""
+    from capdec_amd import clip as cclip
+    from oracle import capdec_oracle as O
+    sd = synth.hot_clip_state_dict(43, synth.CLIP_TINY)
+    toks = synth.synthetic_clip_tokens(150, seed=77, min_len=0, max_len=75)
+    toks[5] = 0                                                     # argmax of an all-zero row: position 0
+    toks[6, :] = torch.arange(1, 78)                                # the maximum sits at the last position
+    lens = toks.argmax(dim=-1)
+    assert int(lens.min()) == 0 and int(lens.max()) == 76 and len(set(lens.tolist())) > 40
+    want = O.clip_encode_text(toks, sd)
+    for precision in ("fp32", "fp16"):
+        monkeypatch.delenv("CAPDEC_CLIP_TRUNC", raising=False)
+        m_t, _ = cclip.load(sd, device=0, precision=precision)
+        got = m_t.encode_text(toks).cpu()
+        monkeypatch.setenv("CAPDEC_CLIP_TRUNC", "0")
+        m_f, _ = cclip.load(sd, device=0, precision=precision)
+        full = m_f.encode_text(toks).cpu()
+        monkeypatch.delenv("CAPDEC_CLIP_TRUNC", raising=False)
+        scale = float(want.abs().max())
+        if precision == "fp32":
+            assert float((got - full).abs().max()) < 2e-5 * scale
+            np.testing.assert_allclose(got.numpy(), want.numpy(), atol=5e-4)
+        else:       # fp16 towers: the same arithmetic class either way (one fp16 plane per attention operand at every length)
+            with O.bf16_gemm_operands(torch.float16):
+                emu = O.clip_encode_text(toks, sd)
+            gap = float((emu - want).abs().max())
+            assert float((got - full).abs().max()) < 0.5 * gap + 2e-4 * scale
+            assert float((got - emu).abs().max()) < 0.5 * gap + 2e-4 * scale
+        np.testing.assert_array_equal(m_t.encode_text(toks[7:8]).cpu().numpy().shape, (1, want.shape[1]))
+
+
 def _rn_check(model, sd, imgs, atol_rel, fixture=None):
     from oracle import capdec_oracle as O
     want = O.clip_encode_image_resnet(imgs, sd) if fixture is None else T(fixture)    # fixture: the torch.nn module witness
