@@ -683,10 +683,11 @@ int launch_attn_prefill(hipStream_t st, const float *qkv, const KvCache &c, int 
     CAPDEC_CHECK(P <= ATT_CTX_MAX && P <= c.ctx, "attention: prefix longer than the supported context");
     (void)layer; (void)beam;                      // K / V come straight from qkv (the cache is filled by kv_scatter_prefill)
     // one fp16 plane per operand in the TOWERS' 16-bit precision modes (a tower keeps no KV cache: c.k == nullptr), two
-    // (fp32-accurate) otherwise; the one-plane form takes every length up to 128 -- the text tower computes as many positions
-    // as its chunk's longest caption has, and a row's arithmetic class must not depend on that
-    const bool split = !((fmt == PK_F16X1 || fmt == PK_BF16X1) && c.k == nullptr);
-    if (!c.bf16 && (P >= ATT_MFMA_MIN_P || !split) && P <= ATT_MFMA_MAX_P && ncap > 0) {
+    // (fp32-accurate) otherwise.  A tower takes this kernel at every length up to 128: the text tower computes as many
+    // positions as its chunk's longest caption has (typically ~20), and a row's arithmetic class must not depend on that
+    const bool tower = c.k == nullptr;
+    const bool split = !((fmt == PK_F16X1 || fmt == PK_BF16X1) && tower);
+    if (!c.bf16 && (P >= ATT_MFMA_MIN_P || tower) && P <= ATT_MFMA_MAX_P && ncap > 0) {
         const int nqt = (P + 31) / 32;
         const size_t lds = attn_mfma_lds_bytes(P, split ? 2 : 1);
 #define LAUNCH_AM(CZ, NTV)                                                                                          \
