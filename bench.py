@@ -474,7 +474,12 @@ def side_workload(args, world, rank, dev, emit=print):
                           "roofline": roof, "cpu_baseline": cpu,
                           "config": {"workload": args.workload, "clip": "RN50x4" if rn else "ViT-B/32",
                                      "items_per_step": n_global, "clip_precision": prec,
-                                     "gemm_mode": model.engine.gemm_mode()}}))
+                                     "gemm_mode": model.engine.gemm_mode(),
+                                     **({"token_rows": "clip.tokenize-shaped: SOT + 8-20 random ids + EOT, zero-padded to 77 "
+                                                       "(synth.synthetic_clip_tokens; mean EOT position %.1f) -- the tower computes the "
+                                                       "positions up to each chunk's last EOT, so the rate depends on caption length "
+                                                       "(CAPDEC_CLIP_TRUNC=0: all 77 positions)" % float(inp.argmax(dim=-1).float().mean())}
+                                        if text else {})}}))
 
 
 def other_configs(args, dev, note):
