@@ -23,7 +23,7 @@ __device__ __forceinline__ float act_apply(float v, int act) {
             const float u2 = v * (c2 + (c2 * 0.044715f) * v * v);
             return __fdividef(v, 1.f + __expf(-u2));
         }
-        case CAPDEC_ACT_QUICK_GELU: return v / (1.f + __expf(-1.702f * v));   // x * sigmoid(1.702 x)
+        case CAPDEC_ACT_QUICK_GELU: return __fdividef(v, 1.f + __expf(-1.702f * v));   // x * sigmoid(1.702 x)
         default: return v;
     }
 }

@@ -42,7 +42,7 @@ template <int ACT> __device__ __forceinline__ float act_const(float v) {
         const float c2 = 2.0f * 0.7978845608028654f;
         const float u2 = v * (c2 + (c2 * 0.044715f) * v * v);
         return __fdividef(v, 1.f + __expf(-u2));
-    } else if constexpr (ACT == CAPDEC_ACT_QUICK_GELU) return v / (1.f + __expf(-1.702f * v));
+    } else if constexpr (ACT == CAPDEC_ACT_QUICK_GELU) return __fdividef(v, 1.f + __expf(-1.702f * v));   // (rcp + mul like gelu_new above: an IEEE division is ~10 VALU instructions per element of a K = 512 tile whose MFMAs take less time than its epilogue)
     else return v;
 }
 template <int ACT> __device__ __forceinline__ float post_resid_const(float v) {
