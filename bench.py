@@ -422,8 +422,16 @@ def side_workload(args, world, rank, dev, emit=print):
                 peak = PEAK_BF16_MFMA_TFLOPS / 3.0 if "f16x2" in k else (PEAK_BF16_MFMA_TFLOPS / 6.0 if "x3" in k else
                                                                        (PEAK_F32_MFMA_TFLOPS if k == "gemm_f32" else PEAK_BF16_MFMA_TFLOPS))
                 ach = v["flops"] / v["ms"] * 1e-9
+                traffic = None
+                try:        # fabric-side bytes per launch of that family from the committed --pmc passes of the same command
+                    pm = json.load(open(os.path.join(ROOT, "profiles", "r6_text_f16_pmc_traffic.json")))
+                    kk = {"gemm_x1": "gemm_x1_kernel", "gemm_f16x2p": "gemm_f16x2p_kernel"}.get(k)
+                    if text and pm.get("gemm_mode") == (args.gemm_mode or "f16x2") and pm.get("captions_per_gpu") == n_global and kk in pm:
+                        traffic = pm[kk]["traffic_bytes_per_launch"]
+                except (OSError, ValueError, KeyError):
+                    pass
                 roof = {"bound": "mfma", "kernel": k, "achieved": round(ach, 1), "peak": round(peak, 1), "unit": "TFLOP/s",
-                        "frac": round(ach / peak, 4), "traffic": None, "avg_launch_ms": round(v["ms"] / v["launches"], 4),
+                        "frac": round(ach / peak, 4), "traffic": traffic, "avg_launch_ms": round(v["ms"] / v["launches"], 4),
                         "launches_timed": v["launches"], "share_of_tower": round(est(v) / tower_ms, 3),
                         "note": "algorithmic 2 M N K of every GEMM of the family / hipEvent time of the timed launches; peak = dense "
                                 "16-bit MFMA 2.5 PFLOP/s (one plane per operand) or / 3 (two fp16 planes, fp32-accurate)"}
